@@ -1,0 +1,239 @@
+"""Pin the oracle against the importable pieces of the reference and emit golden vectors.
+
+Run ONLY in the build container (needs /root/reference; it never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+Step 1 cross-checks ``oracle/lemo_oracle.py`` against the reference's own Python, imported from
+where it lies (nothing is copied):
+    human_body_prior/body_model/lbs.py      (file-path import; vendored smplx.lbs)
+    models/AE_sep.py::Enc, models/AE.py::AE (torchvision stubbed -- unused import)
+    utils/utils.py 6-D / axis-angle helpers (torchgeometry stubbed by the oracle's restatement)
+    human_body_prior/train/vposer_smpl.py::VPoser.decode (torchgeometry/configer/smplx stubbed)
+Step 2 writes small ``.npz`` fixtures (inputs + expected outputs) next to this file.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import lemo_oracle as O                      # noqa: E402
+from lemo_amd import synthetic                           # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def small_model(V=640, seed=3):
+    m = synthetic.make_synthetic_smplx(seed=seed, V=V, F=1200)
+    return m
+
+
+def check_against_reference():
+    report = {}
+    # ---- lbs.py --------------------------------------------------------------------------
+    ref_lbs = _load_by_path('ref_lbs', f'{REF}/human_body_prior/body_model/lbs.py')
+    _v2j = ref_lbs.vertices2joints
+    ref_lbs.vertices2joints = lambda J, v: _v2j(J, v).contiguous()     # torch>=2 .view() fix
+    m = small_model()
+    so = O.SmplxOracle(m)
+    g = torch.Generator().manual_seed(0)
+    B = 4
+    betas = torch.randn(B, 20, generator=g) * 0.5
+    pose = torch.randn(B, 165, generator=g) * 0.3
+    shapedirs = torch.cat([so.shapedirs, so.expr_dirs], -1)
+    v_ref, j_ref = ref_lbs.lbs(betas, pose, so.v_template, shapedirs, so.posedirs, so.J_regressor,
+                               so.parents, so.lbs_weights)
+    v_o, j_o = O.lbs(betas, pose, so.v_template, shapedirs, so.posedirs, so.J_regressor, so.parents,
+                     so.lbs_weights)
+    report['lbs.verts'] = _rel(v_o, v_ref)
+    report['lbs.joints'] = _rel(j_o, j_ref)
+    report['lbs.rodrigues'] = _rel(O.batch_rodrigues(pose.view(-1, 3)), ref_lbs.batch_rodrigues(pose.view(-1, 3)))
+
+    # ---- Enc / AE ------------------------------------------------------------------------
+    sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    sys.path.insert(0, REF)
+    from models.AE_sep import Enc                                         # reference class
+    from models.AE import AE
+    enc = Enc(downsample=False, z_channel=64)
+    sd = torch.load(f'{REF}/runs/15217/Enc_last_model.pkl', map_location='cpu')
+    enc.load_state_dict(sd)
+    enc.eval()
+    x = torch.randn(1, 1, 245, 134, generator=g)
+    with torch.no_grad():
+        report['Enc.z'] = _rel(O.enc_forward(sd, x), enc(x)[0])
+    ae = AE(downsample=True, in_channel=4, kernel=3).eval()
+    ae.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()})
+    xa = torch.randn(1, 4, 210, 135, generator=g)
+    with torch.no_grad():
+        o_ref, z_ref = ae(xa)
+        o_o, z_o = O.ae_forward(ae.state_dict(), xa)
+    report['AE.out'] = _rel(o_o, o_ref)
+    report['AE.z'] = _rel(z_o, z_ref)
+    ae_sd = {k: v.clone() for k, v in ae.state_dict().items()}
+
+    # ---- utils/utils.py 6-D helpers through the tgm restatement ---------------------------
+    tgm = types.ModuleType('torchgeometry')
+    tgm.rotation_matrix_to_angle_axis = O.rotation_matrix_to_angle_axis
+    tgm.angle_axis_to_rotation_matrix = O.angle_axis_to_rotation_matrix
+    sys.modules['torchgeometry'] = tgm
+    import scipy.ndimage
+    if 'scipy.ndimage.filters' not in sys.modules:
+        try:
+            import scipy.ndimage.filters                                  # noqa: F401
+        except Exception:
+            sys.modules['scipy.ndimage.filters'] = scipy.ndimage
+    ref_utils = importlib.import_module('utils.utils')
+    x75 = torch.randn(16, 75, generator=g)
+    report['utils.convert_to_3D_rot'] = _rel(O.convert_to_3D_rot(x75), ref_utils.convert_to_3D_rot(x75))
+    aa = torch.randn(16, 3, generator=g)
+    report['utils.convert_to_6D_all'] = _rel(O.convert_to_6D_all(aa), ref_utils.convert_to_6D_all(aa))
+
+    # ---- VPoser.decode -------------------------------------------------------------------
+    cfg = types.ModuleType('configer'); cfg.Configer = object
+    sys.modules['configer'] = cfg
+    smplx_stub = types.ModuleType('smplx'); smplx_stub.lbs = ref_lbs
+    smplx_lbs = types.ModuleType('smplx.lbs'); smplx_lbs.lbs = ref_lbs.lbs
+    sys.modules['smplx'] = smplx_stub; sys.modules['smplx.lbs'] = smplx_lbs
+    try:
+        vp_mod = importlib.import_module('human_body_prior.train.vposer_smpl')
+        vp = vp_mod.VPoser(num_neurons=512, latentD=32, data_shape=[1, 21, 3]).eval()
+        w = O.make_vposer_weights(seed=2)
+        vp.load_state_dict({**vp.state_dict(), **w})
+        Z = torch.randn(8, 32, generator=g) * 0.7
+        with torch.no_grad():
+            report['VPoser.decode.aa'] = _rel(O.vposer_decode(w, Z, 'aa'), vp.decode(Z, 'aa'))
+            report['VPoser.decode.matrot'] = _rel(O.vposer_decode(w, Z, 'matrot'), vp.decode(Z, 'matrot'))
+    except Exception as e:                                                # pragma: no cover
+        report['VPoser.import_error'] = repr(e)
+    return report, ae_sd
+
+
+def emit_golden(ae_sd):
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    # (5) 6-D -> aa, random + near-singular -------------------------------------------------
+    x6 = torch.randn(64, 6, generator=g)
+    aa_small = torch.randn(8, 3, generator=g) * 1e-4
+    axis = torch.nn.functional.normalize(torch.randn(8, 3, generator=g), dim=1)
+    aa_pi = axis * (np.pi - 1e-3)
+    x6 = torch.cat([x6, O.convert_to_6D_all(aa_small), O.convert_to_6D_all(aa_pi)], 0)
+    out['rot6d_in'] = x6.numpy()
+    out['rot6d_aa'] = O.convert_to_3D_all(x6).numpy()
+    np.savez(os.path.join(HERE, 'rot6d.npz'), **out)
+
+    # (4) VPoser decode ---------------------------------------------------------------------
+    w = O.make_vposer_weights(seed=2)
+    Z = torch.randn(16, 32, generator=g) * 0.7
+    np.savez(os.path.join(HERE, 'vposer_decode.npz'), Z=Z.numpy(),
+             aa=O.vposer_decode(w, Z, 'aa').numpy(), matrot=O.vposer_decode(w, Z, 'matrot').numpy())
+
+    # (1) LBS on a small synthetic model (full tensors) -------------------------------------
+    m = small_model()
+    so = O.SmplxOracle(m)
+    B = 4
+    p = dict(betas=torch.randn(B, 10, generator=g) * 0.5, global_orient=torch.randn(B, 3, generator=g),
+             body_pose=torch.randn(B, 63, generator=g) * 0.3, lh=torch.randn(B, 12, generator=g) * 0.1,
+             rh=torch.randn(B, 12, generator=g) * 0.1, transl=torch.randn(B, 3, generator=g))
+    for k in ('global_orient', 'body_pose', 'transl', 'lh', 'rh', 'betas'):
+        p[k].requires_grad_(True)
+    ex_ids = [5, 17, 33, 100, 200, 300, 400, 500, 600, 610, 620, 7, 9, 11, 13, 15, 19, 21, 23, 25, 27]
+    so.extra_ids = torch.tensor(ex_ids)
+    verts, joints, fp = so.forward(p['betas'], p['global_orient'], p['body_pose'], p['lh'], p['rh'], p['transl'])
+    wv = torch.randn(verts.shape, generator=g)
+    wj = torch.randn(joints.shape, generator=g)
+    ((verts * wv).sum() + (joints * wj).sum()).backward()
+    np.savez(os.path.join(HERE, 'lbs_small.npz'), model_seed=3, model_V=640, extra_ids=np.asarray(ex_ids),
+             **{k: v.detach().numpy() for k, v in p.items()},
+             verts=verts.detach().numpy(), joints=joints.detach().numpy(), full_pose=fp.detach().numpy(),
+             wv=wv.numpy(), wj=wj.numpy(), **{'g_' + k: v.grad.numpy() for k, v in p.items()})
+
+    # (2) Enc with real weights -------------------------------------------------------------
+    enc_w = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, 'lemo_amd/assets/smooth_enc_15217.npz')).items()}
+    x = (torch.randn(1, 1, 245, 134, generator=g) * 0.05).requires_grad_(True)
+    z = O.enc_forward(enc_w, x)
+    ls = torch.mean((z[..., 1:] - z[..., :-1]) ** 2)
+    ls.backward()
+    np.savez(os.path.join(HERE, 'enc_smooth.npz'), x=x.detach().numpy(), loss_smooth=float(ls),
+             z_sum=float(z.double().sum()), z_abs_sum=float(z.double().abs().sum()),
+             z_sub=z.detach()[0, ::8, ::16, ::16].numpy(), gx=x.grad.numpy())
+
+    # (3) AE with numpy-seeded weights (lemo_amd.synthetic.make_ae_weights(7); runs/59547 is absent)
+    xa = torch.randn(1, 4, 210, 135, generator=g).half().float()
+    with torch.no_grad():
+        oa, za = O.ae_forward(ae_sd, xa)
+    np.savez_compressed(os.path.join(HERE, 'ae_infill.npz'), x=xa.numpy().astype(np.float16),
+                        out_sum=float(oa.double().sum()), z_sum=float(za.double().sum()),
+                        out_sub=oa[0, 0, ::7, ::5].numpy(), z=za.numpy())
+
+
+def emit_amass_iteration():
+    """(6) one full AMASS iteration on the full-size synthetic model + 10 Adam steps."""
+    from lemo_amd.assets import load_assets
+    A = load_assets()
+    m = synthetic.make_synthetic_smplx(seed=0)
+    so = O.SmplxOracle(m)
+    vw = O.make_vposer_weights(seed=2)
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    with torch.no_grad():
+        tp = torch.from_numpy(seq['target_params'])
+        bp = O.vposer_decode(vw, tp[:, 16:48], 'aa').view(119, -1)
+        tv, _, _ = so.forward(tp[:, 6:16], tp[:, 3:6], bp, tp[:, 48:60], tp[:, 60:], tp[:, 0:3])
+        markers_rec = tv[:, torch.from_numpy(A['ids']['markers67']).long()].numpy()
+    fit = O.AmassFitOracle(so, vw, A['enc_w_torch'], A['ids'], A['Xmean'], A['Xstd'],
+                           seq['init_params'], markers_rec, seq['contact_lbl'], faithful=False)
+    total, parts, p72, verts = fit.losses()
+    total.backward()
+    out = dict(markers_rec=markers_rec, p75_0=fit.params75().numpy(), p72_0=p72.detach().numpy(),
+               total=float(total), **{'loss_' + k: float(v) for k, v in parts.items()},
+               g_transl=fit.transl.grad.numpy().copy(), g_rot6d=fit.rot6d.grad.numpy().copy(),
+               g_other=fit.other.grad.numpy().copy(),
+               verts_sub=verts.detach()[:, ::97].numpy(), verts_sum=float(verts.double().sum()))
+    fit.opt.zero_grad()
+    hist = []
+    for i in range(10):
+        hist.append(fit.step())
+        if i == 0:
+            out['p75_after1'] = fit.params75().numpy()
+    out['p75_after10'] = fit.params75().numpy()
+    out['total_hist'] = np.asarray([h['total'] for h in hist])
+    out['smooth_hist'] = np.asarray([h['smooth'] for h in hist])
+    np.savez(os.path.join(HERE, 'amass_iter.npz'), **out)
+    print('amass iteration:', {k: (float(v) if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    rep, ae_sd = check_against_reference()
+    print('oracle vs reference (max rel err):')
+    bad = False
+    for k, v in rep.items():
+        print(f'  {k:28s} {v}')
+        if isinstance(v, float) and v > 2e-6:
+            bad = True
+    with open(os.path.join(HERE, 'oracle_vs_reference.txt'), 'w') as f:
+        for k, v in rep.items():
+            f.write(f'{k}\t{v}\n')
+    assert not bad, 'oracle disagrees with the reference'
+    emit_golden(ae_sd)
+    emit_amass_iteration()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
