@@ -1,0 +1,163 @@
+/* lemo_hip.h -- C ABI of liblemo_hip.so, the MI355X (gfx950) kernels of LEMO's temporal fitting hot path.
+ *
+ * The reference (sanweiliti/LEMO) has no native/FFI layer: its boundary for this path is the Python
+ * object API of smplx / VPoser / Enc.  This header is the boundary the build adds
+ * underneath those objects; each entry point names the reference code whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory + sizes; the caller owns every buffer (the Python host side
+ *     allocates them with torch); nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it;
+ *   - return 0 on success, a hipError_t value or LEMO_ERR_* (>= 10001) otherwise;
+ *   - fp32 everywhere (the reference path is fp32; the 1e6-weighted smoothness loss forbids less).
+ */
+#ifndef LEMO_HIP_H
+#define LEMO_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEMO_ERR_SHAPE 10001
+#define LEMO_ERR_ARG 10002
+#define LEMO_ERR_STATE 10003
+
+int lemo_abi_version(void);
+
+/* ---- motion-smoothness encoder, models/AE_sep.py:11-30,77-99 (Enc(downsample=False)) ----------
+ * Activations: CG8P layout act[C/8][(H+2)*(W+2)][8], zero 1-pixel border owned by the caller.
+ * Weights: wt[tap][Cin/8][Cout][8] (packed by lemo_amd.priors.pack_conv3x3 / pack_conv3x3_bwd). */
+/* epi 0: out = lrelu(conv + bias) | 1: out = conv * lrelu'(aux) (backward-data) | 2: out = conv + bias */
+int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
+                      int H, int W, int cin, int cout, int epi, void* stream);
+/* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
+int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
+int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
+/* loss_smooth = mean((z[...,1:]-z[...,:-1])^2)  (opt_amass_temp.py:390-391) fused with d(loss)/d(pre-act):
+ * partial[lemo_smooth_loss_blocks()] receives per-block sums of squares; coef2 = weight*2/count */
+int lemo_smooth_loss_blocks(int H, int W, int C);
+int lemo_smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, void* stream);
+
+/* ---- VPoser.decode, human_body_prior/train/vposer_smpl.py:107-121 ------------------------------ */
+typedef struct lemo_vposer_w {           /* *_t = transposed copy [in][out] */
+  const float *w1, *w1t, *b1;            /* bodyprior_dec_fc1  [512][32]  */
+  const float *w2, *w2t, *b2;            /* bodyprior_dec_fc2  [512][512] */
+  const float *w3, *w3t, *b3;            /* bodyprior_dec_out  [126][512] */
+} lemo_vposer_w;
+int lemo_vposer_decode_fwd(const lemo_vposer_w* w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
+                           float* matrot, float* aa, void* stream);
+int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, const float* o, const float* d_aa,
+                           const float* d_matrot, int B, float* dz, int dz_stride, void* stream);
+/* convert_to_3D_rot's 6-D -> axis-angle, utils/utils.py:111-123 (+63-81) */
+int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream);
+int lemo_rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, void* stream);
+
+/* ---- SMPL-X pose stage: smplx==0.1.26 SMPLX.forward + lbs.py:81-106,166-263 --------------------- */
+typedef struct lemo_body_const {
+  int nj, nshape, ncomp, nlev;
+  const int *parents, *level_start, *level_joints, *child_start, *child_list;
+  const float *J_template, *J_dirs, *pose_mean, *lh_comp, *rh_comp;
+} lemo_body_const;
+typedef struct lemo_pose_in {
+  const float *global_orient, *body_pose, *jaw, *leye, *reye, *lh, *rh;
+  int hand_stride;
+  const float* betas;
+  int betas_stride;
+  const float* expr;
+} lemo_pose_in;
+typedef struct lemo_pose_ws {
+  float *full_pose, *R, *J, *T, *A, *Jtr, *Xg;
+  int Bp;
+} lemo_pose_ws;
+typedef struct lemo_pose_grad_in { const float *dA, *dJtr, *dX; } lemo_pose_grad_in;
+typedef struct lemo_pose_grad_out {
+  float *d_global_orient, *d_body_pose, *d_jaw, *d_leye, *d_reye, *d_lh, *d_rh;
+  int hand_stride;
+  float *d_betas, *d_expr;
+} lemo_pose_grad_out;
+int lemo_smplx_pose_fwd(const lemo_body_const* c, const lemo_pose_in* in, const lemo_pose_ws* ws, int B, void* stream);
+int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const lemo_pose_grad_in* gi,
+                        const lemo_pose_grad_out* go, int B, void* stream);
+
+/* ---- SMPL-X vertex stage (blend shapes + skinning + transl): lbs.py:81,94-99,108-117 ------------ */
+typedef struct lemo_skin_const {
+  int V, NC, KW;
+  const float* Dg;          /* [64][NC][8]  blend directions (shape | pose), K padded to 512 */
+  const float* v_template;  /* [V][3] */
+  const int* w_idx;         /* [V][KW] ELL skinning weights */
+  const float* w_val;
+} lemo_skin_const;
+typedef struct lemo_vertex_set_bwd {
+  int n, NCs;
+  const int *ids, *vp_row;
+  const float* Dk;          /* [512][NCs] */
+  const int *jcsr_start, *jcsr_u;
+  const float* jcsr_w;
+} lemo_vertex_set_bwd;
+int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                       const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
+int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
+                       int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
+                       void* stream);
+int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, const int* extra_rows, int n_extra,
+                         const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
+                         void* stream);
+
+/* ---- AMASS temporal fitting iteration, opt_amass_temp.py:349-455 -------------------------------- */
+typedef struct lemo_fit_const {
+  int n, n67, n81;
+  const int *row67, *row81, *foot_start, *foot_row, *u_row, *u_m67, *u_m81, *u_foot_mask;
+  const float *Xstd, *Xmean;
+} lemo_fit_const;
+
+typedef struct lemo_fit_desc {
+  int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
+  int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
+  lemo_vposer_w vposer;
+  lemo_body_const body;
+  lemo_skin_const skin;
+  lemo_vertex_set_bwd uset;
+  lemo_fit_const fit;
+  const int* fwd_ids;             /* [n] when !full_vertices */
+  /* smoothness encoder: 10 layers; channels ch[0..10] = 1,32,32,64,... */
+  int enc_ch[11];
+  const float* enc_w[10];         /* layer 0: [Cout][9] ; others packed wt[tap][Cin/8][Cout][8] */
+  const float* enc_b[10];
+  const float* enc_wbwd[10];      /* backward-data packs (layer 0: same [Cout][9]) */
+  /* sequence data */
+  const float* target;            /* [B][n67][3]  markers_rec */
+  const float* contact;           /* [B][4] */
+  const float* weights;           /* [6] rec_markers, vposer, shape, hand, contact_vel, smooth (device) */
+  float weights_host[6];          /* same values, host copy (launch-time constants) */
+  /* optimised parameters + Adam state */
+  float *transl, *rot6d, *other;  /* [B][3], [B][6], [B][56] */
+  const float* shape;             /* [B][10] fixed */
+  float *adam_m[3], *adam_v[3];
+  int* step_ctr;
+  float lr0, lr1;
+  int lr_switch;
+  /* workspace (caller-allocated, sizes documented in lemo_amd/fitting.py) */
+  float *go_aa, *body_aa, *h1, *h2, *vo;
+  lemo_pose_ws pose;
+  float *verts, *v_posed, *x0, *canon;
+  float* act[11];                 /* act[0] unused; act[l] = output of layer l, CG8P */
+  float* dact[2];                 /* ping-pong d(pre-activation) buffers, 64-channel CG8P */
+  float *dx0, *spartial, *vpartial, *losses, *dverts, *dvp, *dA, *dX;
+  float *g_transl, *g_rot6d, *g_other, *g_go, *g_body;
+} lemo_fit_desc;
+
+/* Opaque engine: holds a copy of the descriptor (pointers only) and, optionally, a captured hipGraph. */
+void* lemo_fit_create(const lemo_fit_desc* d);
+void lemo_fit_destroy(void* h);
+/* one forward pass only (no backward / Adam): fills verts, losses, ... */
+int lemo_fit_forward(void* h, void* stream);
+/* after lemo_fit_forward: gradients of the total loss into g_transl / g_rot6d / g_other (priors' own
+ * gradient terms are added inside the Adam kernel), no parameter update */
+int lemo_fit_backward(void* h, void* stream);
+/* n full iterations (forward, backward, Adam).  use_graph: capture once, replay. */
+int lemo_fit_step(void* h, int n, int use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,171 @@
+"""ctypes binding of the C ABI declared in ``include/lemo_hip.h`` (``liblemo_hip.so``).
+
+There is NO CPU fallback: :func:`get_lib` raises if the gfx950 library has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C lemo_amd/csrc``).
+``HipLib(path)`` can also open the host-emulated build of the *same* sources
+(``liblemo_emu.so``, tests/hipemu) -- that is done by the CPU test-suite only, explicitly, to check
+kernel index arithmetic without a GPU; product code never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+LIB_PATH = os.path.join(_CSRC, 'liblemo_hip.so')
+EMU_LIB_PATH = os.path.join(_CSRC, 'liblemo_emu.so')
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class VPoserW(C.Structure):
+    _fields_ = [(n, vp) for n in ('w1', 'w1t', 'b1', 'w2', 'w2t', 'b2', 'w3', 'w3t', 'b3')]
+
+
+class BodyConst(C.Structure):
+    _fields_ = [('nj', C.c_int), ('nshape', C.c_int), ('ncomp', C.c_int), ('nlev', C.c_int)] + \
+        [(n, vp) for n in ('parents', 'level_start', 'level_joints', 'child_start', 'child_list',
+                           'J_template', 'J_dirs', 'pose_mean', 'lh_comp', 'rh_comp')]
+
+
+class PoseIn(C.Structure):
+    _fields_ = [(n, vp) for n in ('global_orient', 'body_pose', 'jaw', 'leye', 'reye', 'lh', 'rh')] + \
+        [('hand_stride', C.c_int), ('betas', vp), ('betas_stride', C.c_int), ('expr', vp)]
+
+
+class PoseWs(C.Structure):
+    _fields_ = [(n, vp) for n in ('full_pose', 'R', 'J', 'T', 'A', 'Jtr', 'Xg')] + [('Bp', C.c_int)]
+
+
+class PoseGradIn(C.Structure):
+    _fields_ = [(n, vp) for n in ('dA', 'dJtr', 'dX')]
+
+
+class PoseGradOut(C.Structure):
+    _fields_ = [(n, vp) for n in ('d_global_orient', 'd_body_pose', 'd_jaw', 'd_leye', 'd_reye', 'd_lh', 'd_rh')] + \
+        [('hand_stride', C.c_int), ('d_betas', vp), ('d_expr', vp)]
+
+
+class SkinConst(C.Structure):
+    _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int)] + \
+        [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val')]
+
+
+class VertexSetBwd(C.Structure):
+    _fields_ = [('n', C.c_int), ('NCs', C.c_int)] + \
+        [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'jcsr_start', 'jcsr_u', 'jcsr_w')]
+
+
+class FitConst(C.Structure):
+    _fields_ = [('n', C.c_int), ('n67', C.c_int), ('n81', C.c_int)] + \
+        [(n, vp) for n in ('row67', 'row81', 'foot_start', 'foot_row', 'u_row', 'u_m67', 'u_m81',
+                           'u_foot_mask', 'Xstd', 'Xmean')]
+
+
+class FitDesc(C.Structure):
+    _fields_ = [
+        ('B', C.c_int), ('Bp', C.c_int), ('V', C.c_int), ('nrows', C.c_int), ('full_vertices', C.c_int),
+        ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
+        ('fwd_ids', vp),
+        ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
+        ('target', vp), ('contact', vp), ('weights', vp), ('weights_host', C.c_float * 6),
+        ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
+        ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
+        ('lr0', C.c_float), ('lr1', C.c_float), ('lr_switch', C.c_int),
+        ('go_aa', vp), ('body_aa', vp), ('h1', vp), ('h2', vp), ('vo', vp),
+        ('pose', PoseWs),
+        ('verts', vp), ('v_posed', vp), ('x0', vp), ('canon', vp),
+        ('act', vp * 11), ('dact', vp * 2),
+        ('dx0', vp), ('spartial', vp), ('vpartial', vp), ('losses', vp), ('dverts', vp), ('dvp', vp),
+        ('dA', vp), ('dX', vp),
+        ('g_transl', vp), ('g_rot6d', vp), ('g_other', vp), ('g_go', vp), ('g_body', vp),
+    ]
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'C ABI takes contiguous buffers'
+    return t.data_ptr()
+
+
+class LemoHipError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    'lemo_abi_version': (C.c_int, []),
+    'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_smooth_loss_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'lemo_smooth_loss': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    'lemo_vposer_decode_fwd': (C.c_int, [C.POINTER(VPoserW), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
+    'lemo_vposer_decode_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]),
+    'lemo_rot6d_to_aa_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    'lemo_rot6d_to_aa_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_smplx_pose_fwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseIn), C.POINTER(PoseWs), C.c_int, vp]),
+    'lemo_smplx_pose_bwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseWs), C.POINTER(PoseGradIn),
+                                      C.POINTER(PoseGradOut), C.c_int, vp]),
+    'lemo_lbs_verts_fwd': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    'lemo_lbs_verts_bwd': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp,
+                                     C.c_int, C.c_int, vp, vp, vp, vp, vp]),
+    'lemo_joints_assemble': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
+    'lemo_fit_destroy': (None, [vp]),
+    'lemo_fit_forward': (C.c_int, [vp, vp]),
+    'lemo_fit_backward': (C.c_int, [vp, vp]),
+    'lemo_fit_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+class HipLib:
+    """typed handle on liblemo_hip.so (or, tests only, liblemo_emu.so)."""
+
+    def __init__(self, path: str, is_emu: bool = False):
+        if not os.path.exists(path):
+            raise LemoHipError(
+                f'{path} not found: the HIP extension is not built. Build it with '
+                f'`make -C {_CSRC}` (hipcc --offload-arch=gfx950); there is no CPU fallback.')
+        self.path, self.is_emu = path, is_emu
+        self._dll = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self._dll, name)
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name[len('lemo_'):], fn)
+
+    def check(self, rc: int, what: str = ''):
+        if rc != 0:
+            raise LemoHipError(f'liblemo_hip: {what} failed with code {rc}')
+
+    def stream(self, device) -> Optional[int]:
+        """current torch stream handle on ``device`` (NULL for the host-emulated library)."""
+        if self.is_emu:
+            return None
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+_LIB: Optional[HipLib] = None
+
+
+def get_lib() -> HipLib:
+    """The product library.  Raises LemoHipError when it is missing (never falls back)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLib(LIB_PATH, is_emu=False)
+    return _LIB
+
+
+def check_device(lib: HipLib, t: torch.Tensor):
+    if lib.is_emu:
+        if t.is_cuda:
+            raise LemoHipError('the host-emulated test library only takes CPU tensors')
+    elif not t.is_cuda:
+        raise LemoHipError('lemo_amd compute entry points need tensors on a HIP device (no CPU fallback)')

@@ -1,0 +1,48 @@
+// Shared device helpers for the LEMO hot-path kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LEMO_WAVE 64
+#define LEMO_LRELU_SLOPE 0.2f
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LEMO_LRELU_SLOPE * v; }
+// derivative selected from the *output* sign (slope > 0 keeps the sign; y == 0 <=> x == 0 -> slope,
+// matching torch's `x > 0 ? g : g * slope`)
+__device__ __forceinline__ float lrelu_grad_from_out(float y) { return y > 0.f ? 1.f : LEMO_LRELU_SLOPE; }
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Deterministic block sum (fixed tree order).  `red` must hold blockDim.x/64 floats.  All threads
+// must call; result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+// ---- tiny 3-vector algebra ------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}

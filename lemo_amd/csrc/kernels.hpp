@@ -1,0 +1,64 @@
+// Internal (C++) launcher declarations shared by the kernel translation units and the C-ABI layer.
+// Every launcher enqueues on `s`, never allocates, never synchronises, and returns 0 or an error.
+#pragma once
+#include "common.hpp"
+#include "lemo_hip.h"
+
+namespace lemo {
+
+// ---------------- conv_kernels.hip ----------------
+int conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
+                 int H, int W, int cin, int cout, int epi, hipStream_t s);
+int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
+int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
+int smooth_loss_blocks(int H, int W, int C);
+int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s);
+
+// ---------------- pose_kernels.hip ----------------
+typedef lemo_vposer_w VPoserW;
+typedef lemo_body_const BodyConst;
+typedef lemo_pose_in PoseIn;
+typedef lemo_pose_ws PoseWs;
+typedef lemo_pose_grad_in PoseGradIn;
+typedef lemo_pose_grad_out PoseGradOut;
+typedef lemo_skin_const SkinConst;
+typedef lemo_vertex_set_bwd VertexSetBwd;
+typedef lemo_fit_const FitConst;
+
+// z: [B] rows with stride z_stride floats.  Saves h1,h2 [B][512], o [B][128] for backward.
+int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
+                      float* matrot /*[B][21][9] or null*/, float* aa /*[B][63] or null*/, hipStream_t s);
+// d_aa [B][63] and/or d_matrot [B][21][9] (either may be null) -> dz [B] rows with stride dz_stride
+int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
+                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, hipStream_t s);
+int rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, hipStream_t s);
+int rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, hipStream_t s);
+int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s);
+int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, const PoseGradOut& go, int B, hipStream_t s);
+
+// ---------------- lbs_kernels.hip ----------------
+// verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
+int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s);
+int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
+                  const float* dverts /*[B][n][3]*/, int B, int Bp, float* dvp /*[B][NCs] scratch*/,
+                  float* dA /*[B][nj][12]*/, float* dtransl /*[B][3] or null*/, float* dX /*[B][512]*/, hipStream_t s);
+int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, const int* extra_rows, int n_extra,
+                    const int* lmk_rows /*[n_lmk][3]*/, const float* lmk_bary, int n_lmk, const float* transl,
+                    int B, float* joints /*[B][nj+n_extra+n_lmk][3]*/, hipStream_t s);
+
+// ---------------- loss_kernels.hip ----------------
+int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
+                   float* x0, float* canon, hipStream_t s);
+int vertex_loss_partial(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact, int B,
+                        float* partial, hipStream_t s);
+int loss_finalize(const float* vpartial, int B, int n67, const float* spartial, int n_sp, double smooth_count,
+                  const float* shape, const float* other, const float* weights, float* losses, hipStream_t s);
+int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
+                    const float* dx0, const float* canon, const float* weights, const float* losses, int B,
+                    float* dverts, hipStream_t s);
+int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
+              float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
+              int* step_ctr, float lr0, float lr1, int lr_switch, hipStream_t s);
+
+}  // namespace lemo

@@ -1,0 +1,264 @@
+// Vertex stage of SMPL-X linear blend skinning (human_body_prior/body_model/lbs.py:81,94-99,108-117;
+// smplx SMPLX.forward "+ transl") and its backward.
+//
+// Forward, fused in one kernel per 32-vertex tile:
+//     v_posed = v_template + [shape coefs | pose feature] . D          (lbs.py:81 + :94-99; one
+//                                                                       fp32-MFMA GEMM, K = 20+486 -> 512)
+//     verts   = (sum_j W[v,j] A[b,j]) . [v_posed, 1] + transl           (lbs.py:108-117)
+// GEMM roles: M = columns (3 per vertex; A operand = blend directions D, streamed ONCE from HBM,
+// 64 MB, KG8 layout [K/8][3V][8] -> every load a contiguous 1 KiB dwordx4 run), N = frames
+// (B operand = per-frame features Xg, L2 resident), so no (B,V,3) intermediate ever round-trips
+// through HBM between the blend and the skinning: the GEMM tile is handed over through LDS.
+// Skinning weights are held as ELL (<= KW non-zeros per vertex; real SMPL-X rows are sparse).
+#include "kernels.hpp"
+
+namespace lemo {
+
+#define LBS_VT 32                 // vertices per block
+#define LBS_COLS (LBS_VT * 3)     // 96 columns = 3 MFMA M-tiles
+#define LBS_PITCH 97
+#define LBS_FR 128                // frames per block pass (4 N-tiles)
+
+__global__ void __launch_bounds__(256)
+lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
+                     const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
+                     float* __restrict__ verts, float* __restrict__ v_posed) {
+  __shared__ float vp[LBS_FR * LBS_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int s0 = blockIdx.x * LBS_VT;                  // first vertex slot of this tile
+  const int f0 = blockIdx.y * LBS_FR;                  // first frame of this pass
+  // ---- blend GEMM: wave w owns frames f0+32w..+31 (N-tile) x 96 columns (3 M-tiles)
+  const int fr = f0 + 32 * wave + j;                   // this lane's frame as B-operand column
+  const bool wave_active = (f0 + 32 * wave) < B;       // uniform per wave
+  if (wave_active) {
+    f32x16 acc[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    // per-lane column addresses (A operand rows): local col = m*32 + j -> slot = s0 + col/3
+    size_t colg[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const int lc = m * 32 + j;
+      int slot = s0 + lc / 3;
+      if (slot >= n) slot = n - 1;
+      const int vid = ids ? ids[slot] : slot;
+      colg[m] = (size_t)vid * 3 + (lc % 3);
+    }
+    const int frc = fr < Bp ? fr : Bp - 1;
+    const float* xb = Xg + (size_t)frc * 8 + 4 * h;
+    const float* db = c.Dg + 4 * h;
+    const size_t xg_stride = (size_t)Bp * 8, dg_stride = (size_t)c.NC * 8;
+    float4 b_cur = ld4(xb), a_cur[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) a_cur[m] = ld4(db + colg[m] * 8);
+    for (int g = 0; g < 64; ++g) {
+      float4 b_nxt = b_cur, a_nxt[3] = {a_cur[0], a_cur[1], a_cur[2]};
+      if (g + 1 < 64) {
+        b_nxt = ld4(xb + (size_t)(g + 1) * xg_stride);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) a_nxt[m] = ld4(db + (size_t)(g + 1) * dg_stride + colg[m] * 8);
+      }
+      const float bs[4] = {b_cur.x, b_cur.y, b_cur.z, b_cur.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const float as = s == 0 ? a_cur[m].x : s == 1 ? a_cur[m].y : s == 2 ? a_cur[m].z : a_cur[m].w;
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs[s], acc[m], 0, 0, 0);
+        }
+      b_cur = b_nxt;
+#pragma unroll
+      for (int m = 0; m < 3; ++m) a_cur[m] = a_nxt[m];
+    }
+    // accumulator: col = j -> frame (32*wave + j), row -> column within the M-tile
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        vp[(32 * wave + j) * LBS_PITCH + m * 32 + row] = acc[m][r];
+      }
+  }
+  __syncthreads();
+  // ---- skinning: thread = (vertex lv, frame group); 16 frames each
+  const int lv = threadIdx.x & 31, fg = threadIdx.x >> 5;
+  const int slot = s0 + lv;
+  if (slot >= n) return;
+  const int vid = ids ? ids[slot] : slot;
+  const float tx = c.v_template[(size_t)vid * 3], ty = c.v_template[(size_t)vid * 3 + 1], tz = c.v_template[(size_t)vid * 3 + 2];
+  const int* wi = c.w_idx + (size_t)vid * c.KW;
+  const float* wv = c.w_val + (size_t)vid * c.KW;
+  for (int i = 0; i < LBS_FR / 8; ++i) {
+    const int fl = fg + 8 * i, f = f0 + fl;
+    if (f >= B) break;
+    const float px = vp[fl * LBS_PITCH + 3 * lv] + tx, py = vp[fl * LBS_PITCH + 3 * lv + 1] + ty,
+                pz = vp[fl * LBS_PITCH + 3 * lv + 2] + tz;
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    const float* Af = A + (size_t)f * nj * 12;
+    for (int k = 0; k < c.KW; ++k) {
+      const float w = wv[k];
+      const float* Aj = Af + wi[k] * 12;
+      const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);
+      T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
+      T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
+      T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
+    }
+    float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
+    float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+    float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+    if (transl) { ox += transl[(size_t)f * 3]; oy += transl[(size_t)f * 3 + 1]; oz += transl[(size_t)f * 3 + 2]; }
+    float* o = verts + ((size_t)f * n + slot) * 3;
+    o[0] = ox; o[1] = oy; o[2] = oz;
+    if (v_posed) {
+      float* q = v_posed + ((size_t)f * n + slot) * 3;
+      q[0] = px; q[1] = py; q[2] = pz;
+    }
+  }
+}
+
+int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s) {
+  if (n <= 0 || B <= 0 || B > Bp || (Bp % 32) || (!ids && n != c.V)) return LEMO_ERR_SHAPE;
+  dim3 grid((n + LBS_VT - 1) / LBS_VT, (B + LBS_FR - 1) / LBS_FR);
+  hipLaunchKernelGGL(lbs_verts_fwd_kernel, grid, dim3(256), 0, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward over a vertex set U (all vertices, or only those that carry gradient: the AMASS losses
+// touch 81 markers + 172 heel/toe vertices, opt_amass_temp.py:359,366,414-425 -- every other row of
+// d(verts) is exactly zero, so restricting the backward to U is exact).
+//   kernel 1 (block per frame): dvp = T_R^T g ; dA[j] = sum_u W[u,j] g (x) [v_posed,1] ; dtransl = sum_u g
+//   kernel 2: dX[b][k] = sum_col Dk[k][col] dvp[b][col]        (fp32-MFMA NT GEMM)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
+                     const float* __restrict__ v_posed, int vp_rows, const float* __restrict__ dverts,
+                     float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* Af = A + (size_t)b * nj * 12;
+  const float* g = dverts + (size_t)b * u.n * 3;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int s = t; s < u.n; s += 256) {
+    const int vid = u.ids[s];
+    const float gx = g[3 * s], gy = g[3 * s + 1], gz = g[3 * s + 2];
+    sx += gx; sy += gy; sz += gz;
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+    const int* wi = c.w_idx + (size_t)vid * c.KW;
+    const float* wv = c.w_val + (size_t)vid * c.KW;
+    for (int k = 0; k < c.KW; ++k) {
+      const float w = wv[k];
+      const float* Aj = Af + wi[k] * 12;
+      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
+      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
+      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+    }
+    float* d = dvp + (size_t)b * u.NCs + 3 * s;
+    d[0] = T[0] * gx + T[3] * gy + T[6] * gz;
+    d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
+    d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
+  }
+  // zero the padding columns of this frame's dvp row
+  for (int cidx = 3 * u.n + t; cidx < u.NCs; cidx += 256) dvp[(size_t)b * u.NCs + cidx] = 0.f;
+  // dA via the joint-major CSR (deterministic gather)
+  for (int w = t; w < nj * 12; w += 256) {
+    const int jj = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
+    float acc = 0.f;
+    for (int q = u.jcsr_start[jj]; q < u.jcsr_start[jj + 1]; ++q) {
+      const int s = u.jcsr_u[q];
+      const float gv = g[3 * s + r] * u.jcsr_w[q];
+      acc += cc < 3 ? gv * v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc] : gv;
+    }
+    dA[((size_t)b * nj) * 12 + w] = acc;
+  }
+  if (dtransl) {
+    const float tx = block_sum(sx, red), ty = block_sum(sy, red), tz = block_sum(sz, red);
+    if (t == 0) { dtransl[(size_t)b * 3] = tx; dtransl[(size_t)b * 3 + 1] = ty; dtransl[(size_t)b * 3 + 2] = tz; }
+  }
+}
+
+// C^T[n][m] (ldc) = sum_k A[m][k] B[n][k] ; A:[M][lda], B:[N][ldb], K % 8 == 0, M % 32 == 0.
+// One wave per 32x32 tile; rows of B beyond N are clamped (their results are not stored).
+__global__ void __launch_bounds__(256)
+gemm_nt_mfma_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K,
+                    float* __restrict__ Ct, int ldc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int mt = blockIdx.x * 4 + wave, nt = blockIdx.y;
+  if (mt * 32 >= M) return;
+  const int nrow = nt * 32 + j;
+  const float* ap = Am + (size_t)(mt * 32 + j) * lda + 4 * h;
+  const float* bp = Bm + (size_t)(nrow < N ? nrow : N - 1) * ldb + 4 * h;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += 8) {
+    const float4 a = ld4(ap + k), bb = ld4(bp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, acc, 0, 0, 0);
+  }
+  if (nrow < N) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      Ct[(size_t)nrow * ldc + mt * 32 + row] = acc[r];
+    }
+  }
+}
+
+int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
+                  const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s) {
+  if (u.n <= 0 || B <= 0 || (u.NCs % 8) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
+  (void)Bp;
+  hipLaunchKernelGGL(lbs_bwd_frame_kernel, dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  // dX[b][k] = sum_col Dk[k][col] dvp[b][col]  : A = Dk (M = 512 features), B = dvp (N = B frames)
+  hipLaunchKernelGGL(gemm_nt_mfma_kernel, dim3(512 / 32 / 4, (B + 31) / 32), dim3(256), 0, s,
+                     u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// joints = cat[posed joints, vertex picks, barycentric landmarks] (+ transl)
+// (smplx VertexJointSelector + vertices2landmarks; 55 + 21 + 51 = 127 for SMPL-X)
+// `verts` already contain transl when it is applied; Jtr does not.
+// ------------------------------------------------------------------------------------------------
+__global__ void joints_assemble_kernel(const float* __restrict__ Jtr, int nj, const float* __restrict__ verts, int vrows,
+                                       const int* __restrict__ extra_rows, int n_extra, const int* __restrict__ lmk_rows,
+                                       const float* __restrict__ lmk_bary, int n_lmk, const float* __restrict__ transl,
+                                       float* __restrict__ joints) {
+  const int b = blockIdx.x, nt = nj + n_extra + n_lmk;
+  for (int w = threadIdx.x; w < nt * 3; w += blockDim.x) {
+    const int i = w / 3, cc = w % 3;
+    float v;
+    if (i < nj) v = Jtr[((size_t)b * nj + i) * 3 + cc] + (transl ? transl[(size_t)b * 3 + cc] : 0.f);
+    else if (i < nj + n_extra) v = verts[((size_t)b * vrows + extra_rows[i - nj]) * 3 + cc];
+    else {
+      const int l = i - nj - n_extra;
+      v = 0.f;
+      for (int f = 0; f < 3; ++f) v += verts[((size_t)b * vrows + lmk_rows[3 * l + f]) * 3 + cc] * lmk_bary[3 * l + f];
+    }
+    joints[((size_t)b * nt + i) * 3 + cc] = v;
+  }
+}
+
+int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, const int* extra_rows, int n_extra,
+                    const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(joints_assemble_kernel, dim3(B), dim3(128), 0, s, Jtr, nj, verts, vrows, extra_rows, n_extra,
+                     lmk_rows, lmk_bary, n_lmk, transl, joints);
+  return (int)hipGetLastError();
+}
+
+}  // namespace lemo

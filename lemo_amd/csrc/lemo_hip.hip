@@ -1,0 +1,189 @@
+// C ABI of liblemo_hip.so (see include/lemo_hip.h) and the native fitting engine: the launch
+// sequence of one AMASS temporal-fitting iteration (opt_amass_temp.py:349-455), optionally captured
+// once into a hipGraph and replayed (the iteration is ~40 short kernels: launch-bound without it).
+#include "kernels.hpp"
+
+#include <new>
+
+using namespace lemo;
+
+#define S(x) ((hipStream_t)(x))
+#define CHK(e) do { int _e = (e); if (_e) return _e; } while (0)
+
+extern "C" {
+
+int lemo_abi_version(void) { return 1; }
+
+int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W,
+                      int cin, int cout, int epi, void* stream) {
+  if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
+  return conv3x3_mfma(in, wt, bias, aux, out, H, W, cin, cout, epi, S(stream));
+}
+int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream) {
+  return conv3x3_c1(x0, w, bias, out, H, W, cout, S(stream));
+}
+int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream) {
+  return conv3x3_c1_bwd(dpre, w, dx0, H, W, cout, S(stream));
+}
+int lemo_smooth_loss_blocks(int H, int W, int C) { return smooth_loss_blocks(H, W, C); }
+int lemo_smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, void* stream) {
+  return smooth_loss(z, dpre, partial, H, W, C, coef2, S(stream));
+}
+
+int lemo_vposer_decode_fwd(const lemo_vposer_w* w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
+                           float* matrot, float* aa, void* stream) {
+  if (!w || !z || !h1 || !h2 || !o) return LEMO_ERR_ARG;
+  return vposer_decode_fwd(*w, z, z_stride, B, h1, h2, o, matrot, aa, S(stream));
+}
+int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, const float* o, const float* d_aa,
+                           const float* d_matrot, int B, float* dz, int dz_stride, void* stream) {
+  if (!w || !dz || (!d_aa && !d_matrot)) return LEMO_ERR_ARG;
+  return vposer_decode_bwd(*w, h1, h2, o, nullptr, d_aa, d_matrot, B, dz, dz_stride, S(stream));
+}
+int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream) {
+  return rot6d_to_aa_fwd(x6, stride, N, aa, S(stream));
+}
+int lemo_rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, void* stream) {
+  return rot6d_to_aa_bwd(x6, stride, d_aa, N, dx6, S(stream));
+}
+int lemo_smplx_pose_fwd(const lemo_body_const* c, const lemo_pose_in* in, const lemo_pose_ws* ws, int B, void* stream) {
+  if (!c || !in || !ws) return LEMO_ERR_ARG;
+  return smplx_pose_fwd(*c, *in, *ws, B, S(stream));
+}
+int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const lemo_pose_grad_in* gi,
+                        const lemo_pose_grad_out* go, int B, void* stream) {
+  if (!c || !ws || !gi || !go || !gi->dA) return LEMO_ERR_ARG;
+  return smplx_pose_bwd(*c, *ws, *gi, *go, B, S(stream));
+}
+int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                       const int* ids, int n, int B, float* verts, float* v_posed, void* stream) {
+  if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;
+  return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, S(stream));
+}
+int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
+                       int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
+                       void* stream) {
+  if (!c || !u || !A || !v_posed || !dverts || !dvp || !dA || !dX) return LEMO_ERR_ARG;
+  return lbs_verts_bwd(*c, *u, A, nj, v_posed, vp_rows, dverts, B, Bp, dvp, dA, dtransl, dX, S(stream));
+}
+int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, const int* extra_rows, int n_extra,
+                         const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
+                         void* stream) {
+  return joints_assemble(Jtr, nj, verts, vrows, extra_rows, n_extra, lmk_rows, lmk_bary, n_lmk, transl, B, joints, S(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// fitting engine
+// ------------------------------------------------------------------------------------------------
+struct FitEngine {
+  lemo_fit_desc d;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  hipStream_t graph_stream = nullptr;
+};
+
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s) {
+  const int B = d.B, nj = d.body.nj;
+  const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
+  CHK(rot6d_to_aa_fwd(d.rot6d, 6, B, d.go_aa, s));
+  CHK(vposer_decode_fwd(d.vposer, d.other, 56, B, d.h1, d.h2, d.vo, nullptr, d.body_aa, s));
+  lemo_pose_in in{};
+  in.global_orient = d.go_aa; in.body_pose = d.body_aa;
+  in.lh = d.other + 32; in.rh = d.other + 44; in.hand_stride = 56;
+  in.betas = d.shape; in.betas_stride = 10;
+  CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
+  if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
+  else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
+  CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
+  CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
+  for (int l = 1; l < 10; ++l)
+    CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
+  const double cnt = (double)d.enc_ch[10] * H * (W - 1);
+  const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
+  CHK(smooth_loss(d.act[10], d.dact[0], d.spartial, H, W, d.enc_ch[10], coef2, s));
+  CHK(vertex_loss_partial(d.fit, d.verts, d.nrows, d.target, d.contact, B, d.vpartial, s));
+  CHK(loss_finalize(d.vpartial, B, d.fit.n67, d.spartial, smooth_loss_blocks(H, W, d.enc_ch[10]), cnt, d.shape, d.other,
+                    d.weights, d.losses, s));
+  return 0;
+}
+
+static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
+  const int B = d.B, nj = d.body.nj;
+  const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
+  int cur = 0;
+  for (int l = 9; l >= 1; --l) {   // d(pre-act of layer l+1) -> d(pre-act of layer l)
+    CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
+    cur = 1 - cur;
+  }
+  CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.losses, B, d.dverts, s));
+  CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
+  lemo_pose_grad_in gi{d.dA, nullptr, d.dX};
+  lemo_pose_grad_out go{};
+  go.d_global_orient = d.g_go; go.d_body_pose = d.g_body;
+  go.d_lh = d.g_other + 32; go.d_rh = d.g_other + 44; go.hand_stride = 56;
+  CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
+  CHK(vposer_decode_bwd(d.vposer, d.h1, d.h2, d.vo, nullptr, d.g_body, nullptr, B, d.g_other, 56, s));
+  CHK(rot6d_to_aa_bwd(d.rot6d, 6, d.g_go, B, d.g_rot6d, s));
+  return 0;
+}
+
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
+  CHK(fit_forward(d, s));
+  CHK(fit_backward(d, s));
+  CHK(adam_step(d.transl, d.g_transl, d.adam_m[0], d.adam_v[0], d.rot6d, d.g_rot6d, d.adam_m[1], d.adam_v[1], d.other,
+                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.lr0, d.lr1, d.lr_switch, s));
+  return 0;
+}
+
+void* lemo_fit_create(const lemo_fit_desc* d) {
+  if (!d || d->B < 10 || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
+  FitEngine* e = new (std::nothrow) FitEngine();
+  if (e) e->d = *d;
+  return e;
+}
+
+void lemo_fit_destroy(void* h) {
+  FitEngine* e = (FitEngine*)h;
+  if (!e) return;
+  if (e->exec) hipGraphExecDestroy(e->exec);
+  if (e->graph) hipGraphDestroy(e->graph);
+  delete e;
+}
+
+int lemo_fit_forward(void* h, void* stream) {
+  FitEngine* e = (FitEngine*)h;
+  if (!e) return LEMO_ERR_ARG;
+  return fit_forward(e->d, S(stream));
+}
+
+int lemo_fit_backward(void* h, void* stream) {       // after lemo_fit_forward: gradients only, no Adam
+  FitEngine* e = (FitEngine*)h;
+  if (!e) return LEMO_ERR_ARG;
+  return fit_backward(e->d, S(stream));
+}
+
+int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
+  FitEngine* e = (FitEngine*)h;
+  if (!e || n < 0) return LEMO_ERR_ARG;
+  hipStream_t s = S(stream);
+  if (!use_graph) {
+    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s));
+    return 0;
+  }
+  if (!e->exec || e->graph_stream != s) {
+    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = fit_iteration(e->d, s);
+    const int ec = (int)hipStreamEndCapture(s, &e->graph);
+    if (rc) return rc;
+    CHK(ec);
+    CHK((int)hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    e->graph_stream = s;
+  }
+  for (int i = 0; i < n; ++i) CHK((int)hipGraphLaunch(e->exec, s));
+  return 0;
+}
+
+}  // extern "C"

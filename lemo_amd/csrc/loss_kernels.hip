@@ -1,0 +1,283 @@
+// Loss assembly of the AMASS temporal-fitting iteration (opt_amass_temp.py:366-453), its gradient
+// w.r.t. the vertices that carry loss, and the Adam update (opt_amass_temp.py:342-352,454-455).
+// All data-dependent branches of the reference (`.item()` host syncs at :431-443) are evaluated on
+// the device: counts go through a tiny finalize kernel, nothing ever returns to the host.
+#include "kernels.hpp"
+
+namespace lemo {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// canon[0..8] = R0 (row-major, columns x,y,z axes), canon[9..11] = marker 0 of frame 0
+__device__ __forceinline__ void canonical_frame(const float* verts, int nrows, const int* row81, const float* Jtr,
+                                                int nj, const float* transl, float* canon) {
+  // joints[0, 1:3] (posed joints + transl), opt_amass_temp.py:368-375
+  float j1[3], j2[3];
+  for (int k = 0; k < 3; ++k) {
+    const float tr = transl ? transl[k] : 0.f;
+    j1[k] = Jtr[3 * 1 + k] + tr;
+    j2[k] = Jtr[3 * 2 + k] + tr;
+  }
+  (void)nj;
+  float xx = j2[0] - j1[0], xy = j2[1] - j1[1];
+  const float nx = sqrtf(xx * xx + xy * xy);
+  xx /= nx; xy /= nx;
+  // y = cross(z, x) = (-x.y, x.x, 0), normalised
+  float yx = -xy, yy = xx;
+  const float ny = sqrtf(yx * yx + yy * yy);
+  yx /= ny; yy /= ny;
+  canon[0] = xx; canon[1] = yx; canon[2] = 0.f;
+  canon[3] = xy; canon[4] = yy; canon[5] = 0.f;
+  canon[6] = 0.f; canon[7] = 0.f; canon[8] = 1.f;
+  const float* m0 = verts + (size_t)row81[0] * 3;       // frame 0, marker 0
+  (void)nrows;
+  canon[9] = m0[0]; canon[10] = m0[1]; canon[11] = m0[2];
+}
+
+// Encoder input: canonicalise the 81 smoothness markers, normalise, temporal difference, reflect-pad
+// (8,8,1,1)  -> x0 padded single-channel image [(H+2)][(W+2)], H = 3*n81+2, W = B-1+16.
+__global__ void __launch_bounds__(256)
+marker_feature_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ Jtr, int nj,
+                      const float* __restrict__ transl, int B, float* __restrict__ x0, float* __restrict__ canon_out) {
+  __shared__ float cn[12];
+  if (threadIdx.x == 0) {
+    canonical_frame(verts, nrows, fc.row81, Jtr, nj, transl, cn);
+    if (blockIdx.x == 0) for (int i = 0; i < 12; ++i) canon_out[i] = cn[i];
+  }
+  __syncthreads();
+  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, Wp = W + 2;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const int d = reflect_idx(y - 1, D), tp = reflect_idx(x - 8, B - 1);
+  const int m = d / 3, c = d - 3 * m;
+  const float* v0 = verts + ((size_t)tp * nrows + fc.row81[m]) * 3;
+  const float* v1 = v0 + (size_t)nrows * 3;
+  const float g0 = (v0[0] - cn[9]) * cn[c] + (v0[1] - cn[10]) * cn[3 + c] + (v0[2] - cn[11]) * cn[6 + c];
+  const float g1 = (v1[0] - cn[9]) * cn[c] + (v1[1] - cn[10]) * cn[3 + c] + (v1[2] - cn[11]) * cn[6 + c];
+  const float n0 = (g0 - fc.Xmean[d]) / fc.Xstd[d], n1 = (g1 - fc.Xmean[d]) / fc.Xstd[d];
+  x0[(size_t)(y + 1) * Wp + (x + 1)] = n1 - n0;
+}
+
+int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
+                   float* x0, float* canon, hipStream_t s) {
+  if (B < 10) return LEMO_ERR_SHAPE;                       // reflect pad of 8 needs >= 9 differences
+  const int P = (3 * fc.n81 + 2) * (B - 1 + 16);
+  hipLaunchKernelGGL(marker_feature_kernel, dim3((P + 255) / 256), dim3(256), 0, s, fc, verts, nrows, Jtr, nj, transl, B, x0, canon);
+  return (int)hipGetLastError();
+}
+
+// Per-frame partial sums: [0] marker L1 ; [1+k] contact-velocity sum ; [5+k] count   (k = 4 foot sets)
+__global__ void __launch_bounds__(256)
+vertex_loss_partial_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
+                           const float* __restrict__ contact, int B, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  float acc[9];
+  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+  for (int w = t; w < fc.n67 * 3; w += 256) {
+    const int m = w / 3, c = w % 3;
+    acc[0] += fabsf(verts[((size_t)b * nrows + fc.row67[m]) * 3 + c] - target[((size_t)b * fc.n67 + m) * 3 + c]);
+  }
+  if (b < B - 1) {
+    for (int k = 0; k < 4; ++k) {
+      if (contact[(size_t)b * 4 + k] != 1.f) continue;
+      for (int q = fc.foot_start[k] + t; q < fc.foot_start[k + 1]; q += 256) {
+        const float* v0 = verts + ((size_t)b * nrows + fc.foot_row[q]) * 3;
+        const float* v1 = v0 + (size_t)nrows * 3;
+        const float vx = (v1[0] - v0[0]) * 30.f, vy = (v1[1] - v0[1]) * 30.f, vz = (v1[2] - v0[2]) * 30.f;
+        const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (sp - 0.1f > 0.f) { acc[1 + k] += sp; acc[5 + k] += 1.f; }
+      }
+    }
+  }
+  for (int i = 0; i < 9; ++i) {
+    const float v = block_sum(acc[i], red);
+    if (t == 0) partial[(size_t)b * 9 + i] = v;
+  }
+}
+
+int vertex_loss_partial(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact, int B,
+                        float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(vertex_loss_partial_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, B, partial);
+  return (int)hipGetLastError();
+}
+
+// losses[0..6] = marker, vposer, shape, hand, contact, smooth, total ; losses[8..11] = 1/count per foot set
+// weights[0..5] = rec_markers, vposer, shape, hand, contact_vel, smooth   (opt_amass_temp.py:47-52)
+__global__ void __launch_bounds__(256)
+loss_finalize_kernel(const float* __restrict__ vpartial, int B, int n67, const float* __restrict__ spartial, int n_sp,
+                     double smooth_count, const float* __restrict__ shape, const float* __restrict__ other,
+                     const float* __restrict__ weights, float* __restrict__ losses) {
+  __shared__ double dred[256];
+  const int t = threadIdx.x;
+  double sums[13];
+  for (int i = 0; i < 13; ++i) sums[i] = 0.0;
+  for (int b = t; b < B; b += 256)
+    for (int i = 0; i < 9; ++i) sums[i] += (double)vpartial[(size_t)b * 9 + i];
+  for (int i = t; i < n_sp; i += 256) sums[9] += (double)spartial[i];
+  for (int i = t; i < B * 32; i += 256) { const float v = other[(size_t)(i / 32) * 56 + (i % 32)]; sums[10] += (double)v * v; }
+  for (int i = t; i < B * 10; i += 256) { const float v = shape[i]; sums[11] += (double)v * v; }
+  for (int i = t; i < B * 24; i += 256) { const float v = other[(size_t)(i / 24) * 56 + 32 + (i % 24)]; sums[12] += (double)v * v; }
+  double tot[13];
+  for (int i = 0; i < 13; ++i) {
+    __syncthreads();
+    dred[t] = sums[i];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) dred[t] += dred[t + o]; __syncthreads(); }
+    tot[i] = dred[0];
+  }
+  if (t == 0) {
+    const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
+    float l_contact = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      const double cnt = tot[5 + k];
+      const float part = cnt >= 1.0 ? (float)(tot[1 + k] / cnt) : 0.f;
+      l_contact = l_contact + part;
+      losses[8 + k] = cnt >= 1.0 ? (float)(1.0 / cnt) : 0.f;
+    }
+    const float l_smooth = (float)(tot[9] / smooth_count);
+    const float l_vposer = (float)(tot[10] / ((double)B * 32));
+    const float l_shape = (float)(tot[11] / ((double)B * 10));
+    const float l_hand = (float)(tot[12] / ((double)B * 24));
+    float total = weights[0] * l_marker + weights[1] * l_vposer;
+    total = total + weights[2] * l_shape;
+    total = total + weights[3] * l_hand;
+    total = total + weights[4] * l_contact;
+    total = total + weights[5] * l_smooth;
+    losses[0] = l_marker; losses[1] = l_vposer; losses[2] = l_shape; losses[3] = l_hand;
+    losses[4] = l_contact; losses[5] = l_smooth; losses[6] = total; losses[7] = 0.f;
+  }
+}
+
+int loss_finalize(const float* vpartial, int B, int n67, const float* spartial, int n_sp, double smooth_count,
+                  const float* shape, const float* other, const float* weights, float* losses, hipStream_t s) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, vpartial, B, n67, spartial, n_sp, smooth_count, shape, other, weights, losses);
+  return (int)hipGetLastError();
+}
+
+// d(total)/d(verts) on the active vertex set U (block per frame).
+__global__ void __launch_bounds__(256)
+dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
+                       const float* __restrict__ contact, const float* __restrict__ dx0, const float* __restrict__ canon,
+                       const float* __restrict__ weights, const float* __restrict__ losses, int B,
+                       float* __restrict__ dverts) {
+  const int b = blockIdx.x;
+  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, nd = B - 1;
+  (void)H;
+  const float wm = weights[0] / ((float)B * fc.n67 * 3), wc = weights[4];
+  for (int u = threadIdx.x; u < fc.n; u += 256) {
+    const int row = fc.u_row[u];
+    const float* v = verts + ((size_t)b * nrows + row) * 3;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int m67 = fc.u_m67[u];
+    if (m67 >= 0) {
+      const float* tg = target + ((size_t)b * fc.n67 + m67) * 3;
+      const float d0 = v[0] - tg[0], d1 = v[1] - tg[1], d2 = v[2] - tg[2];
+      gx += wm * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+      gy += wm * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+      gz += wm * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+    }
+    const int fm = fc.u_foot_mask[u];
+    if (fm) {
+      for (int k = 0; k < 4; ++k) {
+        if (!((fm >> k) & 1)) continue;
+        const float coef = wc * losses[8 + k] * 30.f;
+        if (b < B - 1 && contact[(size_t)b * 4 + k] == 1.f) {
+          const float* v1 = v + (size_t)nrows * 3;
+          const float vx = (v1[0] - v[0]) * 30.f, vy = (v1[1] - v[1]) * 30.f, vz = (v1[2] - v[2]) * 30.f;
+          const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
+          if (sp - 0.1f > 0.f) { const float q = coef / sp; gx -= q * vx; gy -= q * vy; gz -= q * vz; }
+        }
+        if (b >= 1 && contact[(size_t)(b - 1) * 4 + k] == 1.f) {
+          const float* vm = v - (size_t)nrows * 3;
+          const float vx = (v[0] - vm[0]) * 30.f, vy = (v[1] - vm[1]) * 30.f, vz = (v[2] - vm[2]) * 30.f;
+          const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
+          if (sp - 0.1f > 0.f) { const float q = coef / sp; gx += q * vx; gy += q * vy; gz += q * vz; }
+        }
+      }
+    }
+    const int m81 = fc.u_m81[u];
+    if (m81 >= 0) {
+      float dg[3];
+      for (int c = 0; c < 3; ++c) {
+        const int d = 3 * m81 + c;
+        // rows of the padded image that read feature row d : y = d+1, plus the reflected copies
+        int ys[3]; int ny = 0;
+        ys[ny++] = d + 1;
+        if (d == 1) ys[ny++] = 0;
+        if (d == D - 2) ys[ny++] = D + 1;
+        float acc = 0.f;
+        for (int side = 0; side < 2; ++side) {               // side 0: difference t'=b-1 (+), side 1: t'=b (-)
+          const int tp = side == 0 ? b - 1 : b;
+          if (tp < 0 || tp > nd - 1) continue;
+          int xs[3]; int nx = 0;
+          xs[nx++] = tp + 8;
+          if (tp >= 1 && tp <= 8) xs[nx++] = 8 - tp;
+          if (tp >= nd - 9 && tp <= nd - 2) xs[nx++] = 2 * (nd - 1) - tp + 8;
+          float sv = 0.f;
+          for (int iy = 0; iy < ny; ++iy)
+            for (int ix = 0; ix < nx; ++ix) sv += dx0[(size_t)ys[iy] * W + xs[ix]];
+          acc += side == 0 ? sv : -sv;
+        }
+        dg[c] = acc / fc.Xstd[d];
+      }
+      gx += canon[0] * dg[0] + canon[1] * dg[1] + canon[2] * dg[2];
+      gy += canon[3] * dg[0] + canon[4] * dg[1] + canon[5] * dg[2];
+      gz += canon[6] * dg[0] + canon[7] * dg[1] + canon[8] * dg[2];
+    }
+    float* o = dverts + ((size_t)b * fc.n + u) * 3;
+    o[0] = gx; o[1] = gy; o[2] = gz;
+  }
+}
+
+int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
+                    const float* dx0, const float* canon, const float* weights, const float* losses, int B,
+                    float* dverts, hipStream_t s) {
+  hipLaunchKernelGGL(dverts_assemble_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, dx0, canon, weights, losses, B, dverts);
+  return (int)hipGetLastError();
+}
+
+// Prior gradients + Adam (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay).
+// state[0] = step counter (as float bits of an int), incremented here.
+// lr = step > lr_switch ? lr1 : lr0   with step counted from 0 (opt_amass_temp.py:349-352).
+struct AdamGroup { float* p; const float* g; float* m; float* v; int n; };
+__global__ void __launch_bounds__(256)
+adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __restrict__ weights, int* __restrict__ step_ctr,
+            float lr0, float lr1, int lr_switch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int step = *step_ctr;                 // iterations completed so far (0-based index of this one)
+  const int ntot = g0.n + g1.n + g2.n;
+  if (i < ntot) {
+    AdamGroup G = g0; int k = i;
+    if (k >= g0.n) { k -= g0.n; G = g1; if (k >= g1.n) { k -= g1.n; G = g2; } }
+    float grad = G.g[k];
+    if (G.p == g2.p) {                       // "other" = [z 32 | hands 24]: L2 priors (opt_amass_temp.py:397-404)
+      const int col = k % 56;
+      const float pv = G.p[k];
+      grad += col < 32 ? weights[1] * 2.f * pv / ((float)B * 32.f) : weights[3] * 2.f * pv / ((float)B * 24.f);
+    }
+    const float lr = step > lr_switch ? lr1 : lr0;
+    const double t1 = (double)(step + 1);
+    const float bc1 = (float)(1.0 - pow(0.9, t1));
+    const float bc2s = (float)sqrt(1.0 - pow(0.999, t1));
+    const float m = G.m[k] + (grad - G.m[k]) * (1.f - 0.9f);           // lerp_
+    const float v = G.v[k] * 0.999f + (1.f - 0.999f) * grad * grad;
+    G.m[k] = m; G.v[k] = v;
+    const float denom = sqrtf(v) / bc2s + 1e-8f;
+    G.p[k] = G.p[k] - (lr / bc1) * (m / denom);
+  }
+}
+__global__ void step_inc_kernel(int* step_ctr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ctr += 1; }
+
+int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
+              float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
+              int* step_ctr, float lr0, float lr1, int lr_switch, hipStream_t s) {
+  AdamGroup a{transl, g_transl, m0, v0, B * 3}, b{rot6d, g_rot, m1, v1, B * 6}, c{other, g_other, m2, v2, B * 56};
+  const int n = B * 65;
+  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, lr0, lr1, lr_switch);
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, step_ctr);
+  return (int)hipGetLastError();
+}
+
+}  // namespace lemo

@@ -1,0 +1,415 @@
+// Per-frame "pose stage" of the fitting iteration: everything between the optimised parameters and
+// the per-joint rigid transforms.  One workgroup per frame (the frames of a window are independent
+// here), per-frame state staged in LDS.
+//   * VPoser decoder            human_body_prior/train/vposer_smpl.py:107-121 (+49-62, 153-161)
+//   * 6-D -> axis-angle         utils/utils.py:111-123
+//   * SMPL-X pose assembly, Rodrigues, joint regression, kinematic chain
+//                               smplx==0.1.26 SMPLX.forward ; human_body_prior/body_model/lbs.py:81-106,
+//                               166-263 (vendored smplx.lbs)
+// and the analytic backward of each.
+#include "kernels.hpp"
+#include "rot.hpp"
+
+namespace lemo {
+
+#define VP_H 512
+#define VP_Z 32
+#define VP_O 126
+#define VP_NJ 21
+
+// ------------------------------------------------------------------------------------------------
+// VPoser.decode forward: z[32] -> lrelu(fc1) -> lrelu(fc2) -> out[126] -> 21 x (6D -> R -> aa)
+// (dropout is identity in eval(), model_loader.py:70)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+vposer_fwd_kernel(VPoserW w, const float* __restrict__ z, int z_stride, float* __restrict__ h1g,
+                  float* __restrict__ h2g, float* __restrict__ og, float* __restrict__ matrot,
+                  float* __restrict__ aa) {
+  __shared__ float zs[VP_Z];
+  __shared__ float h1[VP_H];
+  __shared__ float h2[VP_H];
+  __shared__ float part[2][128];
+  __shared__ float o[128];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < VP_Z) zs[t] = z[(size_t)b * z_stride + t];
+  __syncthreads();
+  for (int j = t; j < VP_H; j += 256) {
+    float a = w.b1[j];
+    for (int i = 0; i < VP_Z; ++i) a = fmaf(w.w1t[i * VP_H + j], zs[i], a);
+    a = lrelu(a);
+    h1[j] = a;
+    h1g[(size_t)b * VP_H + j] = a;
+  }
+  __syncthreads();
+  {
+    float a0 = w.b2[t], a1 = w.b2[t + 256];
+    for (int i = 0; i < VP_H; ++i) {
+      const float hv = h1[i];
+      a0 = fmaf(w.w2t[i * VP_H + t], hv, a0);
+      a1 = fmaf(w.w2t[i * VP_H + t + 256], hv, a1);
+    }
+    a0 = lrelu(a0); a1 = lrelu(a1);
+    h2[t] = a0; h2[t + 256] = a1;
+    h2g[(size_t)b * VP_H + t] = a0;
+    h2g[(size_t)b * VP_H + t + 256] = a1;
+  }
+  __syncthreads();
+  {
+    const int j = t & 127, half = t >> 7;
+    float a = 0.f;
+    if (j < VP_O)
+      for (int i = half * 256; i < half * 256 + 256; ++i) a = fmaf(w.w3t[i * VP_O + j], h2[i], a);
+    part[half][j] = a;
+  }
+  __syncthreads();
+  if (t < 128) {
+    const float v = t < VP_O ? w.b3[t] + part[0][t] + part[1][t] : 0.f;
+    o[t] = v;
+    og[(size_t)b * 128 + t] = v;
+  }
+  __syncthreads();
+  if (t < VP_NJ) {
+    float R[9], a3[3];
+    rot6d_fwd(&o[6 * t], R);
+    if (matrot) for (int i = 0; i < 9; ++i) matrot[((size_t)b * VP_NJ + t) * 9 + i] = R[i];
+    if (aa) {
+      rotmat_to_aa_fwd(R, a3);
+      for (int i = 0; i < 3; ++i) aa[(size_t)b * 63 + 3 * t + i] = a3[i];
+    }
+  }
+}
+
+int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
+                      float* matrot, float* aa, hipStream_t s) {
+  if (B <= 0) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(vposer_fwd_kernel, dim3(B), dim3(256), 0, s, w, z, z_stride, h1, h2, o, matrot, aa);
+  return (int)hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+vposer_bwd_kernel(VPoserW w, const float* __restrict__ h1g, const float* __restrict__ h2g,
+                  const float* __restrict__ og, const float* __restrict__ d_aa,
+                  const float* __restrict__ d_matrot, float* __restrict__ dz, int dz_stride) {
+  __shared__ float dout[128];
+  __shared__ float dh2[VP_H];
+  __shared__ float dh1[VP_H];
+  __shared__ float part[8][VP_Z];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < 128) dout[t] = 0.f;
+  __syncthreads();
+  if (t < VP_NJ) {
+    float o6[6], R[9], dR[9], d6[6];
+    for (int i = 0; i < 6; ++i) o6[i] = og[(size_t)b * 128 + 6 * t + i];
+    rot6d_fwd(o6, R);
+    for (int i = 0; i < 9; ++i) dR[i] = 0.f;
+    if (d_aa) {
+      float g[3];
+      for (int i = 0; i < 3; ++i) g[i] = d_aa[(size_t)b * 63 + 3 * t + i];
+      rotmat_to_aa_bwd(R, g, dR);
+    }
+    if (d_matrot) for (int i = 0; i < 9; ++i) dR[i] += d_matrot[((size_t)b * VP_NJ + t) * 9 + i];
+    rot6d_bwd(o6, dR, d6);
+    for (int i = 0; i < 6; ++i) dout[6 * t + i] = d6[i];
+  }
+  __syncthreads();
+  for (int i = t; i < VP_H; i += 256) {
+    float a = 0.f;
+    for (int oo = 0; oo < VP_O; ++oo) a = fmaf(w.w3[oo * VP_H + i], dout[oo], a);
+    dh2[i] = a * lrelu_grad_from_out(h2g[(size_t)b * VP_H + i]);
+  }
+  __syncthreads();
+  {
+    float a0 = 0.f, a1 = 0.f;
+    for (int oo = 0; oo < VP_H; ++oo) {
+      const float g = dh2[oo];
+      a0 = fmaf(w.w2[oo * VP_H + t], g, a0);
+      a1 = fmaf(w.w2[oo * VP_H + t + 256], g, a1);
+    }
+    dh1[t] = a0 * lrelu_grad_from_out(h1g[(size_t)b * VP_H + t]);
+    dh1[t + 256] = a1 * lrelu_grad_from_out(h1g[(size_t)b * VP_H + t + 256]);
+  }
+  __syncthreads();
+  {
+    const int i = t & 31, p = t >> 5;
+    float a = 0.f;
+    for (int oo = p * 64; oo < p * 64 + 64; ++oo) a = fmaf(w.w1[oo * VP_Z + i], dh1[oo], a);
+    part[p][i] = a;
+  }
+  __syncthreads();
+  if (t < VP_Z) {
+    float a = 0.f;
+    for (int p = 0; p < 8; ++p) a += part[p][t];
+    dz[(size_t)b * dz_stride + t] = a;
+  }
+}
+
+int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
+                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, hipStream_t s) {
+  (void)matrot;
+  if (B <= 0) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(vposer_bwd_kernel, dim3(B), dim3(256), 0, s, w, h1, h2, o, d_aa, d_matrot, dz, dz_stride);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 6-D -> axis-angle rows (convert_to_3D_rot, utils/utils.py:111-123)
+// ------------------------------------------------------------------------------------------------
+__global__ void rot6d_to_aa_fwd_kernel(const float* __restrict__ x6, int stride, int N, float* __restrict__ aa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float x[6], R[9], a[3];
+  for (int k = 0; k < 6; ++k) x[k] = x6[(size_t)i * stride + k];
+  rot6d_fwd(x, R);
+  rotmat_to_aa_fwd(R, a);
+  for (int k = 0; k < 3; ++k) aa[(size_t)i * 3 + k] = a[k];
+}
+__global__ void rot6d_to_aa_bwd_kernel(const float* __restrict__ x6, int stride, const float* __restrict__ d_aa,
+                                       int N, float* __restrict__ dx6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float x[6], R[9], dR[9], g[3], d6[6];
+  for (int k = 0; k < 6; ++k) x[k] = x6[(size_t)i * stride + k];
+  for (int k = 0; k < 3; ++k) g[k] = d_aa[(size_t)i * 3 + k];
+  rot6d_fwd(x, R);
+  rotmat_to_aa_bwd(R, g, dR);
+  rot6d_bwd(x, dR, d6);
+  for (int k = 0; k < 6; ++k) dx6[(size_t)i * 6 + k] = d6[k];
+}
+int rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, hipStream_t s) {
+  hipLaunchKernelGGL(rot6d_to_aa_fwd_kernel, dim3((N + 63) / 64), dim3(64), 0, s, x6, stride, N, aa);
+  return (int)hipGetLastError();
+}
+int rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, hipStream_t s) {
+  hipLaunchKernelGGL(rot6d_to_aa_bwd_kernel, dim3((N + 63) / 64), dim3(64), 0, s, x6, stride, d_aa, N, dx6);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SMPL-X pose stage forward (one block of 256 threads per frame)
+// ------------------------------------------------------------------------------------------------
+#define MAXJ 64
+
+__global__ void __launch_bounds__(256)
+smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
+  __shared__ float fp[MAXJ * 3];
+  __shared__ float Rs[MAXJ * 9];
+  __shared__ float Js[MAXJ * 3];
+  __shared__ float Ts[MAXJ * 12];
+  __shared__ float shp[32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int nj = c.nj, np = nj * 3;
+  // ---- full pose (SMPLX.forward: cat[go, body, jaw, leye, reye, lhand45, rhand45] + pose_mean)
+  for (int i = t; i < np; i += 256) {
+    float v;
+    if (i < 3) v = in.global_orient[(size_t)b * 3 + i];
+    else if (i < 66) v = in.body_pose[(size_t)b * 63 + (i - 3)];
+    else if (i < 69) v = in.jaw ? in.jaw[(size_t)b * 3 + (i - 66)] : 0.f;
+    else if (i < 72) v = in.leye ? in.leye[(size_t)b * 3 + (i - 69)] : 0.f;
+    else if (i < 75) v = in.reye ? in.reye[(size_t)b * 3 + (i - 72)] : 0.f;
+    else {
+      const int hidx = i - 75, side = hidx / 45, cc = hidx - side * 45;
+      const float* hp = (side == 0 ? in.lh : in.rh) + (size_t)b * in.hand_stride;
+      if (c.ncomp > 0) {
+        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
+        float a = 0.f;
+        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hp[k], comp[k * 45 + cc], a);
+        v = a;
+      } else v = hp[cc];
+    }
+    v += c.pose_mean[i];
+    fp[i] = v;
+    ws.full_pose[(size_t)b * np + i] = v;
+  }
+  if (t < c.nshape) {
+    const int nb = c.nshape / 2;
+    shp[t] = t < nb ? in.betas[(size_t)b * in.betas_stride + t] : (in.expr ? in.expr[(size_t)b * nb + (t - nb)] : 0.f);
+  }
+  __syncthreads();
+  // ---- Rodrigues
+  if (t < nj) {
+    float R[9];
+    rodrigues_fwd(&fp[3 * t], R);
+    for (int i = 0; i < 9; ++i) { Rs[9 * t + i] = R[i]; ws.R[((size_t)b * nj + t) * 9 + i] = R[i]; }
+  }
+  // ---- rest joints  J = J_template + J_dirs . shape
+  for (int i = t; i < np; i += 256) {
+    float a = c.J_template[i];
+    for (int k = 0; k < c.nshape; ++k) a = fmaf(c.J_dirs[(size_t)i * c.nshape + k], shp[k], a);
+    Js[i] = a;
+    ws.J[(size_t)b * np + i] = a;
+  }
+  __syncthreads();
+  // ---- GEMM features, KG8 layout: Xg[k>>3][b][k&7]; k < nshape: shape coefs; then (R[1:] - I)
+  {
+    const int nfeat = c.nshape + (nj - 1) * 9;
+    for (int k = t; k < nfeat; k += 256) {
+      float v;
+      if (k < c.nshape) v = shp[k];
+      else {
+        const int f = k - c.nshape, e = f % 9;
+        v = Rs[9 + f] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+      }
+      ws.Xg[((size_t)(k >> 3) * ws.Bp + b) * 8 + (k & 7)] = v;
+    }
+  }
+  // ---- kinematic chain, level-synchronous: T[i] = T[parent] * [R_i | J_i - J_parent]
+  for (int lev = 0; lev < c.nlev; ++lev) {
+    const int s0 = c.level_start[lev], s1 = c.level_start[lev + 1];
+    for (int w = t; w < (s1 - s0) * 12; w += 256) {
+      const int i = c.level_joints[s0 + w / 12], e = w % 12, r = e >> 2, cc = e & 3;
+      const int p = c.parents[i];
+      float v;
+      if (p < 0) v = cc < 3 ? Rs[9 * i + 3 * r + cc] : Js[3 * i + r];
+      else {
+        const float* Tp = &Ts[12 * p + 4 * r];
+        if (cc < 3) v = Tp[0] * Rs[9 * i + cc] + Tp[1] * Rs[9 * i + 3 + cc] + Tp[2] * Rs[9 * i + 6 + cc];
+        else v = Tp[0] * (Js[3 * i] - Js[3 * p]) + Tp[1] * (Js[3 * i + 1] - Js[3 * p + 1]) +
+                 Tp[2] * (Js[3 * i + 2] - Js[3 * p + 2]) + Tp[3];
+      }
+      Ts[12 * i + e] = v;
+    }
+    __syncthreads();
+  }
+  // ---- relative transforms A = [T_R | T_t - T_R J], posed joints
+  for (int w = t; w < nj * 12; w += 256) {
+    const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
+    const float* Ti = &Ts[12 * i + 4 * r];
+    float v = Ti[cc];
+    if (cc == 3) {
+      v -= Ti[0] * Js[3 * i] + Ti[1] * Js[3 * i + 1] + Ti[2] * Js[3 * i + 2];
+      ws.Jtr[((size_t)b * nj + i) * 3 + r] = Ti[3];
+    }
+    ws.A[((size_t)b * nj + i) * 12 + e] = v;
+    ws.T[((size_t)b * nj + i) * 12 + e] = Ti[cc];
+  }
+}
+
+int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s) {
+  if (c.nj > MAXJ || c.nshape > 32 || B <= 0 || B > ws.Bp) return LEMO_ERR_SHAPE;
+  if (c.nshape + (c.nj - 1) * 9 > 512) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(smplx_pose_fwd_kernel, dim3(B), dim3(256), 0, s, c, in, ws);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SMPL-X pose stage backward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
+  __shared__ float G[MAXJ * 12];      // d(global transform) [dT_R | dT_t]
+  __shared__ float Rs[MAXJ * 9];
+  __shared__ float Ts[MAXJ * 12];
+  __shared__ float Js[MAXJ * 3];
+  __shared__ float dJ[MAXJ * 3];
+  __shared__ float drel[MAXJ * 3];
+  __shared__ float dRl[MAXJ * 9];
+  __shared__ float dfp[MAXJ * 3];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int nj = c.nj, np = nj * 3;
+  for (int i = t; i < nj * 9; i += 256) Rs[i] = ws.R[(size_t)b * nj * 9 + i];
+  for (int i = t; i < nj * 12; i += 256) Ts[i] = ws.T[(size_t)b * nj * 12 + i];
+  for (int i = t; i < np; i += 256) Js[i] = ws.J[(size_t)b * np + i];
+  __syncthreads();
+  // own terms: A_R = T_R ; A_t = T_t - T_R J ; Jtr = T_t
+  for (int w = t; w < nj * 12; w += 256) {
+    const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
+    const float* dAi = gi.dA + ((size_t)b * nj + i) * 12;
+    float v;
+    if (cc < 3) v = dAi[4 * r + cc] - dAi[4 * r + 3] * Js[3 * i + cc];
+    else v = dAi[4 * r + 3] + (gi.dJtr ? gi.dJtr[((size_t)b * nj + i) * 3 + r] : 0.f);
+    G[w] = v;
+  }
+  for (int w = t; w < np; w += 256) {          // dJ_i = -T_R^T dA_t
+    const int i = w / 3, cc = w % 3;
+    const float* dAi = gi.dA + ((size_t)b * nj + i) * 12;
+    dJ[w] = -(Ts[12 * i + cc] * dAi[3] + Ts[12 * i + 4 + cc] * dAi[7] + Ts[12 * i + 8 + cc] * dAi[11]);
+  }
+  __syncthreads();
+  // reverse levels: G[p] += sum_children [G_R[ch] R_ch^T + G_t[ch] (x) rel_ch | G_t[ch]]
+  for (int lev = c.nlev - 2; lev >= 0; --lev) {
+    const int s0 = c.level_start[lev], s1 = c.level_start[lev + 1];
+    for (int w = t; w < (s1 - s0) * 12; w += 256) {
+      const int i = c.level_joints[s0 + w / 12], e = w % 12, r = e >> 2, cc = e & 3;
+      float acc = 0.f;
+      for (int q = c.child_start[i]; q < c.child_start[i + 1]; ++q) {
+        const int ch = c.child_list[q];
+        const float* Gc = &G[12 * ch + 4 * r];
+        if (cc < 3) {
+          acc += Gc[0] * Rs[9 * ch + 3 * cc] + Gc[1] * Rs[9 * ch + 3 * cc + 1] + Gc[2] * Rs[9 * ch + 3 * cc + 2] +
+                 Gc[3] * (Js[3 * ch + cc] - Js[3 * i + cc]);
+        } else acc += Gc[3];
+      }
+      G[12 * i + e] += acc;
+    }
+    __syncthreads();
+  }
+  // local grads: dR_i = T_R[p]^T G_R[i] ; drel_i = T_R[p]^T G_t[i]
+  for (int w = t; w < nj * 12; w += 256) {
+    const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;     // (r,cc): element of dR_i (cc<3) or drel (cc==3 -> comp r)
+    const int p = c.parents[i];
+    float v;
+    if (p < 0) v = G[12 * i + 4 * r + cc];
+    else v = Ts[12 * p + r] * G[12 * i + cc] + Ts[12 * p + 4 + r] * G[12 * i + 4 + cc] + Ts[12 * p + 8 + r] * G[12 * i + 8 + cc];
+    if (cc < 3) {
+      float d = v;
+      if (i >= 1 && gi.dX) d += gi.dX[(size_t)b * 512 + c.nshape + (i - 1) * 9 + 3 * r + cc];
+      dRl[9 * i + 3 * r + cc] = d;
+    } else drel[3 * i + r] = v;
+  }
+  __syncthreads();
+  // dJ: J_i enters rel_i (+) and rel_children (-)
+  for (int w = t; w < np; w += 256) {
+    const int i = w / 3, cc = w % 3;
+    float v = dJ[w] + drel[w];
+    for (int q = c.child_start[i]; q < c.child_start[i + 1]; ++q) v -= drel[3 * c.child_list[q] + cc];
+    dJ[w] = v;
+  }
+  // Rodrigues backward
+  if (t < nj) {
+    float fp3[3], d3[3];
+    for (int k = 0; k < 3; ++k) fp3[k] = ws.full_pose[(size_t)b * np + 3 * t + k];
+    rodrigues_bwd(fp3, &dRl[9 * t], d3);
+    for (int k = 0; k < 3; ++k) dfp[3 * t + k] = d3[k];
+  }
+  __syncthreads();
+  // scatter d(full_pose)
+  for (int i = t; i < 75; i += 256) {
+    const float v = dfp[i];
+    if (i < 3) { if (go.d_global_orient) go.d_global_orient[(size_t)b * 3 + i] = v; }
+    else if (i < 66) { if (go.d_body_pose) go.d_body_pose[(size_t)b * 63 + (i - 3)] = v; }
+    else if (i < 69) { if (go.d_jaw) go.d_jaw[(size_t)b * 3 + (i - 66)] = v; }
+    else if (i < 72) { if (go.d_leye) go.d_leye[(size_t)b * 3 + (i - 69)] = v; }
+    else { if (go.d_reye) go.d_reye[(size_t)b * 3 + (i - 72)] = v; }
+  }
+  {
+    const int nh = c.ncomp > 0 ? c.ncomp : 45;
+    for (int w = t; w < 2 * nh; w += 256) {
+      const int side = w / nh, k = w - side * nh;
+      float* dst = side == 0 ? go.d_lh : go.d_rh;
+      if (!dst) continue;
+      float v;
+      if (c.ncomp > 0) {
+        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
+        v = 0.f;
+        for (int cc = 0; cc < 45; ++cc) v = fmaf(comp[k * 45 + cc], dfp[75 + side * 45 + cc], v);
+      } else v = dfp[75 + side * 45 + k];
+      dst[(size_t)b * go.hand_stride + k] = v;
+    }
+  }
+  // d(shape coefs) = dX[:nshape] + J_dirs^T dJ
+  if (t < c.nshape && (go.d_betas || go.d_expr)) {
+    float v = gi.dX ? gi.dX[(size_t)b * 512 + t] : 0.f;
+    for (int i = 0; i < np; ++i) v = fmaf(c.J_dirs[(size_t)i * c.nshape + t], dJ[i], v);
+    const int nb = c.nshape / 2;
+    if (t < nb) { if (go.d_betas) go.d_betas[(size_t)b * nb + t] = v; }
+    else { if (go.d_expr) go.d_expr[(size_t)b * nb + (t - nb)] = v; }
+  }
+}
+
+int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, const PoseGradOut& go, int B, hipStream_t s) {
+  if (c.nj > MAXJ || B <= 0) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(smplx_pose_bwd_kernel, dim3(B), dim3(256), 0, s, c, ws, gi, go);
+  return (int)hipGetLastError();
+}
+
+}  // namespace lemo

@@ -1,0 +1,203 @@
+"""AMASS temporal fitting (stage 2 of LEMO) on the native MI355X engine.
+
+Reference: ``opt_amass_temp.py::optimize`` -- per-clip setup :332-345, the 100-step Adam loop
+:349-455 (the hot path), result :457-458.  One :class:`AmassTemporalFitter` owns every device
+buffer of one sequence (parameters, Adam state, ~0.5 GB of workspace for B=119) and hands raw
+pointers to ``liblemo_hip.so`` once (``lemo_fit_create``); an iteration is then a single C call
+(``lemo_fit_step``) that replays a captured hipGraph of ~45 kernels -- no host sync, no ``.item()``
+(the reference has 4 per iteration, :431-443), SMPL-X evaluated once instead of twice (:357,:364).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import ptr
+from .body_model import BodyModelData, DeviceBody, alloc_pose_ws, K_PAD, load_model_dict
+from .priors import ENC_CHANNELS, EncWeights, cg8p_alloc
+from .rotation import convert_to_6D_all
+from .vposer import vposer_weight_struct
+
+LOSS_WEIGHTS = dict(rec_markers=1.0, vposer=0.02, shape=0.01, hand=0.01, contact_vel=0.03, smooth=1e6)
+"""opt_amass_temp.py:47-52 (order = the C ABI's ``weights[6]``)."""
+FOOT_SETS = ('left_heel', 'right_heel', 'left_toe', 'right_toe')
+"""columns of ``contact_lbl`` (opt_amass_temp.py:409-412)."""
+LOSS_NAMES = ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total')
+
+
+class AmassTemporalFitter:
+    def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
+                 ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
+                 weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, lib: Optional[_hip.HipLib] = None):
+        self.lib = lib or _hip.get_lib()
+        self.device = torch.device(device)
+        if not self.lib.is_emu and self.device.type != 'cuda':
+            raise _hip.LemoHipError('AmassTemporalFitter needs a HIP device (no CPU fallback)')
+        self.B, self.full = int(B), bool(full_vertices)
+        data = body if isinstance(body, BodyModelData) else BodyModelData(load_model_dict(body), num_pca_comps=num_pca_comps)
+        assert data.ncomp == 12, 'the AMASS parameter vector carries 12 PCA coefficients per hand'
+        self.data = data
+        self.dev = DeviceBody(data, self.device)
+        dev = self.device
+        ti = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
+        tf = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+
+        # ---- active vertex set U and the index tables of the loss kernels ---------------------
+        m67, m81 = np.asarray(ids['markers67'], np.int64), np.asarray(ids['markers81'], np.int64)
+        foot = [np.asarray(ids[k], np.int64) for k in FOOT_SETS]
+        U = np.unique(np.concatenate([m67, m81] + foot))
+        self.U, n = U, int(U.shape[0])
+        slot = {int(v): i for i, v in enumerate(U)}
+        row_of = (lambda v: int(v)) if self.full else (lambda v: slot[int(v)])
+        self.nrows = data.V if self.full else n
+        u_m67 = -np.ones(n, np.int32); u_m81 = -np.ones(n, np.int32); u_mask = np.zeros(n, np.int32)
+        for i, v in enumerate(m67): u_m67[slot[int(v)]] = i
+        for i, v in enumerate(m81): u_m81[slot[int(v)]] = i
+        for k, f in enumerate(foot):
+            for v in f: u_mask[slot[int(v)]] |= (1 << k)
+        assert len(set(m67.tolist())) == len(m67) and len(set(m81.tolist())) == len(m81), 'duplicate marker ids'
+        foot_start = np.cumsum([0] + [len(f) for f in foot]).astype(np.int32)
+        self._idx = dict(row67=ti([row_of(v) for v in m67]), row81=ti([row_of(v) for v in m81]),
+                         foot_start=ti(foot_start), foot_row=ti([row_of(v) for f in foot for v in f]),
+                         u_row=ti([row_of(v) for v in U]), u_m67=ti(u_m67), u_m81=ti(u_m81), u_mask=ti(u_mask),
+                         Xstd=tf(np.asarray(Xstd).reshape(-1)), Xmean=tf(np.asarray(Xmean).reshape(-1)),
+                         fwd_ids=ti(U))
+        self.n, self.n67, self.n81 = n, len(m67), len(m81)
+        assert self._idx['Xstd'].numel() == 3 * self.n81
+        I = self._idx
+        fit = _hip.FitConst(n, self.n67, self.n81, ptr(I['row67']), ptr(I['row81']), ptr(I['foot_start']),
+                            ptr(I['foot_row']), ptr(I['u_row']), ptr(I['u_m67']), ptr(I['u_m81']), ptr(I['u_mask']),
+                            ptr(I['Xstd']), ptr(I['Xmean']))
+        vp_row = U if self.full else np.arange(n)
+        uset, self._uset_t = self.dev.vertex_set(('fit', self.full), U, vp_row)
+
+        # ---- model weights ----------------------------------------------------------------
+        self.vposer_struct, self._vp_t = vposer_weight_struct(vposer_weights, dev)
+        self.enc = EncWeights(enc_state, dev)
+        w = dict(LOSS_WEIGHTS if weights is None else weights)
+        self.weights = w
+        wl = [w['rec_markers'], w['vposer'], w['shape'], w['hand'], w['contact_vel'], w['smooth']]
+        self._w_dev = tf(wl)
+
+        # ---- parameters, Adam state, workspace ---------------------------------------------
+        B, nj = self.B, data.nj
+        self.H, self.W = 3 * self.n81 + 2, B - 1 + 16
+        H, W = self.H, self.W
+        self.P = dict(transl=z(B, 3), rot6d=z(B, 6), other=z(B, 56), shape=z(B, 10))
+        self.adam_m = [z(B, 3), z(B, 6), z(B, 56)]
+        self.adam_v = [z(B, 3), z(B, 6), z(B, 56)]
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.target, self.contact = z(B, self.n67, 3), z(B, 4)
+        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
+        self.Bp = Bp
+        nsp = self.lib.smooth_loss_blocks(H, W, ENC_CHANNELS[10])
+        self.ws = dict(go_aa=z(B, 3), body_aa=z(B, 63), h1=z(B, 512), h2=z(B, 512), vo=z(B, 128),
+                       verts=z(B, self.nrows, 3), v_posed=z(B, self.nrows, 3), x0=z((H + 2) * (W + 2)), canon=z(12),
+                       dx0=z(H * W), spartial=z(nsp), vpartial=z(B, 9), losses=z(12), dverts=z(B, n, 3),
+                       dvp=z(B, uset.NCs), dA=z(B, nj, 12), dX=z(B, K_PAD),
+                       g_transl=z(B, 3), g_rot6d=z(B, 6), g_other=z(B, 56), g_go=z(B, 3), g_body=z(B, 63))
+        self.act = [None] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
+        self.dact = [cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)]
+
+        d = _hip.FitDesc()
+        d.B, d.Bp, d.V, d.nrows, d.full_vertices = B, Bp, data.V, self.nrows, int(self.full)
+        d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
+        d.fwd_ids = ptr(I['fwd_ids'])
+        for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
+        for l in range(10):
+            d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
+        d.target, d.contact, d.weights = ptr(self.target), ptr(self.contact), ptr(self._w_dev)
+        for i, v in enumerate(wl): d.weights_host[i] = v
+        d.transl, d.rot6d, d.other, d.shape = (ptr(self.P[k]) for k in ('transl', 'rot6d', 'other', 'shape'))
+        for i in range(3):
+            d.adam_m[i], d.adam_v[i] = ptr(self.adam_m[i]), ptr(self.adam_v[i])
+        d.step_ctr, d.lr0, d.lr1, d.lr_switch = ptr(self.step_ctr), lr0, lr1, lr_switch
+        for k in ('go_aa', 'body_aa', 'h1', 'h2', 'vo', 'verts', 'v_posed', 'x0', 'canon', 'dx0', 'spartial', 'vpartial',
+                  'losses', 'dverts', 'dvp', 'dA', 'dX', 'g_transl', 'g_rot6d', 'g_other', 'g_go', 'g_body'):
+            setattr(d, k, ptr(self.ws[k]))
+        d.pose = pose_ws
+        for l in range(1, 11): d.act[l] = ptr(self.act[l])
+        d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
+        self.desc = d
+        self.handle = self.lib.fit_create(C.byref(d))
+        if not self.handle:
+            raise _hip.LemoHipError('lemo_fit_create rejected the descriptor')
+        self._stream = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h:
+            self.lib.fit_destroy(h)
+
+    # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------
+    @torch.no_grad()
+    def load_sequence(self, init_params: np.ndarray, markers_rec: np.ndarray, contact_lbl: np.ndarray):
+        """init_params [B,72] (per-frame fit result), markers_rec [B,67,3], contact_lbl [B,4] in {0,1}."""
+        p = torch.as_tensor(np.asarray(init_params, np.float32), device=self.device)
+        assert p.shape == (self.B, 72)
+        self.P['transl'].copy_(p[:, 0:3])
+        self.P['rot6d'].copy_(convert_to_6D_all(p[:, 3:6]))
+        self.P['shape'].copy_(p[:, 6:16])
+        self.P['other'].copy_(p[:, 16:])
+        self.target.copy_(torch.as_tensor(np.asarray(markers_rec, np.float32), device=self.device))
+        self.contact.copy_(torch.as_tensor(np.asarray(contact_lbl, np.float32), device=self.device))
+        for t in self.adam_m + self.adam_v:
+            t.zero_()
+        self.step_ctr.zero_()
+
+    # -- execution ---------------------------------------------------------------------------
+    def _s(self):
+        if self.lib.is_emu:
+            return None
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self) -> None:
+        self.lib.check(self.lib.fit_forward(self.handle, self._s()), 'fit_forward')
+
+    def backward(self) -> None:
+        self.lib.check(self.lib.fit_backward(self.handle, self._s()), 'fit_backward')
+
+    def step(self, n: int = 1, use_graph: bool = True) -> None:
+        """``n`` Adam iterations (forward, backward, update) -- asynchronous on the current stream.
+        With ``use_graph`` the iteration is captured once and replayed; capture needs a non-default
+        stream, so call inside ``with torch.cuda.stream(s):``."""
+        self.lib.check(self.lib.fit_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()),
+                       'fit_step')
+
+    # -- results -------------------------------------------------------------------------------
+    def losses(self) -> Dict[str, float]:
+        v = self.ws['losses'].detach().cpu().numpy()
+        return {k: float(v[i]) for i, k in enumerate(LOSS_NAMES)}
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        """raw gradients after ``backward()`` (the L2-prior terms on ``other`` are added inside the
+        Adam kernel; ``grads_with_priors`` adds them here for comparison with autograd)."""
+        return dict(transl=self.ws['g_transl'], rot6d=self.ws['g_rot6d'], other=self.ws['g_other'])
+
+    def grads_with_priors(self) -> Dict[str, torch.Tensor]:
+        g = {k: v.clone() for k, v in self.grads().items()}
+        o, B, w = self.P['other'], self.B, self.weights
+        g['other'][:, :32] += w['vposer'] * 2.0 * o[:, :32] / (B * 32.0)
+        g['other'][:, 32:] += w['hand'] * 2.0 * o[:, 32:] / (B * 24.0)
+        return g
+
+    def params75(self) -> torch.Tensor:
+        return torch.cat([self.P['transl'], self.P['rot6d'], self.P['shape'], self.P['other']], dim=-1)
+
+    def params72(self) -> torch.Tensor:
+        """[transl, global_orient aa, betas, z, hands] of the LAST forward (what the reference saves,
+        opt_amass_temp.py:457-458)."""
+        return torch.cat([self.P['transl'], self.ws['go_aa'], self.P['shape'], self.P['other']], dim=-1)
+
+    def vertices(self) -> torch.Tensor:
+        return self.ws['verts']
+
+    def posed_joints(self) -> torch.Tensor:
+        """the 55 posed skeleton joints + transl of the last forward, [B,55,3]."""
+        return self._pose_t['Jtr'] + self.P['transl'][:, None, :]
