@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Headline benchmark: fitting-iterations/s of the AMASS temporal fit (BASELINE.json configs[1]:
+opt_amass_temp.py, one 4 s / 30 fps clip = B 119 frames, smoothness + contact + marker + prior
+losses, Adam), one independent sequence per GPU.
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE full Adam iteration (forward incl. all 10475 vertices/frame, backward, update).
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (64->64 3x3 fp32-MFMA conv): algorithmic FLOP / measured duration
+  cpu_baseline -- the oracle (faithful restatement, two SMPL-X forwards like the reference) timed on
+                  this node's host cores on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def build_problem(seq_id, B, device, full_vertices):
+    from lemo_amd import synthetic
+    from lemo_amd.assets import load_assets
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.vposer import make_vposer_weights
+    A = load_assets()
+    model = synthetic.make_synthetic_smplx(seed=0)
+    vw = make_vposer_weights(2)
+    fit = AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], B, device,
+                              full_vertices=full_vertices)
+    seq = synthetic.make_synthetic_sequence(seq_id, B=B)
+    # target markers = model markers of the perturbed trajectory, via the product path
+    fit.load_sequence(seq['target_params'], np.zeros((B, 67, 3), np.float32), seq['contact_lbl'])
+    fit.forward()
+    torch.cuda.synchronize(device)
+    rows = fit._idx['row67'].long()
+    markers = fit.vertices()[:, rows].detach().cpu().numpy().copy()
+    fit.load_sequence(seq['init_params'], markers, seq['contact_lbl'])
+    return fit, dict(model=model, vposer_w=vw, enc_w=A['enc_w'], ids=A['ids'], Xmean=A['Xmean'], Xstd=A['Xstd'],
+                     seq=seq, markers=markers)
+
+
+def time_dominant_kernel(fit, stream, reps=50):
+    """Average duration of the 64->64 conv3x3 fp32-MFMA launch (layer 10's shape) on `stream`,
+    measured with HIP events around back-to-back launches on the engine's own buffers."""
+    from lemo_amd._hip import ptr
+    lib = fit.lib
+    H, W = fit.H, fit.W
+    args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            lib.check(lib.conv3x3_mfma(*args, stream.cuda_stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            lib.check(lib.conv3x3_mfma(*args, stream.cuda_stream))
+        e1.record(stream)
+    e1.synchronize()
+    fit.dact[1].zero_()                    # scratch again (border must stay zero; interior rewritten each step)
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * H * W * 64 * 64 * 9
+    return ms, flops
+
+
+def cpu_baseline(prob, B, budget_s=20.0):
+    """oracle (kind 'port'): faithful iteration incl. the reference's two SMPL-X forwards."""
+    from oracle import lemo_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    so = O.SmplxOracle(prob['model'])
+    vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
+    ew = {k: torch.from_numpy(v) for k, v in prob['enc_w'].items()}
+    fit = O.AmassFitOracle(so, vw, ew, prob['ids'], prob['Xmean'], prob['Xstd'], prob['seq']['init_params'],
+                           prob['markers'], prob['seq']['contact_lbl'], faithful=True)
+    for _ in range(2):
+        fit.step()
+    n, t0 = 0, time.time()
+    while n < 40 and (time.time() - t0 < budget_s or n < 3):
+        fit.step()
+        n += 1
+    dt = time.time() - t0
+    return dict(value=n / dt, unit='fitting-iterations/s', cores=int(cores), kind='port',
+                sample=f'{n} iterations of oracle.AmassFitOracle(faithful=True), B={B}, V=10475, after 2 warm-up')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--frames', type=int, default=119, help='B = clip_seconds*30-1 (the "T=120" clip)')
+    ap.add_argument('--active-vertices-only', action='store_true',
+                    help='forward only the 253 vertices the losses read (NOT the headline config)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from lemo_amd.sharding import gather_fitted_params
+    B = args.frames
+    fit, prob = build_problem(rank, B, device, full_vertices=not args.active_vertices_only)
+    stream = torch.cuda.Stream(device)
+    use_graph = not args.no_graph
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        fit.step(args.warmup, use_graph=use_graph)
+    torch.cuda.synchronize(device)
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        fit.step(args.steps, use_graph=use_graph)
+        stream.synchronize()
+    gathered = gather_fitted_params(fit.params72()[None])          # the path's one collective
+    torch.cuda.synchronize(device)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert gathered.shape == (world, B, 72)
+    losses = fit.losses()
+
+    kern_ms, kern_flops = time_dominant_kernel(fit, stream)
+    achieved = kern_flops / (kern_ms * 1e-3) / 1e12
+    out = {
+        'metric': 'fitting-iterations/sec (T=120 frames)', 'value': world * args.steps / dt,
+        'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'opt_amass_temp.py temporal fit, one TotalCapture-shaped clip per GPU: B=119 frames '
+                               '(the T=120 clip), SMPL-X-shaped synthetic model V=10475, VPoser decode, smoothness '
+                               'encoder 245x134, marker+contact+prior losses, Adam',
+                   'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
+                   'sequences': world, 'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
+        'final_total_loss': losses['total'],
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
+                     'kernel': 'conv3x3_mfma_kernel<2,0> 64->64ch 245x134 (16 of the ~45 launches/iteration)',
+                     'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(prob, B)
+        out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

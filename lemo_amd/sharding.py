@@ -1,0 +1,52 @@
+"""Multi-GPU execution of the fitting path: independent motion sequences shard across ranks.
+
+The reference is single-process (no collective anywhere); its outer loop over clips
+(``opt_amass_temp.py:251``) carries no state between sequences, so the natural partition is
+sequence ``s`` -> rank ``s mod world_size``, one process per GPU, model constants replicated, and a
+single all-gather of the fitted ``[B,72]`` blocks (34 KB each) per round -- latency-bound, so ONE
+``all_gather_into_tensor`` over RCCL/xGMI and nothing fancier.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def my_sequences(n_seq: int, rank: int, world: int) -> List[int]:
+    """round-robin partition of sequence ids."""
+    return list(range(rank, n_seq, world))
+
+
+def gather_fitted_params(local: torch.Tensor, group=None) -> torch.Tensor:
+    """local [n_local,B,72] (same n_local on every rank) -> [world*n_local,B,72], rank-major.
+    One collective: ``all_gather_into_tensor`` (nccl == RCCL on ROCm); gloo lacks it for CPU
+    tensors on some builds, so the CPU/gloo path (tests) uses ``all_gather``."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local.clone()
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if local.is_cuda:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=group)
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        out = torch.stack(parts, 0)
+    return out.reshape((-1,) + tuple(local.shape[1:]))
+
+
+def unshard_order(n_seq: int, world: int) -> List[int]:
+    """index into the rank-major gathered tensor for each sequence id 0..n_seq-1 (n_seq % world == 0)."""
+    per = n_seq // world
+    return [(s % world) * per + s // world for s in range(n_seq)]
+
+
+def fit_sharded(n_seq: int, fit_one: Callable[[int], torch.Tensor], rank: int, world: int, group=None) -> torch.Tensor:
+    """Fit sequences ``rank, rank+world, ...`` with ``fit_one(seq_id) -> [B,72]`` and return ALL
+    ``n_seq`` results on every rank, in sequence order.  ``n_seq`` must be a multiple of ``world``."""
+    assert n_seq % world == 0, 'pad the sequence list to a multiple of the world size'
+    mine = [fit_one(s) for s in my_sequences(n_seq, rank, world)]
+    allp = gather_fitted_params(torch.stack(mine, 0), group)
+    return allp[torch.tensor(unshard_order(n_seq, world), device=allp.device)]

@@ -1,0 +1,268 @@
+"""GPU parity gate (-m gpu, runs on the MI355X through liblemo_hip.so / the C ABI).
+
+Tolerances are BASELINE.json's: <= 1e-4 relative on vertices / markers, <= 1e-5 relative on each
+loss scalar, for one iteration from identical inputs; checked against the oracle (recomputed here
+on the host) and against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from lemo_amd import synthetic
+from lemo_amd.assets import load_assets
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL = 1e-5
+VERT_TOL = 1e-4
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    from lemo_amd import _hip
+    assert not _hip.get_lib().is_emu                      # the product library, loaded from the tree
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(scope='module')
+def full_problem(dev):
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.vposer import make_vposer_weights
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
+    model = synthetic.make_synthetic_smplx(seed=0)
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    mk = lambda full: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'],
+                                          119, dev, full_vertices=full)
+    return dict(A=A, g=g, model=model, seq=seq, make=mk)
+
+
+def test_rot6d_vposer_golden(dev):
+    from lemo_amd.rotation import convert_to_3D_all
+    from lemo_amd.vposer import VPoser, make_vposer_weights
+    r = np.load(os.path.join(GOLDEN, 'rot6d.npz'))
+    aa = convert_to_3D_all(torch.from_numpy(r['rot6d_in']).to(dev))
+    assert float((aa.cpu() - torch.from_numpy(r['rot6d_aa'])).abs().max()) < 5e-6
+    g = np.load(os.path.join(GOLDEN, 'vposer_decode.npz'))
+    vp = VPoser().eval()
+    vp.load_state_dict({**vp.state_dict(), **{k: torch.from_numpy(v) for k, v in make_vposer_weights(2).items()}})
+    vp = vp.to(dev)
+    Z = torch.from_numpy(g['Z']).to(dev).requires_grad_(True)
+    aa = vp.decode(Z, 'aa')
+    assert rel_err(aa.detach().cpu(), g['aa']) < VERT_TOL
+    assert rel_err(vp.decode(Z, 'matrot').detach().cpu(), g['matrot']) < VERT_TOL
+    aa.sum().backward()
+    assert torch.isfinite(Z.grad).all()
+
+
+def test_smplx_module_golden(dev):
+    from lemo_amd.body_model import create
+    g = np.load(os.path.join(GOLDEN, 'lbs_small.npz'))
+    m = synthetic.make_synthetic_smplx(seed=int(g['model_seed']), V=int(g['model_V']), F=1200)
+    model = create(m, batch_size=4, extra_joint_ids=g['extra_ids'].tolist()).to(dev)
+    p = {k: torch.from_numpy(g[k]).to(dev).requires_grad_(True) for k in ('betas', 'global_orient', 'body_pose', 'lh', 'rh', 'transl')}
+    out = model(betas=p['betas'], global_orient=p['global_orient'], body_pose=p['body_pose'], left_hand_pose=p['lh'],
+                right_hand_pose=p['rh'], transl=p['transl'], return_full_pose=True)
+    assert rel_err(out.vertices.detach().cpu(), g['verts']) < VERT_TOL
+    assert rel_err(out.joints.detach().cpu(), g['joints']) < VERT_TOL
+    ((out.vertices * torch.from_numpy(g['wv']).to(dev)).sum() + (out.joints * torch.from_numpy(g['wj']).to(dev)).sum()).backward()
+    for k in p:
+        assert rel_err(p[k].grad.cpu(), g['g_' + k]) < 1e-4, k
+
+
+def test_smplx_module_full_size_vs_oracle(dev):
+    """V=10475, B=119: every vertex and joint against the oracle (<= 1e-4 rel)."""
+    from lemo_amd.body_model import create
+    from oracle import lemo_oracle as O
+    m = synthetic.make_synthetic_smplx(seed=0)
+    seq = synthetic.make_synthetic_sequence(1, B=119)
+    p = torch.from_numpy(seq['init_params'])
+    gen = torch.Generator().manual_seed(0)
+    body = torch.randn(119, 63, generator=gen) * 0.3
+    so = O.SmplxOracle(m)
+    with torch.no_grad():
+        v_ref, j_ref, _ = so.forward(p[:, 6:16], p[:, 3:6], body, p[:, 48:60], p[:, 60:], p[:, 0:3])
+    model = create(m, batch_size=119).to(dev)
+    out = model(betas=p[:, 6:16].to(dev), global_orient=p[:, 3:6].to(dev), body_pose=body.to(dev),
+                left_hand_pose=p[:, 48:60].to(dev), right_hand_pose=p[:, 60:].to(dev), transl=p[:, 0:3].to(dev))
+    assert out.vertices.shape == (119, 10475, 3) and out.joints.shape == (119, 127, 3)
+    assert rel_err(out.vertices.cpu(), v_ref) < VERT_TOL
+    assert rel_err(out.joints.cpu(), j_ref) < VERT_TOL
+
+
+def test_encoder_full_size_golden(dev):
+    """10-layer fp32-MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad."""
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import ENC_CHANNELS, EncWeights, cg8p_alloc, from_cg8p
+    lib = _hip.get_lib()
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'enc_smooth.npz'))
+    H, W = 245, 134
+    enc = EncWeights(A['enc_w'], dev)
+    x = torch.from_numpy(g['x'])[0, 0]
+    x0 = torch.zeros(H + 2, W + 2); x0[1:-1, 1:-1] = x
+    x0 = x0.to(dev).contiguous()
+    act = [None] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
+    s = torch.cuda.current_stream(dev).cuda_stream
+    lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, 32, s))
+    for l in range(1, 10):
+        lib.check(lib.conv3x3_mfma(ptr(act[l]), ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(act[l + 1]), H, W,
+                                   ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, s))
+    z = from_cg8p(act[10], H, W)
+    assert abs(float(z.double().sum()) - float(g['z_sum'])) < 1e-5 * float(g['z_abs_sum'])
+    assert rel_err(z[::8, ::16, ::16].cpu(), g['z_sub']) < 1e-5
+    cnt = 64 * H * (W - 1)
+    nb = lib.smooth_loss_blocks(H, W, 64)
+    part, d0, d1 = torch.zeros(nb, device=dev), cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    lib.check(lib.smooth_loss(ptr(act[10]), ptr(d0), ptr(part), H, W, 64, 2.0 / cnt, s))
+    loss = float(part.double().sum() / cnt)
+    assert abs(loss - float(g['loss_smooth'])) <= LOSS_TOL * float(g['loss_smooth'])
+    cur = [d0, d1]
+    ci = 0
+    for l in range(9, 0, -1):
+        lib.check(lib.conv3x3_mfma(ptr(cur[ci]), ptr(enc.wbwd[l]), None, ptr(act[l]), ptr(cur[1 - ci]), H, W,
+                                   ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, s))
+        ci = 1 - ci
+    dx0 = torch.zeros(H * W, device=dev)
+    lib.check(lib.conv3x3_c1_bwd(ptr(cur[ci]), ptr(enc.w[0]), ptr(dx0), H, W, 32, s))
+    assert rel_err(dx0.view(H, W).cpu(), g['gx'][0, 0]) < 1e-4
+
+
+def test_fit_small_vs_oracle_eager_and_graph(dev):
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem()
+    ofit, markers = ge.oracle_for(prob)
+    total, parts, _, verts = ofit.losses()
+    total.backward()
+    fits = []
+    for full in (True, False):
+        fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'],
+                                  prob['Xstd'], prob['B'], dev, full_vertices=full)
+        fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+        fit.forward(); fit.backward()
+        torch.cuda.synchronize()
+        L = fit.losses()
+        for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
+            assert abs(L[k] - float(parts[k])) <= LOSS_TOL * abs(float(parts[k])), (k, L[k], float(parts[k]))
+        g = fit.grads_with_priors()
+        for k, ref in (('transl', ofit.transl.grad), ('rot6d', ofit.rot6d.grad), ('other', ofit.other.grad)):
+            assert rel_err(g[k].cpu(), ref) < 2e-4, k
+        fits.append(fit)
+    assert rel_err(fits[0].vertices().cpu(), verts.detach()) < VERT_TOL
+    # eager vs graph replay: identical kernels -> identical parameters
+    s = torch.cuda.Stream(dev)
+    for fit in fits:
+        fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    with torch.cuda.stream(s):
+        fits[0].step(5, use_graph=False)
+        fits[1].step(5, use_graph=True)
+    torch.cuda.synchronize()
+    ofit.opt.zero_grad()
+    for _ in range(5):
+        ofit.step()
+    for fit in fits:
+        assert float((fit.params75().cpu() - ofit.params75()).abs().max()) < 1e-4
+        assert int(fit.step_ctr.item()) == 5
+
+
+def test_fit_full_size_golden(full_problem, dev):
+    """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
+    1 and 10 Adam steps (graph replay)."""
+    g, seq = full_problem['g'], full_problem['seq']
+    fit = full_problem['make'](True)
+    fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    fit.forward(); fit.backward()
+    torch.cuda.synchronize()
+    L = fit.losses()
+    for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
+        ref = float(g['loss_' + k])
+        assert abs(L[k] - ref) <= LOSS_TOL * abs(ref), (k, L[k], ref)
+    assert abs(L['total'] - float(g['total'])) <= LOSS_TOL * float(g['total'])
+    v = fit.vertices()
+    assert rel_err(v[:, ::97].cpu(), g['verts_sub']) < VERT_TOL
+    assert abs(float(v.double().sum()) - float(g['verts_sum'])) < 1e-6 * float(v.double().abs().sum())
+    assert rel_err(fit.params72().cpu(), g['p72_0']) < 1e-5
+    gr = fit.grads_with_priors()
+    assert rel_err(gr['transl'].cpu(), g['g_transl']) < 1e-3
+    assert rel_err(gr['rot6d'].cpu(), g['g_rot6d']) < 1e-3
+    assert rel_err(gr['other'].cpu(), g['g_other']) < 1e-3
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        fit.step(1, use_graph=True)
+    torch.cuda.synchronize()
+    assert float((fit.params75().cpu() - torch.from_numpy(g['p75_after1'])).abs().max()) < 2e-5
+    with torch.cuda.stream(s):
+        fit.step(9, use_graph=True)
+    torch.cuda.synchronize()
+    d10 = float((fit.params75().cpu() - torch.from_numpy(g['p75_after10'])).abs().max())
+    assert d10 < 2e-3, d10
+    assert abs(fit.losses()['total'] - float(g['total_hist'][9])) < 1e-3 * float(g['total_hist'][9])
+
+
+def test_active_vertex_forward_is_identical(full_problem, dev):
+    """forwarding only the 253 vertices the losses read gives the same losses and gradients."""
+    g, seq = full_problem['g'], full_problem['seq']
+    res = []
+    for full in (True, False):
+        fit = full_problem['make'](full)
+        fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+        fit.forward(); fit.backward()
+        torch.cuda.synchronize()
+        res.append((fit.losses(), {k: v.clone() for k, v in fit.grads().items()}))
+    for k in res[0][0]:
+        assert abs(res[0][0][k] - res[1][0][k]) <= 1e-6 * abs(res[0][0][k]) + 1e-12, k
+    for k in res[0][1]:
+        assert rel_err(res[1][1][k], res[0][1][k]) < 1e-5, k
+
+
+def test_translation_invariance_property(full_problem, dev):
+    """size-independent property at full size: moving the whole clip and its target markers by a
+    constant leaves every loss term unchanged (the smoothness feature is canonicalised to marker 0 of
+    frame 0, opt_amass_temp.py:376-377)."""
+    g, seq = full_problem['g'], full_problem['seq']
+    fit = full_problem['make'](True)
+    out = []
+    for off in (np.zeros(3, np.float32), np.array([0.5, -0.25, 0.125], np.float32)):
+        p = seq['init_params'].copy(); p[:, 0:3] += off
+        fit.load_sequence(p, g['markers_rec'] + off, seq['contact_lbl'])
+        fit.forward()
+        torch.cuda.synchronize()
+        out.append(fit.losses())
+    for k in ('marker', 'contact', 'smooth'):
+        assert abs(out[0][k] - out[1][k]) <= 2e-4 * abs(out[0][k]), (k, out[0][k], out[1][k])
+
+
+@pytest.mark.timeout(900)
+def test_mpjpe_after_full_fit(full_problem, dev):
+    """BASELINE metric 'MPJPE vs ref': 100-step fit on the GPU vs the oracle from identical inputs;
+    mean over frames and the first 22 joints of ||J_gpu - J_oracle||, in mm."""
+    from oracle import lemo_oracle as O
+    g, seq, A = full_problem['g'], full_problem['seq'], full_problem['A']
+    steps = 100
+    fit = full_problem['make'](True)
+    fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        fit.step(steps, use_graph=True)
+        fit.forward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    so = O.SmplxOracle(full_problem['model'])
+    ofit = O.AmassFitOracle(so, O.make_vposer_weights(2), A['enc_w_torch'], A['ids'], A['Xmean'], A['Xstd'],
+                            seq['init_params'], g['markers_rec'], seq['contact_lbl'], faithful=False)
+    first = ofit.step()
+    for _ in range(steps - 1):
+        last = ofit.step()
+    with torch.no_grad():
+        p72 = O.convert_to_3D_rot(ofit.params75())
+        _, j_ref, _ = ofit._body(p72)
+    mpjpe = O.mpjpe_mm(fit.posed_joints().cpu(), j_ref[:, :55])
+    Lg = fit.losses()['total']
+    print(f'MPJPE gpu-vs-oracle after {steps} steps: {mpjpe:.4f} mm ; total loss {first["total"]:.4f} -> oracle {last["total"]:.4f} / gpu {Lg:.4f}')
+    assert Lg < 0.7 * first['total']                    # the fit actually descends
+    assert mpjpe < 5.0, mpjpe

@@ -1,0 +1,186 @@
+"""CPU suite: the UNMODIFIED HIP kernel sources, compiled for the host against tests/hipemu
+(fibers + MFMA lane-map emulation), checked against the oracle at small sizes.  This validates
+index arithmetic / lane maps / host orchestration without a GPU; the real parity gate is
+tests/test_gpu_parity.py (-m gpu) on the MI355X."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from lemo_amd import synthetic
+from lemo_amd._hip import ptr
+from lemo_amd.priors import cg8p_alloc, from_cg8p, pack_conv3x3, pack_conv3x3_bwd, to_cg8p
+from oracle import lemo_oracle as O
+
+
+@pytest.mark.parametrize('ci,co', [(8, 32), (32, 64), (64, 64)])
+def test_conv3x3_mfma_forward_and_backward_data(emu_lib, ci, co):
+    g = torch.Generator().manual_seed(ci + co)
+    H, W = 7, 37                                        # P = 259: ragged last MFMA tile
+    x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
+    ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    xin, out, wt = to_cg8p(x), cg8p_alloc(co, H, W, 'cpu'), torch.from_numpy(pack_conv3x3(w.numpy()))
+    assert emu_lib.conv3x3_mfma(ptr(xin), ptr(wt), ptr(b), None, ptr(out), H, W, ci, co, 0, None) == 0
+    assert rel_err(from_cg8p(out, H, W), ref) < 2e-6
+    assert float(out.reshape(co // 8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0       # border untouched
+    if ci % 32 == 0:
+        dy, aux = torch.randn(co, H, W, generator=g), torch.randn(ci, H, W, generator=g)
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr[None], w, b, padding=1).backward(dy[None])
+        refdx = xr.grad * torch.where(aux > 0, 1.0, 0.2)
+        dyb, auxb, dxb = to_cg8p(dy), to_cg8p(aux), cg8p_alloc(ci, H, W, 'cpu')
+        wtb = torch.from_numpy(pack_conv3x3_bwd(w.numpy()))
+        assert emu_lib.conv3x3_mfma(ptr(dyb), ptr(wtb), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, None) == 0
+        assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
+
+
+def test_conv_rejects_bad_shapes(emu_lib):
+    t = torch.zeros(64)
+    assert emu_lib.conv3x3_mfma(ptr(t), ptr(t), ptr(t), None, ptr(t), 4, 4, 12, 32, 0, None) != 0
+    assert emu_lib.conv3x3_mfma(ptr(t), ptr(t), None, None, ptr(t), 4, 4, 8, 32, 0, None) != 0
+
+
+def test_first_layer_and_smooth_loss(emu_lib):
+    g = torch.Generator().manual_seed(3)
+    H, W = 9, 21
+    x, w, b = torch.randn(1, H, W, generator=g), torch.randn(32, 1, 3, 3, generator=g), torch.randn(32, generator=g)
+    ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    x0 = torch.zeros(H + 2, W + 2); x0[1:-1, 1:-1] = x[0]
+    w9, out = w.reshape(32, 9).contiguous(), cg8p_alloc(32, H, W, 'cpu')
+    assert emu_lib.conv3x3_c1(ptr(x0), ptr(w9), ptr(b), ptr(out), H, W, 32, None) == 0
+    assert rel_err(from_cg8p(out, H, W), ref) < 1e-6
+    dpre = torch.randn(32, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr[None], w, b, padding=1).backward(dpre[None])
+    dpb, dx0 = to_cg8p(dpre), torch.zeros(H, W)
+    assert emu_lib.conv3x3_c1_bwd(ptr(dpb), ptr(w9), ptr(dx0), H, W, 32, None) == 0
+    assert rel_err(dx0, xr.grad[0]) < 1e-5
+    z = torch.randn(64, H, W, generator=g).requires_grad_(True)
+    zz = F.leaky_relu(z, 0.2)
+    loss = torch.mean((zz[..., 1:] - zz[..., :-1]) ** 2)
+    (loss * 1e6).backward()
+    nb, cnt = emu_lib.smooth_loss_blocks(H, W, 64), 64 * H * (W - 1)
+    part, dp, zb = torch.zeros(nb), cg8p_alloc(64, H, W, 'cpu'), to_cg8p(zz.detach())
+    assert emu_lib.smooth_loss(ptr(zb), ptr(dp), ptr(part), H, W, 64, 1e6 * 2 / cnt, None) == 0
+    assert abs(float(part.double().sum() / cnt) - float(loss)) < 1e-6 * float(loss)
+    assert rel_err(from_cg8p(dp, H, W), z.grad) < 1e-6
+
+
+def test_rot6d_and_vposer_vs_golden(emu_lib):
+    from lemo_amd.vposer import VPoser, make_vposer_weights
+    r = np.load(os.path.join(GOLDEN, 'rot6d.npz'))
+    x6 = torch.from_numpy(r['rot6d_in']).contiguous()
+    N = x6.shape[0]
+    aa = torch.empty(N, 3)
+    assert emu_lib.rot6d_to_aa_fwd(ptr(x6), 6, N, ptr(aa), None) == 0
+    assert float((aa - torch.from_numpy(r['rot6d_aa'])).abs().max()) < 5e-6
+    gen = torch.Generator().manual_seed(1)
+    wv = torch.randn(N, 3, generator=gen)
+    xr = x6.clone().requires_grad_(True)
+    (O.convert_to_3D_all(xr) * wv).sum().backward()
+    dx = torch.empty(N, 6)
+    assert emu_lib.rot6d_to_aa_bwd(ptr(x6), 6, ptr(wv), N, ptr(dx), None) == 0
+    err = (dx - xr.grad).abs().max(1).values / (xr.grad.abs().max(1).values + 1e-9)
+    assert float(err.max()) < 1e-4                       # incl. the near-identity and near-pi rows
+
+    g = np.load(os.path.join(GOLDEN, 'vposer_decode.npz'))
+    vp = VPoser(_lib=emu_lib).eval()
+    w = make_vposer_weights(2)
+    vp.load_state_dict({**vp.state_dict(), **{k: torch.from_numpy(v) for k, v in w.items()}})
+    Z = torch.from_numpy(g['Z']).clone().requires_grad_(True)
+    aa = vp.decode(Z, 'aa')
+    assert aa.shape == (16, 1, 21, 3) and rel_err(aa.detach(), g['aa']) < 1e-4
+    assert rel_err(vp.decode(Z, 'matrot').detach(), g['matrot']) < 1e-4
+    wa = torch.randn(aa.shape, generator=gen)
+    (aa * wa).sum().backward()
+    Z2 = torch.from_numpy(g['Z']).clone().requires_grad_(True)
+    (O.vposer_decode({k: torch.from_numpy(v) for k, v in w.items()}, Z2, 'aa') * wa).sum().backward()
+    assert rel_err(Z.grad, Z2.grad) < 1e-4
+    with pytest.raises(RuntimeError):
+        vp.train().decode(Z, 'aa')
+
+
+def test_smplx_module_forward_backward_vs_golden(emu_lib):
+    """smplx-compatible module: vertices, 127 joints, full pose and every input gradient."""
+    from lemo_amd.body_model import create
+    g = np.load(os.path.join(GOLDEN, 'lbs_small.npz'))
+    m = synthetic.make_synthetic_smplx(seed=int(g['model_seed']), V=int(g['model_V']), F=1200)
+    model = create(m, model_type='smplx', gender='male', batch_size=4, num_pca_comps=12,
+                   extra_joint_ids=g['extra_ids'].tolist(), _lib=emu_lib, some_unknown_kwarg=1)
+    assert model.get_num_verts() == 640 and model.faces_tensor.shape == (1200, 3)
+    p = {k: torch.from_numpy(g[k]).clone().requires_grad_(True) for k in ('betas', 'global_orient', 'body_pose', 'lh', 'rh', 'transl')}
+    out = model(betas=p['betas'], global_orient=p['global_orient'], body_pose=p['body_pose'], left_hand_pose=p['lh'],
+                right_hand_pose=p['rh'], transl=p['transl'], return_verts=True, return_full_pose=True)
+    assert out.vertices.shape == (4, 640, 3) and out.joints.shape == (4, 127, 3)
+    assert rel_err(out.vertices.detach(), g['verts']) < 1e-4          # north_star: <= 1e-4 rel on vertices
+    assert rel_err(out.joints.detach(), g['joints']) < 1e-4
+    assert rel_err(out.full_pose.detach(), g['full_pose']) < 1e-6
+    ((out.vertices * torch.from_numpy(g['wv'])).sum() + (out.joints * torch.from_numpy(g['wj'])).sum()).backward()
+    for k in p:
+        assert rel_err(p[k].grad, g['g_' + k]) < 1e-4, k
+    # parameters are used when arguments are omitted; reset_params fills / zeroes
+    model.reset_params(transl=g['transl'], betas=g['betas'], body_pose=np.zeros((4, 63)), unknown=1)
+    assert torch.allclose(model.transl.detach(), torch.from_numpy(g['transl'])) and float(model.jaw_pose.abs().max()) == 0
+    o2 = model(global_orient=p['global_orient'].detach(), body_pose=p['body_pose'].detach(),
+               left_hand_pose=p['lh'].detach(), right_hand_pose=p['rh'].detach())
+    assert rel_err(o2.vertices.detach(), g['verts']) < 1e-4
+    mapper = lambda j: j[:, [0, 5, 126]]
+    model.joint_mapper = mapper
+    assert model(global_orient=p['global_orient'].detach(), body_pose=p['body_pose'].detach()).joints.shape == (4, 3, 3)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('full', [True, False])
+def test_fit_iteration_vs_oracle(emu_lib, full):
+    """whole AMASS iteration through the native engine (C-ABI lemo_fit_*): six loss scalars, total,
+    gradients, and parameters after 3 Adam steps -- full-vertex and active-vertex forward."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem()
+    ofit, markers = ge.oracle_for(prob)
+    total, parts, _, verts = ofit.losses()
+    total.backward()
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                              prob['B'], 'cpu', full_vertices=full, lib=emu_lib)
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    fit.forward()
+    fit.backward()
+    L = fit.losses()
+    for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
+        assert abs(L[k] - float(parts[k])) <= 1e-5 * abs(float(parts[k])), (k, L[k], float(parts[k]))
+    assert abs(L['total'] - float(total)) <= 1e-5 * float(total)
+    if full:
+        assert rel_err(fit.vertices(), verts.detach()) < 1e-4
+    g = fit.grads_with_priors()
+    for k, ref in (('transl', ofit.transl.grad), ('rot6d', ofit.rot6d.grad), ('other', ofit.other.grad)):
+        assert rel_err(g[k], ref) < 2e-4, k
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    ofit.opt.zero_grad()
+    for _ in range(3):
+        ofit.step()
+    fit.step(3, use_graph=False)
+    assert float((fit.params75() - ofit.params75()).abs().max()) < 5e-5
+    assert int(fit.step_ctr.item()) == 3
+
+
+def test_contact_term_empty_selection_is_exactly_zero(emu_lib):
+    """K15: `x[x>thr].mean()` with an empty selection must be exactly 0 (opt_amass_temp.py:429-443)."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                              prob['B'], 'cpu', full_vertices=False, lib=emu_lib)
+    p = prob['seq']['init_params'].copy()
+    p[:] = p[0]                                          # a static pose: every contact velocity is 0
+    fit.load_sequence(p, markers, np.ones_like(prob['seq']['contact_lbl']))
+    fit.forward()
+    fit.backward()
+    assert fit.losses()['contact'] == 0.0
+    assert not torch.isnan(fit.grads()['other']).any()
+    fit.load_sequence(prob['seq']['init_params'], markers, np.zeros_like(prob['seq']['contact_lbl']))
+    fit.forward()
+    assert fit.losses()['contact'] == 0.0                # no contact labels at all
