@@ -27,9 +27,10 @@ int lemo_abi_version(void);
 /* ---- motion-smoothness encoder, models/AE_sep.py:11-30,77-99 (Enc(downsample=False)) ----------
  * Activations: CG8P layout act[C/8][(H+2)*(W+2)][8], zero 1-pixel border owned by the caller.
  * Weights: wt[tap][Cin/8][Cout][8] (packed by lemo_amd.priors.pack_conv3x3 / pack_conv3x3_bwd). */
-/* epi 0: out = lrelu(conv + bias) | 1: out = conv * lrelu'(aux) (backward-data) | 2: out = conv + bias */
+/* epi 0: out = lrelu(conv + bias) | 1: out = conv * lrelu'(aux) (backward-data) | 2: out = conv + bias
+ * variant 0: 4 waves x (32 px x Cout) per block | 1: CU-balanced geometry (256 full blocks + fine tail) */
 int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
-                      int H, int W, int cin, int cout, int epi, void* stream);
+                      int H, int W, int cin, int cout, int epi, int variant, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
@@ -113,6 +114,7 @@ typedef struct lemo_fit_const {
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
+  int conv_variant;               /* lemo_conv3x3_mfma variant used by the engine */
   lemo_vposer_w vposer;
   lemo_body_const body;
   lemo_skin_const skin;

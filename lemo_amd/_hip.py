@@ -70,6 +70,7 @@ class FitConst(C.Structure):
 class FitDesc(C.Structure):
     _fields_ = [
         ('B', C.c_int), ('Bp', C.c_int), ('V', C.c_int), ('nrows', C.c_int), ('full_vertices', C.c_int),
+        ('conv_variant', C.c_int),
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
         ('fwd_ids', vp),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
@@ -101,7 +102,7 @@ class LemoHipError(RuntimeError):
 
 _SIGS = {
     'lemo_abi_version': (C.c_int, []),
-    'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_smooth_loss_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),

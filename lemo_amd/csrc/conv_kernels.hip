@@ -114,16 +114,147 @@ conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 1 ("balanced"): the launch geometry is chosen for the 256 CUs x 4 SIMDs of the MI355X.
+//   * main blocks: 128 pixels x CPB couts; wave w = (32-pixel tile w&3, 32-cout tile w>>2), so a
+//     64-cout layer runs 8 waves per block = 2 waves per SIMD (they cover each other's load
+//     latency and share the activation lines through L1).  245x134 = 32830 px = 256 full blocks
+//     (one per CU) + 62 px.
+//   * tail blocks (the < 128 remaining pixels): 16 px x 16 cout units on v_mfma_f32_16x16x4_f32,
+//     one per wave, so the remainder costs ~1/8 of a main wave instead of doubling the makespan
+//     (a 257th main block would: all 256 CUs are already busy).
+//   * operands are prefetched two k-iterations ahead through a 3-deep register ring.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void conv_store4(float* __restrict__ out, const float* __restrict__ bias,
+                                            const float* __restrict__ aux, size_t o, int c0, float4 v) {
+  if (EPI == 0 || EPI == 2) {
+    const float4 bb = ld4(bias + c0);
+    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+  } else {
+    const float4 yy = ld4(aux + o);
+    v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
+    v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
+  }
+  st4(out + o, v);
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(512)
+conv3x3_mfma_v1_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                       const float* __restrict__ bias, const float* __restrict__ aux,
+                       float* __restrict__ out, int H, int W, int cin_g, int cout, int cpb, int full_blocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const size_t in_gstride = (size_t)HWp * 8;
+  const size_t wt_itstride = (size_t)cout * 8;
+  const int nit = 9 * cin_g;
+  const int cb = blockIdx.y * cpb;                              // first cout of this block column
+  if ((int)blockIdx.x < full_blocks) {
+    // ---------------- main path: 32 px x 32 cout per wave, 32x32x2 MFMA ----------------
+    const int j = lane & 31, h = lane >> 5;
+    const int p = (blockIdx.x * 4 + (wave & 3)) * 32 + j;       // always < P
+    const int m_base = cb + (wave >> 2) * 32;
+    const int y = p / W, x = p - y * W;
+    const int poff = (y + 1) * Wp + (x + 1);
+    const float* in_l = in + (size_t)poff * 8 + 4 * h;
+    const float* wt_l = wt + ((size_t)(m_base + j)) * 8 + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#define LEMO_LOAD(IT, A_, B_)                                                                     \
+    {                                                                                             \
+      const int it_ = (IT) < nit ? (IT) : nit - 1;                                                \
+      const int tap_ = it_ / cin_g, g_ = it_ - tap_ * cin_g;                                      \
+      const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                       \
+      B_ = ld4(in_l + (std::ptrdiff_t)(dy_ * Wp + dx_) * 8 + (size_t)g_ * in_gstride);            \
+      A_ = ld4(wt_l + (size_t)it_ * wt_itstride);                                                 \
+    }
+#define LEMO_MFMA4(A_, B_)                                                                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.x, B_.x, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.y, B_.y, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.z, B_.z, acc, 0, 0, 0);                         \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A_.w, B_.w, acc, 0, 0, 0);
+    float4 a0, b0, a1, b1, a2, b2;
+    LEMO_LOAD(0, a0, b0)
+    LEMO_LOAD(1, a1, b1)
+    for (int it = 0; it < nit; it += 3) {                       // nit = 9*cin_g is a multiple of 3
+      LEMO_LOAD(it + 2, a2, b2)
+      LEMO_MFMA4(a0, b0)
+      LEMO_LOAD(it + 3, a0, b0)
+      LEMO_MFMA4(a1, b1)
+      LEMO_LOAD(it + 4, a1, b1)
+      LEMO_MFMA4(a2, b2)
+    }
+#undef LEMO_LOAD
+#undef LEMO_MFMA4
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = m_base + q * 8 + 4 * h;
+      const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+      conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+    }
+  } else {
+    // ---------------- tail path: 16 px x 16 cout per wave, 16x16x4 MFMA ----------------
+    const int nwaves = blockDim.x >> 6;
+    const int unit = ((int)blockIdx.x - full_blocks) * nwaves + wave;
+    const int ct = cpb >> 4;                                     // cout tiles per px tile
+    const int pt = unit / ct, mt = unit - pt * ct;
+    const int p0 = full_blocks * 128 + pt * 16;
+    if (p0 >= P) return;                                         // uniform per wave
+    const int j = lane & 15, q4 = lane >> 4;                     // pixel / cout row ; k-quarter
+    const int p = p0 + j;
+    const int pc = p < P ? p : P - 1;
+    const int y = pc / W, x = pc - y * W;
+    const int poff = (y + 1) * Wp + (x + 1);
+    const int m_base = cb + mt * 16;
+    // 16 k per step = two 8-channel groups: quarter q4 reads group (2*gp + (q4>>1)), floats 4*(q4&1)..
+    const float* in_l = in + (size_t)poff * 8 + (size_t)(q4 >> 1) * in_gstride + 4 * (q4 & 1);
+    const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int gpairs = cin_g >> 1;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      for (int gp = 0; gp < gpairs; ++gp) {
+        const float4 b = ld4(in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8 + (size_t)(2 * gp) * in_gstride);
+        const float4 a = ld4(wt_l + (size_t)(tap * cin_g + 2 * gp) * wt_itstride);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    if (p < P) {
+      const int c0 = m_base + 4 * q4;                            // D: col = pixel j, rows 4*q4 + r
+      const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+      conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+  }
+}
+
 int conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
-                 int H, int W, int cin, int cout, int epi, hipStream_t s) {
-  if (cin % 8 || cout % 32 || H <= 0 || W <= 0) return LEMO_ERR_SHAPE;
+                 int H, int W, int cin, int cout, int epi, int variant, hipStream_t s) {
+  if (cin % 8 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
   const int P = H * W;
-  const int mt = (cout % 64 == 0) ? 2 : 1;
-  dim3 grid((P + 127) / 128, cout / (mt * 32));
+  if (variant == 0) {
+    const int mt = (cout % 64 == 0) ? 2 : 1;
+    dim3 grid((P + 127) / 128, cout / (mt * 32));
 #define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((conv3x3_mfma_kernel<MT_, EPI_>), grid, dim3(256), 0, s, in, wt, bias, aux, out, H, W, cin / 8, cout)
-  if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
-  else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
+    if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
+    else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
 #undef LAUNCH
+    return (int)hipGetLastError();
+  }
+  if (variant != 1 || (cin % 16)) return LEMO_ERR_ARG;
+  const int cpb = (cout % 64 == 0) ? 64 : 32;                    // couts per block: 8 or 4 waves
+  const int nw = 4 * (cpb / 32);
+  const int full = P / 128, rem = P - full * 128;
+  const int units = ((rem + 15) / 16) * (cpb / 16);
+  dim3 grid(full + (units + nw - 1) / nw, cout / cpb);
+#define LAUNCH1(EPI_) hipLaunchKernelGGL((conv3x3_mfma_v1_kernel<EPI_>), grid, dim3(64 * nw), 0, s, in, wt, bias, aux, out, H, W, cin / 8, cout, cpb, full)
+  if (epi == 0) LAUNCH1(0); else if (epi == 1) LAUNCH1(1); else LAUNCH1(2);
+#undef LAUNCH1
   return (int)hipGetLastError();
 }
 

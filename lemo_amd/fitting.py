@@ -33,7 +33,8 @@ class AmassTemporalFitter:
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
-                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, lib: Optional[_hip.HipLib] = None):
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: int = 1,
+                 lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
         if not self.lib.is_emu and self.device.type != 'cuda':
@@ -107,6 +108,7 @@ class AmassTemporalFitter:
 
         d = _hip.FitDesc()
         d.B, d.Bp, d.V, d.nrows, d.full_vertices = B, Bp, data.V, self.nrows, int(self.full)
+        self.conv_variant = d.conv_variant = int(conv_variant)
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
         d.fwd_ids = ptr(I['fwd_ids'])
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
