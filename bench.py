@@ -57,14 +57,19 @@ def time_dominant_kernel(fit, stream, reps=50):
     from lemo_amd._hip import ptr
     lib = fit.lib
     H, W = fit.H, fit.W
-    args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0, fit.conv_variant)
+    if fit.conv_variant == 2:
+        fn = lib.conv3x3_mfma_lds
+        args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.w2[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
+    else:
+        fn = lib.conv3x3_mfma
+        args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0, fit.conv_variant)
     with torch.cuda.stream(stream):
         for _ in range(5):
-            lib.check(lib.conv3x3_mfma(*args, stream.cuda_stream))
+            lib.check(fn(*args, stream.cuda_stream))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):
-            lib.check(lib.conv3x3_mfma(*args, stream.cuda_stream))
+            lib.check(fn(*args, stream.cuda_stream))
         e1.record(stream)
     e1.synchronize()
     fit.dact[1].zero_()                    # scratch again (border must stay zero; interior rewritten each step)
@@ -120,7 +125,7 @@ def main():
     ap.add_argument('--active-vertices-only', action='store_true',
                     help='forward only the 253 vertices the losses read (NOT the headline config)')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--conv-variant', type=int, default=1)
+    ap.add_argument('--conv-variant', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -31,6 +31,10 @@ int lemo_abi_version(void);
  * variant 0: 4 waves x (32 px x Cout) per block | 1: CU-balanced geometry (256 full blocks + fine tail) */
 int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
                       int H, int W, int cin, int cout, int epi, int variant, void* stream);
+/* LDS-tiled variant (the engine's default): additionally takes the channel-group-major pack
+ * wt2[Cin/8][tap][Cout][8]; W must satisfy 127 + 2*(127/W+1) + 2*(W+2) + 3 <= 416 (W <= 139) */
+int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux,
+                          float* out, int H, int W, int cin, int cout, int epi, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
@@ -114,7 +118,7 @@ typedef struct lemo_fit_const {
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
-  int conv_variant;               /* lemo_conv3x3_mfma variant used by the engine */
+  int conv_variant;               /* 0/1: lemo_conv3x3_mfma variants ; 2: lemo_conv3x3_mfma_lds */
   lemo_vposer_w vposer;
   lemo_body_const body;
   lemo_skin_const skin;
@@ -126,6 +130,8 @@ typedef struct lemo_fit_desc {
   const float* enc_w[10];         /* layer 0: [Cout][9] ; others packed wt[tap][Cin/8][Cout][8] */
   const float* enc_b[10];
   const float* enc_wbwd[10];      /* backward-data packs (layer 0: same [Cout][9]) */
+  const float* enc_w2[10];        /* channel-group-major packs for conv_variant 2 (layer 0 unused) */
+  const float* enc_wbwd2[10];
   /* sequence data */
   const float* target;            /* [B][n67][3]  markers_rec */
   const float* contact;           /* [B][4] */

@@ -74,6 +74,7 @@ class FitDesc(C.Structure):
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
         ('fwd_ids', vp),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
+        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10),
         ('target', vp), ('contact', vp), ('weights', vp), ('weights_host', C.c_float * 6),
         ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
         ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
@@ -103,6 +104,7 @@ class LemoHipError(RuntimeError):
 _SIGS = {
     'lemo_abi_version': (C.c_int, []),
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_smooth_loss_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),

@@ -233,6 +233,151 @@ conv3x3_mfma_v1_kernel(const float* __restrict__ in, const float* __restrict__ w
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 2 ("LDS-tiled"): same CU-balanced geometry as variant 1, but the operands of the main
+// blocks go through LDS.  Per 8-channel group the block stages ONCE
+//     Bs: the 128-pixel tile plus its 3x3 halo (<= 404 padded pixels x 32 B = 12.9 KB)
+//     As: the 9 taps x CPB couts of that group (18 KB for 64 couts; weights packed g-major: wt2)
+// and all 9 taps x 8 waves read them with conflict-free ds_read_b128 (planes split by lane half h:
+// Xs[h][idx][4]) instead of 16x redundant L1/L2 requests per k-step.  Staging is register-staged
+// and double-buffered: global loads for group g+1 are issued before the 36 MFMAs of group g and
+// written to the other LDS buffer after them (one barrier per group).
+// ------------------------------------------------------------------------------------------------
+#define CV2_NPX 416
+template <int EPI, int NT>          // NT threads: 512 (cpb 64) or 256 (cpb 32)
+__global__ void __launch_bounds__(NT)
+conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ wt2,
+                       const float* __restrict__ bias, const float* __restrict__ aux,
+                       float* __restrict__ out, int H, int W, int cin_g, int cout, int full_blocks) {
+  constexpr int CPB = NT / 8;                                   // couts per block (64 or 32)
+  constexpr int NCH_A = 18 * CPB;                               // 16-B chunks of one group's weights
+  constexpr int MAXCH = (2 * CV2_NPX + NCH_A + NT - 1) / NT;
+  __shared__ float Bs[2][2][CV2_NPX][4];
+  __shared__ float As[2][9][2][CPB][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const size_t in_gstride = (size_t)HWp * 8;
+  const int cb = blockIdx.y * CPB;
+  if ((int)blockIdx.x < full_blocks) {
+    const int j = lane & 31, h = lane >> 5;
+    const int pfirst = blockIdx.x * 128, plast = pfirst + 127;
+    const int yf = pfirst / W, yl = plast / W;
+    const int q0 = (yf + 1) * Wp + (pfirst - yf * W + 1), q1 = (yl + 1) * Wp + (plast - yl * W + 1);
+    const int qin = q0 - Wp - 1;                                 // first staged padded pixel
+    const int npx = q1 - q0 + 2 * Wp + 3;                        // staged pixels (<= CV2_NPX, checked on host)
+    const int p = pfirst + (wave & 3) * 32 + j;
+    const int y = p / W, x = p - y * W;
+    const int poff = (y + 1) * Wp + (x + 1);
+    const int li = poff - qin;                                   // local index of the centre tap
+    const int mt = wave >> 2;                                    // cout tile of this wave
+    const int nchB = 2 * npx, nch = nchB + NCH_A;
+    float4 st[MAXCH];
+    // chunk c < nchB: activation (px = c>>1, half = c&1); else weight chunk
+#define CV2_LOAD(G)                                                                               \
+    _Pragma("unroll") for (int k = 0; k < MAXCH; ++k) {                                           \
+      const int c = threadIdx.x + k * NT;                                                         \
+      if (c < nchB) st[k] = ld4(in + (size_t)(G) * in_gstride + (size_t)qin * 8 + (size_t)c * 4);  \
+      else if (c < nch) {                                                                         \
+        const int ca = c - nchB, tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;                    \
+        st[k] = ld4(wt2 + ((size_t)((G) * 9 + tap) * cout + cb) * 8 + (size_t)r * 4);             \
+      }                                                                                           \
+    }
+#define CV2_STORE(BUF)                                                                            \
+    _Pragma("unroll") for (int k = 0; k < MAXCH; ++k) {                                           \
+      const int c = threadIdx.x + k * NT;                                                         \
+      if (c < nchB) st4(&Bs[BUF][c & 1][c >> 1][0], st[k]);                                       \
+      else if (c < nch) {                                                                         \
+        const int ca = c - nchB, tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;                    \
+        st4(&As[BUF][tap][r & 1][r >> 1][0], st[k]);                                              \
+      }                                                                                           \
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    CV2_LOAD(0)
+    CV2_STORE(0)
+    __syncthreads();
+    for (int g = 0; g < cin_g; ++g) {
+      const int buf = g & 1;
+      if (g + 1 < cin_g) { CV2_LOAD(g + 1) }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const float4 a = ld4(&As[buf][tap][h][mt * 32 + j][0]);
+        const float4 b = ld4(&Bs[buf][h][li + dy * Wp + dx][0]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+      if (g + 1 < cin_g) { CV2_STORE(buf ^ 1) }
+      __syncthreads();
+    }
+#undef CV2_LOAD
+#undef CV2_STORE
+    const int m_base = cb + mt * 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = m_base + q * 8 + 4 * h;
+      const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+      conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+    }
+  } else {
+    // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`), as in variant 1
+    const size_t wt_itstride = (size_t)cout * 8;
+    const int nwaves = NT >> 6;
+    const int unit = ((int)blockIdx.x - full_blocks) * nwaves + wave;
+    const int ct = CPB >> 4;
+    const int pt = unit / ct, mt = unit - pt * ct;
+    const int p0 = full_blocks * 128 + pt * 16;
+    if (p0 >= P) return;
+    const int j = lane & 15, q4 = lane >> 4;
+    const int p = p0 + j;
+    const int pc = p < P ? p : P - 1;
+    const int y = pc / W, x = pc - y * W;
+    const int poff = (y + 1) * Wp + (x + 1);
+    const int m_base = cb + mt * 16;
+    const float* in_l = in + (size_t)poff * 8 + (size_t)(q4 >> 1) * in_gstride + 4 * (q4 & 1);
+    const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int gpairs = cin_g >> 1;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      for (int gp = 0; gp < gpairs; ++gp) {
+        const float4 b = ld4(in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8 + (size_t)(2 * gp) * in_gstride);
+        const float4 a = ld4(wt_l + (size_t)(tap * cin_g + 2 * gp) * wt_itstride);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    if (p < P) {
+      const int c0 = m_base + 4 * q4;
+      const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+      conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
+  }
+}
+
+int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
+                     int H, int W, int cin, int cout, int epi, hipStream_t s) {
+  if (cin % 16 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
+  // staged pixels of a 128-pixel run: 127 + 2 per row end crossed + two halo rows + 3
+  if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV2_NPX) return LEMO_ERR_SHAPE;
+  const int P = H * W;
+  const int cpb = (cout % 64 == 0) ? 64 : 32;
+  const int nw = cpb / 8;
+  const int full = P / 128, rem = P - full * 128;
+  const int units = ((rem + 15) / 16) * (cpb / 16);
+  dim3 grid(full + (units + nw - 1) / nw, cout / cpb);
+#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full)
+  if (cpb == 64) { if (epi == 0) LAUNCH2(0, 512); else if (epi == 1) LAUNCH2(1, 512); else LAUNCH2(2, 512); }
+  else           { if (epi == 0) LAUNCH2(0, 256); else if (epi == 1) LAUNCH2(1, 256); else LAUNCH2(2, 256); }
+#undef LAUNCH2
+  return (int)hipGetLastError();
+}
+
 int conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
                  int H, int W, int cin, int cout, int epi, int variant, hipStream_t s) {
   if (cin % 8 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;

@@ -19,6 +19,11 @@ int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const
   if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma(in, wt, bias, aux, out, H, W, cin, cout, epi, variant, S(stream));
 }
+int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux,
+                          float* out, int H, int W, int cin, int cout, int epi, void* stream) {
+  if (!in || !wt || !wt2 || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
+  return conv3x3_mfma_lds(in, wt, wt2, bias, aux, out, H, W, cin, cout, epi, S(stream));
+}
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream) {
   return conv3x3_c1(x0, w, bias, out, H, W, cout, S(stream));
 }
@@ -96,8 +101,12 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s) {
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
   CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
   CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
-  for (int l = 1; l < 10; ++l)
-    CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, d.conv_variant, s));
+  for (int l = 1; l < 10; ++l) {
+    if (d.conv_variant == 2)
+      CHK(conv3x3_mfma_lds(d.act[l], d.enc_w[l], d.enc_w2[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
+    else
+      CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, d.conv_variant, s));
+  }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
   CHK(smooth_loss(d.act[10], d.dact[0], d.spartial, H, W, d.enc_ch[10], coef2, s));
@@ -112,7 +121,10 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   int cur = 0;
   for (int l = 9; l >= 1; --l) {   // d(pre-act of layer l+1) -> d(pre-act of layer l)
-    CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, d.conv_variant, s));
+    if (d.conv_variant == 2)
+      CHK(conv3x3_mfma_lds(d.dact[cur], d.enc_wbwd[l], d.enc_wbwd2[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
+    else
+      CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, d.conv_variant, s));
     cur = 1 - cur;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));

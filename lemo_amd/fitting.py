@@ -33,7 +33,7 @@ class AmassTemporalFitter:
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
-                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: int = 1,
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: int = 2,
                  lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
@@ -108,12 +108,15 @@ class AmassTemporalFitter:
 
         d = _hip.FitDesc()
         d.B, d.Bp, d.V, d.nrows, d.full_vertices = B, Bp, data.V, self.nrows, int(self.full)
+        if int(conv_variant) == 2 and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
+            conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124)
         self.conv_variant = d.conv_variant = int(conv_variant)
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
         d.fwd_ids = ptr(I['fwd_ids'])
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
         for l in range(10):
             d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
+            d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
         d.target, d.contact, d.weights = ptr(self.target), ptr(self.contact), ptr(self._w_dev)
         for i, v in enumerate(wl): d.weights_host[i] = v
         d.transl, d.rot6d, d.other, d.shape = (ptr(self.P[k]) for k in ('transl', 'rot6d', 'other', 'shape'))

@@ -39,6 +39,15 @@ def pack_conv3x3_bwd(w: np.ndarray) -> np.ndarray:
     return pack_conv3x3(np.ascontiguousarray(wf))
 
 
+def pack_conv3x3_gmajor(w: np.ndarray) -> np.ndarray:
+    """[Cout][Cin][3][3] -> wt2[Cin/8][tap][Cout][8] (LDS-tiled kernel: one channel group = 9 contiguous taps)."""
+    return np.ascontiguousarray(pack_conv3x3(w).transpose(1, 0, 2, 3))
+
+
+def pack_conv3x3_bwd_gmajor(w: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(pack_conv3x3_bwd(w).transpose(1, 0, 2, 3))
+
+
 def cg8p_alloc(C_: int, H: int, W: int, device) -> torch.Tensor:
     """zeroed CG8P activation buffer [C/8][(H+2)*(W+2)][8] (border stays zero forever)."""
     return torch.zeros(max(C_ // 8, 1), (H + 2) * (W + 2), 8, dtype=torch.float32, device=device)
@@ -63,7 +72,7 @@ class EncWeights:
     def __init__(self, state: Dict[str, np.ndarray], device):
         self.keys = enc_layer_keys()
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
-        self.w, self.b, self.wbwd = [], [], []
+        self.w, self.b, self.wbwd, self.w2, self.wbwd2 = [], [], [], [], []
         for li, k in enumerate(self.keys):
             w = np.asarray(state[k + '.weight'], np.float32)
             b = np.asarray(state[k + '.bias'], np.float32)
@@ -71,7 +80,10 @@ class EncWeights:
             if li == 0:
                 self.w.append(t(w.reshape(w.shape[0], 9)))
                 self.wbwd.append(self.w[0])
+                self.w2.append(self.w[0]); self.wbwd2.append(self.w[0])
             else:
                 self.w.append(t(pack_conv3x3(w)))
                 self.wbwd.append(t(pack_conv3x3_bwd(w)))
+                self.w2.append(t(pack_conv3x3_gmajor(w)))
+                self.wbwd2.append(t(pack_conv3x3_bwd_gmajor(w)))
             self.b.append(t(b))

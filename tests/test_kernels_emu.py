@@ -16,17 +16,22 @@ from lemo_amd.priors import cg8p_alloc, from_cg8p, pack_conv3x3, pack_conv3x3_bw
 from oracle import lemo_oracle as O
 
 
-@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 @pytest.mark.parametrize('ci,co', [(8, 32), (32, 64), (64, 64), (64, 32)])
 def test_conv3x3_mfma_forward_and_backward_data(emu_lib, ci, co, variant):
-    if variant == 1 and ci % 16:
-        pytest.skip('balanced variant needs Cin % 16 == 0')
+    if variant >= 1 and ci % 16:
+        pytest.skip('balanced / LDS variants need Cin % 16 == 0')
+    from lemo_amd.priors import pack_conv3x3_gmajor, pack_conv3x3_bwd_gmajor
     g = torch.Generator().manual_seed(ci + co)
     H, W = 7, 41                                        # P = 287 = 2 full 128-px blocks + 31 (ragged tail)
     x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
     ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
     xin, out, wt = to_cg8p(x), cg8p_alloc(co, H, W, 'cpu'), torch.from_numpy(pack_conv3x3(w.numpy()))
-    assert emu_lib.conv3x3_mfma(ptr(xin), ptr(wt), ptr(b), None, ptr(out), H, W, ci, co, 0, variant, None) == 0
+    if variant == 2:
+        wt2 = torch.from_numpy(pack_conv3x3_gmajor(w.numpy()))
+        assert emu_lib.conv3x3_mfma_lds(ptr(xin), ptr(wt), ptr(wt2), ptr(b), None, ptr(out), H, W, ci, co, 0, None) == 0
+    else:
+        assert emu_lib.conv3x3_mfma(ptr(xin), ptr(wt), ptr(b), None, ptr(out), H, W, ci, co, 0, variant, None) == 0
     assert rel_err(from_cg8p(out, H, W), ref) < 2e-6
     assert float(out.reshape(co // 8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0       # border untouched
     if ci % 32 == 0:
@@ -36,7 +41,11 @@ def test_conv3x3_mfma_forward_and_backward_data(emu_lib, ci, co, variant):
         refdx = xr.grad * torch.where(aux > 0, 1.0, 0.2)
         dyb, auxb, dxb = to_cg8p(dy), to_cg8p(aux), cg8p_alloc(ci, H, W, 'cpu')
         wtb = torch.from_numpy(pack_conv3x3_bwd(w.numpy()))
-        assert emu_lib.conv3x3_mfma(ptr(dyb), ptr(wtb), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, variant, None) == 0
+        if variant == 2:
+            wtb2 = torch.from_numpy(pack_conv3x3_bwd_gmajor(w.numpy()))
+            assert emu_lib.conv3x3_mfma_lds(ptr(dyb), ptr(wtb), ptr(wtb2), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, None) == 0
+        else:
+            assert emu_lib.conv3x3_mfma(ptr(dyb), ptr(wtb), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, variant, None) == 0
         assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
 
 
