@@ -35,6 +35,10 @@ int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const
  * wt2[Cin/8][tap][Cout][8]; W must satisfy 127 + 2*(127/W+1) + 2*(W+2) + 3 <= 416 (W <= 139) */
 int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux,
                           float* out, int H, int W, int cin, int cout, int epi, void* stream);
+/* diagnostics: same launch (epi 0, Cout % 64 == 0) that also records, per wave, {HW_ID, XCC_ID, start, end}
+ * shader-clock stamps into dbg[(block*8 + wave)*4 ..] -- used by tools/conv_census.py only */
+int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
+                                 int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);

@@ -105,6 +105,7 @@ _SIGS = {
     'lemo_abi_version': (C.c_int, []),
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma_lds_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_smooth_loss_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),

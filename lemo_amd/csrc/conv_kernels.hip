@@ -244,16 +244,21 @@ conv3x3_mfma_v1_kernel(const float* __restrict__ in, const float* __restrict__ w
 // written to the other LDS buffer after them (one barrier per group).
 // ------------------------------------------------------------------------------------------------
 #define CV2_NPX 416
-template <int EPI, int NT>          // NT threads: 512 (cpb 64) or 256 (cpb 32)
+template <int EPI, int NT, bool DBG = false>          // NT threads: 512 (cpb 64) or 256 (cpb 32)
 __global__ void __launch_bounds__(NT)
 conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ wt2,
                        const float* __restrict__ bias, const float* __restrict__ aux,
-                       float* __restrict__ out, int H, int W, int cin_g, int cout, int full_blocks) {
+                       float* __restrict__ out, int H, int W, int cin_g, int cout, int full_blocks,
+                       unsigned long long* __restrict__ dbg) {
+  unsigned long long t_start = 0;
+  if (DBG) t_start = __builtin_amdgcn_s_memtime();
   constexpr int CPB = NT / 8;                                   // couts per block (64 or 32)
   constexpr int NCH_A = 18 * CPB;                               // 16-B chunks of one group's weights
-  constexpr int MAXCH = (2 * CV2_NPX + NCH_A + NT - 1) / NT;
-  __shared__ float Bs[2][2][CV2_NPX][4];
-  __shared__ float As[2][9][2][CPB][4];
+  constexpr int B_BUF = 2 * CV2_NPX * 4;                        // floats per activation buffer [2 planes][NPX][4]
+  constexpr int A_BUF = 9 * 2 * CPB * 4;                        // floats per weight buffer [9][2 planes][CPB][4]
+  constexpr int A_OFF = 2 * B_BUF;
+  // ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read), 16-B aligned
+  __shared__ __attribute__((aligned(16))) float smem[2 * B_BUF + 2 * A_BUF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const size_t in_gstride = (size_t)HWp * 8;
@@ -271,56 +276,89 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int li = poff - qin;                                   // local index of the centre tap
     const int mt = wave >> 2;                                    // cout tile of this wave
     const int nchB = 2 * npx, nch = nchB + NCH_A;
-    float4 st[MAXCH];
-    // chunk c < nchB: activation (px = c>>1, half = c&1); else weight chunk
-#define CV2_LOAD(G)                                                                               \
-    _Pragma("unroll") for (int k = 0; k < MAXCH; ++k) {                                           \
-      const int c = threadIdx.x + k * NT;                                                         \
-      if (c < nchB) st[k] = ld4(in + (size_t)(G) * in_gstride + (size_t)qin * 8 + (size_t)c * 4);  \
-      else if (c < nch) {                                                                         \
-        const int ca = c - nchB, tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;                    \
-        st[k] = ld4(wt2 + ((size_t)((G) * 9 + tap) * cout + cb) * 8 + (size_t)r * 4);             \
-      }                                                                                           \
+    // Staging plan of this thread: NB activation chunks (16 B: pixel c>>1, half c&1) and NA weight
+    // chunks per channel group.  Every slot issues an UNCONDITIONAL global load (out-of-range slots
+    // re-read the last chunk) so that all loads of a group are in flight together and stay
+    // global_load (a pointer select would degrade them to flat_load, which also bumps lgkmcnt and
+    // would stall the ds_read waits); only the LDS write is predicated.
+    constexpr int NB = (2 * CV2_NPX + NT - 1) / NT, NA = (NCH_A + NT - 1) / NT;
+    unsigned offB[NB], offA[NA];
+    int dstB[NB], dstA[NA];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      int c = threadIdx.x + k * NT;
+      const bool ok = c < nchB;
+      if (!ok) c = nchB - 1;
+      offB[k] = (unsigned)qin * 8u + (unsigned)c * 4u;
+      dstB[k] = ok ? ((c & 1) * CV2_NPX + (c >> 1)) * 4 : -1;
     }
-#define CV2_STORE(BUF)                                                                            \
-    _Pragma("unroll") for (int k = 0; k < MAXCH; ++k) {                                           \
-      const int c = threadIdx.x + k * NT;                                                         \
-      if (c < nchB) st4(&Bs[BUF][c & 1][c >> 1][0], st[k]);                                       \
-      else if (c < nch) {                                                                         \
-        const int ca = c - nchB, tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;                    \
-        st4(&As[BUF][tap][r & 1][r >> 1][0], st[k]);                                              \
-      }                                                                                           \
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      int ca = threadIdx.x + k * NT;
+      const bool ok = ca < NCH_A;
+      if (!ok) ca = NCH_A - 1;
+      const int tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;
+      offA[k] = ((unsigned)tap * cout + cb) * 8u + (unsigned)r * 4u;
+      dstA[k] = ok ? A_OFF + ((tap * 2 + (r & 1)) * CPB + (r >> 1)) * 4 : -1;
     }
+    const size_t wt_gstride = (size_t)9 * cout * 8;
+    float4 stB[NB], stA[NA];
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    CV2_LOAD(0)
-    CV2_STORE(0)
+#pragma unroll
+    for (int k = 0; k < NB; ++k) stB[k] = ld4(in + offB[k]);
+#pragma unroll
+    for (int k = 0; k < NA; ++k) stA[k] = ld4(wt2 + offA[k]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) if (dstB[k] >= 0) st4(&smem[dstB[k]], stB[k]);
+#pragma unroll
+    for (int k = 0; k < NA; ++k) if (dstA[k] >= 0) st4(&smem[dstA[k]], stA[k]);
     __syncthreads();
+    const float* a_rd = &smem[A_OFF + (h * CPB + mt * 32 + j) * 4];
+    const float* b_rd = &smem[(h * CV2_NPX + li) * 4];
     for (int g = 0; g < cin_g; ++g) {
       const int buf = g & 1;
-      if (g + 1 < cin_g) { CV2_LOAD(g + 1) }
+      if (g + 1 < cin_g) {
+        const float* ing = in + (size_t)(g + 1) * in_gstride;
+        const float* wtg = wt2 + (size_t)(g + 1) * wt_gstride;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) stB[k] = ld4(ing + offB[k]);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) stA[k] = ld4(wtg + offA[k]);
+      }
+      const float* ar = a_rd + buf * A_BUF;
+      const float* br = b_rd + buf * B_BUF;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const float4 a = ld4(&As[buf][tap][h][mt * 32 + j][0]);
-        const float4 b = ld4(&Bs[buf][h][li + dy * Wp + dx][0]);
+        const float4 a = ld4(ar + tap * (2 * CPB * 4));
+        const float4 b = ld4(br + (dy * Wp + dx) * 4);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
       }
-      if (g + 1 < cin_g) { CV2_STORE(buf ^ 1) }
+      if (g + 1 < cin_g) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (dstB[k] >= 0) st4(&smem[dstB[k] + (buf ^ 1) * B_BUF], stB[k]);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) if (dstA[k] >= 0) st4(&smem[dstA[k] + (buf ^ 1) * A_BUF], stA[k]);
+      }
       __syncthreads();
     }
-#undef CV2_LOAD
-#undef CV2_STORE
     const int m_base = cb + mt * 32;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c0 = m_base + q * 8 + 4 * h;
       const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
       conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+    }
+    if (DBG && lane == 0) {           // census: where and when did this wave run
+      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 4;
+      r[0] = __builtin_amdgcn_s_getreg(63492);        // HW_REG_HW_ID
+      r[1] = __builtin_amdgcn_s_getreg(63508);        // HW_REG_XCC_ID
+      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime();
     }
   } else {
     // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`), as in variant 1
@@ -341,15 +379,22 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
     const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int gpairs = cin_g >> 1;
+    // gpairs is 2 or 4 (Cin 32 / 64): two group pairs (4 loads) in flight per step
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      for (int gp = 0; gp < gpairs; ++gp) {
-        const float4 b = ld4(in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8 + (size_t)(2 * gp) * in_gstride);
-        const float4 a = ld4(wt_l + (size_t)(tap * cin_g + 2 * gp) * wt_itstride);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+      const float* ib = in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8;
+      const float* wb = wt_l + (size_t)(tap * cin_g) * wt_itstride;
+      for (int gp = 0; gp < gpairs; gp += 2) {
+        const float4 b0 = ld4(ib + (size_t)(2 * gp) * in_gstride), b1 = ld4(ib + (size_t)(2 * gp + 2) * in_gstride);
+        const float4 a0 = ld4(wb + (size_t)(2 * gp) * wt_itstride), a1 = ld4(wb + (size_t)(2 * gp + 2) * wt_itstride);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
       }
     }
     if (p < P) {
@@ -357,11 +402,17 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
       conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
+    if (DBG && lane == 0) {
+      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 4;
+      r[0] = __builtin_amdgcn_s_getreg(63492);
+      r[1] = __builtin_amdgcn_s_getreg(63508);
+      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime();
+    }
   }
 }
 
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
-                     int H, int W, int cin, int cout, int epi, hipStream_t s) {
+                     int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg) {
   if (cin % 16 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
   // staged pixels of a 128-pixel run: 127 + 2 per row end crossed + two halo rows + 3
   if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV2_NPX) return LEMO_ERR_SHAPE;
@@ -371,7 +422,12 @@ int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const f
   const int full = P / 128, rem = P - full * 128;
   const int units = ((rem + 15) / 16) * (cpb / 16);
   dim3 grid(full + (units + nw - 1) / nw, cout / cpb);
-#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full)
+  if (dbg) {                                 // census build of the forward 64-cout kernel (tools/conv_census.py)
+    if (cpb != 64 || epi != 0) return LEMO_ERR_ARG;
+    hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<0, 512, true>), grid, dim3(512), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, dbg);
+    return (int)hipGetLastError();
+  }
+#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, (unsigned long long*)nullptr)
   if (cpb == 64) { if (epi == 0) LAUNCH2(0, 512); else if (epi == 1) LAUNCH2(1, 512); else LAUNCH2(2, 512); }
   else           { if (epi == 0) LAUNCH2(0, 256); else if (epi == 1) LAUNCH2(1, 256); else LAUNCH2(2, 256); }
 #undef LAUNCH2

@@ -24,6 +24,11 @@ int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, co
   if (!in || !wt || !wt2 || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma_lds(in, wt, wt2, bias, aux, out, H, W, cin, cout, epi, S(stream));
 }
+int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
+                                 int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
+  if (!in || !wt || !wt2 || !out || !bias || !dbg) return LEMO_ERR_ARG;
+  return conv3x3_mfma_lds(in, wt, wt2, bias, nullptr, out, H, W, cin, cout, 0, S(stream), dbg);
+}
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream) {
   return conv3x3_c1(x0, w, bias, out, H, W, cout, S(stream));
 }

@@ -280,6 +280,9 @@ static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (floa
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
+static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
+
 // ---- math -----------------------------------------------------------------------------------
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
