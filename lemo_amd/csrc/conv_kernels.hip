@@ -140,6 +140,58 @@ __device__ __forceinline__ void conv_store4(float* __restrict__ out, const float
   st4(out + o, v);
 }
 
+// One tail unit: 16 pixels x 16 couts over the full K = 9*Cin on v_mfma_f32_16x16x4_f32, operands
+// straight from global memory (tap-major pack).  The unit runs next to the main blocks, so it must
+// not be latency-bound: all loads of THREE taps (6*GP dwordx4 per lane) are issued before their
+// MFMAs (3 exposed round trips instead of one per k-step).
+template <int EPI, int GP>          // GP = Cin/16 channel-group pairs (2 or 4)
+__device__ __forceinline__ void conv_tail_unit(const float* __restrict__ in, const float* __restrict__ wt,
+                                               const float* __restrict__ bias, const float* __restrict__ aux,
+                                               float* __restrict__ out, int H, int W, int cout, int m_base, int p0) {
+  const int lane = threadIdx.x & 63;
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const size_t in_gstride = (size_t)HWp * 8, wt_itstride = (size_t)cout * 8;
+  const int j = lane & 15, q4 = lane >> 4;                       // pixel / cout row ; k-quarter
+  const int p = p0 + j;
+  const int pc = p < P ? p : P - 1;
+  const int y = pc / W, x = pc - y * W;
+  const int poff = (y + 1) * Wp + (x + 1);
+  // 16 k per step = two 8-channel groups: quarter q4 reads group (2*gp + (q4>>1)), floats 4*(q4&1)..
+  const float* in_l = in + (size_t)poff * 8 + (size_t)(q4 >> 1) * in_gstride + 4 * (q4 & 1);
+  const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int t3 = 0; t3 < 3; ++t3) {
+    float4 a[3][GP], b[3][GP];
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+      const int tap = t3 * 3 + tt, dy = t3 - 1, dx = tt - 1;
+#pragma unroll
+      for (int gp = 0; gp < GP; ++gp) {
+        b[tt][gp] = ld4(in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8 + (size_t)(2 * gp) * in_gstride);
+        a[tt][gp] = ld4(wt_l + (size_t)(tap * 2 * GP + 2 * gp) * wt_itstride);
+      }
+    }
+    // pin the schedule: every load above is issued before the first MFMA below (hipcc otherwise
+    // sinks the loads next to their uses to save registers and waits vmcnt(0) after each one)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+      for (int gp = 0; gp < GP; ++gp) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][gp].x, b[tt][gp].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][gp].y, b[tt][gp].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][gp].z, b[tt][gp].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][gp].w, b[tt][gp].w, acc, 0, 0, 0);
+      }
+  }
+  if (p < P) {
+    const int c0 = m_base + 4 * q4;                              // D: col = pixel j, rows 4*q4 + r
+    const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+    conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  }
+}
+
 template <int EPI>
 __global__ void __launch_bounds__(512)
 conv3x3_mfma_v1_kernel(const float* __restrict__ in, const float* __restrict__ wt,
@@ -248,8 +300,11 @@ template <int EPI, int NT, bool DBG = false>          // NT threads: 512 (cpb 64
 __global__ void __launch_bounds__(NT)
 conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ wt2,
                        const float* __restrict__ bias, const float* __restrict__ aux,
-                       float* __restrict__ out, int H, int W, int cin_g, int cout, int full_blocks,
+                       float* __restrict__ out, int H, int W, int cin_g, int cout, int full_blocks, int tail_blocks,
                        unsigned long long* __restrict__ dbg) {
+  // Tail blocks take the LOWEST block ids: they are dispatched first, so their waves are the oldest
+  // on the SIMDs they share with a main block and win the (age-ordered) issue arbitration instead of
+  // starving behind it (measured: dispatched last they ran 1.35x longer than a main wave).
   unsigned long long t_start = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
   constexpr int CPB = NT / 8;                                   // couts per block (64 or 32)
@@ -263,9 +318,9 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const size_t in_gstride = (size_t)HWp * 8;
   const int cb = blockIdx.y * CPB;
-  if ((int)blockIdx.x < full_blocks) {
+  if ((int)blockIdx.x >= tail_blocks) {
     const int j = lane & 31, h = lane >> 5;
-    const int pfirst = blockIdx.x * 128, plast = pfirst + 127;
+    const int pfirst = ((int)blockIdx.x - tail_blocks) * 128, plast = pfirst + 127;
     const int yf = pfirst / W, yl = plast / W;
     const int q0 = (yf + 1) * Wp + (pfirst - yf * W + 1), q1 = (yl + 1) * Wp + (plast - yl * W + 1);
     const int qin = q0 - Wp - 1;                                 // first staged padded pixel
@@ -361,46 +416,15 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime();
     }
   } else {
-    // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`), as in variant 1
-    const size_t wt_itstride = (size_t)cout * 8;
+    // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`)
     const int nwaves = NT >> 6;
-    const int unit = ((int)blockIdx.x - full_blocks) * nwaves + wave;
+    const int unit = (int)blockIdx.x * nwaves + wave;
     const int ct = CPB >> 4;
-    const int pt = unit / ct, mt = unit - pt * ct;
+    const int pt = unit / ct, mtl = unit - pt * ct;
     const int p0 = full_blocks * 128 + pt * 16;
-    if (p0 >= P) return;
-    const int j = lane & 15, q4 = lane >> 4;
-    const int p = p0 + j;
-    const int pc = p < P ? p : P - 1;
-    const int y = pc / W, x = pc - y * W;
-    const int poff = (y + 1) * Wp + (x + 1);
-    const int m_base = cb + mt * 16;
-    const float* in_l = in + (size_t)poff * 8 + (size_t)(q4 >> 1) * in_gstride + 4 * (q4 & 1);
-    const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int gpairs = cin_g >> 1;
-    // gpairs is 2 or 4 (Cin 32 / 64): two group pairs (4 loads) in flight per step
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const float* ib = in_l + (std::ptrdiff_t)(dy * Wp + dx) * 8;
-      const float* wb = wt_l + (size_t)(tap * cin_g) * wt_itstride;
-      for (int gp = 0; gp < gpairs; gp += 2) {
-        const float4 b0 = ld4(ib + (size_t)(2 * gp) * in_gstride), b1 = ld4(ib + (size_t)(2 * gp + 2) * in_gstride);
-        const float4 a0 = ld4(wb + (size_t)(2 * gp) * wt_itstride), a1 = ld4(wb + (size_t)(2 * gp + 2) * wt_itstride);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
-      }
-    }
-    if (p < P) {
-      const int c0 = m_base + 4 * q4;
-      const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
-      conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    if (p0 < P) {                                                // uniform per wave
+      if (cin_g == 8) conv_tail_unit<EPI, 4>(in, wt, bias, aux, out, H, W, cout, cb + mtl * 16, p0);
+      else if (cin_g == 4) conv_tail_unit<EPI, 2>(in, wt, bias, aux, out, H, W, cout, cb + mtl * 16, p0);
     }
     if (DBG && lane == 0) {
       unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 4;
@@ -413,7 +437,7 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
 
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
                      int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg) {
-  if (cin % 16 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
+  if ((cin != 32 && cin != 64) || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;   // tail units are instantiated for Cin 32 / 64
   // staged pixels of a 128-pixel run: 127 + 2 per row end crossed + two halo rows + 3
   if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV2_NPX) return LEMO_ERR_SHAPE;
   const int P = H * W;
@@ -421,13 +445,14 @@ int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const f
   const int nw = cpb / 8;
   const int full = P / 128, rem = P - full * 128;
   const int units = ((rem + 15) / 16) * (cpb / 16);
-  dim3 grid(full + (units + nw - 1) / nw, cout / cpb);
+  const int tailb = (units + nw - 1) / nw;
+  dim3 grid(full + tailb, cout / cpb);
   if (dbg) {                                 // census build of the forward 64-cout kernel (tools/conv_census.py)
     if (cpb != 64 || epi != 0) return LEMO_ERR_ARG;
-    hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<0, 512, true>), grid, dim3(512), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, dbg);
+    hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<0, 512, true>), grid, dim3(512), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, dbg);
     return (int)hipGetLastError();
   }
-#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, (unsigned long long*)nullptr)
+#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, (unsigned long long*)nullptr)
   if (cpb == 64) { if (epi == 0) LAUNCH2(0, 512); else if (epi == 1) LAUNCH2(1, 512); else LAUNCH2(2, 512); }
   else           { if (epi == 0) LAUNCH2(0, 256); else if (epi == 1) LAUNCH2(1, 256); else LAUNCH2(2, 256); }
 #undef LAUNCH2

@@ -280,6 +280,7 @@ static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (floa
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
 

@@ -36,8 +36,8 @@ dur = (t1 - t0)[valid]
 tmin = t0[valid].min()
 print('per-wave cycles: min %d median %d max %d' % (dur.min(), np.median(dur), dur.max()))
 print('span first-start -> last-end: %d cycles ; start skew (last start - first start): %d' % (t1[valid].max() - tmin, t0[valid].max() - tmin))
-main = valid.copy(); main[H * W // 128:] = False
-print('main waves: median %d ; tail waves: %s' % (np.median((t1 - t0)[main]), (t1 - t0)[H * W // 128:][valid[H * W // 128:]].tolist()))
+main = valid.copy(); main[:2] = False          # tail blocks have the lowest ids
+print('main waves: median %d max %d ; tail waves: %s' % (np.median((t1 - t0)[main]), (t1 - t0)[main].max(), (t1 - t0)[:2][valid[:2]].tolist()))
 wsimd = collections.Counter(zip(cuid[valid].tolist(), simd[valid].tolist()))
 print('waves per (CU,SIMD) histogram:', sorted(collections.Counter(wsimd.values()).items()))
 print('implied clock if 36.9k cycles == MFMA-bound: span cycles / wall = %.2f GHz' % ((t1[valid].max() - tmin) / (ms * 1e-3) / 1e9))
