@@ -6,6 +6,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// dynamic LDS, 16-byte aligned base (guide G17); tests/hipemu pre-defines its own host version
+#ifndef LEMO_DYN_SMEM
+#define LEMO_DYN_SMEM(var) extern __shared__ __attribute__((aligned(16))) float var[]
+#endif
+
 #define LEMO_WAVE 64
 #define LEMO_LRELU_SLOPE 0.2f
 

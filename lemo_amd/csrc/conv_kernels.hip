@@ -296,7 +296,17 @@ conv3x3_mfma_v1_kernel(const float* __restrict__ in, const float* __restrict__ w
 // written to the other LDS buffer after them (one barrier per group).
 // ------------------------------------------------------------------------------------------------
 #define CV2_NPX 416
-template <int EPI, int NT, bool DBG = false>          // NT threads: 512 (cpb 64) or 256 (cpb 32)
+template <int NT, int GPS> struct Cv2Cfg {
+  static constexpr int CPB = NT / 8;                            // couts per block (64 or 32)
+  static constexpr int NCH_A = 18 * CPB;                        // 16-B chunks of one group's weights
+  static constexpr int B_GRP = 2 * CV2_NPX * 4;                 // floats per group: [2 planes][NPX][4]
+  static constexpr int A_GRP = 9 * 2 * CPB * 4;                 // floats per group: [9][2 planes][CPB][4]
+  static constexpr int B_BUF = GPS * B_GRP, A_BUF = GPS * A_GRP;
+  static constexpr int A_OFF = 2 * B_BUF;
+  static constexpr int SMEM_BYTES = (2 * B_BUF + 2 * A_BUF) * 4;
+};
+
+template <int EPI, int NT, int GPS, bool DBG = false>   // NT threads: 512 (cpb 64) / 256 (cpb 32); GPS groups per stage
 __global__ void __launch_bounds__(NT)
 conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ wt2,
                        const float* __restrict__ bias, const float* __restrict__ aux,
@@ -307,13 +317,12 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
   // starving behind it (measured: dispatched last they ran 1.35x longer than a main wave).
   unsigned long long t_start = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
-  constexpr int CPB = NT / 8;                                   // couts per block (64 or 32)
-  constexpr int NCH_A = 18 * CPB;                               // 16-B chunks of one group's weights
-  constexpr int B_BUF = 2 * CV2_NPX * 4;                        // floats per activation buffer [2 planes][NPX][4]
-  constexpr int A_BUF = 9 * 2 * CPB * 4;                        // floats per weight buffer [9][2 planes][CPB][4]
-  constexpr int A_OFF = 2 * B_BUF;
-  // ONE LDS object (a second one makes hipcc drain vmcnt before every ds_read), 16-B aligned
-  __shared__ __attribute__((aligned(16))) float smem[2 * B_BUF + 2 * A_BUF];
+  typedef Cv2Cfg<NT, GPS> Cfg;
+  constexpr int CPB = Cfg::CPB, NCH_A = Cfg::NCH_A, B_GRP = Cfg::B_GRP, A_GRP = Cfg::A_GRP;
+  constexpr int B_BUF = Cfg::B_BUF, A_BUF = Cfg::A_BUF, A_OFF = Cfg::A_OFF;
+  // ONE dynamic LDS object (a second one makes hipcc drain vmcnt before every ds_read), 16-B aligned:
+  // [2 buffers][GPS groups] activations, then [2 buffers][GPS groups] weights (127 KB at GPS = 2)
+  LEMO_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const size_t in_gstride = (size_t)HWp * 8;
@@ -330,33 +339,37 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int poff = (y + 1) * Wp + (x + 1);
     const int li = poff - qin;                                   // local index of the centre tap
     const int mt = wave >> 2;                                    // cout tile of this wave
-    const int nchB = 2 * npx, nch = nchB + NCH_A;
+    const int nchB = 2 * npx;
+    const unsigned wt_gstride = 9u * cout * 8u;
     // Staging plan of this thread: NB activation chunks (16 B: pixel c>>1, half c&1) and NA weight
-    // chunks per channel group.  Every slot issues an UNCONDITIONAL global load (out-of-range slots
-    // re-read the last chunk) so that all loads of a group are in flight together and stay
-    // global_load (a pointer select would degrade them to flat_load, which also bumps lgkmcnt and
-    // would stall the ds_read waits); only the LDS write is predicated.
-    constexpr int NB = (2 * CV2_NPX + NT - 1) / NT, NA = (NCH_A + NT - 1) / NT;
+    // chunks per STAGE (= GPS channel groups).  Every slot issues an UNCONDITIONAL global load
+    // (out-of-range slots re-read the last chunk) so that all loads of a stage are in flight together
+    // and stay global_load (a pointer select would degrade them to flat_load, which also bumps
+    // lgkmcnt and would stall the ds_read waits); only the LDS write is predicated.
+    constexpr int NB = (GPS * 2 * CV2_NPX + NT - 1) / NT, NA = (GPS * NCH_A + NT - 1) / NT;
     unsigned offB[NB], offA[NA];
     int dstB[NB], dstA[NA];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       int c = threadIdx.x + k * NT;
-      const bool ok = c < nchB;
-      if (!ok) c = nchB - 1;
-      offB[k] = (unsigned)qin * 8u + (unsigned)c * 4u;
-      dstB[k] = ok ? ((c & 1) * CV2_NPX + (c >> 1)) * 4 : -1;
+      const bool ok = c < GPS * nchB;
+      if (!ok) c = GPS * nchB - 1;
+      const int gg = c / nchB;
+      c -= gg * nchB;
+      offB[k] = (unsigned)gg * (unsigned)in_gstride + (unsigned)qin * 8u + (unsigned)c * 4u;
+      dstB[k] = ok ? gg * B_GRP + ((c & 1) * CV2_NPX + (c >> 1)) * 4 : -1;
     }
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       int ca = threadIdx.x + k * NT;
-      const bool ok = ca < NCH_A;
-      if (!ok) ca = NCH_A - 1;
+      const bool ok = ca < GPS * NCH_A;
+      if (!ok) ca = GPS * NCH_A - 1;
+      const int gg = ca / NCH_A;
+      ca -= gg * NCH_A;
       const int tap = ca / (2 * CPB), r = ca - tap * 2 * CPB;
-      offA[k] = ((unsigned)tap * cout + cb) * 8u + (unsigned)r * 4u;
-      dstA[k] = ok ? A_OFF + ((tap * 2 + (r & 1)) * CPB + (r >> 1)) * 4 : -1;
+      offA[k] = (unsigned)gg * wt_gstride + ((unsigned)tap * cout + cb) * 8u + (unsigned)r * 4u;
+      dstA[k] = ok ? A_OFF + gg * A_GRP + ((tap * 2 + (r & 1)) * CPB + (r >> 1)) * 4 : -1;
     }
-    const size_t wt_gstride = (size_t)9 * cout * 8;
     float4 stB[NB], stA[NA];
     f32x16 acc;
 #pragma unroll
@@ -372,11 +385,12 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
     __syncthreads();
     const float* a_rd = &smem[A_OFF + (h * CPB + mt * 32 + j) * 4];
     const float* b_rd = &smem[(h * CV2_NPX + li) * 4];
-    for (int g = 0; g < cin_g; ++g) {
-      const int buf = g & 1;
-      if (g + 1 < cin_g) {
-        const float* ing = in + (size_t)(g + 1) * in_gstride;
-        const float* wtg = wt2 + (size_t)(g + 1) * wt_gstride;
+    const int nstage = cin_g / GPS;
+    for (int sg = 0; sg < nstage; ++sg) {
+      const int buf = sg & 1;
+      if (sg + 1 < nstage) {
+        const float* ing = in + (size_t)(sg + 1) * GPS * in_gstride;
+        const float* wtg = wt2 + (size_t)(sg + 1) * GPS * wt_gstride;
 #pragma unroll
         for (int k = 0; k < NB; ++k) stB[k] = ld4(ing + offB[k]);
 #pragma unroll
@@ -385,16 +399,19 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       const float* ar = a_rd + buf * A_BUF;
       const float* br = b_rd + buf * B_BUF;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const float4 a = ld4(ar + tap * (2 * CPB * 4));
-        const float4 b = ld4(br + (dy * Wp + dx) * 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      for (int gg = 0; gg < GPS; ++gg) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+          const float4 a = ld4(ar + gg * A_GRP + tap * (2 * CPB * 4));
+          const float4 b = ld4(br + gg * B_GRP + (dy * Wp + dx) * 4);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
       }
-      if (g + 1 < cin_g) {
+      if (sg + 1 < nstage) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) if (dstB[k] >= 0) st4(&smem[dstB[k] + (buf ^ 1) * B_BUF], stB[k]);
 #pragma unroll
@@ -417,12 +434,13 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
     }
   } else {
     // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`)
-    const int nwaves = NT >> 6;
-    const int unit = (int)blockIdx.x * nwaves + wave;
+    // ONE unit per tail block (wave 0 only; the other waves retire at once): 16 units land on 16
+    // different CUs instead of loading 2 CUs with 8 extra waves each (measured: +40 % on those CUs)
+    const int unit = (int)blockIdx.x;
     const int ct = CPB >> 4;
     const int pt = unit / ct, mtl = unit - pt * ct;
     const int p0 = full_blocks * 128 + pt * 16;
-    if (p0 < P) {                                                // uniform per wave
+    if (wave == 0 && p0 < P) {                                   // uniform per wave
       if (cin_g == 8) conv_tail_unit<EPI, 4>(in, wt, bias, aux, out, H, W, cout, cb + mtl * 16, p0);
       else if (cin_g == 4) conv_tail_unit<EPI, 2>(in, wt, bias, aux, out, H, W, cout, cb + mtl * 16, p0);
     }
@@ -435,6 +453,20 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
   }
 }
 
+// > 64 KB of dynamic LDS needs an explicit opt-in per kernel (once per process; never inside a capture
+// because lemo_fit_create / the first eager call runs it first)
+int conv_lds_init() {
+  static int rc = -1;
+  if (rc >= 0) return rc;
+  rc = 0;
+#define OPTIN(EPI_, NT_, DBG_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_v2_kernel<EPI_, NT_, 2, DBG_>), hipFuncAttributeMaxDynamicSharedMemorySize, Cv2Cfg<NT_, 2>::SMEM_BYTES); if (e != hipSuccess) rc = (int)e; }
+  OPTIN(0, 512, false) OPTIN(1, 512, false) OPTIN(2, 512, false)
+  OPTIN(0, 256, false) OPTIN(1, 256, false) OPTIN(2, 256, false)
+  OPTIN(0, 512, true)
+#undef OPTIN
+  return rc;
+}
+
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
                      int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg) {
   if ((cin != 32 && cin != 64) || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;   // tail units are instantiated for Cin 32 / 64
@@ -442,17 +474,17 @@ int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const f
   if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV2_NPX) return LEMO_ERR_SHAPE;
   const int P = H * W;
   const int cpb = (cout % 64 == 0) ? 64 : 32;
-  const int nw = cpb / 8;
   const int full = P / 128, rem = P - full * 128;
   const int units = ((rem + 15) / 16) * (cpb / 16);
-  const int tailb = (units + nw - 1) / nw;
+  const int tailb = units;                                       // one 16x16 unit per tail block
   dim3 grid(full + tailb, cout / cpb);
+  conv_lds_init();
   if (dbg) {                                 // census build of the forward 64-cout kernel (tools/conv_census.py)
     if (cpb != 64 || epi != 0) return LEMO_ERR_ARG;
-    hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<0, 512, true>), grid, dim3(512), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, dbg);
+    hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<0, 512, 2, true>), grid, dim3(512), (Cv2Cfg<512, 2>::SMEM_BYTES), s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, dbg);
     return (int)hipGetLastError();
   }
-#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_>), grid, dim3(NT_), 0, s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, (unsigned long long*)nullptr)
+#define LAUNCH2(EPI_, NT_) hipLaunchKernelGGL((conv3x3_mfma_v2_kernel<EPI_, NT_, 2, false>), grid, dim3(NT_), (Cv2Cfg<NT_, 2>::SMEM_BYTES), s, in, wt, wt2, bias, aux, out, H, W, cin / 8, cout, full, tailb, (unsigned long long*)nullptr)
   if (cpb == 64) { if (epi == 0) LAUNCH2(0, 512); else if (epi == 1) LAUNCH2(1, 512); else LAUNCH2(2, 512); }
   else           { if (epi == 0) LAUNCH2(0, 256); else if (epi == 1) LAUNCH2(1, 256); else LAUNCH2(2, 256); }
 #undef LAUNCH2

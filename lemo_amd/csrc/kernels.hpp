@@ -11,6 +11,7 @@ int conv3x3_mfma(const float* in, const float* wt, const float* bias, const floa
                  int H, int W, int cin, int cout, int epi, int variant, hipStream_t s);
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
                      int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
+int conv_lds_init();
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);

@@ -69,6 +69,8 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
@@ -135,8 +137,12 @@ inline void fiber_entry() {
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
 
-inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
+inline std::vector<char>& dyn_smem_buf() { static std::vector<char> b; return b; }
+inline void* dyn_smem() { return (void*)(((uintptr_t)dyn_smem_buf().data() + 63) & ~(uintptr_t)63); }
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
   State& s = st();
+  if (dyn_smem_buf().size() < shmem + 64) dyn_smem_buf().resize(shmem + 64);
   const int nthr = (int)(block.x * block.y * block.z);
   const int nw = (nthr + WAVE - 1) / WAVE;
   while ((int)s.stacks.size() < nthr) {
@@ -184,7 +190,8 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> body) {
 }  // namespace hipemu
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-  hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+  hipemu::launch((grid), (block), (size_t)(shmem), [=]() { kernel(__VA_ARGS__); })
+#define LEMO_DYN_SMEM(var) float* var = (float*)hipemu::dyn_smem()
 
 // ---- synchronisation & cross-lane ---------------------------------------------------------
 static inline void __syncthreads() { hipemu::barrier(hipemu::st().block); }

@@ -14,7 +14,7 @@ w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).numpy()
 wt, wt2 = torch.from_numpy(pack_conv3x3(w)).to(dev), torch.from_numpy(pack_conv3x3_gmajor(w)).to(dev)
 b = torch.zeros(64, device=dev)
 x = cg8p_alloc(64, H, W, dev); x.normal_(); out = cg8p_alloc(64, H, W, dev)
-nblk = H * W // 128 + 2
+nblk = H * W // 128 + 16
 dbg = torch.zeros(nblk * 8 * 4, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream(dev).cuda_stream
 for it in range(3):
@@ -36,8 +36,8 @@ dur = (t1 - t0)[valid]
 tmin = t0[valid].min()
 print('per-wave cycles: min %d median %d max %d' % (dur.min(), np.median(dur), dur.max()))
 print('span first-start -> last-end: %d cycles ; start skew (last start - first start): %d' % (t1[valid].max() - tmin, t0[valid].max() - tmin))
-main = valid.copy(); main[:2] = False          # tail blocks have the lowest ids
-print('main waves: median %d max %d ; tail waves: %s' % (np.median((t1 - t0)[main]), (t1 - t0)[main].max(), (t1 - t0)[:2][valid[:2]].tolist()))
+main = valid.copy(); main[:16] = False          # tail blocks have the lowest ids
+print('main waves: median %d max %d ; tail waves: %s' % (np.median((t1 - t0)[main]), (t1 - t0)[main].max(), (t1 - t0)[:16][valid[:16]].tolist()))
 wsimd = collections.Counter(zip(cuid[valid].tolist(), simd[valid].tolist()))
 print('waves per (CU,SIMD) histogram:', sorted(collections.Counter(wsimd.values()).items()))
 print('implied clock if 36.9k cycles == MFMA-bound: span cycles / wall = %.2f GHz' % ((t1[valid].max() - tmin) / (ms * 1e-3) / 1e9))
