@@ -398,19 +398,50 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       }
       const float* ar = a_rd + buf * A_BUF;
       const float* br = b_rd + buf * B_BUF;
-#pragma unroll
-      for (int gg = 0; gg < GPS; ++gg) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-          const float4 a = ld4(ar + gg * A_GRP + tap * (2 * CPB * 4));
-          const float4 b = ld4(br + gg * B_GRP + (dy * Wp + dx) * 4);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-        }
+      // Operands are read from LDS one 3-tap chunk (one kernel row) AHEAD of the MFMAs that consume
+      // them, through two register sets; the sched_barriers pin "reads of chunk c+1, then the 12 MFMAs
+      // of chunk c".  Without this hipcc issues each tap's two ds_reads right before its 4 MFMAs and
+      // both waves of a SIMD stall on the same LDS round trip after every tap (measured 24 % idle).
+      float4 ra[2][3], rb[2][3];
+#define CV2_READ3(SET, CH)                                                                        \
+      _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                          \
+        constexpr int gg_ = (CH) / 3, dy_ = (CH) % 3 - 1;                                         \
+        ra[SET][t_] = ld4(ar + gg_ * A_GRP + (((CH) % 3) * 3 + t_) * (2 * CPB * 4));             \
+        rb[SET][t_] = ld4(br + gg_ * B_GRP + (dy_ * Wp + (t_ - 1)) * 4);                          \
       }
+#define CV2_MFMA3(SET)                                                                            \
+      _Pragma("unroll") for (int t_ = 0; t_ < 3; ++t_) {                                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][t_].x, rb[SET][t_].x, acc, 0, 0, 0);   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][t_].y, rb[SET][t_].y, acc, 0, 0, 0);   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][t_].z, rb[SET][t_].z, acc, 0, 0, 0);   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][t_].w, rb[SET][t_].w, acc, 0, 0, 0);   \
+      }
+      static_assert(GPS == 2, "chunk schedule below is written for 2 groups per stage");
+      CV2_READ3(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_READ3(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(0)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_READ3(0, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(1)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_READ3(1, 3)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(0)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_READ3(0, 4)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(1)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_READ3(1, 5)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(0)
+      __builtin_amdgcn_sched_barrier(0);
+      CV2_MFMA3(1)
+#undef CV2_READ3
+#undef CV2_MFMA3
       if (sg + 1 < nstage) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) if (dstB[k] >= 0) st4(&smem[dstB[k] + (buf ^ 1) * B_BUF], stB[k]);
