@@ -48,15 +48,19 @@ int lemo_smooth_loss_blocks(int H, int W, int C);
 int lemo_smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, void* stream);
 
 /* ---- VPoser.decode, human_body_prior/train/vposer_smpl.py:107-121 ------------------------------ */
-typedef struct lemo_vposer_w {           /* *_t = transposed copy [in][out] */
-  const float *w1, *w1t, *b1;            /* bodyprior_dec_fc1  [512][32]  */
-  const float *w2, *w2t, *b2;            /* bodyprior_dec_fc2  [512][512] */
-  const float *w3, *w3t, *b3;            /* bodyprior_dec_out  [126][512] */
+typedef struct lemo_vposer_w {           /* *_t = transposed copy [in][out]; the out layer is zero-padded 126 -> 128 */
+  const float *w1, *w1t, *b1;            /* bodyprior_dec_fc1  [512][32]  / [32][512]  / [512] */
+  const float *w2, *w2t, *b2;            /* bodyprior_dec_fc2  [512][512] / [512][512] / [512] */
+  const float *w3, *w3t, *b3;            /* bodyprior_dec_out  [128][512] / [512][128] / [128] */
 } lemo_vposer_w;
 int lemo_vposer_decode_fwd(const lemo_vposer_w* w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
                            float* matrot, float* aa, void* stream);
+/* scratch: [B][1152] floats */
 int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, const float* o, const float* d_aa,
-                           const float* d_matrot, int B, float* dz, int dz_stride, void* stream);
+                           const float* d_matrot, int B, float* dz, int dz_stride, float* scratch, void* stream);
+/* generic small NT GEMM on the matrix cores: C[n][m] = epi(sum_k A[m][k] B[n][k]); M, K multiples of 16 */
+int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                   const float* bias, const float* aux, int ldaux, int epi, void* stream);
 /* convert_to_3D_rot's 6-D -> axis-angle, utils/utils.py:111-123 (+63-81) */
 int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream);
 int lemo_rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, void* stream);
@@ -149,7 +153,7 @@ typedef struct lemo_fit_desc {
   float lr0, lr1;
   int lr_switch;
   /* workspace (caller-allocated, sizes documented in lemo_amd/fitting.py) */
-  float *go_aa, *body_aa, *h1, *h2, *vo;
+  float *go_aa, *body_aa, *h1, *h2, *vo, *vp_scratch;   /* vp_scratch [B][1152] */
   lemo_pose_ws pose;
   float *verts, *v_posed, *x0, *canon;
   float* act[11];                 /* act[0] unused; act[l] = output of layer l, CG8P */

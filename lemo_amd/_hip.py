@@ -79,7 +79,7 @@ class FitDesc(C.Structure):
         ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
         ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
         ('lr0', C.c_float), ('lr1', C.c_float), ('lr_switch', C.c_int),
-        ('go_aa', vp), ('body_aa', vp), ('h1', vp), ('h2', vp), ('vo', vp),
+        ('go_aa', vp), ('body_aa', vp), ('h1', vp), ('h2', vp), ('vo', vp), ('vp_scratch', vp),
         ('pose', PoseWs),
         ('verts', vp), ('v_posed', vp), ('x0', vp), ('canon', vp),
         ('act', vp * 11), ('dact', vp * 2),
@@ -111,7 +111,8 @@ _SIGS = {
     'lemo_smooth_loss_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'lemo_smooth_loss': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     'lemo_vposer_decode_fwd': (C.c_int, [C.POINTER(VPoserW), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
-    'lemo_vposer_decode_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp]),
+    'lemo_vposer_decode_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_gemm_nt16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     'lemo_rot6d_to_aa_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     'lemo_rot6d_to_aa_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_smplx_pose_fwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseIn), C.POINTER(PoseWs), C.c_int, vp]),

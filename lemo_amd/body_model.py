@@ -131,7 +131,7 @@ class BodyModelData:
     def vertex_set(self, ids: np.ndarray, vp_row: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
         ids = np.asarray(ids, np.int64)
         n = ids.shape[0]
-        NCs = _roundup(3 * n, 8)
+        NCs = _roundup(3 * n, 16)
         Dk = np.zeros((K_PAD, NCs), np.float32)
         cols = (ids[:, None] * 3 + np.arange(3)[None]).reshape(-1)
         Dk[:, :3 * n] = self.D[:, cols]

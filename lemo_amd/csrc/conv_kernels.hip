@@ -383,6 +383,8 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
 #pragma unroll
     for (int k = 0; k < NA; ++k) if (dstA[k] >= 0) st4(&smem[dstA[k]], stA[k]);
     __syncthreads();
+    unsigned long long t_pro = 0, t_loop = 0;
+    if (DBG) t_pro = __builtin_amdgcn_s_memtime();
     const float* a_rd = &smem[A_OFF + (h * CPB + mt * 32 + j) * 4];
     const float* b_rd = &smem[(h * CV2_NPX + li) * 4];
     const int nstage = cin_g / GPS;
@@ -450,6 +452,7 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       }
       __syncthreads();
     }
+    if (DBG) t_loop = __builtin_amdgcn_s_memtime();
     const int m_base = cb + mt * 32;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -458,10 +461,10 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       conv_store4<EPI>(out, bias, aux, o, c0, make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
     }
     if (DBG && lane == 0) {           // census: where and when did this wave run
-      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 4;
+      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 8;
       r[0] = __builtin_amdgcn_s_getreg(63492);        // HW_REG_HW_ID
       r[1] = __builtin_amdgcn_s_getreg(63508);        // HW_REG_XCC_ID
-      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime();
+      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = t_pro; r[5] = t_loop;
     }
   } else {
     // tail: 16 px x 16 cout units straight from global (tap-major pack `wt`)
@@ -476,10 +479,10 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
       else if (cin_g == 4) conv_tail_unit<EPI, 2>(in, wt, bias, aux, out, H, W, cout, cb + mtl * 16, p0);
     }
     if (DBG && lane == 0) {
-      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 4;
+      unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * (NT / 64) + wave) * 8;
       r[0] = __builtin_amdgcn_s_getreg(63492);
       r[1] = __builtin_amdgcn_s_getreg(63508);
-      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime();
+      r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = 0; r[5] = 0;
     }
   }
 }

@@ -17,6 +17,11 @@ int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, 
 int smooth_loss_blocks(int H, int W, int C);
 int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s);
 
+// ---------------- gemm_kernels.hip ----------------
+// C[n][m] = epi(sum_k A[m][k] B[n][k]); epi 0 none | 1 lrelu(v+bias[m]) | 2 v+bias[m] | 3 v*lrelu'(aux[n][m])
+int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+              const float* bias, const float* aux, int ldaux, int epi, hipStream_t s);
+
 // ---------------- pose_kernels.hip ----------------
 typedef lemo_vposer_w VPoserW;
 typedef lemo_body_const BodyConst;
@@ -33,7 +38,8 @@ int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, flo
                       float* matrot /*[B][21][9] or null*/, float* aa /*[B][63] or null*/, hipStream_t s);
 // d_aa [B][63] and/or d_matrot [B][21][9] (either may be null) -> dz [B] rows with stride dz_stride
 int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
-                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, hipStream_t s);
+                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, float* scratch /*[B][1152]*/,
+                      hipStream_t s);
 int rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, hipStream_t s);
 int rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, hipStream_t s);
 int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s);

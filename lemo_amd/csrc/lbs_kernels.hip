@@ -136,18 +136,31 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
 //   kernel 1 (block per frame): dvp = T_R^T g ; dA[j] = sum_u W[u,j] g (x) [v_posed,1] ; dtransl = sum_u g
 //   kernel 2: dX[b][k] = sum_col Dk[k][col] dvp[b][col]        (fp32-MFMA NT GEMM)
 // ------------------------------------------------------------------------------------------------
+#define LBS_BWD_STAGE 1024          // vertex sets up to this size keep g / v_posed of the frame in LDS
+template <bool STAGE>
 __global__ void __launch_bounds__(256)
 lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
                      const float* __restrict__ v_posed, int vp_rows, const float* __restrict__ dverts,
                      float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
   __shared__ float red[4];
+  __shared__ float gs[STAGE ? LBS_BWD_STAGE * 3 : 1];
+  __shared__ float vs[STAGE ? LBS_BWD_STAGE * 3 : 1];
+  __shared__ float As[STAGE ? 64 * 12 : 1];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
   const float* g = dverts + (size_t)b * u.n * 3;
+  if (STAGE) {                        // coalesced / gathered once, then every inner loop reads LDS
+    for (int i = t; i < u.n * 3; i += 256) gs[i] = g[i];
+    for (int i = t; i < u.n * 3; i += 256) vs[i] = v_posed[((size_t)b * vp_rows + u.vp_row[i / 3]) * 3 + (i % 3)];
+    for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
+    __syncthreads();
+  }
+  const float* gp = STAGE ? gs : g;
+  const float* Ap = STAGE ? As : Af;
   float sx = 0.f, sy = 0.f, sz = 0.f;
   for (int s = t; s < u.n; s += 256) {
     const int vid = u.ids[s];
-    const float gx = g[3 * s], gy = g[3 * s + 1], gz = g[3 * s + 2];
+    const float gx = gp[3 * s], gy = gp[3 * s + 1], gz = gp[3 * s + 2];
     sx += gx; sy += gy; sz += gz;
     float T[9];
 #pragma unroll
@@ -156,7 +169,7 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     const float* wv = c.w_val + (size_t)vid * c.KW;
     for (int k = 0; k < c.KW; ++k) {
       const float w = wv[k];
-      const float* Aj = Af + wi[k] * 12;
+      const float* Aj = Ap + wi[k] * 12;
       T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
       T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
       T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
@@ -174,8 +187,9 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     float acc = 0.f;
     for (int q = u.jcsr_start[jj]; q < u.jcsr_start[jj + 1]; ++q) {
       const int s = u.jcsr_u[q];
-      const float gv = g[3 * s + r] * u.jcsr_w[q];
-      acc += cc < 3 ? gv * v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc] : gv;
+      const float gv = gp[3 * s + r] * u.jcsr_w[q];
+      if (cc < 3) acc += gv * (STAGE ? vs[3 * s + cc] : v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc]);
+      else acc += gv;
     }
     dA[((size_t)b * nj) * 12 + w] = acc;
   }
@@ -185,48 +199,18 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   }
 }
 
-// C^T[n][m] (ldc) = sum_k A[m][k] B[n][k] ; A:[M][lda], B:[N][ldb], K % 8 == 0, M % 32 == 0.
-// One wave per 32x32 tile; rows of B beyond N are clamped (their results are not stored).
-__global__ void __launch_bounds__(256)
-gemm_nt_mfma_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K,
-                    float* __restrict__ Ct, int ldc) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  const int mt = blockIdx.x * 4 + wave, nt = blockIdx.y;
-  if (mt * 32 >= M) return;
-  const int nrow = nt * 32 + j;
-  const float* ap = Am + (size_t)(mt * 32 + j) * lda + 4 * h;
-  const float* bp = Bm + (size_t)(nrow < N ? nrow : N - 1) * ldb + 4 * h;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int k = 0; k < K; k += 8) {
-    const float4 a = ld4(ap + k), bb = ld4(bp + k);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bb.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bb.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bb.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bb.w, acc, 0, 0, 0);
-  }
-  if (nrow < N) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      Ct[(size_t)nrow * ldc + mt * 32 + row] = acc[r];
-    }
-  }
-}
-
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s) {
-  if (u.n <= 0 || B <= 0 || (u.NCs % 8) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
+  if (u.n <= 0 || B <= 0 || (u.NCs % 16) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
   (void)Bp;
-  hipLaunchKernelGGL(lbs_bwd_frame_kernel, dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+  if (u.n <= LBS_BWD_STAGE && nj <= 64)
+    hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+  else
+    hipLaunchKernelGGL((lbs_bwd_frame_kernel<false>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
   int e = (int)hipGetLastError();
   if (e) return e;
   // dX[b][k] = sum_col Dk[k][col] dvp[b][col]  : A = Dk (M = 512 features), B = dvp (N = B frames)
-  hipLaunchKernelGGL(gemm_nt_mfma_kernel, dim3(512 / 32 / 4, (B + 31) / 32), dim3(256), 0, s,
-                     u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512);
-  return (int)hipGetLastError();
+  return gemm_nt16(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, nullptr, nullptr, 0, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------

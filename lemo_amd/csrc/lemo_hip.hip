@@ -46,9 +46,14 @@ int lemo_vposer_decode_fwd(const lemo_vposer_w* w, const float* z, int z_stride,
   return vposer_decode_fwd(*w, z, z_stride, B, h1, h2, o, matrot, aa, S(stream));
 }
 int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, const float* o, const float* d_aa,
-                           const float* d_matrot, int B, float* dz, int dz_stride, void* stream) {
-  if (!w || !dz || (!d_aa && !d_matrot)) return LEMO_ERR_ARG;
-  return vposer_decode_bwd(*w, h1, h2, o, nullptr, d_aa, d_matrot, B, dz, dz_stride, S(stream));
+                           const float* d_matrot, int B, float* dz, int dz_stride, float* scratch, void* stream) {
+  if (!w || !dz || !scratch || (!d_aa && !d_matrot)) return LEMO_ERR_ARG;
+  return vposer_decode_bwd(*w, h1, h2, o, nullptr, d_aa, d_matrot, B, dz, dz_stride, scratch, S(stream));
+}
+int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
+                   const float* bias, const float* aux, int ldaux, int epi, void* stream) {
+  if (!A || !B || !C) return LEMO_ERR_ARG;
+  return gemm_nt16(A, lda, B, ldb, M, N, K, C, ldc, bias, aux, ldaux, epi, S(stream));
 }
 int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream) {
   return rot6d_to_aa_fwd(x6, stride, N, aa, S(stream));
@@ -140,7 +145,7 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   go.d_global_orient = d.g_go; go.d_body_pose = d.g_body;
   go.d_lh = d.g_other + 32; go.d_rh = d.g_other + 44; go.hand_stride = 56;
   CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
-  CHK(vposer_decode_bwd(d.vposer, d.h1, d.h2, d.vo, nullptr, d.g_body, nullptr, B, d.g_other, 56, s));
+  CHK(vposer_decode_bwd(d.vposer, d.h1, d.h2, d.vo, nullptr, d.g_body, nullptr, B, d.g_other, 56, d.vp_scratch, s));
   CHK(rot6d_to_aa_bwd(d.rot6d, 6, d.g_go, B, d.g_rot6d, s));
   return 0;
 }

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256)
 loss_finalize_kernel(const float* __restrict__ vpartial, int B, int n67, const float* __restrict__ spartial, int n_sp,
                      double smooth_count, const float* __restrict__ shape, const float* __restrict__ other,
                      const float* __restrict__ weights, float* __restrict__ losses) {
-  __shared__ double dred[256];
+  __shared__ double dred[4][13];
   const int t = threadIdx.x;
   double sums[13];
   for (int i = 0; i < 13; ++i) sums[i] = 0.0;
@@ -119,14 +119,17 @@ loss_finalize_kernel(const float* __restrict__ vpartial, int B, int n67, const f
   for (int i = t; i < B * 32; i += 256) { const float v = other[(size_t)(i / 32) * 56 + (i % 32)]; sums[10] += (double)v * v; }
   for (int i = t; i < B * 10; i += 256) { const float v = shape[i]; sums[11] += (double)v * v; }
   for (int i = t; i < B * 24; i += 256) { const float v = other[(size_t)(i / 24) * 56 + 32 + (i % 24)]; sums[12] += (double)v * v; }
-  double tot[13];
+  // all 13 sums at once: butterfly inside each wave, then 4 wave partials in a fixed order
+#pragma unroll
   for (int i = 0; i < 13; ++i) {
-    __syncthreads();
-    dred[t] = sums[i];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (t < o) dred[t] += dred[t + o]; __syncthreads(); }
-    tot[i] = dred[0];
+    double v = sums[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((t & 63) == 0) dred[t >> 6][i] = v;
   }
+  __syncthreads();
+  double tot[13];
+  for (int i = 0; i < 13; ++i) tot[i] = dred[0][i] + dred[1][i] + dred[2][i] + dred[3][i];
   if (t == 0) {
     const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
     float l_contact = 0.f;

@@ -18,137 +18,74 @@ namespace lemo {
 #define VP_NJ 21
 
 // ------------------------------------------------------------------------------------------------
-// VPoser.decode forward: z[32] -> lrelu(fc1) -> lrelu(fc2) -> out[126] -> 21 x (6D -> R -> aa)
-// (dropout is identity in eval(), model_loader.py:70)
+// VPoser.decode: z[32] -> lrelu(fc1) -> lrelu(fc2) -> out[126] -> 21 x (6D -> R -> aa)
+// (dropout is identity in eval(), model_loader.py:70).  The three Linear layers run as fp32-MFMA
+// GEMMs over all frames (gemm_kernels.hip); the per-joint rotation conversions are below.
+// `o` is [B][128] (126 used; the out layer is packed to 128 rows of zeros-padded weights).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-vposer_fwd_kernel(VPoserW w, const float* __restrict__ z, int z_stride, float* __restrict__ h1g,
-                  float* __restrict__ h2g, float* __restrict__ og, float* __restrict__ matrot,
-                  float* __restrict__ aa) {
-  __shared__ float zs[VP_Z];
-  __shared__ float h1[VP_H];
-  __shared__ float h2[VP_H];
-  __shared__ float part[2][128];
-  __shared__ float o[128];
-  const int b = blockIdx.x, t = threadIdx.x;
-  if (t < VP_Z) zs[t] = z[(size_t)b * z_stride + t];
-  __syncthreads();
-  for (int j = t; j < VP_H; j += 256) {
-    float a = w.b1[j];
-    for (int i = 0; i < VP_Z; ++i) a = fmaf(w.w1t[i * VP_H + j], zs[i], a);
-    a = lrelu(a);
-    h1[j] = a;
-    h1g[(size_t)b * VP_H + j] = a;
-  }
-  __syncthreads();
-  {
-    float a0 = w.b2[t], a1 = w.b2[t + 256];
-    for (int i = 0; i < VP_H; ++i) {
-      const float hv = h1[i];
-      a0 = fmaf(w.w2t[i * VP_H + t], hv, a0);
-      a1 = fmaf(w.w2t[i * VP_H + t + 256], hv, a1);
-    }
-    a0 = lrelu(a0); a1 = lrelu(a1);
-    h2[t] = a0; h2[t + 256] = a1;
-    h2g[(size_t)b * VP_H + t] = a0;
-    h2g[(size_t)b * VP_H + t + 256] = a1;
-  }
-  __syncthreads();
-  {
-    const int j = t & 127, half = t >> 7;
-    float a = 0.f;
-    if (j < VP_O)
-      for (int i = half * 256; i < half * 256 + 256; ++i) a = fmaf(w.w3t[i * VP_O + j], h2[i], a);
-    part[half][j] = a;
-  }
-  __syncthreads();
-  if (t < 128) {
-    const float v = t < VP_O ? w.b3[t] + part[0][t] + part[1][t] : 0.f;
-    o[t] = v;
-    og[(size_t)b * 128 + t] = v;
-  }
-  __syncthreads();
-  if (t < VP_NJ) {
-    float R[9], a3[3];
-    rot6d_fwd(&o[6 * t], R);
-    if (matrot) for (int i = 0; i < 9; ++i) matrot[((size_t)b * VP_NJ + t) * 9 + i] = R[i];
-    if (aa) {
-      rotmat_to_aa_fwd(R, a3);
-      for (int i = 0; i < 3; ++i) aa[(size_t)b * 63 + 3 * t + i] = a3[i];
-    }
+__global__ void vposer_rot_fwd_kernel(const float* __restrict__ og, int B, float* __restrict__ matrot, float* __restrict__ aa) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * VP_NJ) return;
+  const int b = idx / VP_NJ, t = idx - b * VP_NJ;
+  float o6[6], R[9], a3[3];
+  for (int i = 0; i < 6; ++i) o6[i] = og[(size_t)b * 128 + 6 * t + i];
+  rot6d_fwd(o6, R);
+  if (matrot) for (int i = 0; i < 9; ++i) matrot[((size_t)b * VP_NJ + t) * 9 + i] = R[i];
+  if (aa) {
+    rotmat_to_aa_fwd(R, a3);
+    for (int i = 0; i < 3; ++i) aa[(size_t)b * 63 + 3 * t + i] = a3[i];
   }
 }
 
 int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
                       float* matrot, float* aa, hipStream_t s) {
   if (B <= 0) return LEMO_ERR_SHAPE;
-  hipLaunchKernelGGL(vposer_fwd_kernel, dim3(B), dim3(256), 0, s, w, z, z_stride, h1, h2, o, matrot, aa);
+  int e;
+  if ((e = gemm_nt16(w.w1, VP_Z, z, z_stride, VP_H, B, VP_Z, h1, VP_H, w.b1, nullptr, 0, 1, s))) return e;
+  if ((e = gemm_nt16(w.w2, VP_H, h1, VP_H, VP_H, B, VP_H, h2, VP_H, w.b2, nullptr, 0, 1, s))) return e;
+  if ((e = gemm_nt16(w.w3, VP_H, h2, VP_H, 128, B, VP_H, o, 128, w.b3, nullptr, 0, 2, s))) return e;
+  const int n = B * VP_NJ;
+  hipLaunchKernelGGL(vposer_rot_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, o, B, matrot, aa);
   return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256)
-vposer_bwd_kernel(VPoserW w, const float* __restrict__ h1g, const float* __restrict__ h2g,
-                  const float* __restrict__ og, const float* __restrict__ d_aa,
-                  const float* __restrict__ d_matrot, float* __restrict__ dz, int dz_stride) {
-  __shared__ float dout[128];
-  __shared__ float dh2[VP_H];
-  __shared__ float dh1[VP_H];
-  __shared__ float part[8][VP_Z];
-  const int b = blockIdx.x, t = threadIdx.x;
-  if (t < 128) dout[t] = 0.f;
-  __syncthreads();
-  if (t < VP_NJ) {
-    float o6[6], R[9], dR[9], d6[6];
-    for (int i = 0; i < 6; ++i) o6[i] = og[(size_t)b * 128 + 6 * t + i];
-    rot6d_fwd(o6, R);
-    for (int i = 0; i < 9; ++i) dR[i] = 0.f;
-    if (d_aa) {
-      float g[3];
-      for (int i = 0; i < 3; ++i) g[i] = d_aa[(size_t)b * 63 + 3 * t + i];
-      rotmat_to_aa_bwd(R, g, dR);
-    }
-    if (d_matrot) for (int i = 0; i < 9; ++i) dR[i] += d_matrot[((size_t)b * VP_NJ + t) * 9 + i];
-    rot6d_bwd(o6, dR, d6);
-    for (int i = 0; i < 6; ++i) dout[6 * t + i] = d6[i];
+// d_aa / d_matrot -> d(out layer) [B][128]
+__global__ void vposer_rot_bwd_kernel(const float* __restrict__ og, const float* __restrict__ d_aa,
+                                      const float* __restrict__ d_matrot, int B, float* __restrict__ dout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * 22) return;
+  const int b = idx / 22, t = idx - b * 22;
+  if (t == VP_NJ) { dout[(size_t)b * 128 + 126] = 0.f; dout[(size_t)b * 128 + 127] = 0.f; return; }
+  float o6[6], R[9], dR[9], d6[6];
+  for (int i = 0; i < 6; ++i) o6[i] = og[(size_t)b * 128 + 6 * t + i];
+  rot6d_fwd(o6, R);
+  for (int i = 0; i < 9; ++i) dR[i] = 0.f;
+  if (d_aa) {
+    float g[3];
+    for (int i = 0; i < 3; ++i) g[i] = d_aa[(size_t)b * 63 + 3 * t + i];
+    rotmat_to_aa_bwd(R, g, dR);
   }
-  __syncthreads();
-  for (int i = t; i < VP_H; i += 256) {
-    float a = 0.f;
-    for (int oo = 0; oo < VP_O; ++oo) a = fmaf(w.w3[oo * VP_H + i], dout[oo], a);
-    dh2[i] = a * lrelu_grad_from_out(h2g[(size_t)b * VP_H + i]);
-  }
-  __syncthreads();
-  {
-    float a0 = 0.f, a1 = 0.f;
-    for (int oo = 0; oo < VP_H; ++oo) {
-      const float g = dh2[oo];
-      a0 = fmaf(w.w2[oo * VP_H + t], g, a0);
-      a1 = fmaf(w.w2[oo * VP_H + t + 256], g, a1);
-    }
-    dh1[t] = a0 * lrelu_grad_from_out(h1g[(size_t)b * VP_H + t]);
-    dh1[t + 256] = a1 * lrelu_grad_from_out(h1g[(size_t)b * VP_H + t + 256]);
-  }
-  __syncthreads();
-  {
-    const int i = t & 31, p = t >> 5;
-    float a = 0.f;
-    for (int oo = p * 64; oo < p * 64 + 64; ++oo) a = fmaf(w.w1[oo * VP_Z + i], dh1[oo], a);
-    part[p][i] = a;
-  }
-  __syncthreads();
-  if (t < VP_Z) {
-    float a = 0.f;
-    for (int p = 0; p < 8; ++p) a += part[p][t];
-    dz[(size_t)b * dz_stride + t] = a;
-  }
+  if (d_matrot) for (int i = 0; i < 9; ++i) dR[i] += d_matrot[((size_t)b * VP_NJ + t) * 9 + i];
+  rot6d_bwd(o6, dR, d6);
+  for (int i = 0; i < 6; ++i) dout[(size_t)b * 128 + 6 * t + i] = d6[i];
 }
 
+// scratch: dout [B][128], dh2 [B][512], dh1 [B][512]
 int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
-                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, hipStream_t s) {
+                      const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, float* scratch, hipStream_t s) {
   (void)matrot;
-  if (B <= 0) return LEMO_ERR_SHAPE;
-  hipLaunchKernelGGL(vposer_bwd_kernel, dim3(B), dim3(256), 0, s, w, h1, h2, o, d_aa, d_matrot, dz, dz_stride);
-  return (int)hipGetLastError();
+  if (B <= 0 || !scratch) return LEMO_ERR_SHAPE;
+  float* dout = scratch;
+  float* dh2 = scratch + (size_t)B * 128;
+  float* dh1 = dh2 + (size_t)B * VP_H;
+  const int n = B * 22;
+  hipLaunchKernelGGL(vposer_rot_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, o, d_aa, d_matrot, B, dout);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  // dh2 = (dout . W3) * lrelu'(h2) ; dh1 = (dh2 . W2) * lrelu'(h1) ; dz = dh1 . W1   (transposed packs as A)
+  if ((e = gemm_nt16(w.w3t, 128, dout, 128, VP_H, B, 128, dh2, VP_H, nullptr, h2, VP_H, 3, s))) return e;
+  if ((e = gemm_nt16(w.w2t, VP_H, dh2, VP_H, VP_H, B, VP_H, dh1, VP_H, nullptr, h1, VP_H, 3, s))) return e;
+  return gemm_nt16(w.w1t, VP_H, dh1, VP_H, VP_Z, B, VP_H, dz, dz_stride, nullptr, nullptr, 0, 0, s);
 }
 
 // ------------------------------------------------------------------------------------------------

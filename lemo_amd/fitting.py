@@ -98,7 +98,7 @@ class AmassTemporalFitter:
         pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
         self.Bp = Bp
         nsp = self.lib.smooth_loss_blocks(H, W, ENC_CHANNELS[10])
-        self.ws = dict(go_aa=z(B, 3), body_aa=z(B, 63), h1=z(B, 512), h2=z(B, 512), vo=z(B, 128),
+        self.ws = dict(go_aa=z(B, 3), body_aa=z(B, 63), h1=z(B, 512), h2=z(B, 512), vo=z(B, 128), vp_scratch=z(B, 1152),
                        verts=z(B, self.nrows, 3), v_posed=z(B, self.nrows, 3), x0=z((H + 2) * (W + 2)), canon=z(12),
                        dx0=z(H * W), spartial=z(nsp), vpartial=z(B, 9), losses=z(12), dverts=z(B, n, 3),
                        dvp=z(B, uset.NCs), dA=z(B, nj, 12), dX=z(B, K_PAD),
@@ -123,7 +123,7 @@ class AmassTemporalFitter:
         for i in range(3):
             d.adam_m[i], d.adam_v[i] = ptr(self.adam_m[i]), ptr(self.adam_v[i])
         d.step_ctr, d.lr0, d.lr1, d.lr_switch = ptr(self.step_ctr), lr0, lr1, lr_switch
-        for k in ('go_aa', 'body_aa', 'h1', 'h2', 'vo', 'verts', 'v_posed', 'x0', 'canon', 'dx0', 'spartial', 'vpartial',
+        for k in ('go_aa', 'body_aa', 'h1', 'h2', 'vo', 'vp_scratch', 'verts', 'v_posed', 'x0', 'canon', 'dx0', 'spartial', 'vpartial',
                   'losses', 'dverts', 'dvp', 'dA', 'dX', 'g_transl', 'g_rot6d', 'g_other', 'g_go', 'g_body'):
             setattr(d, k, ptr(self.ws[k]))
         d.pose = pose_ws

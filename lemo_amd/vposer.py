@@ -44,8 +44,9 @@ class _DecodeFn(torch.autograd.Function):
         g = g.contiguous().float()
         dz = torch.empty(B, 32, dtype=torch.float32, device=dev)
         d_aa, d_m = (ptr(g), None) if ctx.want_aa else (None, ptr(g))
+        scratch = torch.empty(B, 1152, dtype=torch.float32, device=dev)
         ctx.lib.check(ctx.lib.vposer_decode_bwd(C.byref(w['struct']), ptr(h1), ptr(h2), ptr(o), d_aa, d_m, B, ptr(dz),
-                                                32, ctx.lib.stream(dev)), 'vposer_decode_bwd')
+                                                32, ptr(scratch), ctx.lib.stream(dev)), 'vposer_decode_bwd')
         return None, None, dz, None
 
 
@@ -78,8 +79,10 @@ class VPoser(nn.Module):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._pack_cache.get('key') != key:
             t = [p.detach().to(device=device, dtype=torch.float32).contiguous() for p in ps]
+            w3 = torch.zeros(128, 512, dtype=torch.float32, device=device); w3[:126] = t[4]
+            b3 = torch.zeros(128, dtype=torch.float32, device=device); b3[:126] = t[5]
             tt = dict(w1=t[0], w1t=t[0].t().contiguous(), b1=t[1], w2=t[2], w2t=t[2].t().contiguous(), b2=t[3],
-                      w3=t[4], w3t=t[4].t().contiguous(), b3=t[5])
+                      w3=w3, w3t=w3.t().contiguous(), b3=b3)
             st = _hip.VPoserW(*[ptr(tt[k]) for k in ('w1', 'w1t', 'b1', 'w2', 'w2t', 'b2', 'w3', 'w3t', 'b3')])
             self._pack_cache = dict(key=key, tensors=tt, struct=st)
         return self._pack_cache
@@ -97,9 +100,11 @@ def vposer_weight_struct(weights: Dict[str, np.ndarray], device):
     """Pack ``bodyprior_dec_*`` arrays for the fitting engine -> (ctypes struct, tensors)."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
     w1, w2, w3 = (np.asarray(weights[f'bodyprior_dec_{n}.weight'], np.float32) for n in ('fc1', 'fc2', 'out'))
+    w3p = np.zeros((128, 512), np.float32); w3p[:126] = w3            # out layer padded 126 -> 128 rows
+    b3p = np.zeros(128, np.float32); b3p[:126] = np.asarray(weights['bodyprior_dec_out.bias'], np.float32)
     tt = dict(w1=t(w1), w1t=t(w1.T), b1=t(weights['bodyprior_dec_fc1.bias']),
               w2=t(w2), w2t=t(w2.T), b2=t(weights['bodyprior_dec_fc2.bias']),
-              w3=t(w3), w3t=t(w3.T), b3=t(weights['bodyprior_dec_out.bias']))
+              w3=t(w3p), w3t=t(w3p.T), b3=t(b3p))
     st = _hip.VPoserW(*[ptr(tt[k]) for k in ('w1', 'w1t', 'b1', 'w2', 'w2t', 'b2', 'w3', 'w3t', 'b3')])
     return st, tt
 

@@ -15,7 +15,7 @@ wt, wt2 = torch.from_numpy(pack_conv3x3(w)).to(dev), torch.from_numpy(pack_conv3
 b = torch.zeros(64, device=dev)
 x = cg8p_alloc(64, H, W, dev); x.normal_(); out = cg8p_alloc(64, H, W, dev)
 nblk = H * W // 128 + 16
-dbg = torch.zeros(nblk * 8 * 4, dtype=torch.int64, device=dev)
+dbg = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
 s = torch.cuda.current_stream(dev).cuda_stream
 for it in range(3):
     dbg.zero_()
@@ -24,7 +24,8 @@ for it in range(3):
     lib.check(lib.conv3x3_mfma_lds_census(ptr(x), ptr(wt), ptr(wt2), ptr(b), ptr(out), H, W, 64, 64, ptr(dbg), s))
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-d = dbg.cpu().numpy().reshape(nblk, 8, 4)
+d = dbg.cpu().numpy().reshape(nblk, 8, 8)
+tp, tl = d[..., 4], d[..., 5]
 hw, xcc, t0, t1 = d[..., 0], d[..., 1] & 0xf, d[..., 2], d[..., 3]
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; simd = (hw >> 4) & 3
 valid = t1 > 0
@@ -41,3 +42,5 @@ print('main waves: median %d max %d ; tail waves: %s' % (np.median((t1 - t0)[mai
 wsimd = collections.Counter(zip(cuid[valid].tolist(), simd[valid].tolist()))
 print('waves per (CU,SIMD) histogram:', sorted(collections.Counter(wsimd.values()).items()))
 print('implied clock if 36.9k cycles == MFMA-bound: span cycles / wall = %.2f GHz' % ((t1[valid].max() - tmin) / (ms * 1e-3) / 1e9))
+mm = main & (tp > 0)
+print('main-wave breakdown (median cycles): prologue %d  loop %d  epilogue %d' % (np.median((tp - t0)[mm]), np.median((tl - tp)[mm]), np.median((t1 - tl)[mm])))
