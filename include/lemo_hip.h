@@ -58,6 +58,9 @@ int lemo_vposer_decode_fwd(const lemo_vposer_w* w, const float* z, int z_stride,
 /* scratch: [B][1152] floats */
 int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, const float* o, const float* d_aa,
                            const float* d_matrot, int B, float* dz, int dz_stride, float* scratch, void* stream);
+/* MLP part of the VPoser backward alone: dout [B][128] (= scratch[0 .. B*128)) -> dz */
+int lemo_vposer_mlp_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, int B, float* dz, int dz_stride,
+                        float* scratch, void* stream);
 /* generic small NT GEMM on the matrix cores: C[n][m] = epi(sum_k A[m][k] B[n][k]); M, K multiples of 16 */
 int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
                    const float* bias, const float* aux, int ldaux, int epi, void* stream);
@@ -77,6 +80,15 @@ typedef struct lemo_pose_in {
   const float* betas;
   int betas_stride;
   const float* expr;
+  /* optional fused producers (fitting engine): when non-null they replace global_orient / body_pose */
+  const float* rot6d;        /* [B][6]  -> global_orient = 6-D -> axis-angle (utils/utils.py:111-123) */
+  const float* vposer_o;     /* [B][128] VPoser out layer -> body_pose = 21 x (6-D -> aa) */
+  float* go_out;             /* [B][3] receives the global_orient derived from rot6d */
+  /* optional per-iteration bookkeeping done by block 0: zero n_zero doubles, latch the step counter */
+  double* zero_f64;
+  int n_zero;
+  const int* step_ctr;
+  int* step_cur;
 } lemo_pose_in;
 typedef struct lemo_pose_ws {
   float *full_pose, *R, *J, *T, *A, *Jtr, *Xg;
@@ -87,6 +99,11 @@ typedef struct lemo_pose_grad_out {
   float *d_global_orient, *d_body_pose, *d_jaw, *d_leye, *d_reye, *d_lh, *d_rh;
   int hand_stride;
   float *d_betas, *d_expr;
+  /* optional fused consumers (fitting engine) */
+  const float* rot6d;        /* [B][6] with d_rot6d: chain d(global_orient) back to the 6-D parameters */
+  float* d_rot6d;            /* [B][6] */
+  const float* vposer_o;     /* [B][128] with d_vposer_o: chain d(body_pose) back to the VPoser out layer */
+  float* d_vposer_o;         /* [B][128] */
 } lemo_pose_grad_out;
 int lemo_smplx_pose_fwd(const lemo_body_const* c, const lemo_pose_in* in, const lemo_pose_ws* ws, int B, void* stream);
 int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const lemo_pose_grad_in* gi,
@@ -159,6 +176,8 @@ typedef struct lemo_fit_desc {
   float* act[11];                 /* act[0] unused; act[l] = output of layer l, CG8P */
   float* dact[2];                 /* ping-pong d(pre-activation) buffers, 64-channel CG8P */
   float *dx0, *spartial, *vpartial, *losses, *dverts, *dvp, *dA, *dX;
+  double* loss_acc;               /* [16] per-iteration loss accumulators (f64 atomics) */
+  int* step_cur;                  /* [1] step index latched at the start of the iteration */
   float *g_transl, *g_rot6d, *g_other, *g_go, *g_body;
 } lemo_fit_desc;
 

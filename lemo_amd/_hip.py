@@ -35,7 +35,9 @@ class BodyConst(C.Structure):
 
 class PoseIn(C.Structure):
     _fields_ = [(n, vp) for n in ('global_orient', 'body_pose', 'jaw', 'leye', 'reye', 'lh', 'rh')] + \
-        [('hand_stride', C.c_int), ('betas', vp), ('betas_stride', C.c_int), ('expr', vp)]
+        [('hand_stride', C.c_int), ('betas', vp), ('betas_stride', C.c_int), ('expr', vp),
+         ('rot6d', vp), ('vposer_o', vp), ('go_out', vp), ('zero_f64', vp), ('n_zero', C.c_int),
+         ('step_ctr', vp), ('step_cur', vp)]
 
 
 class PoseWs(C.Structure):
@@ -48,7 +50,8 @@ class PoseGradIn(C.Structure):
 
 class PoseGradOut(C.Structure):
     _fields_ = [(n, vp) for n in ('d_global_orient', 'd_body_pose', 'd_jaw', 'd_leye', 'd_reye', 'd_lh', 'd_rh')] + \
-        [('hand_stride', C.c_int), ('d_betas', vp), ('d_expr', vp)]
+        [('hand_stride', C.c_int), ('d_betas', vp), ('d_expr', vp),
+         ('rot6d', vp), ('d_rot6d', vp), ('vposer_o', vp), ('d_vposer_o', vp)]
 
 
 class SkinConst(C.Structure):
@@ -84,7 +87,7 @@ class FitDesc(C.Structure):
         ('verts', vp), ('v_posed', vp), ('x0', vp), ('canon', vp),
         ('act', vp * 11), ('dact', vp * 2),
         ('dx0', vp), ('spartial', vp), ('vpartial', vp), ('losses', vp), ('dverts', vp), ('dvp', vp),
-        ('dA', vp), ('dX', vp),
+        ('dA', vp), ('dX', vp), ('loss_acc', vp), ('step_cur', vp),
         ('g_transl', vp), ('g_rot6d', vp), ('g_other', vp), ('g_go', vp), ('g_body', vp),
     ]
 
@@ -112,6 +115,7 @@ _SIGS = {
     'lemo_smooth_loss': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     'lemo_vposer_decode_fwd': (C.c_int, [C.POINTER(VPoserW), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     'lemo_vposer_decode_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_vposer_mlp_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_gemm_nt16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
     'lemo_rot6d_to_aa_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     'lemo_rot6d_to_aa_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),

@@ -626,7 +626,7 @@ int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, 
 // `partial[blockIdx.x]` (fixed-order final reduction elsewhere -> deterministic).
 __global__ void __launch_bounds__(256)
 smooth_loss_kernel(const float* __restrict__ z, float* __restrict__ dpre, float* __restrict__ partial,
-                   int H, int W, int C, float coef2) {
+                   int H, int W, int C, float coef2, double* __restrict__ acc) {
   __shared__ float red[4];
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,14 +653,17 @@ smooth_loss_kernel(const float* __restrict__ z, float* __restrict__ dpre, float*
                               coef2 * gr.z * lrelu_grad_from_out(c.z), coef2 * gr.w * lrelu_grad_from_out(c.w)));
   }
   const float s = block_sum(sq, red);
-  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    if (acc) atomicAdd(acc, (double)s);      // f64 accumulation: order effects ~1e-16, invisible after the f32 cast
+    else partial[blockIdx.x] = s;
+  }
 }
 
 int smooth_loss_blocks(int H, int W, int C) { return (H * W * (C / 8) * 2 + 255) / 256; }
 
-int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s) {
-  if (C % 8) return LEMO_ERR_SHAPE;
-  hipLaunchKernelGGL(smooth_loss_kernel, dim3(smooth_loss_blocks(H, W, C)), dim3(256), 0, s, z, dpre, partial, H, W, C, coef2);
+int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s, double* acc) {
+  if (C % 8 || (!partial && !acc)) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(smooth_loss_kernel, dim3(smooth_loss_blocks(H, W, C)), dim3(256), 0, s, z, dpre, partial, H, W, C, coef2, acc);
   return (int)hipGetLastError();
 }
 

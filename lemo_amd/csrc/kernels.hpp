@@ -15,7 +15,8 @@ int conv_lds_init();
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);
-int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s);
+int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s,
+                double* acc = nullptr);
 
 // ---------------- gemm_kernels.hip ----------------
 // C[n][m] = epi(sum_k A[m][k] B[n][k]); epi 0 none | 1 lrelu(v+bias[m]) | 2 v+bias[m] | 3 v*lrelu'(aux[n][m])
@@ -40,6 +41,8 @@ int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, flo
 int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
                       const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, float* scratch /*[B][1152]*/,
                       hipStream_t s);
+int vposer_mlp_bwd(const VPoserW& w, const float* h1, const float* h2, int B, float* dz, int dz_stride, float* scratch,
+                   hipStream_t s);
 int rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, hipStream_t s);
 int rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, hipStream_t s);
 int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s);
@@ -59,15 +62,17 @@ int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, con
 // ---------------- loss_kernels.hip ----------------
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);
-int vertex_loss_partial(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact, int B,
-                        float* partial, hipStream_t s);
-int loss_finalize(const float* vpartial, int B, int n67, const float* spartial, int n_sp, double smooth_count,
-                  const float* shape, const float* other, const float* weights, float* losses, hipStream_t s);
+// acc (f64[16], zeroed at the start of the iteration): [0] marker L1 sum, [1..4] contact sums, [5..8] contact
+// counts, [9] smoothness sum of squares, [10] sum z^2, [11] sum betas^2, [12] sum hands^2
+int vertex_loss_accumulate(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
+                           const float* shape, const float* other, int B, double* acc, hipStream_t s);
+int loss_finalize(const double* acc, int B, int n67, double smooth_count, const float* weights, float* losses, hipStream_t s);
+// finalises the losses from `acc` in its prologue (block 0 publishes them to `losses`)
 int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
-                    const float* dx0, const float* canon, const float* weights, const float* losses, int B,
-                    float* dverts, hipStream_t s);
+                    const float* dx0, const float* canon, const float* weights, const double* acc, double smooth_count,
+                    float* losses, int B, float* dverts, hipStream_t s);
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
-              int* step_ctr, float lr0, float lr1, int lr_switch, hipStream_t s);
+              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s);
 
 }  // namespace lemo

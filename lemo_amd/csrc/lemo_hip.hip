@@ -50,6 +50,11 @@ int lemo_vposer_decode_bwd(const lemo_vposer_w* w, const float* h1, const float*
   if (!w || !dz || !scratch || (!d_aa && !d_matrot)) return LEMO_ERR_ARG;
   return vposer_decode_bwd(*w, h1, h2, o, nullptr, d_aa, d_matrot, B, dz, dz_stride, scratch, S(stream));
 }
+int lemo_vposer_mlp_bwd(const lemo_vposer_w* w, const float* h1, const float* h2, int B, float* dz, int dz_stride,
+                        float* scratch, void* stream) {
+  if (!w || !h1 || !h2 || !dz || !scratch) return LEMO_ERR_ARG;
+  return vposer_mlp_bwd(*w, h1, h2, B, dz, dz_stride, scratch, S(stream));
+}
 int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
                    const float* bias, const float* aux, int ldaux, int epi, void* stream) {
   if (!A || !B || !C) return LEMO_ERR_ARG;
@@ -97,15 +102,20 @@ struct FitEngine {
   hipStream_t graph_stream = nullptr;
 };
 
-static int fit_forward(const lemo_fit_desc& d, hipStream_t s) {
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
-  CHK(rot6d_to_aa_fwd(d.rot6d, 6, B, d.go_aa, s));
-  CHK(vposer_decode_fwd(d.vposer, d.other, 56, B, d.h1, d.h2, d.vo, nullptr, d.body_aa, s));
+  // VPoser MLP (3 MFMA GEMMs); its rotation head and the 6-D -> axis-angle conversion of the global
+  // orientation are fused into the pose-stage kernel, which also zeroes the loss accumulators and
+  // latches the step counter for this iteration.
+  CHK(gemm_nt16(d.vposer.w1, 32, d.other, 56, 512, B, 32, d.h1, 512, d.vposer.b1, nullptr, 0, 1, s));
+  CHK(gemm_nt16(d.vposer.w2, 512, d.h1, 512, 512, B, 512, d.h2, 512, d.vposer.b2, nullptr, 0, 1, s));
+  CHK(gemm_nt16(d.vposer.w3, 512, d.h2, 512, 128, B, 512, d.vo, 128, d.vposer.b3, nullptr, 0, 2, s));
   lemo_pose_in in{};
-  in.global_orient = d.go_aa; in.body_pose = d.body_aa;
+  in.rot6d = d.rot6d; in.vposer_o = d.vo; in.go_out = d.go_aa;
   in.lh = d.other + 32; in.rh = d.other + 44; in.hand_stride = 56;
   in.betas = d.shape; in.betas_stride = 10;
+  in.zero_f64 = d.loss_acc; in.n_zero = 16; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
@@ -119,16 +129,16 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s) {
   }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
-  CHK(smooth_loss(d.act[10], d.dact[0], d.spartial, H, W, d.enc_ch[10], coef2, s));
-  CHK(vertex_loss_partial(d.fit, d.verts, d.nrows, d.target, d.contact, B, d.vpartial, s));
-  CHK(loss_finalize(d.vpartial, B, d.fit.n67, d.spartial, smooth_loss_blocks(H, W, d.enc_ch[10]), cnt, d.shape, d.other,
-                    d.weights, d.losses, s));
+  CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 9));
+  CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
+  if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, cnt, d.weights, d.losses, s));
   return 0;
 }
 
 static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
+  const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
   for (int l = 9; l >= 1; --l) {   // d(pre-act of layer l+1) -> d(pre-act of layer l)
     if (d.conv_variant == 2)
@@ -138,23 +148,23 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
     cur = 1 - cur;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
-  CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.losses, B, d.dverts, s));
+  CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s));
   CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
   lemo_pose_grad_in gi{d.dA, nullptr, d.dX};
   lemo_pose_grad_out go{};
-  go.d_global_orient = d.g_go; go.d_body_pose = d.g_body;
   go.d_lh = d.g_other + 32; go.d_rh = d.g_other + 44; go.hand_stride = 56;
+  go.rot6d = d.rot6d; go.d_rot6d = d.g_rot6d;            // d(global_orient) -> d(rot6d), fused
+  go.vposer_o = d.vo; go.d_vposer_o = d.vp_scratch;      // d(body_pose) -> d(VPoser out layer), fused
   CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
-  CHK(vposer_decode_bwd(d.vposer, d.h1, d.h2, d.vo, nullptr, d.g_body, nullptr, B, d.g_other, 56, d.vp_scratch, s));
-  CHK(rot6d_to_aa_bwd(d.rot6d, 6, d.g_go, B, d.g_rot6d, s));
+  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, d.g_other, 56, d.vp_scratch, s));
   return 0;
 }
 
 static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
-  CHK(fit_forward(d, s));
+  CHK(fit_forward(d, s, false));
   CHK(fit_backward(d, s));
   CHK(adam_step(d.transl, d.g_transl, d.adam_m[0], d.adam_v[0], d.rot6d, d.g_rot6d, d.adam_m[1], d.adam_v[1], d.other,
-                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.lr0, d.lr1, d.lr_switch, s));
+                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.step_cur, d.lr0, d.lr1, d.lr_switch, s));
   return 0;
 }
 
@@ -177,7 +187,7 @@ void lemo_fit_destroy(void* h) {
 int lemo_fit_forward(void* h, void* stream) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return LEMO_ERR_ARG;
-  return fit_forward(e->d, S(stream));
+  return fit_forward(e->d, S(stream), true);
 }
 
 int lemo_fit_backward(void* h, void* stream) {       // after lemo_fit_forward: gradients only, no Adam

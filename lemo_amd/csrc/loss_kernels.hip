@@ -67,14 +67,19 @@ int marker_feature(const FitConst& fc, const float* verts, int nrows, const floa
   return (int)hipGetLastError();
 }
 
-// Per-frame partial sums: [0] marker L1 ; [1+k] contact-velocity sum ; [5+k] count   (k = 4 foot sets)
+// Loss accumulators (f64[16], zeroed at the start of every iteration by the pose-stage kernel):
+//   [0] marker L1 sum ; [1+k] contact-velocity sum, [5+k] count (k = 4 foot sets) ; [9] smoothness sum of
+//   squares ; [10] sum z^2 ; [11] sum betas^2 ; [12] sum hands^2.
+// Accumulating f32 block sums into f64 with atomics is order-dependent only at ~1e-16 relative, far
+// below the f32 value that is finally reported.
 __global__ void __launch_bounds__(256)
-vertex_loss_partial_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
-                           const float* __restrict__ contact, int B, float* __restrict__ partial) {
+vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
+                              const float* __restrict__ contact, const float* __restrict__ shape,
+                              const float* __restrict__ other, int B, double* __restrict__ accg) {
   __shared__ float red[4];
   const int b = blockIdx.x, t = threadIdx.x;
-  float acc[9];
-  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+  float acc[12];
+  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
   for (int w = t; w < fc.n67 * 3; w += 256) {
     const int m = w / 3, c = w % 3;
     acc[0] += fabsf(verts[((size_t)b * nrows + fc.row67[m]) * 3 + c] - target[((size_t)b * fc.n67 + m) * 3 + c]);
@@ -91,71 +96,58 @@ vertex_loss_partial_kernel(FitConst fc, const float* __restrict__ verts, int nro
       }
     }
   }
-  for (int i = 0; i < 9; ++i) {
+  // L2 priors of this frame (opt_amass_temp.py:397-404): z (32), betas (10), hands (24)
+  if (t < 32) { const float v = other[(size_t)b * 56 + t]; acc[9] = v * v; }
+  else if (t >= 64 && t < 74) { const float v = shape[(size_t)b * 10 + (t - 64)]; acc[10] = v * v; }
+  else if (t >= 128 && t < 152) { const float v = other[(size_t)b * 56 + 32 + (t - 128)]; acc[11] = v * v; }
+  for (int i = 0; i < 12; ++i) {
     const float v = block_sum(acc[i], red);
-    if (t == 0) partial[(size_t)b * 9 + i] = v;
+    if (t == 0 && v != 0.f) atomicAdd(accg + (i < 9 ? i : i + 1), (double)v);
   }
 }
 
-int vertex_loss_partial(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact, int B,
-                        float* partial, hipStream_t s) {
-  hipLaunchKernelGGL(vertex_loss_partial_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, B, partial);
+int vertex_loss_accumulate(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
+                           const float* shape, const float* other, int B, double* acc, hipStream_t s) {
+  hipLaunchKernelGGL(vertex_loss_accumulate_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, shape, other, B, acc);
   return (int)hipGetLastError();
 }
 
 // losses[0..6] = marker, vposer, shape, hand, contact, smooth, total ; losses[8..11] = 1/count per foot set
 // weights[0..5] = rec_markers, vposer, shape, hand, contact_vel, smooth   (opt_amass_temp.py:47-52)
-__global__ void __launch_bounds__(256)
-loss_finalize_kernel(const float* __restrict__ vpartial, int B, int n67, const float* __restrict__ spartial, int n_sp,
-                     double smooth_count, const float* __restrict__ shape, const float* __restrict__ other,
-                     const float* __restrict__ weights, float* __restrict__ losses) {
-  __shared__ double dred[4][13];
-  const int t = threadIdx.x;
-  double sums[13];
-  for (int i = 0; i < 13; ++i) sums[i] = 0.0;
-  for (int b = t; b < B; b += 256)
-    for (int i = 0; i < 9; ++i) sums[i] += (double)vpartial[(size_t)b * 9 + i];
-  for (int i = t; i < n_sp; i += 256) sums[9] += (double)spartial[i];
-  for (int i = t; i < B * 32; i += 256) { const float v = other[(size_t)(i / 32) * 56 + (i % 32)]; sums[10] += (double)v * v; }
-  for (int i = t; i < B * 10; i += 256) { const float v = shape[i]; sums[11] += (double)v * v; }
-  for (int i = t; i < B * 24; i += 256) { const float v = other[(size_t)(i / 24) * 56 + 32 + (i % 24)]; sums[12] += (double)v * v; }
-  // all 13 sums at once: butterfly inside each wave, then 4 wave partials in a fixed order
-#pragma unroll
-  for (int i = 0; i < 13; ++i) {
-    double v = sums[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((t & 63) == 0) dred[t >> 6][i] = v;
+__device__ __forceinline__ void finalize_losses(const double* tot, int B, int n67, double smooth_count,
+                                                const float* weights, float* losses) {
+  const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
+  float l_contact = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const double cnt = tot[5 + k];
+    const float part = cnt >= 1.0 ? (float)(tot[1 + k] / cnt) : 0.f;
+    l_contact = l_contact + part;
+    losses[8 + k] = cnt >= 1.0 ? (float)(1.0 / cnt) : 0.f;
   }
-  __syncthreads();
-  double tot[13];
-  for (int i = 0; i < 13; ++i) tot[i] = dred[0][i] + dred[1][i] + dred[2][i] + dred[3][i];
-  if (t == 0) {
-    const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
-    float l_contact = 0.f;
-    for (int k = 0; k < 4; ++k) {
-      const double cnt = tot[5 + k];
-      const float part = cnt >= 1.0 ? (float)(tot[1 + k] / cnt) : 0.f;
-      l_contact = l_contact + part;
-      losses[8 + k] = cnt >= 1.0 ? (float)(1.0 / cnt) : 0.f;
-    }
-    const float l_smooth = (float)(tot[9] / smooth_count);
-    const float l_vposer = (float)(tot[10] / ((double)B * 32));
-    const float l_shape = (float)(tot[11] / ((double)B * 10));
-    const float l_hand = (float)(tot[12] / ((double)B * 24));
-    float total = weights[0] * l_marker + weights[1] * l_vposer;
-    total = total + weights[2] * l_shape;
-    total = total + weights[3] * l_hand;
-    total = total + weights[4] * l_contact;
-    total = total + weights[5] * l_smooth;
-    losses[0] = l_marker; losses[1] = l_vposer; losses[2] = l_shape; losses[3] = l_hand;
-    losses[4] = l_contact; losses[5] = l_smooth; losses[6] = total; losses[7] = 0.f;
+  const float l_smooth = (float)(tot[9] / smooth_count);
+  const float l_vposer = (float)(tot[10] / ((double)B * 32));
+  const float l_shape = (float)(tot[11] / ((double)B * 10));
+  const float l_hand = (float)(tot[12] / ((double)B * 24));
+  float total = weights[0] * l_marker + weights[1] * l_vposer;
+  total = total + weights[2] * l_shape;
+  total = total + weights[3] * l_hand;
+  total = total + weights[4] * l_contact;
+  total = total + weights[5] * l_smooth;
+  losses[0] = l_marker; losses[1] = l_vposer; losses[2] = l_shape; losses[3] = l_hand;
+  losses[4] = l_contact; losses[5] = l_smooth; losses[6] = total; losses[7] = 0.f;
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ acc, int B, int n67, double smooth_count,
+                                     const float* __restrict__ weights, float* __restrict__ losses) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double tot[13];
+    for (int i = 0; i < 13; ++i) tot[i] = acc[i];
+    finalize_losses(tot, B, n67, smooth_count, weights, losses);
   }
 }
 
-int loss_finalize(const float* vpartial, int B, int n67, const float* spartial, int n_sp, double smooth_count,
-                  const float* shape, const float* other, const float* weights, float* losses, hipStream_t s) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, vpartial, B, n67, spartial, n_sp, smooth_count, shape, other, weights, losses);
+int loss_finalize(const double* acc, int B, int n67, double smooth_count, const float* weights, float* losses, hipStream_t s) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, acc, B, n67, smooth_count, weights, losses);
   return (int)hipGetLastError();
 }
 
@@ -163,9 +155,17 @@ int loss_finalize(const float* vpartial, int B, int n67, const float* spartial, 
 __global__ void __launch_bounds__(256)
 dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                        const float* __restrict__ contact, const float* __restrict__ dx0, const float* __restrict__ canon,
-                       const float* __restrict__ weights, const float* __restrict__ losses, int B,
-                       float* __restrict__ dverts) {
+                       const float* __restrict__ weights, const double* __restrict__ acc, double smooth_count,
+                       float* __restrict__ losses_out, int B, float* __restrict__ dverts) {
+  __shared__ float losses[12];
   const int b = blockIdx.x;
+  if (threadIdx.x == 0) {             // every block finalises the (tiny) loss record itself; block 0 publishes it
+    double tot[13];
+    for (int i = 0; i < 13; ++i) tot[i] = acc[i];
+    finalize_losses(tot, B, fc.n67, smooth_count, weights, losses);
+    if (b == 0) for (int i = 0; i < 12; ++i) losses_out[i] = losses[i];
+  }
+  __syncthreads();
   const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, nd = B - 1;
   (void)H;
   const float wm = weights[0] / ((float)B * fc.n67 * 3), wc = weights[4];
@@ -235,9 +235,9 @@ dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, 
 }
 
 int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
-                    const float* dx0, const float* canon, const float* weights, const float* losses, int B,
-                    float* dverts, hipStream_t s) {
-  hipLaunchKernelGGL(dverts_assemble_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, dx0, canon, weights, losses, B, dverts);
+                    const float* dx0, const float* canon, const float* weights, const double* acc, double smooth_count,
+                    float* losses, int B, float* dverts, hipStream_t s) {
+  hipLaunchKernelGGL(dverts_assemble_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, dx0, canon, weights, acc, smooth_count, losses, B, dverts);
   return (int)hipGetLastError();
 }
 
@@ -247,9 +247,12 @@ int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const flo
 struct AdamGroup { float* p; const float* g; float* m; float* v; int n; };
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __restrict__ weights, int* __restrict__ step_ctr,
-            float lr0, float lr1, int lr_switch) {
+            const int* __restrict__ step_cur, float lr0, float lr1, int lr_switch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int step = *step_ctr;                 // iterations completed so far (0-based index of this one)
+  // 0-based index of this iteration, latched into step_cur at the start of the iteration (every thread
+  // reads the latch; one thread advances the counter -> no read/write race, no extra launch)
+  const int step = *step_cur;
+  if (i == 0) *step_ctr = step + 1;
   const int ntot = g0.n + g1.n + g2.n;
   if (i < ntot) {
     AdamGroup G = g0; int k = i;
@@ -271,15 +274,12 @@ adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __rest
     G.p[k] = G.p[k] - (lr / bc1) * (m / denom);
   }
 }
-__global__ void step_inc_kernel(int* step_ctr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ctr += 1; }
-
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
-              int* step_ctr, float lr0, float lr1, int lr_switch, hipStream_t s) {
+              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s) {
   AdamGroup a{transl, g_transl, m0, v0, B * 3}, b{rot6d, g_rot, m1, v1, B * 6}, c{other, g_other, m2, v2, B * 56};
   const int n = B * 65;
-  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, lr0, lr1, lr_switch);
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, step_ctr);
+  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr0, lr1, lr_switch);
   return (int)hipGetLastError();
 }
 

@@ -82,7 +82,18 @@ int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const 
   hipLaunchKernelGGL(vposer_rot_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, o, d_aa, d_matrot, B, dout);
   int e = (int)hipGetLastError();
   if (e) return e;
-  // dh2 = (dout . W3) * lrelu'(h2) ; dh1 = (dh2 . W2) * lrelu'(h1) ; dz = dh1 . W1   (transposed packs as A)
+  (void)dh2; (void)dh1;
+  return vposer_mlp_bwd(w, h1, h2, B, dz, dz_stride, scratch, s);
+}
+
+// dout = scratch[0 .. B*128) ; dh2 = (dout . W3) * lrelu'(h2) ; dh1 = (dh2 . W2) * lrelu'(h1) ; dz = dh1 . W1
+int vposer_mlp_bwd(const VPoserW& w, const float* h1, const float* h2, int B, float* dz, int dz_stride, float* scratch,
+                   hipStream_t s) {
+  if (B <= 0 || !scratch) return LEMO_ERR_SHAPE;
+  float* dout = scratch;
+  float* dh2 = scratch + (size_t)B * 128;
+  float* dh1 = dh2 + (size_t)B * VP_H;
+  int e;
   if ((e = gemm_nt16(w.w3t, 128, dout, 128, VP_H, B, 128, dh2, VP_H, nullptr, h2, VP_H, 3, s))) return e;
   if ((e = gemm_nt16(w.w2t, VP_H, dh2, VP_H, VP_H, B, VP_H, dh1, VP_H, nullptr, h1, VP_H, 3, s))) return e;
   return gemm_nt16(w.w1t, VP_H, dh1, VP_H, VP_Z, B, VP_H, dz, dz_stride, nullptr, nullptr, 0, 0, s);
@@ -133,13 +144,39 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   __shared__ float Js[MAXJ * 3];
   __shared__ float Ts[MAXJ * 12];
   __shared__ float shp[32];
+  __shared__ float gob[66];           // global_orient (3) | body_pose (63) of this frame
   const int b = blockIdx.x, t = threadIdx.x;
   const int nj = c.nj, np = nj * 3;
+  // ---- per-iteration bookkeeping of the fitting engine (block 0 only)
+  if (b == 0) {
+    if (in.zero_f64) for (int i = t; i < in.n_zero; i += 256) in.zero_f64[i] = 0.0;
+    if (in.step_cur && t == 0) *in.step_cur = *in.step_ctr;
+  }
+  // ---- global_orient / body_pose: given, or derived from the 6-D rotation / VPoser out layer
+  if (in.rot6d) {
+    if (t == 0) {
+      float x6[6], R[9], a3[3];
+      for (int k = 0; k < 6; ++k) x6[k] = in.rot6d[(size_t)b * 6 + k];
+      rot6d_fwd(x6, R);
+      rotmat_to_aa_fwd(R, a3);
+      for (int k = 0; k < 3; ++k) { gob[k] = a3[k]; if (in.go_out) in.go_out[(size_t)b * 3 + k] = a3[k]; }
+    }
+  } else if (t < 3) gob[t] = in.global_orient[(size_t)b * 3 + t];
+  if (in.vposer_o) {
+    if (t >= 64 && t < 64 + VP_NJ) {
+      const int jn = t - 64;
+      float o6[6], R[9], a3[3];
+      for (int k = 0; k < 6; ++k) o6[k] = in.vposer_o[(size_t)b * 128 + 6 * jn + k];
+      rot6d_fwd(o6, R);
+      rotmat_to_aa_fwd(R, a3);
+      for (int k = 0; k < 3; ++k) gob[3 + 3 * jn + k] = a3[k];
+    }
+  } else if (t >= 64 && t < 64 + 63) gob[3 + t - 64] = in.body_pose[(size_t)b * 63 + (t - 64)];
+  __syncthreads();
   // ---- full pose (SMPLX.forward: cat[go, body, jaw, leye, reye, lhand45, rhand45] + pose_mean)
   for (int i = t; i < np; i += 256) {
     float v;
-    if (i < 3) v = in.global_orient[(size_t)b * 3 + i];
-    else if (i < 66) v = in.body_pose[(size_t)b * 63 + (i - 3)];
+    if (i < 66) v = gob[i];
     else if (i < 69) v = in.jaw ? in.jaw[(size_t)b * 3 + (i - 66)] : 0.f;
     else if (i < 72) v = in.leye ? in.leye[(size_t)b * 3 + (i - 69)] : 0.f;
     else if (i < 75) v = in.reye ? in.reye[(size_t)b * 3 + (i - 72)] : 0.f;
@@ -309,6 +346,27 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     for (int k = 0; k < 3; ++k) dfp[3 * t + k] = d3[k];
   }
   __syncthreads();
+  // fused consumers: d(global_orient) -> d(rot6d) ; d(body_pose) -> d(VPoser out layer)
+  if (go.d_rot6d && t == 0) {
+    float x6[6], R[9], dR[9], d6[6];
+    for (int k = 0; k < 6; ++k) x6[k] = go.rot6d[(size_t)b * 6 + k];
+    rot6d_fwd(x6, R);
+    rotmat_to_aa_bwd(R, &dfp[0], dR);
+    rot6d_bwd(x6, dR, d6);
+    for (int k = 0; k < 6; ++k) go.d_rot6d[(size_t)b * 6 + k] = d6[k];
+  }
+  if (go.d_vposer_o && t >= 64 && t < 64 + VP_NJ + 1) {
+    const int jn = t - 64;
+    if (jn == VP_NJ) { go.d_vposer_o[(size_t)b * 128 + 126] = 0.f; go.d_vposer_o[(size_t)b * 128 + 127] = 0.f; }
+    else {
+      float o6[6], R[9], dR[9], d6[6];
+      for (int k = 0; k < 6; ++k) o6[k] = go.vposer_o[(size_t)b * 128 + 6 * jn + k];
+      rot6d_fwd(o6, R);
+      rotmat_to_aa_bwd(R, &dfp[3 + 3 * jn], dR);
+      rot6d_bwd(o6, dR, d6);
+      for (int k = 0; k < 6; ++k) go.d_vposer_o[(size_t)b * 128 + 6 * jn + k] = d6[k];
+    }
+  }
   // scatter d(full_pose)
   for (int i = t; i < 75; i += 256) {
     const float v = dfp[i];

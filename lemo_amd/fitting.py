@@ -94,6 +94,8 @@ class AmassTemporalFitter:
         self.adam_m = [z(B, 3), z(B, 6), z(B, 56)]
         self.adam_v = [z(B, 3), z(B, 6), z(B, 56)]
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_cur = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss_acc = torch.zeros(16, dtype=torch.float64, device=dev)
         self.target, self.contact = z(B, self.n67, 3), z(B, 4)
         pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
         self.Bp = Bp
@@ -127,6 +129,7 @@ class AmassTemporalFitter:
                   'losses', 'dverts', 'dvp', 'dA', 'dX', 'g_transl', 'g_rot6d', 'g_other', 'g_go', 'g_body'):
             setattr(d, k, ptr(self.ws[k]))
         d.pose = pose_ws
+        d.loss_acc, d.step_cur = ptr(self.loss_acc), ptr(self.step_cur)
         for l in range(1, 11): d.act[l] = ptr(self.act[l])
         d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
         self.desc = d
