@@ -49,6 +49,7 @@ int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B
 int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, const PoseGradOut& go, int B, hipStream_t s);
 
 // ---------------- lbs_kernels.hip ----------------
+int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s);

@@ -14,85 +14,135 @@
 
 namespace lemo {
 
-#define LBS_VT 32                 // vertices per block
-#define LBS_COLS (LBS_VT * 3)     // 96 columns = 3 MFMA M-tiles
-#define LBS_PITCH 97
+#define LBS_VPB 42                // vertices per block -> 126 of 128 columns (4 MFMA M-tiles): V=10475 -> 250 blocks ~ 1 per CU
+#define LBS_COLS 128
 #define LBS_FR 128                // frames per block pass (4 N-tiles)
+#define LBS_KC 8                  // 8-feature groups staged per LDS stage (64 features)
+#define LBS_PITCH 129
+#define LBS_STAGE_FLOATS (LBS_KC * 2 * 128 * 4)                   // one operand, one buffer: [KC][2 planes][128][4]
+#define LBS_SMEM_BYTES (4 * LBS_STAGE_FLOATS * 4)                 // A,B x double buffer = 128 KB (>= vp tile 66 KB)
 
-__global__ void __launch_bounds__(256)
+// 8 waves: wave w = (frame tile w&3, column-tile pair w>>2) -> 2 waves per SIMD.  Both GEMM operands go
+// through LDS (register-staged, double-buffered, all loads of a stage issued up front); operand
+// reads run one 2-group chunk ahead of the MFMAs that consume them.
+__global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
                      float* __restrict__ verts, float* __restrict__ v_posed) {
-  __shared__ float vp[LBS_FR * LBS_PITCH];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  LEMO_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int s0 = blockIdx.x * LBS_VT;                  // first vertex slot of this tile
+  const int s0 = blockIdx.x * LBS_VPB;                 // first vertex slot of this tile
   const int f0 = blockIdx.y * LBS_FR;                  // first frame of this pass
-  // ---- blend GEMM: wave w owns frames f0+32w..+31 (N-tile) x 96 columns (3 M-tiles)
-  const int fr = f0 + 32 * wave + j;                   // this lane's frame as B-operand column
-  const bool wave_active = (f0 + 32 * wave) < B;       // uniform per wave
-  if (wave_active) {
-    f32x16 acc[3];
+  const int nt = wave & 3, mp = wave >> 2;
+  // ---- staging plan: thread -> fixed (column, half) of A and (frame, half) of B; groups (tid>>8) + 2k
+  const int rem = tid & 255, scol = rem >> 1, shalf = rem & 1, sg0 = tid >> 8;
+  size_t a_off;                                        // float offset of this thread's column in one group of Dg
+  {
+    int slot = s0 + scol / 3;
+    if (slot >= n) slot = n - 1;
+    const int vid = ids ? ids[slot] : slot;
+    a_off = ((size_t)vid * 3 + (scol % 3)) * 8 + 4 * shalf;
+  }
+  const int fr_s = (f0 + scol < Bp) ? f0 + scol : Bp - 1;
+  const size_t b_off = (size_t)fr_s * 8 + 4 * shalf;
+  const size_t dg_stride = (size_t)c.NC * 8, xg_stride = (size_t)Bp * 8;
+  const int lds_dst = ((sg0 * 2 + shalf) * 128 + scol) * 4;     // + k * (2 groups) ; same for A and B tiles
+  float* As0 = smem;                                   // [2 buffers] of LBS_STAGE_FLOATS
+  float* Bs0 = smem + 2 * LBS_STAGE_FLOATS;
+  float4 sa[4], sb[4];
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+  for (int k = 0; k < 4; ++k) {
+    sa[k] = ld4(c.Dg + (size_t)(sg0 + 2 * k) * dg_stride + a_off);
+    sb[k] = ld4(Xg + (size_t)(sg0 + 2 * k) * xg_stride + b_off);
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    // per-lane column addresses (A operand rows): local col = m*32 + j -> slot = s0 + col/3
-    size_t colg[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const int lc = m * 32 + j;
-      int slot = s0 + lc / 3;
-      if (slot >= n) slot = n - 1;
-      const int vid = ids ? ids[slot] : slot;
-      colg[m] = (size_t)vid * 3 + (lc % 3);
-    }
-    const int frc = fr < Bp ? fr : Bp - 1;
-    const float* xb = Xg + (size_t)frc * 8 + 4 * h;
-    const float* db = c.Dg + 4 * h;
-    const size_t xg_stride = (size_t)Bp * 8, dg_stride = (size_t)c.NC * 8;
-    float4 b_cur = ld4(xb), a_cur[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) a_cur[m] = ld4(db + colg[m] * 8);
-    for (int g = 0; g < 64; ++g) {
-      float4 b_nxt = b_cur, a_nxt[3] = {a_cur[0], a_cur[1], a_cur[2]};
-      if (g + 1 < 64) {
-        b_nxt = ld4(xb + (size_t)(g + 1) * xg_stride);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) a_nxt[m] = ld4(db + (size_t)(g + 1) * dg_stride + colg[m] * 8);
-      }
-      const float bs[4] = {b_cur.x, b_cur.y, b_cur.z, b_cur.w};
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const float as = s == 0 ? a_cur[m].x : s == 1 ? a_cur[m].y : s == 2 ? a_cur[m].z : a_cur[m].w;
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs[s], acc[m], 0, 0, 0);
-        }
-      b_cur = b_nxt;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) a_cur[m] = a_nxt[m];
-    }
-    // accumulator: col = j -> frame (32*wave + j), row -> column within the M-tile
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        vp[(32 * wave + j) * LBS_PITCH + m * 32 + row] = acc[m][r];
-      }
+  for (int k = 0; k < 4; ++k) {
+    st4(As0 + lds_dst + k * (2 * 2 * 128 * 4), sa[k]);
+    st4(Bs0 + lds_dst + k * (2 * 2 * 128 * 4), sb[k]);
   }
   __syncthreads();
-  // ---- skinning: thread = (vertex lv, frame group); 16 frames each
-  const int lv = threadIdx.x & 31, fg = threadIdx.x >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  const int a_rd = (h * 128 + mp * 64 + j) * 4, b_rd = (h * 128 + nt * 32 + j) * 4;
+  constexpr int NST = 64 / LBS_KC;
+  for (int st = 0; st < NST; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < NST) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sa[k] = ld4(c.Dg + (size_t)((st + 1) * LBS_KC + sg0 + 2 * k) * dg_stride + a_off);
+        sb[k] = ld4(Xg + (size_t)((st + 1) * LBS_KC + sg0 + 2 * k) * xg_stride + b_off);
+      }
+    }
+    const float* ar = As0 + buf * LBS_STAGE_FLOATS + a_rd;
+    const float* br = Bs0 + buf * LBS_STAGE_FLOATS + b_rd;
+    float4 ra[2][2][2], rb[2][2];                      // [set][group in chunk][m-tile]
+#define LBS_READ2(SET, CH)                                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                            \
+      const int go_ = ((CH) * 2 + g_) * (2 * 128 * 4);                                            \
+      ra[SET][g_][0] = ld4(ar + go_); ra[SET][g_][1] = ld4(ar + go_ + 32 * 4);                    \
+      rb[SET][g_] = ld4(br + go_);                                                                \
+    }
+#define LBS_MFMA2(SET)                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                                            \
+      _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) {                                          \
+        acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][g_][m_].x, rb[SET][g_].x, acc[m_], 0, 0, 0);  \
+        acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][g_][m_].y, rb[SET][g_].y, acc[m_], 0, 0, 0);  \
+        acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][g_][m_].z, rb[SET][g_].z, acc[m_], 0, 0, 0);  \
+        acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SET][g_][m_].w, rb[SET][g_].w, acc[m_], 0, 0, 0);  \
+      }                                                                                           \
+    }
+    LBS_READ2(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_READ2(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_MFMA2(0)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_READ2(0, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_MFMA2(1)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_READ2(1, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_MFMA2(0)
+    __builtin_amdgcn_sched_barrier(0);
+    LBS_MFMA2(1)
+#undef LBS_READ2
+#undef LBS_MFMA2
+    if (st + 1 < NST) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        st4(As0 + (buf ^ 1) * LBS_STAGE_FLOATS + lds_dst + k * (2 * 2 * 128 * 4), sa[k]);
+        st4(Bs0 + (buf ^ 1) * LBS_STAGE_FLOATS + lds_dst + k * (2 * 2 * 128 * 4), sb[k]);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- hand the blend tile over through LDS (aliases the staging buffers: everyone is past the last read)
+  float* vp = smem;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;             // D: col = frame j, row -> column of the M-tile
+      vp[(nt * 32 + j) * LBS_PITCH + (mp * 2 + m) * 32 + row] = acc[m][r];
+    }
+  __syncthreads();
+  // ---- skinning: thread = (vertex lv < 42, frame group of 12)
+  if (tid >= 12 * LBS_VPB) return;
+  const int lv = tid % LBS_VPB, fg = tid / LBS_VPB;
   const int slot = s0 + lv;
   if (slot >= n) return;
   const int vid = ids ? ids[slot] : slot;
   const float tx = c.v_template[(size_t)vid * 3], ty = c.v_template[(size_t)vid * 3 + 1], tz = c.v_template[(size_t)vid * 3 + 2];
   const int* wi = c.w_idx + (size_t)vid * c.KW;
   const float* wv = c.w_val + (size_t)vid * c.KW;
-  for (int i = 0; i < LBS_FR / 8; ++i) {
-    const int fl = fg + 8 * i, f = f0 + fl;
+  for (int fl = fg; fl < LBS_FR; fl += 12) {
+    const int f = f0 + fl;
     if (f >= B) break;
     const float px = vp[fl * LBS_PITCH + 3 * lv] + tx, py = vp[fl * LBS_PITCH + 3 * lv + 1] + ty,
                 pz = vp[fl * LBS_PITCH + 3 * lv + 2] + tz;
@@ -121,11 +171,20 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
 }
 
+int lbs_init() {
+  static int rc = -1;
+  if (rc >= 0) return rc;
+  rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_BYTES);
+  return rc;
+}
+
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s) {
   if (n <= 0 || B <= 0 || B > Bp || (Bp % 32) || (!ids && n != c.V)) return LEMO_ERR_SHAPE;
-  dim3 grid((n + LBS_VT - 1) / LBS_VT, (B + LBS_FR - 1) / LBS_FR);
-  hipLaunchKernelGGL(lbs_verts_fwd_kernel, grid, dim3(256), 0, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed);
+  if (lbs_init()) return LEMO_ERR_STATE;
+  dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
+  hipLaunchKernelGGL(lbs_verts_fwd_kernel, grid, dim3(512), LBS_SMEM_BYTES, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed);
   return (int)hipGetLastError();
 }
 

@@ -170,7 +170,7 @@ static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
 
 void* lemo_fit_create(const lemo_fit_desc* d) {
   if (!d || d->B < 10 || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
-  if (conv_lds_init()) return nullptr;
+  if (conv_lds_init() || lbs_init()) return nullptr;
   FitEngine* e = new (std::nothrow) FitEngine();
   if (e) e->d = *d;
   return e;
