@@ -126,6 +126,9 @@ typedef struct lemo_vertex_set_bwd {
 } lemo_vertex_set_bwd;
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
+/* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */
+int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream);
 int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
                        int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
                        void* stream);
@@ -176,7 +179,7 @@ typedef struct lemo_fit_desc {
   float* act[11];                 /* act[0] unused; act[l] = output of layer l, CG8P */
   float* dact[2];                 /* ping-pong d(pre-activation) buffers, 64-channel CG8P */
   float *dx0, *spartial, *vpartial, *losses, *dverts, *dvp, *dA, *dX;
-  double* loss_acc;               /* [16] per-iteration loss accumulators (f64 atomics) */
+  double* loss_acc;               /* [32][16] per-iteration loss accumulators (f64 atomics, 32 slots) */
   int* step_cur;                  /* [1] step index latched at the start of the iteration */
   float *g_transl, *g_rot6d, *g_other, *g_go, *g_body;
 } lemo_fit_desc;

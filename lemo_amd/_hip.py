@@ -123,6 +123,7 @@ _SIGS = {
     'lemo_smplx_pose_bwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseWs), C.POINTER(PoseGradIn),
                                       C.POINTER(PoseGradOut), C.c_int, vp]),
     'lemo_lbs_verts_fwd': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    'lemo_lbs_verts_fwd_census': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     'lemo_lbs_verts_bwd': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp,
                                      C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     'lemo_joints_assemble': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),

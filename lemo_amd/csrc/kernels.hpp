@@ -52,7 +52,7 @@ int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, c
 int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s);
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts /*[B][n][3]*/, int B, int Bp, float* dvp /*[B][NCs] scratch*/,
                   float* dA /*[B][nj][12]*/, float* dtransl /*[B][3] or null*/, float* dX /*[B][512]*/, hipStream_t s);

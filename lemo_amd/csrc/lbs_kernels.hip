@@ -20,16 +20,22 @@ namespace lemo {
 #define LBS_KC 8                  // 8-feature groups staged per LDS stage (64 features)
 #define LBS_PITCH 129
 #define LBS_STAGE_FLOATS (LBS_KC * 2 * 128 * 4)                   // one operand, one buffer: [KC][2 planes][128][4]
-#define LBS_SMEM_BYTES (4 * LBS_STAGE_FLOATS * 4)                 // A,B x double buffer = 128 KB (>= vp tile 66 KB)
+#define LBS_SMEM_BYTES (4 * LBS_STAGE_FLOATS * 4)                 // A,B x double buffer = 128 KB
+#define LBS_SMEM_MAX 163840
+// GEMM staging (128 KB), later aliased by [blend tile 128 x 129] + [2 x 12 frames of A]
+static inline int lbs_smem_bytes(int nj) { const int b = (LBS_FR * LBS_PITCH + 2 * 12 * nj * 12) * 4; return b > LBS_SMEM_BYTES ? b : LBS_SMEM_BYTES; }
 
 // 8 waves: wave w = (frame tile w&3, column-tile pair w>>2) -> 2 waves per SIMD.  Both GEMM operands go
 // through LDS (register-staged, double-buffered, all loads of a stage issued up front); operand
 // reads run one 2-group chunk ahead of the MFMAs that consume them.
+template <bool DBG>
 __global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
-                     float* __restrict__ verts, float* __restrict__ v_posed) {
+                     float* __restrict__ verts, float* __restrict__ v_posed, unsigned long long* __restrict__ dbg) {
   LEMO_DYN_SMEM(smem);
+  unsigned long long t_start = 0, t_pro = 0, t_gemm = 0;
+  if (DBG) t_start = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int s0 = blockIdx.x * LBS_VPB;                 // first vertex slot of this tile
@@ -62,6 +68,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     st4(Bs0 + lds_dst + k * (2 * 2 * 128 * 4), sb[k]);
   }
   __syncthreads();
+  if (DBG) t_pro = __builtin_amdgcn_s_memtime();
   f32x16 acc[2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -122,6 +129,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     }
     __syncthreads();
   }
+  if (DBG) t_gemm = __builtin_amdgcn_s_memtime();
   // ---- hand the blend tile over through LDS (aliases the staging buffers: everyone is past the last read)
   float* vp = smem;
 #pragma unroll
@@ -133,58 +141,102 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     }
   __syncthreads();
   // ---- skinning: thread = (vertex lv < 42, frame group of 12)
-  if (tid >= 12 * LBS_VPB) return;
   const int lv = tid % LBS_VPB, fg = tid / LBS_VPB;
   const int slot = s0 + lv;
-  if (slot >= n) return;
-  const int vid = ids ? ids[slot] : slot;
-  const float tx = c.v_template[(size_t)vid * 3], ty = c.v_template[(size_t)vid * 3 + 1], tz = c.v_template[(size_t)vid * 3 + 2];
+  const bool skin = tid < 12 * LBS_VPB && slot < n;
+  // The per-joint transforms A[f][nj][12] are gathered (KW joints per vertex) for every (vertex, frame)
+  // pair: straight from L2 that is a chain of exposed round trips (measured 51k cycles per block), so
+  // they are staged through LDS in chunks of 12 frames (one frame per thread group), double-buffered
+  // behind the blend tile, the next chunk loading while the current one is consumed.
+  const int fpf = nj * 12;                                        // floats per frame of A
+  float* Ab = smem + LBS_FR * LBS_PITCH;                           // [2][12 * fpf]
+  const int nfr = (B - f0 < LBS_FR) ? B - f0 : LBS_FR;
+  const int nchunk = (nfr + 11) / 12;
+  const int n4 = 3 * fpf;                                          // float4 per chunk (12 * fpf / 4)
+  const int a_last4 = B * fpf / 4 - 1;                             // clamp: last float4 of A
+  float4 sA[5];
+#define LBS_ALOAD(CH)                                                                             \
+  _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                 \
+    int i4 = (f0 + (CH) * 12) * (fpf / 4) + tid + k * 512;                                        \
+    if (i4 > a_last4) i4 = a_last4;                                                               \
+    sA[k] = ld4(A + (size_t)i4 * 4);                                                              \
+  }
+#define LBS_ASTORE(BUF)                                                                           \
+  _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                 \
+    const int l4 = tid + k * 512;                                                                 \
+    if (l4 < n4) st4(Ab + (BUF) * 12 * fpf + l4 * 4, sA[k]);                                      \
+  }
+  int vid = 0;
+  float tx = 0.f, ty = 0.f, tz = 0.f;
+  if (skin) {
+    vid = ids ? ids[slot] : slot;
+    tx = c.v_template[(size_t)vid * 3]; ty = c.v_template[(size_t)vid * 3 + 1]; tz = c.v_template[(size_t)vid * 3 + 2];
+  }
   const int* wi = c.w_idx + (size_t)vid * c.KW;
   const float* wv = c.w_val + (size_t)vid * c.KW;
-  for (int fl = fg; fl < LBS_FR; fl += 12) {
-    const int f = f0 + fl;
-    if (f >= B) break;
-    const float px = vp[fl * LBS_PITCH + 3 * lv] + tx, py = vp[fl * LBS_PITCH + 3 * lv + 1] + ty,
-                pz = vp[fl * LBS_PITCH + 3 * lv + 2] + tz;
-    float T[12];
+  LBS_ALOAD(0)
+  LBS_ASTORE(0)
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunk) { LBS_ALOAD(ch + 1) }
+    const int fl = ch * 12 + fg, f = f0 + fl;
+    if (skin && fl < nfr) {
+      const float px = vp[fl * LBS_PITCH + 3 * lv] + tx, py = vp[fl * LBS_PITCH + 3 * lv + 1] + ty,
+                  pz = vp[fl * LBS_PITCH + 3 * lv + 2] + tz;
+      float T[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) T[e] = 0.f;
-    const float* Af = A + (size_t)f * nj * 12;
-    for (int k = 0; k < c.KW; ++k) {
-      const float w = wv[k];
-      const float* Aj = Af + wi[k] * 12;
-      const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);
-      T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
-      T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
-      T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
+      for (int e = 0; e < 12; ++e) T[e] = 0.f;
+      const float* Af = Ab + buf * 12 * fpf + fg * fpf;
+      for (int k = 0; k < c.KW; ++k) {
+        const float w = wv[k];
+        const float* Aj = Af + wi[k] * 12;
+        const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);
+        T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
+        T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
+        T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
+      }
+      float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
+      float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+      float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+      if (transl) { ox += transl[(size_t)f * 3]; oy += transl[(size_t)f * 3 + 1]; oz += transl[(size_t)f * 3 + 2]; }
+      float* o = verts + ((size_t)f * n + slot) * 3;
+      o[0] = ox; o[1] = oy; o[2] = oz;
+      if (v_posed) {
+        float* q = v_posed + ((size_t)f * n + slot) * 3;
+        q[0] = px; q[1] = py; q[2] = pz;
+      }
     }
-    float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
-    float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
-    float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-    if (transl) { ox += transl[(size_t)f * 3]; oy += transl[(size_t)f * 3 + 1]; oz += transl[(size_t)f * 3 + 2]; }
-    float* o = verts + ((size_t)f * n + slot) * 3;
-    o[0] = ox; o[1] = oy; o[2] = oz;
-    if (v_posed) {
-      float* q = v_posed + ((size_t)f * n + slot) * 3;
-      q[0] = px; q[1] = py; q[2] = pz;
-    }
+    if (ch + 1 < nchunk) { LBS_ASTORE(buf ^ 1) }
+    __syncthreads();
+  }
+#undef LBS_ALOAD
+#undef LBS_ASTORE
+  if (DBG && lane == 0) {
+    unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+    r[0] = t_start; r[1] = t_pro; r[2] = t_gemm; r[3] = __builtin_amdgcn_s_memtime();
   }
 }
 
 int lbs_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
-  rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_BYTES);
+  rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
+  if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
   return rc;
 }
 
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s) {
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg) {
   if (n <= 0 || B <= 0 || B > Bp || (Bp % 32) || (!ids && n != c.V)) return LEMO_ERR_SHAPE;
   if (lbs_init()) return LEMO_ERR_STATE;
+  if (nj > 64 || 3 * nj * 12 > 5 * 512) return LEMO_ERR_SHAPE;
+  const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
-  hipLaunchKernelGGL(lbs_verts_fwd_kernel, grid, dim3(512), LBS_SMEM_BYTES, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed);
+  if (dbg) hipLaunchKernelGGL(lbs_verts_fwd_kernel<true>, grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg);
+  else hipLaunchKernelGGL(lbs_verts_fwd_kernel<false>, grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg);
   return (int)hipGetLastError();
 }
 

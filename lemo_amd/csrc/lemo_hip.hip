@@ -80,6 +80,11 @@ int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const 
   if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;
   return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, S(stream));
 }
+int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
+                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream) {
+  if (!c || !Xg || !A || !verts || !dbg) return LEMO_ERR_ARG;
+  return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, nullptr, n, B, verts, v_posed, S(stream), dbg);
+}
 int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
                        int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
                        void* stream) {
@@ -115,7 +120,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   in.rot6d = d.rot6d; in.vposer_o = d.vo; in.go_out = d.go_aa;
   in.lh = d.other + 32; in.rh = d.other + 44; in.hand_stride = 56;
   in.betas = d.shape; in.betas_stride = 10;
-  in.zero_f64 = d.loss_acc; in.n_zero = 16; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
+  in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));

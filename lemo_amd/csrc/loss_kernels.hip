@@ -67,7 +67,8 @@ int marker_feature(const FitConst& fc, const float* verts, int nrows, const floa
   return (int)hipGetLastError();
 }
 
-// Loss accumulators (f64[16], zeroed at the start of every iteration by the pose-stage kernel):
+// Loss accumulators (f64 [32 slots][16], zeroed at the start of every iteration by the pose-stage kernel;
+// a block adds to slot blockIdx & 31 to keep the L2 atomics from serialising on one address):
 //   [0] marker L1 sum ; [1+k] contact-velocity sum, [5+k] count (k = 4 foot sets) ; [9] smoothness sum of
 //   squares ; [10] sum z^2 ; [11] sum betas^2 ; [12] sum hands^2.
 // Accumulating f32 block sums into f64 with atomics is order-dependent only at ~1e-16 relative, far
@@ -102,7 +103,7 @@ vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int 
   else if (t >= 128 && t < 152) { const float v = other[(size_t)b * 56 + 32 + (t - 128)]; acc[11] = v * v; }
   for (int i = 0; i < 12; ++i) {
     const float v = block_sum(acc[i], red);
-    if (t == 0 && v != 0.f) atomicAdd(accg + (i < 9 ? i : i + 1), (double)v);
+    if (t == 0 && v != 0.f) atomicAdd(accg + (b & 31) * 16 + (i < 9 ? i : i + 1), (double)v);
   }
 }
 
@@ -141,7 +142,7 @@ __global__ void loss_finalize_kernel(const double* __restrict__ acc, int B, int 
                                      const float* __restrict__ weights, float* __restrict__ losses) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double tot[13];
-    for (int i = 0; i < 13; ++i) tot[i] = acc[i];
+    for (int i = 0; i < 13; ++i) { double v = 0.0; for (int sl = 0; sl < 32; ++sl) v += acc[sl * 16 + i]; tot[i] = v; }
     finalize_losses(tot, B, n67, smooth_count, weights, losses);
   }
 }
@@ -159,9 +160,16 @@ dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, 
                        float* __restrict__ losses_out, int B, float* __restrict__ dverts) {
   __shared__ float losses[12];
   const int b = blockIdx.x;
-  if (threadIdx.x == 0) {             // every block finalises the (tiny) loss record itself; block 0 publishes it
+  __shared__ double tots[13];
+  if (threadIdx.x < 13) {             // every block finalises the (tiny) loss record itself; block 0 publishes it
+    double v = 0.0;
+    for (int sl = 0; sl < 32; ++sl) v += acc[sl * 16 + threadIdx.x];
+    tots[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     double tot[13];
-    for (int i = 0; i < 13; ++i) tot[i] = acc[i];
+    for (int i = 0; i < 13; ++i) tot[i] = tots[i];
     finalize_losses(tot, B, fc.n67, smooth_count, weights, losses);
     if (b == 0) for (int i = 0; i < 12; ++i) losses_out[i] = losses[i];
   }

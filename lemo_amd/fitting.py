@@ -95,7 +95,7 @@ class AmassTemporalFitter:
         self.adam_v = [z(B, 3), z(B, 6), z(B, 56)]
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
         self.step_cur = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.loss_acc = torch.zeros(16, dtype=torch.float64, device=dev)
+        self.loss_acc = torch.zeros(32 * 16, dtype=torch.float64, device=dev)
         self.target, self.contact = z(B, self.n67, 3), z(B, 4)
         pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
         self.Bp = Bp

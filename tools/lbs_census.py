@@ -1,0 +1,23 @@
+"""phase breakdown of the LBS vertex-forward kernel (diagnostic, GPU box only)"""
+import os, sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lemo_amd import _hip, synthetic
+from lemo_amd._hip import ptr
+from lemo_amd.body_model import BodyModelData, DeviceBody, alloc_pose_ws
+lib = _hip.get_lib(); dev = torch.device('cuda:0')
+data = BodyModelData(synthetic.make_synthetic_smplx(seed=0)); db = DeviceBody(data, dev)
+B = 119
+ws, tt, Bp = alloc_pose_ws(B, data.nj, dev)
+tt['Xg'].normal_(); tt['A'].normal_()
+verts = torch.empty(B, data.V, 3, device=dev); vp = torch.empty_like(verts)
+nblk = (data.V + 41) // 42
+dbg = torch.zeros(nblk * 8 * 4, dtype=torch.int64, device=dev)
+s = torch.cuda.current_stream(dev).cuda_stream
+for _ in range(3):
+    lib.check(lib.lbs_verts_fwd_census(C.byref(db.skin), ptr(tt['Xg']), Bp, ptr(tt['A']), data.nj, None, data.V, B, ptr(verts), ptr(vp), ptr(dbg), s))
+torch.cuda.synchronize()
+d = dbg.cpu().numpy().reshape(nblk, 8, 4)
+t0, tp, tg, t1 = d[..., 0], d[..., 1], d[..., 2], d[..., 3]
+print('blocks', nblk, 'median cycles: prologue %d  gemm %d  handover+skinning %d  total %d (max %d)' % (
+    np.median(tp - t0), np.median(tg - tp), np.median(t1 - tg), np.median(t1 - t0), (t1 - t0).max()))
