@@ -329,7 +329,15 @@ conv3x3_mfma_v2_kernel(const float* __restrict__ in, const float* __restrict__ w
   const int cb = blockIdx.y * CPB;
   if ((int)blockIdx.x >= tail_blocks) {
     const int j = lane & 31, h = lane >> 5;
-    const int pfirst = ((int)blockIdx.x - tail_blocks) * 128, plast = pfirst + 127;
+    // XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8, so give XCD x the contiguous
+    // run of tiles [x*q, x*q+q): vertically adjacent tiles then share their halo rows in ONE L2
+    // instead of each XCD fetching them from the fabric (PMC: 26.8 MB fetched for an 8.4 MB input).
+    int tile = (int)blockIdx.x - tail_blocks;
+    {
+      const int q = full_blocks >> 3, r = full_blocks & 7, xcd = tile & 7, k = tile >> 3;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective for any count
+    }
+    const int pfirst = tile * 128, plast = pfirst + 127;
     const int yf = pfirst / W, yl = plast / W;
     const int q0 = (yf + 1) * Wp + (pfirst - yf * W + 1), q1 = (yl + 1) * Wp + (plast - yl * W + 1);
     const int qin = q0 - Wp - 1;                                 // first staged padded pixel
