@@ -78,6 +78,19 @@ def time_dominant_kernel(fit, stream, reps=50):
     return ms, flops
 
 
+def pmc_traffic(conv_variant):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/gpu_pmc.sh ->
+    profiles/r01_pmc_summary.json): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
+    the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    if conv_variant != 2 or not os.path.exists(path):
+        return None
+    d = json.load(open(path)).get('lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>')
+    if not d or 'FETCH_SIZE' not in d or 'WRITE_SIZE' not in d:
+        return None
+    return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+
+
 def cpu_baseline(prob, B, budget_s=20.0):
     """oracle (kind 'port'): faithful iteration incl. the reference's two SMPL-X forwards."""
     from oracle import lemo_oracle as O
@@ -185,8 +198,10 @@ def main():
                    'sequences': world, 'conv_variant': args.conv_variant, 'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': None,
-                     'kernel': f'conv3x3_mfma (variant {args.conv_variant}) 64->64ch 245x134, 16 of the ~45 launches/iteration',
+                     'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': pmc_traffic(args.conv_variant),
+                     'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
+                                     'algorithmic minimum 17.1e6)',
+                     'kernel': f'conv3x3_mfma (variant {args.conv_variant}) 64->64ch 245x134, 14 of the 41 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
