@@ -136,6 +136,12 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
                          const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
                          void* stream);
 
+/* ---- PROX scene terms: F.grid_sample(sdf, verts, padding_mode='border') of temp_prox/fitting_temp_slide.py:685-739
+ * sdf [D][H][W] device; pts [N][3] device world coordinates; gmin/gmax HOST float[3]; val [N]; dval [N][3] or NULL
+ * (d val / d pts).  Grid axis order follows the reference's norm_vertices[:, :, [2,1,0]]. */
+int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
+                    float* val, float* dval, void* stream);
+
 /* ---- AMASS temporal fitting iteration, opt_amass_temp.py:349-455 -------------------------------- */
 typedef struct lemo_fit_const {
   int n, n67, n81;

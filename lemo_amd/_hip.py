@@ -127,6 +127,7 @@ _SIGS = {
     'lemo_lbs_verts_bwd': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp,
                                      C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     'lemo_joints_assemble': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
     'lemo_fit_destroy': (None, [vp]),
     'lemo_fit_forward': (C.c_int, [vp, vp]),

@@ -60,6 +60,10 @@ int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, con
                     const int* lmk_rows /*[n_lmk][3]*/, const float* lmk_bary, int n_lmk, const float* transl,
                     int B, float* joints /*[B][nj+n_extra+n_lmk][3]*/, hipStream_t s);
 
+// ---------------- scene_kernels.hip ----------------
+int sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin /*host[3]*/,
+               const float* gmax /*host[3]*/, float* val, float* dval, hipStream_t s);
+
 // ---------------- loss_kernels.hip ----------------
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);

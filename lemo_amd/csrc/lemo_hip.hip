@@ -97,6 +97,12 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
   return joints_assemble(Jtr, nj, verts, vrows, extra_rows, n_extra, lmk_rows, lmk_bary, n_lmk, transl, B, joints, S(stream));
 }
 
+int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
+                    float* val, float* dval, void* stream) {
+  if (!sdf || !pts || !gmin || !gmax || !val) return LEMO_ERR_ARG;
+  return sdf_sample(sdf, D, H, W, pts, N, gmin, gmax, val, dval, S(stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // fitting engine
 // ------------------------------------------------------------------------------------------------

@@ -87,3 +87,142 @@ class EncWeights:
                 self.w2.append(t(pack_conv3x3_gmajor(w)))
                 self.wbwd2.append(t(pack_conv3x3_bwd_gmajor(w)))
             self.b.append(t(b))
+
+
+# ----------------------------------------------------------------------------------------------
+# Encoder as autograd ops over the C ABI
+# ----------------------------------------------------------------------------------------------
+
+def _enc_forward(lib, enc: EncWeights, x: torch.Tensor):
+    """x [H,W] float32 on the device -> list of CG8P activations act[1..10] (act[0] = padded input)."""
+    H, W = x.shape
+    dev = x.device
+    s = lib.stream(dev)
+    x0 = torch.zeros(H + 2, W + 2, dtype=torch.float32, device=dev)
+    x0[1:-1, 1:-1] = x
+    act = [x0] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
+    lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, ENC_CHANNELS[1], s), 'conv3x3_c1')
+    use_lds = 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 <= 416
+    for l in range(1, 10):
+        if use_lds:
+            lib.check(lib.conv3x3_mfma_lds(ptr(act[l]), ptr(enc.w[l]), ptr(enc.w2[l]), ptr(enc.b[l]), None, ptr(act[l + 1]),
+                                           H, W, ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, s), 'conv3x3_mfma_lds')
+        else:
+            lib.check(lib.conv3x3_mfma(ptr(act[l]), ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(act[l + 1]), H, W,
+                                       ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, 1, s), 'conv3x3_mfma')
+    return act, use_lds
+
+
+def _enc_backward(lib, enc: EncWeights, act, dpre10: torch.Tensor, use_lds: bool) -> torch.Tensor:
+    """d(pre-activation of layer 10) in CG8P -> d(input) [H,W]."""
+    H, W = act[0].shape[0] - 2, act[0].shape[1] - 2
+    dev = dpre10.device
+    s = lib.stream(dev)
+    cur, other = dpre10, cg8p_alloc(64, H, W, dev)
+    for l in range(9, 0, -1):
+        if use_lds:
+            lib.check(lib.conv3x3_mfma_lds(ptr(cur), ptr(enc.wbwd[l]), ptr(enc.wbwd2[l]), None, ptr(act[l]), ptr(other),
+                                           H, W, ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, s), 'conv3x3_mfma_lds(bwd)')
+        else:
+            lib.check(lib.conv3x3_mfma(ptr(cur), ptr(enc.wbwd[l]), None, ptr(act[l]), ptr(other), H, W,
+                                       ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, 1, s), 'conv3x3_mfma(bwd)')
+        cur, other = other, cur
+    dx = torch.empty(H, W, dtype=torch.float32, device=dev)
+    lib.check(lib.conv3x3_c1_bwd(ptr(cur), ptr(enc.w[0]), ptr(dx), H, W, ENC_CHANNELS[1], s), 'conv3x3_c1_bwd')
+    return dx
+
+
+class _SmoothPriorLoss(torch.autograd.Function):
+    """x [H,W] -> mean((z[...,1:] - z[...,:-1])**2) with z = Enc(x): opt_amass_temp.py:389-391,
+    temp_prox/fitting_temp_slide.py:1026-1031.  Loss and d(loss)/d(pre-act 10) come from one fused kernel."""
+
+    @staticmethod
+    def forward(ctx, x, enc: EncWeights, lib):
+        x = x.contiguous().float()
+        _hip.check_device(lib, x)
+        H, W = x.shape
+        act, use_lds = _enc_forward(lib, enc, x)
+        cnt = 64 * H * (W - 1)
+        nb = lib.smooth_loss_blocks(H, W, 64)
+        part = torch.zeros(nb, dtype=torch.float32, device=x.device)
+        dpre = cg8p_alloc(64, H, W, x.device)
+        lib.check(lib.smooth_loss(ptr(act[10]), ptr(dpre), ptr(part), H, W, 64, 2.0 / cnt, lib.stream(x.device)), 'smooth_loss')
+        ctx.enc, ctx.lib, ctx.act, ctx.dpre, ctx.use_lds = enc, lib, act, dpre, use_lds
+        return (part.double().sum() / cnt).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        dx = _enc_backward(ctx.lib, ctx.enc, ctx.act, ctx.dpre, ctx.use_lds)
+        return dx * g, None, None
+
+
+class _EncFn(torch.autograd.Function):
+    """x [H,W] -> z [64,H,W] (NCHW view of the last activation)."""
+
+    @staticmethod
+    def forward(ctx, x, enc: EncWeights, lib):
+        x = x.contiguous().float()
+        _hip.check_device(lib, x)
+        act, use_lds = _enc_forward(lib, enc, x)
+        ctx.enc, ctx.lib, ctx.act, ctx.use_lds = enc, lib, act, use_lds
+        H, W = x.shape
+        return from_cg8p(act[10], H, W)
+
+    @staticmethod
+    def backward(ctx, dz):
+        H, W = dz.shape[1:]
+        dz = dz.contiguous().float()
+        z = from_cg8p(ctx.act[10], H, W)
+        dpre = to_cg8p(dz * torch.where(z > 0, 1.0, 0.2))           # LeakyReLU'(pre-act 10) from the output sign
+        return _enc_backward(ctx.lib, ctx.enc, ctx.act, dpre, ctx.use_lds), None, None
+
+
+class _Conv3x3Param(nn.Module):
+    """holds weight/bias under the reference's `main.{0,2}` key names"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _EncBlockParams(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.main = nn.ModuleDict({'0': _Conv3x3Param(cin, cout), '2': _Conv3x3Param(cout, cout)})
+
+
+class Enc(nn.Module):
+    """Drop-in for ``models/AE_sep.py::Enc(downsample=False, z_channel=64)`` (the smoothness prior):
+    same ``state_dict`` keys (``enc_blcN.main.{0,2}.{weight,bias}``), ``forward(x[1,1,H,W]) ->
+    (z, x.size(), s1, s2, s3, s4)`` like AE_sep.py:91-99.  Weights are treated as frozen (LEMO sets
+    ``requires_grad=False``, opt_amass_temp.py:140-142); the backward is w.r.t. the input."""
+
+    def __init__(self, downsample=False, z_channel=64, _lib=None):
+        super().__init__()
+        if downsample or z_channel != 64:
+            raise NotImplementedError('LEMO instantiates the smoothness encoder as Enc(downsample=False, z_channel=64)')
+        ch = ENC_CHANNELS
+        for b in range(1, 6):
+            setattr(self, f'enc_blc{b}', _EncBlockParams(ch[2 * b - 2], ch[2 * b]))
+        self._lib_override, self._cache = _lib, {}
+
+    def packed(self, device) -> EncWeights:
+        ps = list(self.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if self._cache.get('key') != key:
+            sd = {k: v.detach().cpu().numpy() for k, v in self.state_dict().items()}
+            self._cache = dict(key=key, enc=EncWeights(sd, device))
+        return self._cache['enc']
+
+    def forward(self, x):
+        assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 1, 'the fitting path feeds [1,1,d,T] clips'
+        lib = self._lib_override or _hip.get_lib()
+        z = _EncFn.apply(x[0, 0], self.packed(x.device), lib)
+        sz = lambda c: torch.Size([1, c, x.shape[2], x.shape[3]])
+        return z.unsqueeze(0), x.size(), sz(32), sz(64), sz(64), sz(64)
+
+    def smooth_loss(self, x):
+        """mean((z[...,1:]-z[...,:-1])**2) for x [1,1,d,T] without materialising z in NCHW."""
+        lib = self._lib_override or _hip.get_lib()
+        return _SmoothPriorLoss.apply(x[0, 0], self.packed(x.device), lib)

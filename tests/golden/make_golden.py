@@ -221,6 +221,25 @@ def emit_amass_iteration():
     print('amass iteration:', {k: (float(v) if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
 
 
+def emit_prox_iteration():
+    """(7) one PROX S3 / S2 iteration on the reduced seeded window of __graft_entry__.prox_small_problem: the 14
+    loss_dict entries and grads w.r.t. pose_embedding / transl / global_orient with and without the erase."""
+    import __graft_entry__ as ge
+    from oracle.prox_oracle import LOSS_KEYS
+    out = {}
+    for stage in ('S3', 'S2'):
+        for first in (False, True):
+            of = ge.prox_oracle_for(ge.prox_small_problem(stage=stage), first_batch_flag=first)
+            ld = of.closure()
+            tag = f'{stage}_{"first" if first else "later"}'
+            out[tag + '_loss'] = np.asarray([float(ld[k]) for k in LOSS_KEYS])
+            out[tag + '_g_pose_embedding'] = of.pose_embedding.grad.numpy().copy()
+            out[tag + '_g_transl'] = of.p['transl'].grad.numpy().copy()
+            out[tag + '_g_global_orient'] = of.p['global_orient'].grad.numpy().copy()
+    np.savez(os.path.join(HERE, 'prox_iter.npz'), **out)
+    print('prox iteration:', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
     rep, ae_sd = check_against_reference()
     print('oracle vs reference (max rel err):')
@@ -235,5 +254,6 @@ if __name__ == '__main__':
     assert not bad, 'oracle disagrees with the reference'
     emit_golden(ae_sd)
     emit_amass_iteration()
+    emit_prox_iteration()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

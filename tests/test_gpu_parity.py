@@ -278,3 +278,61 @@ def test_mpjpe_after_full_fit(full_problem, dev):
     print(f'MPJPE gpu-vs-oracle after {steps} steps: {mpjpe:.4f} mm ; total loss {first["total"]:.4f} -> oracle {last["total"]:.4f} / gpu {Lg:.4f}')
     assert Lg < 0.7 * first['total']                    # the fit actually descends
     assert mpjpe < 5.0, mpjpe
+
+
+@pytest.mark.parametrize('stage,first', [('S3', False), ('S2', True)])
+def test_prox_iteration_vs_oracle(dev, stage, first):
+    """PROX twin (a11/a12/a14): 14 loss_dict entries, gradients, first-window erase, 3 Adam steps."""
+    import __graft_entry__ as ge
+    from lemo_amd.prox import LOSS_KEYS
+    prob = ge.prox_small_problem(stage=stage)
+    of = ge.prox_oracle_for(prob, first_batch_flag=first)
+    old = of.closure()
+    fit, bm = ge.prox_fitter_for(prob, dev, first_batch_flag=first)
+    ld = fit.closure()
+    for k in LOSS_KEYS:
+        a, b = float(ld[k]), float(old[k])
+        assert abs(a - b) <= LOSS_TOL * abs(b) + 1e-12, (k, a, b)
+    assert float(old['sdf_penetration_loss']) > 0 and float(old['loss_fric_tangent']) > 0
+    for a, b in [(fit.pose_embedding.grad, of.pose_embedding.grad)] + \
+                [(getattr(bm, n).grad, of.p[n].grad) for n in ('transl', 'global_orient', 'left_hand_pose', 'expression')]:
+        assert rel_err(a.cpu(), b) < 2e-4
+    n_erase = int(prob['B'] * 0.15)
+    assert (float(fit.pose_embedding.grad[:n_erase].abs().max()) > 0) == first
+    for _ in range(3):
+        o = of.step()
+        l = fit.step()
+    assert abs(float(l['total_loss']) - o['total_loss']) <= 1e-4 * abs(o['total_loss'])
+    assert float((fit.pose_embedding.detach().cpu() - of.pose_embedding.detach()).abs().max()) < 1e-4
+
+
+def test_prox_full_size_window_runs(dev):
+    """B = 100 window, V = 10475, 256^3 SDF (BASELINE configs 4-5 shape): finite losses, loss decreases;
+    prints the iteration rate of the module-level (autograd) PROX path."""
+    import time
+    import __graft_entry__ as ge
+    from lemo_amd.assets import load_assets
+    from lemo_amd.prox import S3_WEIGHTS, load_prox_tables
+    A = load_assets()
+    B = 100
+    small = ge.prox_small_problem(B=B, stage='S3')
+    rng = np.random.default_rng(3)
+    D = 256
+    zz = np.linspace(-3, 6, D, dtype=np.float32)
+    prob = dict(small, model=synthetic.make_synthetic_smplx(seed=0), V=10475, ids=A['ids'], Xmean=A['Xmean'], Xstd=A['Xstd'],
+                fric_ids=load_prox_tables()['contact_fric_verts_ids'],
+                sdf=(np.broadcast_to(zz[None, None, :], (D, D, D)) - 1.40).astype(np.float32).copy(), weights=S3_WEIGHTS)
+    mask = np.ones((B, 67), np.float32); mask[40:60, :22] = 0
+    prob['infill'] = dict(marker_mask=mask, body_markers_rec=(rng.standard_normal((B - 1, 67, 3)) * 0.3).astype(np.float32),
+                          contact_lbl_rec=(rng.random((B - 1, 4)) < 0.7).astype(np.float32))
+    fit, bm = ge.prox_fitter_for(prob, dev, first_batch_flag=False)
+    l0 = float(fit.step(1)['total_loss'])
+    torch.cuda.synchronize()
+    t0 = time.time()
+    n = 20
+    ld = fit.step(n)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    l1 = float(ld['total_loss'])
+    print(f'PROX S3 window B=100 V=10475: {n / dt:.1f} iterations/s ({dt / n * 1e3:.2f} ms/iteration); total {l0:.3f} -> {l1:.3f}')
+    assert np.isfinite(l1) and l1 < l0

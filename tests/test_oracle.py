@@ -120,3 +120,18 @@ def test_amass_iteration_golden():
                             seq['init_params'], g['markers_rec'], seq['contact_lbl'], faithful=True)
     t2, _, _, _ = fit2.losses()
     assert abs(float(t2) - float(g['total'])) <= 2e-6 * float(g['total'])
+
+
+def test_prox_iteration_golden():
+    """golden (7): PROX S2/S3 iteration of the oracle (14 loss_dict entries + three gradients, +/- erase)."""
+    import __graft_entry__ as ge
+    from oracle.prox_oracle import LOSS_KEYS
+    g = np.load(os.path.join(GOLDEN, 'prox_iter.npz'))
+    of = ge.prox_oracle_for(ge.prox_small_problem(stage='S3'), first_batch_flag=False)
+    ld = of.closure()
+    got = np.asarray([float(ld[k]) for k in LOSS_KEYS])
+    assert np.allclose(got, g['S3_later_loss'], rtol=2e-6, atol=1e-12)
+    assert got[LOSS_KEYS.index('sdf_penetration_loss')] > 0 and got[LOSS_KEYS.index('loss_fric_normal')] >= 0
+    assert rel_err(of.pose_embedding.grad, g['S3_later_g_pose_embedding']) < 1e-4
+    assert float(np.abs(g['S3_later_g_transl'][:2]).max()) == 0.0 and float(np.abs(g['S3_first_g_transl'][:2]).max()) > 0
+    assert np.allclose(g['S2_later_loss'][LOSS_KEYS.index('motion_infill_loss')], 0.0)

@@ -51,6 +51,20 @@ def main():
     np.savez(os.path.join(OUT, 'example_clip0.npz'),
              body_params=np.load(f'{d}/body_params_opt_clip_0.npy'),
              contact_lbl=np.load(f'{d}/contact_lbl_rec_clip_0.npy'))
+    # PROX index tables: OpenPose(118) <- SMPL-X(127) joint map (temp_prox/misc_utils.py:87-197 called as
+    # data_parser_slide.py:225-229 does) and the friction vertex set L_Leg + R_Leg + gluteus
+    # (fit_temp_loadprox_slide.py:349-354, again through list(set(...)) order)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_misc_utils', f'{REF}/temp_prox/misc_utils.py')
+    mu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mu)
+    jmap = mu.smpl_to_openpose('smplx', use_hands=True, use_face=True, use_face_contour=False, openpose_format='coco25')
+    fric = []
+    for seg in ('L_Leg', 'R_Leg', 'gluteus'):
+        with open(f'{REF}/body_segments/{seg}.json') as f:
+            fric.append(list(set(json.load(f)['verts_ind'])))
+    np.savez(os.path.join(OUT, 'prox_tables.npz'), joint_map=np.asarray(jmap, np.int32),
+             contact_fric_verts_ids=np.concatenate(fric).astype(np.int32))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
