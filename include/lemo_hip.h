@@ -136,6 +136,22 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
                          const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
                          void* stream);
 
+/* ---- motion-infilling autoencoder, models/AE.py:11-108 and its finetune step, opt_amass_temp.py:154-214 ----
+ * (stride-1 convs / transposed convs run on lemo_conv3x3_mfma; these are the remaining layer types) */
+/* MaxPool2d(3,2,1): out is CG8P of ((H-1)/2+1) x ((W-1)/2+1); idx [C/8][Ho*Wo][8] winning tap (uint8) */
+int lemo_maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, void* stream);
+/* din = scatter of dout to the argmax positions (gather form), optionally times lrelu'(act) */
+int lemo_maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, void* stream);
+/* zero-stuffing of ConvTranspose2d(stride 2, output_size = H x W): out[2i][2j] = in[i][j]; and its adjoint */
+int lemo_stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, void* stream);
+int lemo_stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, void* stream);
+/* dW[co][ci][3][3] = sum_p dY[co][p] X[ci][p+tap] (+ db[co] = sum_p dY) ; partial: [nslab][9][cout][cin] scratch */
+int lemo_conv3x3_wgrad_nslab(int H, int W);
+int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
+                       float* partial, float* dw, float* db, void* stream);
+/* torch.optim.Adam (defaults) over a flat buffer; step is 1-based */
+int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream);
+
 /* ---- PROX scene terms: F.grid_sample(sdf, verts, padding_mode='border') of temp_prox/fitting_temp_slide.py:685-739
  * sdf [D][H][W] device; pts [N][3] device world coordinates; gmin/gmax HOST float[3]; val [N]; dval [N][3] or NULL
  * (d val / d pts).  Grid axis order follows the reference's norm_vertices[:, :, [2,1,0]]. */

@@ -127,6 +127,13 @@ _SIGS = {
     'lemo_lbs_verts_bwd': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp,
                                      C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     'lemo_joints_assemble': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    'lemo_maxpool3s2_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
+    'lemo_maxpool3s2_bwd': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_stuff2_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_stuff2_bwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_wgrad_nslab': (C.c_int, [C.c_int, C.c_int]),
+    'lemo_conv3x3_wgrad': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    'lemo_adam_flat': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
     'lemo_fit_destroy': (None, [vp]),

@@ -1,0 +1,271 @@
+// Building blocks of the motion-infilling autoencoder (models/AE.py:11-108: EncBlock = conv,lrelu,conv,lrelu,
+// MaxPool2d(3,2,1); DecBlock = ConvTranspose2d(k3,s2,p1,output_size), lrelu, ConvTranspose2d(k3,s1,p1)[, lrelu])
+// and of its per-clip self-supervised finetune step (opt_amass_temp.py:154-214: forward, L1 on the unmasked rows,
+// backward incl. WEIGHT gradients, Adam lr 3e-6).  All activations are CG8P (conv_kernels.hip); the 3x3 / stride-1
+// convolutions themselves (and the transposed ones, as convolutions with flipped-transposed weights) run on
+// conv3x3_mfma.  A stride-2 transposed convolution is "zero-stuff to the output size, then a stride-1 one".
+#include "kernels.hpp"
+
+namespace lemo {
+
+// ---- MaxPool2d(kernel 3, stride 2, padding 1) on CG8P; idx = winning tap 0..8 (first maximum in
+// row-major window order, like torch) or 255 -------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool3s2_fwd_kernel(const float* __restrict__ in, int H, int W, float* __restrict__ out, unsigned char* __restrict__ idx,
+                      int Ho, int Wo, int C) {
+  const int Wp = W + 2, HWp = (H + 2) * Wp, Wop = Wo + 2, HWop = (Ho + 2) * Wop;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (C >> 3) * Ho * Wo;
+  if (t >= n) return;
+  const int g = t / (Ho * Wo), p = t - g * Ho * Wo, yo = p / Wo, xo = p - yo * Wo;
+  float best[8];
+  unsigned char bi[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { best[c] = -3.402823466e38f; bi[c] = 255; }
+  for (int ky = 0; ky < 3; ++ky) {
+    const int y = 2 * yo - 1 + ky;
+    if (y < 0 || y >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int x = 2 * xo - 1 + kx;
+      if (x < 0 || x >= W) continue;
+      const float* q = in + ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8;
+      const float4 v0 = ld4(q), v1 = ld4(q + 4);
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (v[c] > best[c]) { best[c] = v[c]; bi[c] = (unsigned char)(ky * 3 + kx); }
+    }
+  }
+  float* o = out + ((size_t)g * HWop + (yo + 1) * Wop + (xo + 1)) * 8;
+  st4(o, make_float4(best[0], best[1], best[2], best[3]));
+  st4(o + 4, make_float4(best[4], best[5], best[6], best[7]));
+  unsigned char* io = idx + ((size_t)g * Ho * Wo + p) * 8;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) io[c] = bi[c];
+}
+
+// din[y][x] = sum over the <= 4 windows covering (y,x) whose argmax is (y,x) of dout ; optionally
+// multiplied by lrelu'(act[y][x]) (act = the pooled layer's input = a LeakyReLU output)
+__global__ void __launch_bounds__(256)
+maxpool3s2_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx, int Ho, int Wo,
+                      const float* __restrict__ act, float* __restrict__ din, int H, int W, int C) {
+  const int Wp = W + 2, HWp = (H + 2) * Wp, Wop = Wo + 2, HWop = (Ho + 2) * Wop;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (C >> 3) * H * W;
+  if (t >= n) return;
+  const int g = t / (H * W), p = t - g * H * W, y = p / W, x = p - y * W;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int yo = (y >> 1); yo <= ((y + 1) >> 1); ++yo) {            // windows with 2*yo-1 <= y <= 2*yo+1
+    if (yo < 0 || yo >= Ho) continue;
+    const int ky = y - (2 * yo - 1);
+    if (ky < 0 || ky > 2) continue;
+    for (int xo = (x >> 1); xo <= ((x + 1) >> 1); ++xo) {
+      if (xo < 0 || xo >= Wo) continue;
+      const int kx = x - (2 * xo - 1);
+      if (kx < 0 || kx > 2) continue;
+      const unsigned char want = (unsigned char)(ky * 3 + kx);
+      const unsigned char* io = idx + ((size_t)g * Ho * Wo + yo * Wo + xo) * 8;
+      const float* q = dout + ((size_t)g * HWop + (yo + 1) * Wop + (xo + 1)) * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (io[c] == want) acc[c] += q[c];
+    }
+  }
+  const size_t o = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8;
+  if (act) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] *= lrelu_grad_from_out(act[o + c]);
+  }
+  st4(din + o, make_float4(acc[0], acc[1], acc[2], acc[3]));
+  st4(din + o + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
+}
+
+int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s) {
+  if (C % 8 || H < 1 || W < 1) return LEMO_ERR_SHAPE;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;             // floor((H + 2 - 3) / 2) + 1
+  const int n = (C / 8) * Ho * Wo;
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, H, W, out, idx, Ho, Wo, C);
+  return (int)hipGetLastError();
+}
+int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s) {
+  if (C % 8) return LEMO_ERR_SHAPE;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int n = (C / 8) * H * W;
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dout, idx, Ho, Wo, act, din, H, W, C);
+  return (int)hipGetLastError();
+}
+
+// ---- zero-stuffing for ConvTranspose2d(stride 2): out[2i][2j] = in[i][j], everything else 0 (out: H x W given
+// by output_size); backward = the gather out[2i][2j] (optionally times lrelu'(act[i][j])) ----------------
+__global__ void __launch_bounds__(256)
+stuff2_fwd_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out, int H, int W, int C) {
+  const int Wp = W + 2, HWp = (H + 2) * Wp, wp = w + 2, hwp = (h + 2) * wp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (C >> 3) * H * W;
+  if (t >= n) return;
+  const int g = t / (H * W), p = t - g * H * W, y = p / W, x = p - y * W;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (!(y & 1) && !(x & 1) && (y >> 1) < h && (x >> 1) < w) {
+    const float* q = in + ((size_t)g * hwp + ((y >> 1) + 1) * wp + ((x >> 1) + 1)) * 8;
+    v0 = ld4(q); v1 = ld4(q + 4);
+  }
+  float* o = out + ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8;
+  st4(o, v0); st4(o + 4, v1);
+}
+__global__ void __launch_bounds__(256)
+stuff2_bwd_kernel(const float* __restrict__ dout, int H, int W, const float* __restrict__ act, float* __restrict__ din,
+                  int h, int w, int C) {
+  const int Wp = W + 2, HWp = (H + 2) * Wp, wp = w + 2, hwp = (h + 2) * wp;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (C >> 3) * h * w;
+  if (t >= n) return;
+  const int g = t / (h * w), p = t - g * h * w, i = p / w, j = p - i * w;
+  const float* q = dout + ((size_t)g * HWp + (2 * i + 1) * Wp + (2 * j + 1)) * 8;
+  float4 v0 = ld4(q), v1 = ld4(q + 4);
+  const size_t o = ((size_t)g * hwp + (i + 1) * wp + (j + 1)) * 8;
+  if (act) {
+    const float4 a0 = ld4(act + o), a1 = ld4(act + o + 4);
+    v0.x *= lrelu_grad_from_out(a0.x); v0.y *= lrelu_grad_from_out(a0.y); v0.z *= lrelu_grad_from_out(a0.z); v0.w *= lrelu_grad_from_out(a0.w);
+    v1.x *= lrelu_grad_from_out(a1.x); v1.y *= lrelu_grad_from_out(a1.y); v1.z *= lrelu_grad_from_out(a1.z); v1.w *= lrelu_grad_from_out(a1.w);
+  }
+  st4(din + o, v0); st4(din + o + 4, v1);
+}
+int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s) {
+  if (C % 8 || 2 * (h - 1) > H - 1 || 2 * (w - 1) > W - 1) return LEMO_ERR_SHAPE;
+  const int n = (C / 8) * H * W;
+  hipLaunchKernelGGL(stuff2_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, h, w, out, H, W, C);
+  return (int)hipGetLastError();
+}
+int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, hipStream_t s) {
+  if (C % 8) return LEMO_ERR_SHAPE;
+  const int n = (C / 8) * h * w;
+  hipLaunchKernelGGL(stuff2_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dout, H, W, act, din, h, w, C);
+  return (int)hipGetLastError();
+}
+
+// ---- weight gradient of a 3x3 / stride-1 / pad-1 convolution on the matrix cores --------------------------
+//   dW[co][ci][tap] = sum_p dY[co][p] * X[ci][p + tap]      (X zero-padded: CG8P border)
+// GEMM per tap: M = co (A = dY), N = ci (B = X shifted), K = pixels.  One wave = one 32(co) x 32(ci) tile
+// of one tap over a slab of pixels; v_mfma_f32_32x32x2_f32 consumes 2 pixels per step (lane half = pixel
+// parity), 8 steps in flight.  Slabs write partial tiles; a second kernel reduces them in a fixed order
+// (deterministic) and also produces the bias gradient sum_p dY[co][p].
+#define WG_SLAB 512               // pixels per slab
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int H, int W, int cin, int cout,
+                     float* __restrict__ partial /*[nslab][9][cout][cin]*/, int nslab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const int cot = cout >> 5, cit = (cin + 31) >> 5;
+  int tile = blockIdx.x * 4 + wave;                                // (slab, tap, co tile, ci tile)
+  const int ntile = nslab * 9 * cot * cit;
+  if (tile >= ntile) return;
+  const int ct = tile % cit; tile /= cit;
+  const int mt = tile % cot; tile /= cot;
+  const int tap = tile % 9, slab = tile / 9;
+  const int dyo = tap / 3 - 1, dxo = tap % 3 - 1;
+  const int co = mt * 32 + i;
+  int ci = ct * 32 + i;
+  const bool ci_ok = ci < cin;
+  if (!ci_ok) ci = cin - 1;
+  const float* ap = dy + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
+  const float* bp = x + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int p0 = slab * WG_SLAB, p1 = (p0 + WG_SLAB < P) ? p0 + WG_SLAB : P;
+  for (int pb = p0; pb < p1; pb += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = pb + 2 * u + kk;
+      const bool ok = p < p1;
+      const int pc = ok ? p : p1 - 1;
+      const int y = pc / W, xx = pc - y * W;
+      const int q = (y + 1) * Wp + (xx + 1);
+      const float av = ap[(size_t)q * 8];
+      const float bv = bp[(size_t)(q + dyo * Wp + dxo) * 8];
+      a[u] = ok ? av : 0.f;
+      b[u] = (ok && ci_ok) ? bv : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  // D: col = lane&31 -> ci (B index), rows -> co (A index)
+  float* out = partial + (((size_t)slab * 9 + tap) * cout) * cin;
+  if (ci_ok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+      out[(size_t)(mt * 32 + row) * cin + (ct * 32 + i)] = acc[r];
+    }
+  }
+}
+
+// dw[co][ci][tap] (torch conv layout) = sum_slab partial ; db[co] = sum_p dy[co][p]
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, int nslab, int cin, int cout, int cin_real, int cout_real,
+                            float* __restrict__ dw, const float* __restrict__ dy, int H, int W, float* __restrict__ db) {
+  __shared__ float red[4];
+  const int n = cout_real * cin_real * 9;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x < (unsigned)((n + 255) / 256)) {
+    if (t < n) {
+      const int tap = t % 9, ci = (t / 9) % cin_real, co = t / (9 * cin_real);
+      float a = 0.f;
+      for (int s = 0; s < nslab; ++s) a += partial[(((size_t)s * 9 + tap) * cout + co) * cin + ci];
+      dw[t] = a;
+    }
+  } else if (db) {                                                  // one block per output channel
+    const int co = blockIdx.x - (n + 255) / 256;
+    const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+    float a = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const int y = p / W, xx = p - y * W;
+      a += dy[((size_t)(co >> 3) * HWp + (y + 1) * Wp + (xx + 1)) * 8 + (co & 7)];
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) db[co] = a;
+  }
+}
+
+int conv3x3_wgrad_nslab(int H, int W) { return (H * W + WG_SLAB - 1) / WG_SLAB; }
+
+// dy: CG8P with `cout` (multiple of 32) channels, x: CG8P with `cin` (multiple of 8) channels; dw [cout_real][cin_real][3][3]
+int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
+                  float* partial, float* dw, float* db, hipStream_t s) {
+  if (cin % 8 || cout % 32 || cin_real > cin || cout_real > cout || H < 1 || W < 1) return LEMO_ERR_SHAPE;
+  const int nslab = conv3x3_wgrad_nslab(H, W);
+  const int ntile = nslab * 9 * (cout / 32) * ((cin + 31) / 32);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((ntile + 3) / 4), dim3(256), 0, s, dy, x, H, W, cin, cout, partial, nslab);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  const int n = cout_real * cin_real * 9;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((n + 255) / 256 + (db ? cout_real : 0)), dim3(256), 0, s, partial, nslab,
+                     cin, cout, cin_real, cout_real, dw, dy, H, W, db);
+  return (int)hipGetLastError();
+}
+
+// ---- Adam over one flat parameter buffer (torch.optim.Adam defaults; opt_amass_temp.py:162-164: lr 3e-6) ----
+__global__ void __launch_bounds__(256)
+adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                 float lr, int step /*1-based*/) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float bc1 = (float)(1.0 - pow(0.9, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
+  const float gi = g[i];
+  const float mi = m[i] + (gi - m[i]) * (1.f - 0.9f);
+  const float vi = v[i] * 0.999f + (1.f - 0.999f) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + 1e-8f));
+}
+int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, hipStream_t s) {
+  if (n <= 0 || step < 1) return LEMO_ERR_ARG;
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, g, m, v, n, lr, step);
+  return (int)hipGetLastError();
+}
+
+}  // namespace lemo

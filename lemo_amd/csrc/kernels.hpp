@@ -64,6 +64,16 @@ int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, con
 int sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin /*host[3]*/,
                const float* gmax /*host[3]*/, float* val, float* dval, hipStream_t s);
 
+// ---------------- ae_kernels.hip ----------------
+int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s);
+int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s);
+int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s);
+int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, hipStream_t s);
+int conv3x3_wgrad_nslab(int H, int W);
+int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
+                  float* partial, float* dw, float* db, hipStream_t s);
+int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, hipStream_t s);
+
 // ---------------- loss_kernels.hip ----------------
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);

@@ -97,6 +97,32 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
   return joints_assemble(Jtr, nj, verts, vrows, extra_rows, n_extra, lmk_rows, lmk_bary, n_lmk, transl, B, joints, S(stream));
 }
 
+int lemo_maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, void* stream) {
+  if (!in || !out || !idx) return LEMO_ERR_ARG;
+  return maxpool3s2_fwd(in, H, W, out, idx, C, S(stream));
+}
+int lemo_maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, void* stream) {
+  if (!dout || !idx || !din) return LEMO_ERR_ARG;
+  return maxpool3s2_bwd(dout, idx, act, din, H, W, C, S(stream));
+}
+int lemo_stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, void* stream) {
+  if (!in || !out) return LEMO_ERR_ARG;
+  return stuff2_fwd(in, h, w, out, H, W, C, S(stream));
+}
+int lemo_stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, void* stream) {
+  if (!dout || !din) return LEMO_ERR_ARG;
+  return stuff2_bwd(dout, H, W, act, din, h, w, C, S(stream));
+}
+int lemo_conv3x3_wgrad_nslab(int H, int W) { return conv3x3_wgrad_nslab(H, W); }
+int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
+                       float* partial, float* dw, float* db, void* stream) {
+  if (!dy || !x || !partial || !dw) return LEMO_ERR_ARG;
+  return conv3x3_wgrad(dy, x, H, W, cin, cout, cin_real, cout_real, partial, dw, db, S(stream));
+}
+int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream) {
+  if (!p || !g || !m || !v) return LEMO_ERR_ARG;
+  return adam_flat(p, g, m, v, n, lr, step, S(stream));
+}
 int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
                     float* val, float* dval, void* stream) {
   if (!sdf || !pts || !gmin || !gmax || !val) return LEMO_ERR_ARG;

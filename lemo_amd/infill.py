@@ -1,0 +1,288 @@
+"""Motion-infilling autoencoder ``AE`` (the infilling prior) on the HIP kernels, forward AND training step.
+
+Reference: ``models/AE.py:11-108`` (``AE(downsample=True, in_channel=4, kernel=3)``: 5 x [conv, LeakyReLU,
+conv, LeakyReLU, MaxPool2d(3,2,1)] then 5 x [ConvTranspose2d(k3,s2,p1)(x, output_size=...), LeakyReLU,
+ConvTranspose2d(k3,s1,p1)(, LeakyReLU)]) and its per-clip self-supervised finetune
+(``opt_amass_temp.py:154-214``, ``temp_prox/fitting_temp_slide.py:861-893``: 60 x [forward, L1 on the unmasked
+rows, backward, Adam lr 3e-6] + one eval forward).
+
+Same ``state_dict`` keys as the reference.  Every layer runs in liblemo_hip.so on CG8P activations:
+stride-1 (transposed) convolutions on the fp32-MFMA ``conv3x3_mfma``; a stride-2 transposed convolution is
+zero-stuffing to ``output_size`` followed by a stride-1 one; weight gradients on the MFMA ``conv3x3_wgrad``.
+Channel counts that are not MFMA-tile multiples (4 inputs, 1 output) are zero-padded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _hip
+from ._hip import ptr
+from .priors import cg8p_alloc, from_cg8p, to_cg8p
+
+ENC_CH = [(4, 32), (32, 64), (64, 128), (128, 256), (256, 256)]
+DEC_CH = [(256, 256), (256, 128), (128, 64), (64, 32), (32, 1)]
+"""models/AE.py:81-91 with in_channel = 4."""
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _pack_fwd(w: torch.Tensor) -> torch.Tensor:
+    """[Co][Ci][3][3] (channel counts already padded) -> wt[tap][Ci/8][Co][8] (priors.pack_conv3x3 on device)."""
+    co, ci = w.shape[:2]
+    return w.reshape(co, ci // 8, 8, 9).permute(3, 1, 0, 2).contiguous()
+
+
+def _pack_bwd(w: torch.Tensor) -> torch.Tensor:
+    """backward-data pack of the same conv (priors.pack_conv3x3_bwd on device)."""
+    return _pack_fwd(w.flip(2, 3).transpose(0, 1).contiguous())
+
+
+class _Layer:
+    """one 3x3 stride-1 convolution in conv-equivalent form"""
+
+    def __init__(self, name, cin, cout, deconv, cin_pad, cout_pad):
+        self.name, self.cin, self.cout, self.deconv, self.cin_pad, self.cout_pad = name, cin, cout, deconv, cin_pad, cout_pad
+
+    def conv_weight(self, w: torch.Tensor) -> torch.Tensor:
+        """parameter -> padded conv weight [cout_pad][cin_pad][3][3]"""
+        if self.deconv:                                            # ConvTranspose2d weight is [in][out][kh][kw]
+            w = w.flip(2, 3).transpose(0, 1)
+        out = torch.zeros(self.cout_pad, self.cin_pad, 3, 3, dtype=torch.float32, device=w.device)
+        out[:self.cout, :self.cin] = w
+        return out
+
+    def param_grad(self, dw: torch.Tensor) -> torch.Tensor:
+        """conv-equivalent gradient [cout][cin][3][3] -> gradient in the parameter's own layout"""
+        return dw.flip(2, 3).transpose(0, 1).contiguous() if self.deconv else dw
+
+
+def _layers() -> List[_Layer]:
+    L = []
+    for b, (ci, co) in enumerate(ENC_CH, 1):
+        L.append(_Layer(f'enc_blc{b}.main.0', ci, co, False, _pad8(ci), _pad32(co)))
+        L.append(_Layer(f'enc_blc{b}.main.2', co, co, False, _pad32(co), _pad32(co)))
+    for b, (ci, co) in enumerate(DEC_CH, 1):
+        L.append(_Layer(f'dec_blc{b}.deconv1', ci, co, True, _pad32(ci), _pad32(co)))
+        L.append(_Layer(f'dec_blc{b}.deconv2', co, co, True, _pad32(co), _pad32(co)))
+    return L
+
+
+def _conv(lib, x, wt, bias, aux, out, H, W, cin, cout, epi, s):
+    lib.check(lib.conv3x3_mfma(ptr(x), ptr(wt), ptr(bias), ptr(aux), ptr(out), H, W, cin, cout, epi, 0, s), 'conv3x3_mfma')
+
+
+class _AEFn(torch.autograd.Function):
+    """(x [4,H,W], *parameters in _layers() order: weight, bias, ...) -> (out [H,W], z [256,h,w])"""
+
+    @staticmethod
+    def forward(ctx, lib, x, *params):
+        x = x.contiguous().float()
+        _hip.check_device(lib, x)
+        dev, s = x.device, lib.stream(x.device)
+        L = _layers()
+        W_ = [L[i].conv_weight(params[2 * i].detach().float()) for i in range(20)]
+        B_ = []
+        for i in range(20):
+            b = torch.zeros(L[i].cout_pad, dtype=torch.float32, device=dev)
+            b[:L[i].cout] = params[2 * i + 1].detach().float()
+            B_.append(b)
+        Wf = [_pack_fwd(w) for w in W_]
+        H, Wd = x.shape[1:]
+        xin = torch.zeros(8, H, Wd, dtype=torch.float32, device=dev)
+        xin[:4] = x
+        cur, curH, curW = to_cg8p(xin), H, Wd
+        enc_rec, sizes = [], [(H, Wd)]
+        for b in range(5):
+            l0, l2 = L[2 * b], L[2 * b + 1]
+            a0 = cg8p_alloc(l0.cout_pad, curH, curW, dev)
+            _conv(lib, cur, Wf[2 * b], B_[2 * b], None, a0, curH, curW, l0.cin_pad, l0.cout_pad, 0, s)
+            a2 = cg8p_alloc(l2.cout_pad, curH, curW, dev)
+            _conv(lib, a0, Wf[2 * b + 1], B_[2 * b + 1], None, a2, curH, curW, l2.cin_pad, l2.cout_pad, 0, s)
+            Ho, Wo = (curH - 1) // 2 + 1, (curW - 1) // 2 + 1
+            P = cg8p_alloc(l2.cout_pad, Ho, Wo, dev)
+            idx = torch.empty(l2.cout_pad // 8, Ho * Wo, 8, dtype=torch.uint8, device=dev)
+            lib.check(lib.maxpool3s2_fwd(ptr(a2), curH, curW, ptr(P), ptr(idx), l2.cout_pad, s), 'maxpool3s2_fwd')
+            enc_rec.append((cur, a0, a2, idx, curH, curW))
+            cur, curH, curW = P, Ho, Wo
+            sizes.append((Ho, Wo))
+        z_buf, zH, zW = cur, curH, curW
+        dec_rec = []
+        for b in range(5):
+            l1, l2 = L[10 + 2 * b], L[11 + 2 * b]
+            tH, tW = sizes[4 - b]                                     # output_size = the matching encoder level
+            S = cg8p_alloc(l1.cin_pad, tH, tW, dev)
+            lib.check(lib.stuff2_fwd(ptr(cur), curH, curW, ptr(S), tH, tW, l1.cin_pad, s), 'stuff2_fwd')
+            b1 = cg8p_alloc(l1.cout_pad, tH, tW, dev)
+            _conv(lib, S, Wf[10 + 2 * b], B_[10 + 2 * b], None, b1, tH, tW, l1.cin_pad, l1.cout_pad, 0, s)
+            b2 = cg8p_alloc(l2.cout_pad, tH, tW, dev)
+            _conv(lib, b1, Wf[11 + 2 * b], B_[11 + 2 * b], None, b2, tH, tW, l2.cin_pad, l2.cout_pad, 0 if b < 4 else 2, s)
+            dec_rec.append((cur, curH, curW, S, b1, b2, tH, tW))
+            cur, curH, curW = b2, tH, tW
+        out = from_cg8p(cur, H, Wd)[0]
+        z = from_cg8p(z_buf, zH, zW)[:256]
+        ctx.lib, ctx.L, ctx.W_, ctx.enc_rec, ctx.dec_rec, ctx.shape = lib, L, W_, enc_rec, dec_rec, (H, Wd, zH, zW)
+        ctx.need_w = any(p.requires_grad for p in params)
+        return out, z
+
+    @staticmethod
+    def backward(ctx, dout, dz):
+        lib, L, W_ = ctx.lib, ctx.L, ctx.W_
+        H, Wd, zH, zW = ctx.shape
+        dev = W_[0].device
+        s = lib.stream(dev)
+        Wb = {i: _pack_bwd(W_[i]) for i in range(1, 20)}              # layer 0 needs no backward-data
+        grads: List[Optional[torch.Tensor]] = [None] * 40
+        zeros_bias = torch.zeros(256, dtype=torch.float32, device=dev)
+        nsl = lambda h, w: lib.conv3x3_wgrad_nslab(h, w)
+
+        def wgrad(i, dpre, xin, h, w):
+            l = L[i]
+            part = torch.empty(nsl(h, w) * 9 * l.cout_pad * l.cin_pad, dtype=torch.float32, device=dev)
+            dw = torch.empty(l.cout, l.cin, 3, 3, dtype=torch.float32, device=dev)
+            db = torch.empty(l.cout, dtype=torch.float32, device=dev)
+            lib.check(lib.conv3x3_wgrad(ptr(dpre), ptr(xin), h, w, l.cin_pad, l.cout_pad, l.cin, l.cout, ptr(part), ptr(dw),
+                                        ptr(db), s), 'conv3x3_wgrad')
+            grads[2 * i], grads[2 * i + 1] = l.param_grad(dw), db
+
+        # ---- decoder, last block first.  dpre = d(pre-activation of the block's deconv2 output)
+        d = torch.zeros(32, H, Wd, dtype=torch.float32, device=dev)
+        if dout is not None:
+            d[0] = dout.float()
+        dpre = to_cg8p(d)
+        for b in range(4, -1, -1):
+            zin, zh, zw, S, b1, b2, tH, tW = ctx.dec_rec[b]
+            i1, i2 = 10 + 2 * b, 11 + 2 * b
+            wgrad(i2, dpre, b1, tH, tW)
+            dpre1 = cg8p_alloc(L[i1].cout_pad, tH, tW, dev)
+            _conv(lib, dpre, Wb[i2], None, b1, dpre1, tH, tW, L[i2].cout_pad, L[i2].cin_pad, 1, s)     # * lrelu'(b1)
+            wgrad(i1, dpre1, S, tH, tW)
+            dS = cg8p_alloc(L[i1].cin_pad, tH, tW, dev)
+            _conv(lib, dpre1, Wb[i1], zeros_bias, None, dS, tH, tW, L[i1].cout_pad, L[i1].cin_pad, 2, s)
+            dzin = cg8p_alloc(L[i1].cin_pad, zh, zw, dev)
+            # the block's input is the previous decoder block's LeakyReLU output (mask) or the latent z (no activation)
+            lib.check(lib.stuff2_bwd(ptr(dS), tH, tW, ptr(zin) if b > 0 else None, ptr(dzin), zh, zw, L[i1].cin_pad, s), 'stuff2_bwd')
+            dpre = dzin
+        if dz is not None:
+            dzp = torch.zeros(256, zH, zW, dtype=torch.float32, device=dev)
+            dzp[:] = dz.float()
+            dpre = dpre + to_cg8p(dzp)
+        # ---- encoder, last block first.  dpre = d(pool output of the block)
+        for b in range(4, -1, -1):
+            xin, a0, a2, idx, h, w = ctx.enc_rec[b]
+            i0, i2 = 2 * b, 2 * b + 1
+            dpre2 = cg8p_alloc(L[i2].cout_pad, h, w, dev)
+            lib.check(lib.maxpool3s2_bwd(ptr(dpre), ptr(idx), ptr(a2), ptr(dpre2), h, w, L[i2].cout_pad, s), 'maxpool3s2_bwd')
+            wgrad(i2, dpre2, a0, h, w)
+            dpre0 = cg8p_alloc(L[i0].cout_pad, h, w, dev)
+            _conv(lib, dpre2, Wb[i2], None, a0, dpre0, h, w, L[i2].cout_pad, L[i2].cin_pad, 1, s)
+            wgrad(i0, dpre0, xin, h, w)
+            if b > 0:
+                dprev = cg8p_alloc(L[i0].cin_pad, h, w, dev)
+                _conv(lib, dpre0, Wb[i0], zeros_bias, None, dprev, h, w, L[i0].cout_pad, L[i0].cin_pad, 2, s)
+                dpre = dprev
+        return (None, None) + tuple(grads)
+
+
+class _Conv(nn.Module):
+    def __init__(self, cin, cout, transposed=False):
+        super().__init__()
+        shape = (cin, cout, 3, 3) if transposed else (cout, cin, 3, 3)
+        self.weight = nn.Parameter(torch.zeros(*shape))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _EncBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.main = nn.ModuleDict({'0': _Conv(cin, cout), '2': _Conv(cout, cout)})
+
+
+class _DecBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.deconv1, self.deconv2 = _Conv(cin, cout, True), _Conv(cout, cout, True)
+
+
+class AE(nn.Module):
+    """Drop-in for ``models/AE.py::AE(downsample=True, in_channel=4, kernel=3)``: ``forward(x[1,4,d,T]) -> (out[1,1,d,T], z)``."""
+
+    def __init__(self, downsample=True, in_channel=4, kernel=3, _lib: Optional[_hip.HipLib] = None):
+        super().__init__()
+        if not downsample or in_channel != 4 or kernel != 3:
+            raise NotImplementedError('LEMO instantiates the infilling prior as AE(downsample=True, in_channel=4, kernel=3)')
+        for b, (ci, co) in enumerate(ENC_CH, 1):
+            setattr(self, f'enc_blc{b}', _EncBlock(ci, co))
+        for b, (ci, co) in enumerate(DEC_CH, 1):
+            setattr(self, f'dec_blc{b}', _DecBlock(ci, co))
+        self._lib_override = _lib
+
+    def ordered_parameters(self) -> List[nn.Parameter]:
+        sd = dict(self.named_parameters())
+        out = []
+        for l in _layers():
+            out += [sd[l.name + '.weight'], sd[l.name + '.bias']]
+        return out
+
+    def forward(self, x):
+        assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 4, 'the infilling prior is fed [1,4,d,T] clips'
+        lib = self._lib_override or _hip.get_lib()
+        out, z = _AEFn.apply(lib, x[0], *self.ordered_parameters())
+        return out[None, None], z[None]
+
+
+class FlatAdam:
+    """torch.optim.Adam-equivalent (defaults, no weight decay) running ONE HIP kernel over a flat copy of the
+    parameters: the finetune optimiser of opt_amass_temp.py:162-164 (lr 3e-6)."""
+
+    def __init__(self, params: List[nn.Parameter], lr: float, lib: Optional[_hip.HipLib] = None):
+        self.params, self.lr, self.lib, self.t = [p for p in params if p.requires_grad], lr, lib or _hip.get_lib(), 0
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.cat([p.detach().reshape(-1).float() for p in self.params])
+        self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in self.params])
+        self.lib.check(self.lib.adam_flat(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), self.lr, self.t,
+                                          self.lib.stream(self.flat.device)), 'adam_flat')
+        o = 0
+        for p in self.params:
+            p.copy_(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+
+def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, train_mask: torch.Tensor, steps: int = 60,
+                        lr: float = 3e-6):
+    """The per-clip block of opt_amass_temp.py:160-215: reload the pretrained weights, ``steps`` x [forward, L1 on
+    ``train_mask`` (bool [d+2, T+16] over channel 0), backward, Adam], then one eval forward.  Returns
+    ``(clip_img_rec [1,1,d,T] un-padded, z)``."""
+    model.load_state_dict(weights)
+    opt = FlatAdam(list(model.parameters()), lr, model._lib_override)
+    m = train_mask.to(clip_img_input.dtype)
+    cnt = m.sum()
+    for _ in range(steps):
+        opt.zero_grad()
+        rec, _ = model(clip_img_input)
+        loss = ((rec[0, 0] - clip_img_input[0, 0]).abs() * m).sum() / cnt
+        loss.backward()
+        opt.step()
+    with torch.no_grad():
+        rec, z = model(clip_img_input)
+    return rec[:, :, 1:-1, 8:-8], z

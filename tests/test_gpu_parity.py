@@ -336,3 +336,38 @@ def test_prox_full_size_window_runs(dev):
     l1 = float(ld['total_loss'])
     print(f'PROX S3 window B=100 V=10475: {n / dt:.1f} iterations/s ({dt / n * 1e3:.2f} ms/iteration); total {l0:.3f} -> {l1:.3f}')
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_infill_ae_full_size_golden_and_finetune(dev):
+    """a13 / N1: infilling AE at the reference shape [1,4,210,135] (z [1,256,7,5], AE.py:93-108): golden forward,
+    every parameter gradient vs the oracle, and the timing of the 60-step finetune + eval of one clip."""
+    import time
+    from lemo_amd.infill import AE, finetune_and_infill
+    from oracle import lemo_oracle as O
+    g = np.load(os.path.join(GOLDEN, 'ae_infill.npz'))
+    w = {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
+    ae = AE().to(dev)
+    ae.load_state_dict(w)
+    x = torch.from_numpy(g['x'].astype(np.float32)).to(dev)
+    out, z = ae(x)
+    assert out.shape == (1, 1, 210, 135) and z.shape == (1, 256, 7, 5)
+    assert rel_err(z.detach().cpu(), g['z']) < 1e-4 and rel_err(out.detach().cpu()[0, 0, ::7, ::5], g['out_sub']) < 1e-4
+    assert abs(float(out.double().sum()) - float(g['out_sum'])) < 1e-4 * float(out.double().abs().sum())
+    # gradients of the finetune loss w.r.t. all 40 parameter tensors
+    gen = torch.Generator().manual_seed(0)
+    mask = (torch.rand(210, 135, generator=gen) > 0.3)
+    loss = ((out[0, 0] - x[0, 0]).abs() * mask.to(dev)).sum() / mask.sum()
+    loss.backward()
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    xc = x.cpu()
+    oo, _ = O.ae_forward(wr, xc)
+    (oo[0, 0] - xc[0, 0])[mask].abs().mean().backward()
+    for k, p in ae.named_parameters():
+        assert rel_err(p.grad.cpu(), wr[k].grad) < 2e-3, k
+    torch.cuda.synchronize()
+    t0 = time.time()
+    rec, zz = finetune_and_infill(ae, {k: v.to(dev) for k, v in w.items()}, x, mask.to(dev), steps=60, lr=3e-6)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f'infilling AE: 60 finetune steps + eval at [1,4,210,135]: {dt * 1e3:.1f} ms per clip ({dt / 61 * 1e3:.2f} ms per pass)')
+    assert rec.shape == (1, 1, 208, 119) and torch.isfinite(rec).all()

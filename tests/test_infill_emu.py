@@ -1,0 +1,92 @@
+"""CPU suite: infilling autoencoder (models/AE.py) forward, all 40 parameter gradients and the finetune
+loop (opt_amass_temp.py:160-215) through the HIP kernels on the host emulator vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from lemo_amd import synthetic
+from lemo_amd._hip import ptr
+from oracle import lemo_oracle as O
+
+
+def _weights():
+    return {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
+
+
+@pytest.mark.timeout(600)
+def test_ae_forward_and_all_parameter_gradients(emu_lib):
+    from lemo_amd.infill import AE
+    w = _weights()
+    ae = AE(downsample=True, in_channel=4, kernel=3, _lib=emu_lib)
+    assert set(ae.state_dict().keys()) == set(w.keys())
+    ae.load_state_dict(w)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 34, 21, generator=g)                       # odd sizes: 34x21 -> 17x11 -> 9x6 -> 5x3 -> 3x2 -> 2x1
+    out, z = ae(x)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    oo, zo = O.ae_forward(wr, x)
+    assert out.shape == (1, 1, 34, 21) and z.shape == (1, 256, 2, 1)
+    assert rel_err(out.detach(), oo.detach()) < 1e-5 and rel_err(z.detach(), zo.detach()) < 1e-5
+    wo, wz = torch.randn(out.shape, generator=g), torch.randn(z.shape, generator=g) * 0.1
+    ((out * wo).sum() + (z * wz).sum()).backward()
+    ((oo * wo).sum() + (zo * wz).sum()).backward()
+    for k, p in ae.named_parameters():
+        assert rel_err(p.grad, wr[k].grad) < 1e-4, k
+    with pytest.raises(NotImplementedError):
+        AE(downsample=False)
+
+
+def test_pool_and_stuffing_adjoints(emu_lib):
+    """<pool_bwd(g), x'> and <stuff_bwd(g), x> against torch on ragged sizes."""
+    import torch.nn.functional as F
+    from lemo_amd.priors import cg8p_alloc, from_cg8p, to_cg8p
+    g = torch.Generator().manual_seed(1)
+    C, H, W = 16, 7, 10
+    x = torch.randn(C, H, W, generator=g).requires_grad_(True)
+    ref = F.max_pool2d(x[None], 3, 2, 1)[0]
+    Ho, Wo = ref.shape[1:]
+    xb, out = to_cg8p(x.detach()), cg8p_alloc(C, Ho, Wo, 'cpu')
+    idx = torch.empty(C // 8, Ho * Wo, 8, dtype=torch.uint8)
+    assert emu_lib.maxpool3s2_fwd(ptr(xb), H, W, ptr(out), ptr(idx), C, None) == 0
+    assert torch.equal(from_cg8p(out, Ho, Wo), ref.detach())
+    go = torch.randn(C, Ho, Wo, generator=g)
+    ref.backward(go)
+    gob, din = to_cg8p(go), cg8p_alloc(C, H, W, 'cpu')
+    assert emu_lib.maxpool3s2_bwd(ptr(gob), ptr(idx), None, ptr(din), H, W, C, None) == 0
+    assert rel_err(from_cg8p(din, H, W), x.grad) < 1e-6
+    # stuffing: ConvTranspose2d(k3,s2,p1)(z, output_size) == conv_transpose2d(stuffed, stride 1)
+    z = torch.randn(8, 4, 5, generator=g)
+    wt = torch.randn(8, 8, 3, 3, generator=g)
+    for tH, tW in ((7, 9), (8, 10), (7, 10)):
+        S = cg8p_alloc(8, tH, tW, 'cpu')
+        zb = to_cg8p(z)
+        assert emu_lib.stuff2_fwd(ptr(zb), 4, 5, ptr(S), tH, tW, 8, None) == 0
+        a = F.conv_transpose2d(from_cg8p(S, tH, tW)[None], wt, stride=1, padding=1)
+        b = F.conv_transpose2d(z[None], wt, stride=2, padding=1, output_padding=(tH - 7, tW - 9))
+        assert rel_err(a, b) < 1e-6
+
+
+@pytest.mark.timeout(900)
+def test_finetune_loop_matches_torch_adam(emu_lib):
+    """3 finetune steps (forward, masked L1, backward, Adam lr 3e-6 -> raised to 1e-3 to be visible) + eval forward."""
+    from lemo_amd.infill import AE, finetune_and_infill
+    w = _weights()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 4, 18, 22, generator=g)
+    mask = torch.rand(18, 22, generator=g) > 0.3
+    ae = AE(_lib=emu_lib)
+    rec, z = finetune_and_infill(ae, w, x, mask, steps=3, lr=1e-3)
+    wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    opt = torch.optim.Adam(list(wr.values()), lr=1e-3)
+    for _ in range(3):
+        opt.zero_grad()
+        r, _ = O.ae_forward(wr, x)
+        (r[0, 0] - x[0, 0])[mask].abs().mean().backward()
+        opt.step()
+    with torch.no_grad():
+        r, zr = O.ae_forward(wr, x)
+    assert rec.shape == (1, 1, 16, 6)
+    assert rel_err(rec, r[:, :, 1:-1, 8:-8]) < 1e-3 and rel_err(z, zr) < 1e-3
+    for k, p in ae.named_parameters():
+        assert float((p.detach() - wr[k].detach()).abs().max()) < 2e-5, k
