@@ -353,17 +353,27 @@ def test_infill_ae_full_size_golden_and_finetune(dev):
     assert out.shape == (1, 1, 210, 135) and z.shape == (1, 256, 7, 5)
     assert rel_err(z.detach().cpu(), g['z']) < 1e-4 and rel_err(out.detach().cpu()[0, 0, ::7, ::5], g['out_sub']) < 1e-4
     assert abs(float(out.double().sum()) - float(g['out_sum'])) < 1e-4 * float(out.double().abs().sum())
-    # gradients of the finetune loss w.r.t. all 40 parameter tensors
+    # gradients w.r.t. all 40 parameter tensors.  A linear functional of the output is used for the strict
+    # check: the finetune L1 (sign) and the max-pool argmax are discontinuous, so fp32 noise flips a few
+    # decisions at 28k pixels x 20 layers and exact agreement is not defined there (checked loosely below).
     gen = torch.Generator().manual_seed(0)
     mask = (torch.rand(210, 135, generator=gen) > 0.3)
-    loss = ((out[0, 0] - x[0, 0]).abs() * mask.to(dev)).sum() / mask.sum()
-    loss.backward()
+    wo = torch.randn(210, 135, generator=gen)
+    (out[0, 0] * wo.to(dev)).sum().backward(retain_graph=True)
     wr = {k: v.clone().requires_grad_(True) for k, v in w.items()}
     xc = x.cpu()
     oo, _ = O.ae_forward(wr, xc)
-    (oo[0, 0] - xc[0, 0])[mask].abs().mean().backward()
+    (oo[0, 0] * wo).sum().backward(retain_graph=True)
     for k, p in ae.named_parameters():
         assert rel_err(p.grad.cpu(), wr[k].grad) < 2e-3, k
+    for p in ae.parameters():
+        p.grad = None
+    for v in wr.values():
+        v.grad = None
+    (((out[0, 0] - x[0, 0]).abs() * mask.to(dev)).sum() / mask.sum()).backward()
+    (oo[0, 0] - xc[0, 0])[mask].abs().mean().backward()
+    for k, p in ae.named_parameters():
+        assert rel_err(p.grad.cpu(), wr[k].grad) < 5e-2, k
     torch.cuda.synchronize()
     t0 = time.time()
     rec, zz = finetune_and_infill(ae, {k: v.to(dev) for k, v in w.items()}, x, mask.to(dev), steps=60, lr=3e-6)
