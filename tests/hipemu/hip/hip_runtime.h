@@ -14,7 +14,6 @@
 //   16x16x4 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]  D: col=l&15, row=4*(l>>4)+r
 // and numerics are a k-ordered fmaf chain (bit-exact per the guide).
 #pragma once
-#include <ucontext.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -90,14 +89,40 @@ struct WaveBuf {
   float c[WAVE][16];
   unsigned long long u[WAVE];
 };
-struct Fiber { ucontext_t ctx; bool done = false; dim3 tid; int wave = 0, lane = 0; };
+// Minimal x86-64 fiber switch (callee-saved registers + stack pointer).  glibc's swapcontext makes a
+// sigprocmask syscall per switch, which dominated the emulation time (2 switches per lane per MFMA).
+struct Ctx { void* sp = nullptr; };
+extern "C" void hipemu_switch(Ctx* from, Ctx* to);
+asm(R"(
+.text
+.weak hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+struct Fiber { Ctx ctx; bool done = false; dim3 tid; int wave = 0, lane = 0; };
 
 struct State {
   std::vector<Fiber> fibers;
   std::vector<WaveBuf> waves;
   std::vector<char*> stacks;
   Group block;
-  ucontext_t sched;
+  Ctx sched;
   int cur = -1;
   std::function<void()> body;
 };
@@ -120,7 +145,7 @@ namespace hipemu {
 inline void yield() {
   State& s = st();
   Fiber& f = s.fibers[s.cur];
-  swapcontext(&f.ctx, &s.sched);
+  hipemu_switch(&f.ctx, &s.sched);
 }
 inline void barrier(Group& g) {
   unsigned gen = g.gen;
@@ -134,7 +159,8 @@ inline void fiber_entry() {
   State& s = st();
   s.body();
   s.fibers[s.cur].done = true;
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  hipemu_switch(&s.fibers[s.cur].ctx, &s.sched);
+  abort();                                                   // a finished fiber is never resumed
 }
 
 inline std::vector<char>& dyn_smem_buf() { static std::vector<char> b; return b; }
@@ -166,11 +192,13 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
           f.wave = t / WAVE;
           f.lane = t % WAVE;
           s.waves[f.wave].g.count++;
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = s.stacks[t];
-          f.ctx.uc_stack.ss_size = STACK;
-          f.ctx.uc_link = nullptr;
-          makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+          // initial frame: 6 callee-saved slots + return address = fiber_entry; after the `ret` the stack
+          // pointer is == 8 (mod 16), as at any function entry
+          uintptr_t top = ((uintptr_t)s.stacks[t] + STACK) & ~(uintptr_t)15;
+          void** sp = (void**)(top - 8) - 7;
+          for (int q = 0; q < 6; ++q) sp[q] = nullptr;
+          sp[6] = (void*)&fiber_entry;
+          f.ctx.sp = sp;
         }
         int alive = nthr;
         while (alive > 0) {
@@ -180,7 +208,7 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
             s.cur = t;
             hipemu_threadIdx() = f.tid;
             hipemu_blockIdx() = dim3(bx, by, bz);
-            swapcontext(&s.sched, &f.ctx);
+            hipemu_switch(&s.sched, &f.ctx);
             if (f.done) --alive;
           }
         }
