@@ -57,7 +57,10 @@ def time_dominant_kernel(fit, stream, reps=50):
     from lemo_amd._hip import ptr
     lib = fit.lib
     H, W = fit.H, fit.W
-    if fit.conv_variant == 2:
+    if fit.conv_variant == 3:
+        fn = lib.conv3x3_mfma_split
+        args = (ptr(fit.act[9]), ptr(fit.enc.w3[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
+    elif fit.conv_variant == 2:
         fn = lib.conv3x3_mfma_lds
         args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.w2[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
     else:

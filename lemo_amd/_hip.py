@@ -77,7 +77,7 @@ class FitDesc(C.Structure):
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
         ('fwd_ids', vp),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
-        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10),
+        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10),
         ('target', vp), ('contact', vp), ('weights', vp), ('weights_host', C.c_float * 6),
         ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
         ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
@@ -108,6 +108,9 @@ _SIGS = {
     'lemo_abi_version': (C.c_int, []),
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'lemo_conv3x3_mfma_split': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma_split_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_mfma_lds_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -14,13 +14,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LEMO_WAVE 64
 #define LEMO_LRELU_SLOPE 0.2f
 
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LEMO_LRELU_SLOPE * v; }
+// max(v, 0.2 v) == (v > 0 ? v : 0.2 v) bit for bit (slope in (0,1)); v_mul + v_max instead of mul + cmp + cndmask
+__device__ __forceinline__ float lrelu(float v) { return fmaxf(v, LEMO_LRELU_SLOPE * v); }
 // derivative selected from the *output* sign (slope > 0 keeps the sign; y == 0 <=> x == 0 -> slope,
 // matching torch's `x > 0 ? g : g * slope`)
 __device__ __forceinline__ float lrelu_grad_from_out(float y) { return y > 0.f ? 1.f : LEMO_LRELU_SLOPE; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {      // global_store_dwordx4 ... nt
+  __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(p));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

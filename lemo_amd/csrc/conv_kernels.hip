@@ -18,14 +18,11 @@
 // consecutive MFMA k-steps (lane half h consumes channels 4h..4h+3 of the 8-group), and the
 // accumulator map (col=l&31 -> pixel, row=(r&3)+8*(r>>2)+4*(l>>5) -> cout) makes the epilogue a
 // dwordx4 store per (lane, 8-cout group): 1 KiB contiguous per wave again.
-#include "kernels.hpp"
+#include "conv_common.hpp"
 
 namespace lemo {
 
-// EPI 0: out = lrelu(acc + bias)            (forward layer)
-// EPI 1: out = acc * lrelu'(aux)            (backward-data; aux = saved forward activation at the
-//                                             output position, same layout/channels as `out`)
-// EPI 2: out = acc + bias                   (plain conv, no activation)
+// epilogues EPI 0/1/2: conv_common.hpp
 template <int MT, int EPI>
 __global__ void __launch_bounds__(256)
 conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
@@ -125,21 +122,6 @@ conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
 //     (a 257th main block would: all 256 CUs are already busy).
 //   * operands are prefetched two k-iterations ahead through a 3-deep register ring.
 // ------------------------------------------------------------------------------------------------
-template <int EPI>
-__device__ __forceinline__ void conv_store4(float* __restrict__ out, const float* __restrict__ bias,
-                                            const float* __restrict__ aux, size_t o, int c0, float4 v) {
-  if (EPI == 0 || EPI == 2) {
-    const float4 bb = ld4(bias + c0);
-    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-    if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
-  } else {
-    const float4 yy = ld4(aux + o);
-    v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
-    v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
-  }
-  st4(out + o, v);
-}
-
 // One tail unit: 16 pixels x 16 couts over the full K = 9*Cin on v_mfma_f32_16x16x4_f32, operands
 // straight from global memory (tap-major pack).  The unit runs next to the main blocks, so it must
 // not be latency-bound: all loads of THREE taps (6*GP dwordx4 per lane) are issued before their

@@ -1,0 +1,377 @@
+// 64 -> 64 channel 3x3 convolution of the smoothness encoder (models/AE_sep.py:11-30, 77-99) on the
+// bf16 matrix cores with EXACT fp32 operands ("split-bf16", conv variant 3).
+//
+// Every fp32 operand x is split into three bf16 pieces x = hi + mid + lo (hi = bf16(x),
+// mid = bf16(x - hi), lo = bf16(x - hi - mid); 3 x 8 significand bits, the sum is exact) and
+//     a*b  ~=  a_hi*b_lo + a_lo*b_hi + a_mid*b_mid + a_hi*b_mid + a_mid*b_hi + a_hi*b_hi
+// is accumulated in fp32 by six v_mfma_f32_32x32x16_bf16 per 16-deep k-chunk.  Each bf16 x bf16
+// product is exact in fp32; the three dropped terms are < 2^-24 |ab| each.  Measured on the encoder's
+// own weights: dropped-term error 3e-9 of max|out| vs 3e-7 for the fp32 accumulation rounding that any
+// fp32 convolution (the fp32 MFMA, cuDNN, an fmaf chain) carries; on gfx950 the 6-product sum of a
+// K = 576 dot product has max error 7.4e-7 vs 8.2e-7 for v_mfma_f32_32x32x2_f32
+// (tools/ubench/split_ubench.hip).  Six bf16 MFMAs run at 16x the fp32-MFMA rate, so one fp32-exact
+// multiply-accumulate costs 6/16 of the fp32 matrix pipe: the 1e-5 loss-parity budget stays on fp32
+// numerics while the MFMA floor of the layer drops from 18 us to 6.9 us.
+//
+// Work decomposition (one 512-thread block per CU, all 256 CUs, no second wave of blocks):
+//   block  = 128 consecutive pixels x 64 couts x K = 9 taps x 64 cin
+//   wave w = pixel half (w&1: 64 px = 2 MFMA N-tiles) x cout half (w>>1&1: 32 = 1 M-tile) x K half
+//            (w>>2: channel groups 4kh..4kh+3) -> 18 (chunk, tap) steps x 12 MFMAs, 32 accumulators
+//   roles  : A = weights (M = cout), B = activations (N = pixel), lane half h takes channel group 2kc+h
+// Activations: the block stages its 128-pixel tile + 3x3 halo of all 64 channels ONCE, converting
+// fp32 CG8P -> three bf16 planes in LDS ([group 8][split 3][pixel][8 bf16]: 153 KB), in two phases so
+// that the MFMAs of the first k-chunk overlap the global loads of the second.  Every B fragment is one
+// conflict-free ds_read_b128.  Weights are pre-split on the host (w3[kc][tap][mt][split][lane][8]) and
+// read straight from global memory/L2 as one coalesced 1 KB dwordx4 per fragment (no LDS room left,
+// and only 2 waves share each fragment).  The two K halves are summed through LDS (4 KB per wave).
+// The P % 128 remainder pixels are cut into 4 px x 4 cout patches, one per block, computed with plain
+// fp32 FMAs (one output pair per wave) inside the latency shadow of the first staging loads - no tail
+// blocks, exactly one block per CU.
+#include "conv_common.hpp"
+
+namespace lemo {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CV3_NPX 408
+struct Cv3Cfg {
+  static constexpr int PLANE = CV3_NPX * 16;                    // bytes of one (group, split) plane
+  static constexpr int GRP = 3 * PLANE;
+  static constexpr int ACT_BYTES = 8 * GRP;                     // 156,672
+  static constexpr int SMEM_BYTES = ACT_BYTES;
+};
+
+// p / W for 0 <= p < 2^24 with magic = 2^32 / W + 1 (host): one v_mul_hi instead of the ~40-instruction
+// runtime division (the prologue had 13 of them per thread: 3.6k of its 6.9k cycles were address math)
+__device__ __forceinline__ int div_w(int p, unsigned magic) { return (int)__umulhi((unsigned)p, magic); }
+
+__device__ __forceinline__ void split3x4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (__bf16)x[e];
+    float r = x[e] - (float)h[e];
+    m[e] = (__bf16)r;
+    r -= (float)m[e];
+    l[e] = (__bf16)r;
+  }
+  hi = __builtin_bit_cast(uint2, h);
+  mid = __builtin_bit_cast(uint2, m);
+  lo = __builtin_bit_cast(uint2, l);
+}
+
+// One remainder patch = 4 px x 4 couts over K = 576, no LDS, no barrier: wave w owns pixel w>>1 and the
+// cout pair 2*(w&1), +1; lane l takes channel l of every tap (9 activation + 18 weight dwords, coalesced
+// 256-B runs), 18 fp32 FMAs, two wave sums.  `load` and `finish` are separate so that the kernel can put
+// the block's first patch into the latency shadow of its staging loads.
+struct SplitPatch {
+  float a[9], w0[9], w1[9];
+  float e0, e1;                                                 // epilogue operands (bias or saved activation)
+  int poff, co, valid;
+};
+template <int EPI>
+__device__ __forceinline__ void split_patch_load(SplitPatch& pt, const float* __restrict__ in, const float* __restrict__ wt,
+                                                 const float* __restrict__ bias, const float* __restrict__ aux,
+                                                 int W, unsigned wmagic, int Wp, int HWp, int P, int rem0, int patch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pq = patch >> 4, cq = patch & 15;
+  int p = rem0 + pq * 4 + (wave >> 1);
+  pt.valid = p < P;
+  p = p < P ? p : P - 1;
+  const int y = div_w(p, wmagic), x = p - y * W;
+  pt.poff = (y + 1) * Wp + (x + 1);
+  pt.co = cq * 4 + 2 * (wave & 1);
+  const float* ia = in + (unsigned)(lane >> 3) * ((unsigned)HWp * 8u) + (unsigned)pt.poff * 8u + (lane & 7);
+  const float* wa = wt + ((unsigned)(lane >> 3) * 64u + pt.co) * 8u + (lane & 7);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    pt.a[t] = ia[((t / 3 - 1) * Wp + (t % 3 - 1)) * 8];
+    pt.w0[t] = wa[t * 4096];                                    // wt[tap][8 groups][64 couts][8]
+    pt.w1[t] = wa[t * 4096 + 8];
+  }
+  // loaded here, ahead of the kernel's staging loads: a load issued after them returns after them
+  // wave-uniform address -> scalar loads (lgkmcnt): as vector loads hipcc sinks them to their first use,
+  // i.e. behind the staging loads, and the patch would wait for the whole staging round trip
+  const int cou = __builtin_amdgcn_readfirstlane(pt.co), pou = __builtin_amdgcn_readfirstlane(pt.poff);
+  const float* ep = EPI == 1 ? aux + ((size_t)(cou >> 3) * HWp + pou) * 8 + (cou & 7) : bias + cou;
+  pt.e0 = ep[0];
+  pt.e1 = ep[1];
+}
+template <int EPI>
+__device__ __forceinline__ void split_patch_finish(const SplitPatch& pt, float* __restrict__ out, int HWp) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { s0 = fmaf(pt.a[t], pt.w0[t], s0); s1 = fmaf(pt.a[t], pt.w1[t], s1); }
+  // bias / lrelu' enter BEFORE the wave sums (in straight-line code): used only inside the lane-0 store
+  // block, hipcc sinks their loads into it, i.e. behind the kernel's staging loads
+  const bool l0 = (threadIdx.x & 63) == 0;
+  if (EPI == 1) { s0 *= lrelu_grad_from_out(pt.e0); s1 *= lrelu_grad_from_out(pt.e1); }
+  else { s0 += l0 ? pt.e0 : 0.f; s1 += l0 ? pt.e1 : 0.f; }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (EPI == 0) { s0 = lrelu(s0); s1 = lrelu(s1); }
+  if ((threadIdx.x & 63) == 0 && pt.valid) {                    // co is even: both couts in one 8-group
+    float* o = out + ((size_t)(pt.co >> 3) * HWp + pt.poff) * 8 + (pt.co & 7);
+    o[0] = s0; o[1] = s1;
+  }
+}
+
+// hand `give` to the partner wave through LDS, add the partner's tile to `keep` (fixed order: K half 0 +
+// K half 1), epilogue, store 32 couts x 32 px
+template <int EPI>
+__device__ __forceinline__ void split_reduce_store(const f32x16& give, const f32x16& keep, float* mine, const float* theirs,
+                                                   bool second, float* __restrict__ out, const float* __restrict__ bias,
+                                                   const float* __restrict__ aux, int HWp, int poff, int m_base, int h) {
+  // epilogue operands (bias, or the saved activation for lrelu') are requested before the LDS exchange:
+  // their L2 round trip hides behind the barrier instead of following it
+  float4 eo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = m_base + q * 8 + 4 * h;
+    eo[q] = EPI == 1 ? ld4(aux + ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7)) : ld4(bias + c0);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) st4(mine + q * 256, make_float4(give[4 * q], give[4 * q + 1], give[4 * q + 2], give[4 * q + 3]));
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = ld4(theirs + q * 256);
+    const int c0 = m_base + q * 8 + 4 * h;
+    float4 v;
+    v.x = second ? t.x + keep[4 * q] : keep[4 * q] + t.x;
+    v.y = second ? t.y + keep[4 * q + 1] : keep[4 * q + 1] + t.y;
+    v.z = second ? t.z + keep[4 * q + 2] : keep[4 * q + 2] + t.z;
+    v.w = second ? t.w + keep[4 * q + 3] : keep[4 * q + 3] + t.w;
+    if (EPI == 1) {
+      v.x *= lrelu_grad_from_out(eo[q].x); v.y *= lrelu_grad_from_out(eo[q].y);
+      v.z *= lrelu_grad_from_out(eo[q].z); v.w *= lrelu_grad_from_out(eo[q].w);
+    } else {
+      v.x += eo[q].x; v.y += eo[q].y; v.z += eo[q].z; v.w += eo[q].w;
+      if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+    }
+    float* o = out + ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
+    // streaming store: the tile is not read again by this kernel, and lines that are not left dirty in L2
+    // do not have to be written back by the end-of-kernel release (measured -0.7 us per launch)
+    st4_nt(o, v);
+  }
+}
+
+template <int EPI, bool DBG>
+__global__ void __launch_bounds__(512)
+conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3, const float* __restrict__ wt,
+                     const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
+                     int H, int W, unsigned wmagic, int full_blocks, unsigned long long* __restrict__ dbg) {
+  unsigned long long t_start = 0, t_pro = 0, t_loop = 0, t_mid0 = 0, t_mid1 = 0;
+  if (DBG) t_start = __builtin_amdgcn_s_memtime();
+  constexpr int PLANE = Cv3Cfg::PLANE, GRP = Cv3Cfg::GRP;
+  LEMO_DYN_SMEM(smem_f);
+  unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int ph = wave & 1, ch = (wave >> 1) & 1, kh = wave >> 2;
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const unsigned in_gstride = (unsigned)HWp * 8u;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8): XCD x owns a contiguous run of tiles so that
+  // vertically adjacent tiles share their halo rows in one L2
+  int tile = (int)blockIdx.x;
+  {
+    const int q = full_blocks >> 3, r = full_blocks & 7, xcd = tile & 7, k = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+
+  // Operand pipeline over the 18 (chunk, tap) steps u: weight fragments come from L2 (~1 us away) and are
+  // requested TWO steps ahead through a ring of three register sets; activation fragments come from LDS
+  // one step ahead (two sets; not across the phase barrier).  The sched_barriers keep hipcc from sinking
+  // the loads next to their uses.
+  uint4 ra[3][3], rb[2][2][3];
+#define CV3_LOAD_A(SET, U)                                                                         \
+  _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                                 \
+    ra[SET][s_] = w3[(unsigned)((((2 * kh + (U) / 9) * 9 + (U) % 9) * 2 + ch) * 3 + s_) * 64u + lane];
+#define CV3_LOAD_B(SET, U)                                                                         \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                               \
+      rb[SET][nt_][s_] = *reinterpret_cast<const uint4*>(                                         \
+          smem + (2 * (2 * kh + (U) / 9) + h) * GRP + s_ * PLANE + (li[nt_] + (((U) % 9) / 3 - 1) * Wp + (((U) % 9) % 3 - 1)) * 16);
+#define CV3_MFMA1(SA, SETA, SB, SETB)                                                              \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
+    acc[nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[SETA][SA]),   \
+                                                       __builtin_bit_cast(bf16x8, rb[SETB][nt_][SB]), acc[nt_], 0, 0, 0);
+  // smallest products first
+#define CV3_MFMA(SETA, SETB)                                                                       \
+  CV3_MFMA1(0, SETA, 2, SETB) CV3_MFMA1(2, SETA, 0, SETB) CV3_MFMA1(1, SETA, 1, SETB)              \
+  CV3_MFMA1(0, SETA, 1, SETB) CV3_MFMA1(1, SETA, 0, SETB) CV3_MFMA1(0, SETA, 0, SETB)
+
+  // the first two weight fragments are requested before anything else (nothing depends on them)
+  CV3_LOAD_A(0, 0)
+  CV3_LOAD_A(1, 1)
+
+  // ---- remainder patch of this block: 4 px x 4 couts, K = 576 spread over the 512 threads ---------
+  const int rem0 = full_blocks * 128;
+  const int npatch = ((P - rem0 + 3) >> 2) * 16;
+  const bool has_patch = tile < npatch;                          // uniform
+  // Its loads are issued at the first tap of the main loop and consumed four taps later: the VALU work
+  // rides between MFMAs.  (Unconditional loads + straight-line code: inside an `if` hipcc merges the FMAs
+  // back into the load block and waits there.)
+  SplitPatch pt;
+
+  // ---- staging plan ---------------------------------------------------------------------------------
+  const int pfirst = tile * 128, plast = pfirst + 127;
+  const int yf = div_w(pfirst, wmagic), yl = div_w(plast, wmagic);
+  const int q0 = (yf + 1) * Wp + (pfirst - yf * W + 1), q1 = (yl + 1) * Wp + (plast - yl * W + 1);
+  const int qin = q0 - Wp - 1;                                   // first staged padded pixel
+  const int npx = q1 - q0 + 2 * Wp + 3;                          // staged pixels (<= CV3_NPX, checked on host)
+  const int nchB = 2 * npx;                                      // 16-B chunks (4 floats) per channel group
+  // phase f stages groups {2f, 2f+1, 4+2f, 4+2f+1}: the first / second k-chunk of both K halves.
+  // Slot c = tid + 512 k covers chunk c % 816 of group c / 816 (constant stride = the LDS plane size, so the
+  // map costs a handful of VALU ops: every prologue instruction is paid twice per SIMD with the MFMA pipe
+  // idle); chunks past the tile's own nchB re-read its last one.  No predicates anywhere: a load whose only
+  // use sits inside an `if` is sunk into it by hipcc and then waited for with vmcnt(0).
+  constexpr int NB = (4 * 2 * CV3_NPX + 511) / 512;
+  unsigned offB[NB];
+  int dstB[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    int c0 = (int)threadIdx.x + k * 512;
+    c0 = c0 < 4 * 2 * CV3_NPX ? c0 : 4 * 2 * CV3_NPX - 1;        // surplus slots redo the last chunk (same data, same place)
+    const int gg = c0 / (2 * CV3_NPX), c = c0 - gg * (2 * CV3_NPX);
+    const int g0 = (gg >> 1) * 4 + (gg & 1);
+    const int cl = c < nchB ? c : nchB - 1;
+    offB[k] = (unsigned)g0 * in_gstride + (unsigned)qin * 8u + (unsigned)cl * 4u;
+    dstB[k] = g0 * GRP + c * 8;
+  }
+  float4 stB[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) stB[k] = ld4(in + offB[k]);
+
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    uint2 s0, s1, s2;
+    split3x4(stB[k], s0, s1, s2);
+    *reinterpret_cast<uint2*>(smem + dstB[k]) = s0;
+    *reinterpret_cast<uint2*>(smem + dstB[k] + PLANE) = s1;
+    *reinterpret_cast<uint2*>(smem + dstB[k] + 2 * PLANE) = s2;
+  }
+  // second phase: loads in flight during the first k-chunk's MFMAs
+#pragma unroll
+  for (int k = 0; k < NB; ++k) stB[k] = ld4(in + 2u * in_gstride + offB[k]);
+  __syncthreads();
+  if (DBG) t_pro = __builtin_amdgcn_s_memtime();
+
+  // ---- main loop -------------------------------------------------------------------------------------
+  int li[2];
+  int poffn[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int p = pfirst + ph * 64 + nt * 32 + j;
+    const int y = div_w(p, wmagic), x = p - y * W;
+    poffn[nt] = (y + 1) * Wp + (x + 1);
+    li[nt] = poffn[nt] - qin;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    CV3_LOAD_B((cc * 9) & 1, cc * 9)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int u = cc * 9 + tap;
+      if (u + 2 < 18) { CV3_LOAD_A((u + 2) % 3, u + 2) }
+      if (tap + 1 < 9) { CV3_LOAD_B((u + 1) & 1, u + 1) }
+      if (u == 0) {
+        split_patch_load<EPI>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, has_patch ? tile : 0);
+        pt.valid = pt.valid && has_patch;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      CV3_MFMA(u % 3, u & 1)
+      if (u == 4) split_patch_finish<EPI>(pt, out, HWp);
+      // second-phase staging, one slot per tap: its ~30 VALU ops and 3 LDS writes issue between this
+      // tap's MFMAs instead of in one MFMA-idle burst before the phase barrier
+      if (cc == 0 && tap >= 2 && tap - 2 < NB) {
+        const int k = tap - 2;
+        uint2 s0, s1, s2;
+        split3x4(stB[k], s0, s1, s2);
+        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k]) = s0;
+        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + PLANE) = s1;
+        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + 2 * PLANE) = s2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(NB <= 7, "second-phase slots are spread over taps 2..8");
+    if (DBG && cc == 0) t_mid0 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    if (DBG && cc == 0) t_mid1 = __builtin_amdgcn_s_memtime();
+  }
+#undef CV3_LOAD_A
+#undef CV3_LOAD_B
+#undef CV3_MFMA1
+#undef CV3_MFMA
+  if (DBG) t_loop = __builtin_amdgcn_s_memtime();
+
+  // ---- sum the two K halves: wave kh keeps pixel tile nt = kh and hands the other one over ---------
+  // (kh is wave-uniform: a scalar branch instead of 32 v_cndmask on the accumulators)
+  {
+    float* red = smem_f + (((ph * 2 + ch) * 2) * 4) * 256 + lane * 4;   // [ph*2+ch][kh][4][64][4] floats (32 KB), tile LDS is dead
+    const int m_base = ch * 32;
+    if (__builtin_amdgcn_readfirstlane(kh))
+      split_reduce_store<EPI>(acc[0], acc[1], red + 1024, red, true, out, bias, aux, HWp, poffn[1], m_base, h);
+    else
+      split_reduce_store<EPI>(acc[1], acc[0], red, red + 1024, false, out, bias, aux, HWp, poffn[0], m_base, h);
+  }
+  // shapes with more remainder patches than blocks: the rest, round-robin (not on the headline shapes)
+  for (int patch = tile + full_blocks; patch < npatch; patch += full_blocks) {
+    split_patch_load<EPI>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, patch);
+    split_patch_finish<EPI>(pt, out, HWp);
+  }
+  if (DBG && lane == 0) {           // census record, same format as conv3x3_mfma_v2_kernel
+    unsigned long long* r = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    r[0] = __builtin_amdgcn_s_getreg(63492);
+    r[1] = __builtin_amdgcn_s_getreg(63508);
+    r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = t_pro; r[5] = t_loop; r[6] = t_mid0; r[7] = t_mid1;
+  }
+}
+
+int conv_split_init() {
+  static int rc = -1;
+  if (rc >= 0) return rc;
+  rc = 0;
+#define OPTIN(EPI_, DBG_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<EPI_, DBG_>), hipFuncAttributeMaxDynamicSharedMemorySize, Cv3Cfg::SMEM_BYTES); if (e != hipSuccess) rc = (int)e; }
+  OPTIN(0, false) OPTIN(1, false) OPTIN(2, false) OPTIN(0, true)
+#undef OPTIN
+  return rc;
+}
+
+// shapes the split kernel takes; everything else stays on conv3x3_mfma_lds
+bool conv3x3_split_supported(int H, int W, int cin, int cout) {
+  if (cin != 64 || cout != 64 || H <= 0 || W <= 0) return false;
+  const long P = (long)H * W;
+  const long full = P / 128;
+  if (full < 1 || P > (1l << 24)) return false;
+  if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV3_NPX) return false;
+  return true;
+}
+
+int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const float* bias, const float* aux, float* out,
+                       int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg) {
+  if (!conv3x3_split_supported(H, W, cin, cout) || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
+  const int full = (H * W) / 128;
+  if (int rc = conv_split_init()) return rc;
+  const uint4* w3v = reinterpret_cast<const uint4*>(w3);
+  const unsigned wmagic = (unsigned)((1ull << 32) / (unsigned)W + 1);       // exact for p < 2^32 / W (P <= 2^24 checked)
+  if (dbg) {
+    if (epi != 0) return LEMO_ERR_ARG;
+    hipLaunchKernelGGL((conv3x3_split_kernel<0, true>), dim3(full), dim3(512), (Cv3Cfg::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, dbg);
+    return (int)hipGetLastError();
+  }
+#define LAUNCH3(EPI_) hipLaunchKernelGGL((conv3x3_split_kernel<EPI_, false>), dim3(full), dim3(512), (Cv3Cfg::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, (unsigned long long*)nullptr)
+  if (epi == 0) LAUNCH3(0); else if (epi == 1) LAUNCH3(1); else LAUNCH3(2);
+#undef LAUNCH3
+  return (int)hipGetLastError();
+}
+
+}  // namespace lemo

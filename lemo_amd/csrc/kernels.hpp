@@ -12,6 +12,12 @@ int conv3x3_mfma(const float* in, const float* wt, const float* bias, const floa
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
                      int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
 int conv_lds_init();
+// ---------------- conv_split_kernels.hip ----------------
+// variant 3: fp32-exact 64->64 conv on the bf16 matrix cores (3-way bf16 operand split, 6 products)
+bool conv3x3_split_supported(int H, int W, int cin, int cout);
+int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const float* bias, const float* aux, float* out,
+                       int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
+int conv_split_init();
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);

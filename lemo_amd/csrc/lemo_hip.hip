@@ -24,6 +24,17 @@ int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, co
   if (!in || !wt || !wt2 || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma_lds(in, wt, wt2, bias, aux, out, H, W, cin, cout, epi, S(stream));
 }
+int lemo_conv3x3_split_supported(int H, int W, int cin, int cout) { return conv3x3_split_supported(H, W, cin, cout) ? 1 : 0; }
+int lemo_conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const float* bias, const float* aux,
+                            float* out, int H, int W, int cin, int cout, int epi, void* stream) {
+  if (!in || !w3 || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
+  return conv3x3_mfma_split(in, w3, wt, bias, aux, out, H, W, cin, cout, epi, S(stream));
+}
+int lemo_conv3x3_mfma_split_census(const float* in, const void* w3, const float* wt, const float* bias, float* out,
+                                   int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
+  if (!in || !w3 || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
+  return conv3x3_mfma_split(in, w3, wt, bias, nullptr, out, H, W, cin, cout, 0, S(stream), dbg);
+}
 int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
                                  int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
   if (!in || !wt || !wt2 || !out || !bias || !dbg) return LEMO_ERR_ARG;
@@ -159,7 +170,9 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
   CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
   for (int l = 1; l < 10; ++l) {
-    if (d.conv_variant == 2)
+    if (d.conv_variant == 3 && d.enc_w3[l] && conv3x3_split_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1]))
+      CHK(conv3x3_mfma_split(d.act[l], d.enc_w3[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
+    else if (d.conv_variant >= 2)
       CHK(conv3x3_mfma_lds(d.act[l], d.enc_w[l], d.enc_w2[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
     else
       CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, d.conv_variant, s));
@@ -178,7 +191,9 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
   for (int l = 9; l >= 1; --l) {   // d(pre-act of layer l+1) -> d(pre-act of layer l)
-    if (d.conv_variant == 2)
+    if (d.conv_variant == 3 && d.enc_wbwd3[l] && conv3x3_split_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l]))
+      CHK(conv3x3_mfma_split(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
+    else if (d.conv_variant >= 2)
       CHK(conv3x3_mfma_lds(d.dact[cur], d.enc_wbwd[l], d.enc_wbwd2[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
     else
       CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, d.conv_variant, s));
@@ -207,7 +222,7 @@ static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
 
 void* lemo_fit_create(const lemo_fit_desc* d) {
   if (!d || d->B < 10 || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
-  if (conv_lds_init() || lbs_init()) return nullptr;
+  if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
   FitEngine* e = new (std::nothrow) FitEngine();
   if (e) e->d = *d;
   return e;

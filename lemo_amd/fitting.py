@@ -26,6 +26,9 @@ LOSS_WEIGHTS = dict(rec_markers=1.0, vposer=0.02, shape=0.01, hand=0.01, contact
 """opt_amass_temp.py:47-52 (order = the C ABI's ``weights[6]``)."""
 FOOT_SETS = ('left_heel', 'right_heel', 'left_toe', 'right_toe')
 """columns of ``contact_lbl`` (opt_amass_temp.py:409-412)."""
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '2'))
+"""conv kernel family of the smoothness encoder's MFMA layers (include/lemo_hip.h ``conv_variant``); the
+environment override exists for A/B runs of the parity suite."""
 LOSS_NAMES = ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total')
 
 
@@ -33,7 +36,7 @@ class AmassTemporalFitter:
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
-                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: int = 2,
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None,
                  lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
@@ -110,7 +113,9 @@ class AmassTemporalFitter:
 
         d = _hip.FitDesc()
         d.B, d.Bp, d.V, d.nrows, d.full_vertices = B, Bp, data.V, self.nrows, int(self.full)
-        if int(conv_variant) == 2 and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
+        if conv_variant is None:
+            conv_variant = DEFAULT_CONV_VARIANT
+        if int(conv_variant) >= 2 and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
             conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124)
         self.conv_variant = d.conv_variant = int(conv_variant)
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
@@ -119,6 +124,8 @@ class AmassTemporalFitter:
         for l in range(10):
             d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
             d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
+            d.enc_w3[l] = ptr(self.enc.w3[l]) if self.enc.w3[l] is not None else None
+            d.enc_wbwd3[l] = ptr(self.enc.wbwd3[l]) if self.enc.wbwd3[l] is not None else None
         d.target, d.contact, d.weights = ptr(self.target), ptr(self.contact), ptr(self._w_dev)
         for i, v in enumerate(wl): d.weights_host[i] = v
         d.transl, d.rot6d, d.other, d.shape = (ptr(self.P[k]) for k in ('transl', 'rot6d', 'other', 'shape'))

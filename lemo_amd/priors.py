@@ -48,6 +48,41 @@ def pack_conv3x3_bwd_gmajor(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(pack_conv3x3_bwd(w).transpose(1, 0, 2, 3))
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest-even bf16, returned as fp32 (low 16 bits zero)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def bf16_split3(x: np.ndarray):
+    """x = hi + mid + lo exactly, each piece a bf16 value (held as fp32)."""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = bf16_round(x)
+    r1 = x - hi
+    mid = bf16_round(r1)
+    lo = bf16_round(r1 - mid)
+    assert np.array_equal(hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64), x.astype(np.float64))
+    return hi, mid, lo
+
+
+def pack_conv3x3_split(w: np.ndarray) -> np.ndarray:
+    """[Cout][Cin][3][3] fp32 -> uint16 (bf16 bits) w3[Cin/16][tap][Cout/32][split 3][lane 64][8] for
+    lemo_conv3x3_mfma_split: lane l = (cout & 31) + 32 * (channel group parity), 8 channels of the group."""
+    co, ci = w.shape[:2]
+    assert ci % 16 == 0 and co % 32 == 0
+    pieces = np.stack(bf16_split3(w), 0)                    # [3][co][ci][3][3]
+    bits = (pieces.view(np.uint32) >> 16).astype(np.uint16)
+    t = bits.reshape(3, co // 32, 32, ci // 16, 2, 8, 9)    # [s][mt][i][kc][h][e][tap]
+    t = t.transpose(3, 6, 1, 0, 4, 2, 5)                    # [kc][tap][mt][s][h][i][e]
+    return np.ascontiguousarray(t).reshape(ci // 16, 9, co // 32, 3, 64, 8)
+
+
+def pack_conv3x3_bwd_split(w: np.ndarray) -> np.ndarray:
+    wf = w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)
+    return pack_conv3x3_split(np.ascontiguousarray(wf))
+
+
 def cg8p_alloc(C_: int, H: int, W: int, device) -> torch.Tensor:
     """zeroed CG8P activation buffer [C/8][(H+2)*(W+2)][8] (border stays zero forever)."""
     return torch.zeros(max(C_ // 8, 1), (H + 2) * (W + 2), 8, dtype=torch.float32, device=device)
@@ -73,6 +108,8 @@ class EncWeights:
         self.keys = enc_layer_keys()
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
         self.w, self.b, self.wbwd, self.w2, self.wbwd2 = [], [], [], [], []
+        self.w3, self.wbwd3 = [], []                       # split-bf16 packs of the 64->64 layers (else None)
+        t16 = lambda a: torch.from_numpy(a.view(np.int16)).to(device)
         for li, k in enumerate(self.keys):
             w = np.asarray(state[k + '.weight'], np.float32)
             b = np.asarray(state[k + '.bias'], np.float32)
@@ -81,11 +118,15 @@ class EncWeights:
                 self.w.append(t(w.reshape(w.shape[0], 9)))
                 self.wbwd.append(self.w[0])
                 self.w2.append(self.w[0]); self.wbwd2.append(self.w[0])
+                self.w3.append(None); self.wbwd3.append(None)
             else:
                 self.w.append(t(pack_conv3x3(w)))
                 self.wbwd.append(t(pack_conv3x3_bwd(w)))
                 self.w2.append(t(pack_conv3x3_gmajor(w)))
                 self.wbwd2.append(t(pack_conv3x3_bwd_gmajor(w)))
+                both64 = w.shape[0] == 64 and w.shape[1] == 64
+                self.w3.append(t16(pack_conv3x3_split(w)) if both64 else None)
+                self.wbwd3.append(t16(pack_conv3x3_bwd_split(w)) if both64 else None)
             self.b.append(t(b))
 
 

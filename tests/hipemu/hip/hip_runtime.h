@@ -88,6 +88,7 @@ struct WaveBuf {
   float a[WAVE], b[WAVE];
   float c[WAVE][16];
   unsigned long long u[WAVE];
+  float a8[WAVE][8], b8[WAVE][8];
 };
 // Minimal x86-64 fiber switch (callee-saved registers + stack pointer).  glibc's swapcontext makes a
 // sigprocmask syscall per switch, which dominated the emulation time (2 switches per lane per MFMA).
@@ -309,6 +310,27 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
   return d;
 }
 
+// gfx950 bf16 MFMA: A[i = l&31][k = 8*(l>>5)+e], B[k][j = l&31], C/D as the f32 32x32 form; the 16
+// products of one instruction are exact and summed before the single fp32 rounding
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+  hipemu::WaveBuf& w = hipemu::mywave();
+  const int l = hipemu::me().lane;
+  for (int e = 0; e < 8; ++e) { w.a8[l][e] = (float)a[e]; w.b8[l][e] = (float)b[e]; }
+  hipemu::barrier(w.g);
+  hipemu_f32x16 d;
+  const int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = c[r];
+    for (int hh = 0; hh < 2; ++hh)
+      for (int e = 0; e < 8; ++e) acc += (double)w.a8[row + 32 * hh][e] * (double)w.b8[col + 32 * hh][e];
+    d[r] = (float)acc;
+  }
+  hipemu::barrier(w.g);
+  return d;
+}
+
 // ---- atomics (single OS thread => plain RMW is atomic w.r.t. other fibers) --------------------
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (float)v; return o; }
@@ -316,6 +338,9 @@ template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std:
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+// only ever applied to wave-uniform values in the kernels
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
 

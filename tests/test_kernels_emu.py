@@ -49,6 +49,38 @@ def test_conv3x3_mfma_forward_and_backward_data(emu_lib, ci, co, variant):
         assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
 
 
+@pytest.mark.parametrize('H,W', [(7, 41), (36, 57)])
+def test_conv3x3_split_bf16_forward_and_backward_data(emu_lib, H, W):
+    """conv variant 3 (fp32-exact 3-way bf16 operand split on the bf16 MFMA) against torch fp32 AND float64:
+    its error must be of the size of the fp32 convolution's own rounding error, not a bf16-sized one.
+    (7, 41): 2 blocks + 31 remainder pixels = 128 patches -> 64 patches per block (generic patch loop);
+    (36, 57): 16 blocks + 4 remainder pixels = one patch per block (the headline-shape code path)."""
+    from lemo_amd.priors import pack_conv3x3_split, pack_conv3x3_bwd_split, bf16_split3
+    ci = co = 64
+    g = torch.Generator().manual_seed(H * W)
+    x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
+    hi, mid, lo = bf16_split3(w.numpy())
+    assert np.abs(mid).max() <= 2.0 ** -8 * np.abs(w.numpy()).max() and np.abs(lo).max() <= 2.0 ** -16 * np.abs(w.numpy()).max()
+    assert emu_lib.conv3x3_split_supported(H, W, ci, co) == 1 and emu_lib.conv3x3_split_supported(H, W, 32, 64) == 0
+    ref64 = F.leaky_relu(F.conv2d(x[None].double(), w.double(), b.double(), padding=1), 0.2)[0]
+    ref32 = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    xin, out = to_cg8p(x), cg8p_alloc(co, H, W, 'cpu')
+    wt, w3 = torch.from_numpy(pack_conv3x3(w.numpy())), torch.from_numpy(pack_conv3x3_split(w.numpy()).view(np.int16))
+    assert emu_lib.conv3x3_mfma_split(ptr(xin), ptr(w3), ptr(wt), ptr(b), None, ptr(out), H, W, ci, co, 0, None) == 0
+    got = from_cg8p(out, H, W)
+    e_split, e_f32 = rel_err(got.double(), ref64), rel_err(ref32.double(), ref64)
+    assert e_split < 2e-6 and e_split < 4 * e_f32, (e_split, e_f32)
+    assert float(out.reshape(co // 8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0       # border untouched
+    dy, aux = torch.randn(co, H, W, generator=g), torch.randn(ci, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr[None], w, b, padding=1).backward(dy[None])
+    refdx = xr.grad * torch.where(aux > 0, 1.0, 0.2)
+    dyb, auxb, dxb = to_cg8p(dy), to_cg8p(aux), cg8p_alloc(ci, H, W, 'cpu')
+    wtb, wb3 = torch.from_numpy(pack_conv3x3_bwd(w.numpy())), torch.from_numpy(pack_conv3x3_bwd_split(w.numpy()).view(np.int16))
+    assert emu_lib.conv3x3_mfma_split(ptr(dyb), ptr(wb3), ptr(wtb), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, None) == 0
+    assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
+
+
 def test_conv_rejects_bad_shapes(emu_lib):
     t = torch.zeros(64)
     assert emu_lib.conv3x3_mfma(ptr(t), ptr(t), ptr(t), None, ptr(t), 4, 4, 12, 32, 0, 0, None) != 0
