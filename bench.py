@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 MFMA (guide: ~2.5 PF; AMD's 5 PF headline is 2:1 sparse)
 
 
 def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
@@ -86,9 +87,10 @@ def pmc_traffic(conv_variant):
     profiles/r01_pmc_summary.json): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
     the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    if conv_variant != 2 or not os.path.exists(path):
+    name = {2: 'lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>', 3: 'lemo::conv3x3_split_kernel<0, false>'}.get(conv_variant)
+    if name is None or not os.path.exists(path):
         return None
-    d = json.load(open(path)).get('lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>')
+    d = json.load(open(path)).get(name)
     if not d or 'FETCH_SIZE' not in d or 'WRITE_SIZE' not in d:
         return None
     return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
@@ -141,7 +143,7 @@ def main():
     ap.add_argument('--active-vertices-only', action='store_true',
                     help='forward only the 253 vertices the losses read (NOT the headline config)')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--conv-variant', type=int, default=2)
+    ap.add_argument('--conv-variant', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -189,6 +191,15 @@ def main():
 
     kern_ms, kern_flops = time_dominant_kernel(fit, stream)
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12
+    if fit.conv_variant == 3:
+        # every fp32 multiply-accumulate is 6 bf16 MFMA products (exact 3-way operand split, fp32 accumulate):
+        # the pipe that bounds the kernel is the bf16 matrix pipe at 1/6 of its dense peak
+        peak, kname = PEAK_BF16_MATRIX_TFLOPS / 6.0, 'conv3x3_split_kernel (variant 3: fp32-exact 3xbf16 operand split on v_mfma_f32_32x32x16_bf16)'
+        peak_note = ('algorithmic fp32 FLOP/s against bf16 dense MFMA peak %.0f TF / 6 products per fp32-exact MAC; the '
+                     'fp32-MFMA kernel (--conv-variant 2) is priced against %.1f TF' % (PEAK_BF16_MATRIX_TFLOPS, PEAK_FP32_MATRIX_TFLOPS))
+    else:
+        peak, kname = PEAK_FP32_MATRIX_TFLOPS, f'conv3x3_mfma (variant {fit.conv_variant}, v_mfma_f32_32x32x2_f32)'
+        peak_note = 'fp32-input MFMA peak'
     out = {
         'metric': 'fitting-iterations/sec (T=120 frames)', 'value': world * args.steps / dt,
         'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -198,13 +209,18 @@ def main():
                                '(the T=120 clip), SMPL-X-shaped synthetic model V=10475, VPoser decode, smoothness '
                                'encoder 245x134, marker+contact+prior losses, Adam',
                    'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
-                   'sequences': world, 'conv_variant': args.conv_variant, 'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
+                   'sequences': world, 'conv_variant': fit.conv_variant,
+                   'arithmetic': 'fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
+                                 'each (6 bf16-MFMA products, fp32 accumulate; error vs float64 <= the fp32-MFMA kernel\'s)'
+                                 if fit.conv_variant == 3 else 'fp32 throughout (fp32-input MFMA)',
+                   'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
-        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MATRIX_TFLOPS, 'traffic': pmc_traffic(args.conv_variant),
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': achieved / peak, 'traffic': pmc_traffic(fit.conv_variant),
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',
-                     'kernel': f'conv3x3_mfma (variant {args.conv_variant}) 64->64ch 245x134, 14 of the 41 launches/iteration',
+                     'peak_note': peak_note,
+                     'kernel': kname + ' 64->64ch 245x134, 14 of the 41 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

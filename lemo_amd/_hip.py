@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-LIB_PATH = os.path.join(_CSRC, 'liblemo_hip.so')
+LIB_PATH = os.environ.get('LEMO_HIP_LIB') or os.path.join(_CSRC, 'liblemo_hip.so')   # override: A/B builds (tools/ab_build.sh)
 EMU_LIB_PATH = os.path.join(_CSRC, 'liblemo_emu.so')
 
 fp = C.POINTER(C.c_float)

@@ -22,9 +22,6 @@ __device__ __forceinline__ float lrelu_grad_from_out(float y) { return y > 0.f ?
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void st4_nt(float* p, float4 v) {      // global_store_dwordx4 ... nt
-  __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(p));
-}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

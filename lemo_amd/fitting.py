@@ -18,7 +18,7 @@ import torch
 from . import _hip
 from ._hip import ptr
 from .body_model import BodyModelData, DeviceBody, alloc_pose_ws, K_PAD, load_model_dict
-from .priors import ENC_CHANNELS, EncWeights, cg8p_alloc
+from .priors import DEFAULT_CONV_VARIANT, ENC_CHANNELS, EncWeights, cg8p_alloc
 from .rotation import convert_to_6D_all
 from .vposer import vposer_weight_struct
 
@@ -26,9 +26,6 @@ LOSS_WEIGHTS = dict(rec_markers=1.0, vposer=0.02, shape=0.01, hand=0.01, contact
 """opt_amass_temp.py:47-52 (order = the C ABI's ``weights[6]``)."""
 FOOT_SETS = ('left_heel', 'right_heel', 'left_toe', 'right_toe')
 """columns of ``contact_lbl`` (opt_amass_temp.py:409-412)."""
-DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '2'))
-"""conv kernel family of the smoothness encoder's MFMA layers (include/lemo_hip.h ``conv_variant``); the
-environment override exists for A/B runs of the parity suite."""
 LOSS_NAMES = ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total')
 
 

@@ -134,39 +134,50 @@ class EncWeights:
 # Encoder as autograd ops over the C ABI
 # ----------------------------------------------------------------------------------------------
 
-def _enc_forward(lib, enc: EncWeights, x: torch.Tensor):
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '3'))
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 3 = fp32-exact
+split-bf16 kernel for the 64->64 layers + LDS-tiled fp32-MFMA kernel (2) for the rest; 2 / 1 = fp32 MFMA only.
+The environment override exists for A/B runs of the parity suite."""
+
+
+def _conv_layer(lib, enc: EncWeights, l: int, bwd: bool, x, out, aux, H, W, variant, s):
+    """one MFMA layer (forward: epi 0 with bias; backward-data: epi 1 with the saved activation) on the best
+    kernel family `variant` allows for its shape"""
+    cin, cout = (ENC_CHANNELS[l + 1], ENC_CHANNELS[l]) if bwd else (ENC_CHANNELS[l], ENC_CHANNELS[l + 1])
+    wt, wt2, w3 = (enc.wbwd[l], enc.wbwd2[l], enc.wbwd3[l]) if bwd else (enc.w[l], enc.w2[l], enc.w3[l])
+    bias, epi = (None, 1) if bwd else (ptr(enc.b[l]), 0)
+    auxp = ptr(aux) if bwd else None
+    if variant >= 3 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
+        lib.check(lib.conv3x3_mfma_split(ptr(x), ptr(w3), ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_split')
+    elif variant >= 2 and 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 <= 416:
+        lib.check(lib.conv3x3_mfma_lds(ptr(x), ptr(wt), ptr(wt2), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_lds')
+    else:
+        lib.check(lib.conv3x3_mfma(ptr(x), ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, 1, s), 'conv3x3_mfma')
+
+
+def _enc_forward(lib, enc: EncWeights, x: torch.Tensor, variant: int = None):
     """x [H,W] float32 on the device -> list of CG8P activations act[1..10] (act[0] = padded input)."""
     H, W = x.shape
     dev = x.device
     s = lib.stream(dev)
+    variant = DEFAULT_CONV_VARIANT if variant is None else variant
     x0 = torch.zeros(H + 2, W + 2, dtype=torch.float32, device=dev)
     x0[1:-1, 1:-1] = x
     act = [x0] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
     lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, ENC_CHANNELS[1], s), 'conv3x3_c1')
-    use_lds = 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 <= 416
     for l in range(1, 10):
-        if use_lds:
-            lib.check(lib.conv3x3_mfma_lds(ptr(act[l]), ptr(enc.w[l]), ptr(enc.w2[l]), ptr(enc.b[l]), None, ptr(act[l + 1]),
-                                           H, W, ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, s), 'conv3x3_mfma_lds')
-        else:
-            lib.check(lib.conv3x3_mfma(ptr(act[l]), ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(act[l + 1]), H, W,
-                                       ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, 1, s), 'conv3x3_mfma')
-    return act, use_lds
+        _conv_layer(lib, enc, l, False, act[l], act[l + 1], None, H, W, variant, s)
+    return act, variant
 
 
-def _enc_backward(lib, enc: EncWeights, act, dpre10: torch.Tensor, use_lds: bool) -> torch.Tensor:
+def _enc_backward(lib, enc: EncWeights, act, dpre10: torch.Tensor, variant: int) -> torch.Tensor:
     """d(pre-activation of layer 10) in CG8P -> d(input) [H,W]."""
     H, W = act[0].shape[0] - 2, act[0].shape[1] - 2
     dev = dpre10.device
     s = lib.stream(dev)
     cur, other = dpre10, cg8p_alloc(64, H, W, dev)
     for l in range(9, 0, -1):
-        if use_lds:
-            lib.check(lib.conv3x3_mfma_lds(ptr(cur), ptr(enc.wbwd[l]), ptr(enc.wbwd2[l]), None, ptr(act[l]), ptr(other),
-                                           H, W, ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, s), 'conv3x3_mfma_lds(bwd)')
-        else:
-            lib.check(lib.conv3x3_mfma(ptr(cur), ptr(enc.wbwd[l]), None, ptr(act[l]), ptr(other), H, W,
-                                       ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, 1, s), 'conv3x3_mfma(bwd)')
+        _conv_layer(lib, enc, l, True, cur, other, act[l], H, W, variant, s)
         cur, other = other, cur
     dx = torch.empty(H, W, dtype=torch.float32, device=dev)
     lib.check(lib.conv3x3_c1_bwd(ptr(cur), ptr(enc.w[0]), ptr(dx), H, W, ENC_CHANNELS[1], s), 'conv3x3_c1_bwd')

@@ -35,8 +35,8 @@ def full_problem(dev):
     g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
     model = synthetic.make_synthetic_smplx(seed=0)
     seq = synthetic.make_synthetic_sequence(0, B=119)
-    mk = lambda full: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'],
-                                          119, dev, full_vertices=full)
+    mk = lambda full, variant=None: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'],
+                                                        119, dev, full_vertices=full, conv_variant=variant)
     return dict(A=A, g=g, model=model, seq=seq, make=mk)
 
 
@@ -93,12 +93,55 @@ def test_smplx_module_full_size_vs_oracle(dev):
     assert rel_err(out.joints.cpu(), j_ref) < VERT_TOL
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
-def test_encoder_full_size_golden(dev, variant):
-    """10-layer fp32-MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad."""
+def test_split_bf16_conv_error_is_fp32_sized(dev):
+    """conv variant 3 multiplies exact fp32 operands as 3 bf16 pieces each (6 bf16-MFMA products, fp32 accumulate).
+    Against a float64 convolution its error must be the size of an fp32 convolution's own rounding error: not
+    larger than 1.5x the fp32-MFMA kernel's on the same data (measured: smaller), and < 2e-6 of max|out|."""
+    import torch.nn.functional as F
     from lemo_amd import _hip
     from lemo_amd._hip import ptr
-    from lemo_amd.priors import ENC_CHANNELS, EncWeights, cg8p_alloc, from_cg8p
+    from lemo_amd.priors import (cg8p_alloc, from_cg8p, to_cg8p, pack_conv3x3, pack_conv3x3_gmajor, pack_conv3x3_split,
+                                 pack_conv3x3_bwd, pack_conv3x3_bwd_split)
+    lib = _hip.get_lib()
+    A = load_assets()
+    H, W = 245, 134
+    assert lib.conv3x3_split_supported(H, W, 64, 64) == 1
+    w, b = np.asarray(A['enc_w']['enc_blc4.main.2.weight'], np.float32), np.asarray(A['enc_w']['enc_blc4.main.2.bias'], np.float32)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, H, W, generator=g).abs() * 0.3                       # post-LeakyReLU-like (mostly positive) input
+    ref = F.leaky_relu(F.conv2d(x[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1), 0.2)[0]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    wt, wt2, w3, bd, xin = t(pack_conv3x3(w)), t(pack_conv3x3_gmajor(w)), t(pack_conv3x3_split(w).view(np.int16)), t(b), to_cg8p(x).to(dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    o2, o3 = cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    lib.check(lib.conv3x3_mfma_lds(ptr(xin), ptr(wt), ptr(wt2), ptr(bd), None, ptr(o2), H, W, 64, 64, 0, s))
+    lib.check(lib.conv3x3_mfma_split(ptr(xin), ptr(w3), ptr(wt), ptr(bd), None, ptr(o3), H, W, 64, 64, 0, s))
+    torch.cuda.synchronize()
+    e2 = float((from_cg8p(o2.cpu(), H, W).double() - ref).abs().max() / ref.abs().max())
+    e3 = float((from_cg8p(o3.cpu(), H, W).double() - ref).abs().max() / ref.abs().max())
+    r3 = float((from_cg8p(o3.cpu(), H, W).double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f'\nmax err / max|ref| vs float64: fp32-MFMA {e2:.3e}   split-bf16 {e3:.3e} (rms {r3:.3e})')
+    assert e3 < 2e-6 and e3 <= 1.5 * e2 and r3 < 5e-7
+    assert float(o3.reshape(8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0          # zero border untouched
+    # backward-data epilogue (x lrelu'(saved activation)), remainder pixels included (P % 128 = 62)
+    dy, aux = torch.randn(64, H, W, generator=g), torch.randn(64, H, W, generator=g)
+    refdx = F.conv_transpose2d(dy[None].double(), torch.from_numpy(w).double(), padding=1)[0] * torch.where(aux > 0, 1.0, 0.2).double()
+    wb, wb3 = t(pack_conv3x3_bwd(w)), t(pack_conv3x3_bwd_split(w).view(np.int16))
+    dyb, auxb, dxb = to_cg8p(dy).to(dev), to_cg8p(aux).to(dev), cg8p_alloc(64, H, W, dev)
+    lib.check(lib.conv3x3_mfma_split(ptr(dyb), ptr(wb3), ptr(wb), None, ptr(auxb), ptr(dxb), H, W, 64, 64, 1, s))
+    torch.cuda.synchronize()
+    got = from_cg8p(dxb.cpu(), H, W).double()
+    assert float((got - refdx).abs().max() / refdx.abs().max()) < 2e-6
+    assert float((got[-1, -62:] - refdx[-1, -62:]).abs().max() / refdx.abs().max()) < 2e-6      # the remainder patches
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+def test_encoder_full_size_golden(dev, variant):
+    """10-layer MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad.  Variants 0-2 run
+    every layer on the fp32 MFMA; 3 runs the seven 64->64 layers (forward and backward-data) on the split-bf16 kernel."""
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import ENC_CHANNELS, EncWeights, cg8p_alloc, from_cg8p, _conv_layer
     lib = _hip.get_lib()
     A = load_assets()
     g = np.load(os.path.join(GOLDEN, 'enc_smooth.npz'))
@@ -111,9 +154,8 @@ def test_encoder_full_size_golden(dev, variant):
     s = torch.cuda.current_stream(dev).cuda_stream
     lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, 32, s))
     for l in range(1, 10):
-        if variant == 2:
-            lib.check(lib.conv3x3_mfma_lds(ptr(act[l]), ptr(enc.w[l]), ptr(enc.w2[l]), ptr(enc.b[l]), None, ptr(act[l + 1]),
-                                           H, W, ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, s))
+        if variant >= 2:
+            _conv_layer(lib, enc, l, False, act[l], act[l + 1], None, H, W, variant, s)
         else:
             lib.check(lib.conv3x3_mfma(ptr(act[l]), ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(act[l + 1]), H, W,
                                        ENC_CHANNELS[l], ENC_CHANNELS[l + 1], 0, variant, s))
@@ -129,9 +171,8 @@ def test_encoder_full_size_golden(dev, variant):
     cur = [d0, d1]
     ci = 0
     for l in range(9, 0, -1):
-        if variant == 2:
-            lib.check(lib.conv3x3_mfma_lds(ptr(cur[ci]), ptr(enc.wbwd[l]), ptr(enc.wbwd2[l]), None, ptr(act[l]),
-                                           ptr(cur[1 - ci]), H, W, ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, s))
+        if variant >= 2:
+            _conv_layer(lib, enc, l, True, cur[ci], cur[1 - ci], act[l], H, W, variant, s)
         else:
             lib.check(lib.conv3x3_mfma(ptr(cur[ci]), ptr(enc.wbwd[l]), None, ptr(act[l]), ptr(cur[1 - ci]), H, W,
                                        ENC_CHANNELS[l + 1], ENC_CHANNELS[l], 1, variant, s))
@@ -179,11 +220,13 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert int(fit.step_ctr.item()) == 5
 
 
-def test_fit_full_size_golden(full_problem, dev):
+@pytest.mark.parametrize('conv_variant', [3, 2])
+def test_fit_full_size_golden(full_problem, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
-    1 and 10 Adam steps (graph replay)."""
+    1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
     g, seq = full_problem['g'], full_problem['seq']
-    fit = full_problem['make'](True)
+    fit = full_problem['make'](True, conv_variant)
+    assert fit.conv_variant == conv_variant
     fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
     fit.forward(); fit.backward()
     torch.cuda.synchronize()

@@ -12,7 +12,7 @@ echo "pytest exit: $?" >> $OUT/pytest_gpu.log
 timeout 400 python bench.py --steps 100 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/bench.err
 timeout 200 python bench.py --steps 100 --warmup 10 --active-vertices-only --no-cpu-baseline > $OUT/bench_active.json 2>> $OUT/bench.err
-timeout 200 python bench.py --steps 100 --warmup 10 --conv-variant 0 --no-cpu-baseline > $OUT/bench_v0.json 2>> $OUT/bench.err
+timeout 200 python bench.py --steps 100 --warmup 10 --conv-variant 2 --no-cpu-baseline > $OUT/bench_v2.json 2>> $OUT/bench.err
 cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/bench_prof.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err
 cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*kernel_stats*" | head -3 | while read f; do cp "$f" $OUT/kernel_stats.csv; done

@@ -10,8 +10,6 @@ from lemo_amd.assets import load_assets
 from lemo_amd.priors import (cg8p_alloc, to_cg8p, from_cg8p, pack_conv3x3, pack_conv3x3_gmajor, pack_conv3x3_split,
                              pack_conv3x3_bwd, pack_conv3x3_bwd_split)
 
-if os.environ.get('LEMO_AB_LIB'):
-    _hip.LIB_PATH = os.environ['LEMO_AB_LIB']          # A/B build of the kernels (tools/ab_build.sh)
 lib = _hip.get_lib(); dev = torch.device('cuda:0')
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (245, 134)
 enc = load_assets()['enc_w']
