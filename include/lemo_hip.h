@@ -39,7 +39,7 @@ int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, co
  * shader-clock stamps into dbg[(block*8 + wave)*4 ..] -- used by tools/conv_census.py only */
 int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
                                  int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
-/* variant 3 ("split-bf16"): the same fp32 convolution for Cin = Cout = 64 on the bf16 matrix cores.  Each fp32
+/* variant 3 ("split-bf16"): the same fp32 convolution for Cin, Cout in {32, 64} on the bf16 matrix cores.  Each fp32
  * operand is split exactly into three bf16 pieces and six of the nine piece products are accumulated in fp32
  * (error of the dropped terms < 2^-24 per product, 100x below the fp32 accumulation rounding of any fp32 conv).
  * w3 = weights pre-split on the host: bf16 w3[Cin/16][tap 9][Cout/32][split 3][lane 64][8] with lane l holding
@@ -180,7 +180,7 @@ typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
   int conv_variant;               /* 0/1: lemo_conv3x3_mfma variants ; 2: lemo_conv3x3_mfma_lds ;
-                                   * 3: lemo_conv3x3_mfma_split for the 64->64 layers, variant 2 for the others */
+                                   * 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;
   lemo_skin_const skin;
@@ -194,7 +194,7 @@ typedef struct lemo_fit_desc {
   const float* enc_wbwd[10];      /* backward-data packs (layer 0: same [Cout][9]) */
   const float* enc_w2[10];        /* channel-group-major packs for conv_variant 2 (layer 0 unused) */
   const float* enc_wbwd2[10];
-  const void* enc_w3[10];         /* split-bf16 packs for conv_variant 3 (NULL where the layer is not 64->64) */
+  const void* enc_w3[10];         /* split-bf16 packs for conv_variant 3 (layer 0: NULL) */
   const void* enc_wbwd3[10];
   /* sequence data */
   const float* target;            /* [B][n67][3]  markers_rec */

@@ -1,5 +1,5 @@
-// 64 -> 64 channel 3x3 convolution of the smoothness encoder (models/AE_sep.py:11-30, 77-99) on the
-// bf16 matrix cores with EXACT fp32 operands ("split-bf16", conv variant 3).
+// 3x3 convolutions of the smoothness encoder with 32 / 64 input and output channels (models/AE_sep.py:
+// 11-30, 77-99) on the bf16 matrix cores with EXACT fp32 operands ("split-bf16", conv variant 3).
 //
 // Every fp32 operand x is split into three bf16 pieces x = hi + mid + lo (hi = bf16(x),
 // mid = bf16(x - hi), lo = bf16(x - hi - mid); 3 x 8 significand bits, the sum is exact) and
@@ -13,7 +13,8 @@
 // multiply-accumulate costs 6/16 of the fp32 matrix pipe: the 1e-5 loss-parity budget stays on fp32
 // numerics while the MFMA floor of the layer drops from 18 us to 6.9 us.
 //
-// Work decomposition (one 512-thread block per CU, all 256 CUs, no second wave of blocks):
+// Work decomposition, written for the 64 -> 64 layers (one 512-thread block per CU, all 256 CUs, no second
+// wave of blocks; Cout 32 halves the waves, Cin 32 halves the k-chunks and needs one staging phase only):
 //   block  = 128 consecutive pixels x 64 couts x K = 9 taps x 64 cin
 //   wave w = pixel half (w&1: 64 px = 2 MFMA N-tiles) x cout half (w>>1&1: 32 = 1 M-tile) x K half
 //            (w>>2: channel groups 4kh..4kh+3) -> 18 (chunk, tap) steps x 12 MFMAs, 32 accumulators
@@ -35,11 +36,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CV3_NPX 408
-struct Cv3Cfg {
+template <int CIN, int COUT> struct Cv3Cfg {
+  static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "encoder layer shapes");
   static constexpr int PLANE = CV3_NPX * 16;                    // bytes of one (group, split) plane
   static constexpr int GRP = 3 * PLANE;
-  static constexpr int ACT_BYTES = 8 * GRP;                     // 156,672
-  static constexpr int SMEM_BYTES = ACT_BYTES;
+  static constexpr int MT = COUT / 32;                          // cout tiles = waves along cout
+  static constexpr int NT = 256 * MT;                           // threads: (2 pixel halves) x MT x (2 K halves) waves
+  static constexpr int NCC = CIN / 32;                          // 16-channel k-chunks per K half = staging phases
+  static constexpr int GH = 2 * NCC;                            // channel groups per K half
+  static constexpr int SMEM_BYTES = (CIN / 8) * GRP;            // 156,672 (Cin 64) / 78,336 (Cin 32)
+  static constexpr int NB = (4 * 2 * CV3_NPX + NT - 1) / NT;    // staging slots per thread and phase (4 groups)
+  static constexpr int PPX = NT / 128;                          // pixels of a remainder patch (one (px, cout pair) per wave)
+  static constexpr int CQ = COUT / 4;                           // cout quads
+  static constexpr int NTI = CIN == 64 ? 9 : 5;                 // patch: taps per lane (Cin 32: lane half = tap parity)
 };
 
 // p / W for 0 <= p < 2^24 with magic = 2^32 / W + 1 (host): one v_mul_hi instead of the ~40-instruction
@@ -62,50 +71,56 @@ __device__ __forceinline__ void split3x4(float4 v, uint2& hi, uint2& mid, uint2&
   lo = __builtin_bit_cast(uint2, l);
 }
 
-// One remainder patch = 4 px x 4 couts over K = 576, no LDS, no barrier: wave w owns pixel w>>1 and the
-// cout pair 2*(w&1), +1; lane l takes channel l of every tap (9 activation + 18 weight dwords, coalesced
-// 256-B runs), 18 fp32 FMAs, two wave sums.  `load` and `finish` are separate so that the kernel can put
-// the block's first patch into the latency shadow of its staging loads.
-struct SplitPatch {
-  float a[9], w0[9], w1[9];
+// One remainder patch = PPX px x 4 couts over K = 9 Cin, no LDS, no barrier: wave w owns pixel w>>1 and the
+// cout pair 2*(w&1), +1; lane l takes channel l of every tap (Cin 64; Cin 32: channel l&31 of the taps of
+// parity l>>5): 9 (5) activation + 18 (10) weight dwords in coalesced runs, fp32 FMAs, two wave sums.
+// `load` and `finish` are separate so that the kernel can put the loads several taps ahead of their use.
+template <int CIN> struct SplitPatch {
+  static constexpr int NTI = CIN == 64 ? 9 : 5;
+  float a[NTI], w0[NTI], w1[NTI];
   float e0, e1;                                                 // epilogue operands (bias or saved activation)
   int poff, co, valid;
 };
-template <int EPI>
-__device__ __forceinline__ void split_patch_load(SplitPatch& pt, const float* __restrict__ in, const float* __restrict__ wt,
+template <int EPI, int CIN, int COUT>
+__device__ __forceinline__ void split_patch_load(SplitPatch<CIN>& pt, const float* __restrict__ in, const float* __restrict__ wt,
                                                  const float* __restrict__ bias, const float* __restrict__ aux,
                                                  int W, unsigned wmagic, int Wp, int HWp, int P, int rem0, int patch) {
+  typedef Cv3Cfg<CIN, COUT> Cfg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pq = patch >> 4, cq = patch & 15;
-  int p = rem0 + pq * 4 + (wave >> 1);
+  const int pq = patch / Cfg::CQ, cq = patch - pq * Cfg::CQ;
+  int p = rem0 + pq * Cfg::PPX + (wave >> 1);
   pt.valid = p < P;
   p = p < P ? p : P - 1;
   const int y = div_w(p, wmagic), x = p - y * W;
   pt.poff = (y + 1) * Wp + (x + 1);
   pt.co = cq * 4 + 2 * (wave & 1);
-  const float* ia = in + (unsigned)(lane >> 3) * ((unsigned)HWp * 8u) + (unsigned)pt.poff * 8u + (lane & 7);
-  const float* wa = wt + ((unsigned)(lane >> 3) * 64u + pt.co) * 8u + (lane & 7);
+  const int c = lane & (CIN - 1);
+  const float* ia = in + (unsigned)(c >> 3) * ((unsigned)HWp * 8u) + (unsigned)pt.poff * 8u + (c & 7);
+  const float* wa = wt + ((unsigned)(c >> 3) * COUT + pt.co) * 8u + (c & 7);     // wt[tap][Cin/8][Cout][8]
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    pt.a[t] = ia[((t / 3 - 1) * Wp + (t % 3 - 1)) * 8];
-    pt.w0[t] = wa[t * 4096];                                    // wt[tap][8 groups][64 couts][8]
-    pt.w1[t] = wa[t * 4096 + 8];
+  for (int m = 0; m < Cfg::NTI; ++m) {
+    int t = CIN == 64 ? m : 2 * m + (lane >> 5);
+    const bool live = t < 9;
+    t = live ? t : 8;
+    const float av = ia[((t / 3 - 1) * Wp + (t % 3 - 1)) * 8];
+    pt.a[m] = live ? av : 0.f;
+    pt.w0[m] = wa[t * (CIN * COUT)];
+    pt.w1[m] = wa[t * (CIN * COUT) + 8];
   }
-  // loaded here, ahead of the kernel's staging loads: a load issued after them returns after them
   // wave-uniform address -> scalar loads (lgkmcnt): as vector loads hipcc sinks them to their first use,
-  // i.e. behind the staging loads, and the patch would wait for the whole staging round trip
+  // behind whatever vector loads were issued in between
   const int cou = __builtin_amdgcn_readfirstlane(pt.co), pou = __builtin_amdgcn_readfirstlane(pt.poff);
   const float* ep = EPI == 1 ? aux + ((size_t)(cou >> 3) * HWp + pou) * 8 + (cou & 7) : bias + cou;
   pt.e0 = ep[0];
   pt.e1 = ep[1];
 }
-template <int EPI>
-__device__ __forceinline__ void split_patch_finish(const SplitPatch& pt, float* __restrict__ out, int HWp) {
+template <int EPI, int CIN>
+__device__ __forceinline__ void split_patch_finish(const SplitPatch<CIN>& pt, float* __restrict__ out, int HWp) {
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) { s0 = fmaf(pt.a[t], pt.w0[t], s0); s1 = fmaf(pt.a[t], pt.w1[t], s1); }
+  for (int t = 0; t < SplitPatch<CIN>::NTI; ++t) { s0 = fmaf(pt.a[t], pt.w0[t], s0); s1 = fmaf(pt.a[t], pt.w1[t], s1); }
   // bias / lrelu' enter BEFORE the wave sums (in straight-line code): used only inside the lane-0 store
-  // block, hipcc sinks their loads into it, i.e. behind the kernel's staging loads
+  // block, hipcc sinks their loads into it
   const bool l0 = (threadIdx.x & 63) == 0;
   if (EPI == 1) { s0 *= lrelu_grad_from_out(pt.e0); s1 *= lrelu_grad_from_out(pt.e1); }
   else { s0 += l0 ? pt.e0 : 0.f; s1 += l0 ? pt.e1 : 0.f; }
@@ -156,19 +171,21 @@ __device__ __forceinline__ void split_reduce_store(const f32x16& give, const f32
   }
 }
 
-template <int EPI, bool DBG>
-__global__ void __launch_bounds__(512)
+template <int EPI, int CIN, int COUT, bool DBG>
+__global__ void __launch_bounds__((Cv3Cfg<CIN, COUT>::NT))
 conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3, const float* __restrict__ wt,
                      const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
                      int H, int W, unsigned wmagic, int full_blocks, unsigned long long* __restrict__ dbg) {
   unsigned long long t_start = 0, t_pro = 0, t_loop = 0, t_mid0 = 0, t_mid1 = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
-  constexpr int PLANE = Cv3Cfg::PLANE, GRP = Cv3Cfg::GRP;
+  typedef Cv3Cfg<CIN, COUT> Cfg;
+  constexpr int PLANE = Cfg::PLANE, GRP = Cfg::GRP, MT = Cfg::MT, NT = Cfg::NT, NCC = Cfg::NCC, GH = Cfg::GH, NB = Cfg::NB;
+  constexpr int NU = 9 * NCC;                                   // (chunk, tap) steps of one wave
   LEMO_DYN_SMEM(smem_f);
   unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int ph = wave & 1, ch = (wave >> 1) & 1, kh = wave >> 2;
+  const int ph = wave & 1, ch = MT == 2 ? (wave >> 1) & 1 : 0, kh = wave >> (MT == 2 ? 2 : 1);
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const unsigned in_gstride = (unsigned)HWp * 8u;
   // XCD-aware tile order (workgroup b runs on XCD b % 8): XCD x owns a contiguous run of tiles so that
@@ -179,19 +196,19 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
 
-  // Operand pipeline over the 18 (chunk, tap) steps u: weight fragments come from L2 (~1 us away) and are
+  // Operand pipeline over the 9 NCC (chunk, tap) steps u: weight fragments come from L2 (~1 us away) and are
   // requested TWO steps ahead through a ring of three register sets; activation fragments come from LDS
   // one step ahead (two sets; not across the phase barrier).  The sched_barriers keep hipcc from sinking
   // the loads next to their uses.
   uint4 ra[3][3], rb[2][2][3];
 #define CV3_LOAD_A(SET, U)                                                                         \
   _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                                 \
-    ra[SET][s_] = w3[(unsigned)((((2 * kh + (U) / 9) * 9 + (U) % 9) * 2 + ch) * 3 + s_) * 64u + lane];
+    ra[SET][s_] = w3[(unsigned)((((NCC * kh + (U) / 9) * 9 + (U) % 9) * MT + ch) * 3 + s_) * 64u + lane];
 #define CV3_LOAD_B(SET, U)                                                                         \
   _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
     _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                               \
       rb[SET][nt_][s_] = *reinterpret_cast<const uint4*>(                                         \
-          smem + (2 * (2 * kh + (U) / 9) + h) * GRP + s_ * PLANE + (li[nt_] + (((U) % 9) / 3 - 1) * Wp + (((U) % 9) % 3 - 1)) * 16);
+          smem + (2 * (NCC * kh + (U) / 9) + h) * GRP + s_ * PLANE + (li[nt_] + (((U) % 9) / 3 - 1) * Wp + (((U) % 9) % 3 - 1)) * 16);
 #define CV3_MFMA1(SA, SETA, SB, SETB)                                                              \
   _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
     acc[nt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[SETA][SA]),   \
@@ -205,14 +222,14 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
   CV3_LOAD_A(0, 0)
   CV3_LOAD_A(1, 1)
 
-  // ---- remainder patch of this block: 4 px x 4 couts, K = 576 spread over the 512 threads ---------
+  // ---- remainder patch of this block: PPX px x 4 couts ---------------------------------------------
   const int rem0 = full_blocks * 128;
-  const int npatch = ((P - rem0 + 3) >> 2) * 16;
+  const int npatch = ((P - rem0 + Cfg::PPX - 1) / Cfg::PPX) * Cfg::CQ;
   const bool has_patch = tile < npatch;                          // uniform
   // Its loads are issued at the first tap of the main loop and consumed four taps later: the VALU work
   // rides between MFMAs.  (Unconditional loads + straight-line code: inside an `if` hipcc merges the FMAs
   // back into the load block and waits there.)
-  SplitPatch pt;
+  SplitPatch<CIN> pt;
 
   // ---- staging plan ---------------------------------------------------------------------------------
   const int pfirst = tile * 128, plast = pfirst + 127;
@@ -221,20 +238,19 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
   const int qin = q0 - Wp - 1;                                   // first staged padded pixel
   const int npx = q1 - q0 + 2 * Wp + 3;                          // staged pixels (<= CV3_NPX, checked on host)
   const int nchB = 2 * npx;                                      // 16-B chunks (4 floats) per channel group
-  // phase f stages groups {2f, 2f+1, 4+2f, 4+2f+1}: the first / second k-chunk of both K halves.
-  // Slot c = tid + 512 k covers chunk c % 816 of group c / 816 (constant stride = the LDS plane size, so the
+  // phase f stages groups {2f, 2f+1, GH+2f, GH+2f+1}: the f-th k-chunk of both K halves.
+  // Slot c = tid + NT k covers chunk c % 816 of group c / 816 (constant stride = the LDS plane size, so the
   // map costs a handful of VALU ops: every prologue instruction is paid twice per SIMD with the MFMA pipe
   // idle); chunks past the tile's own nchB re-read its last one.  No predicates anywhere: a load whose only
   // use sits inside an `if` is sunk into it by hipcc and then waited for with vmcnt(0).
-  constexpr int NB = (4 * 2 * CV3_NPX + 511) / 512;
   unsigned offB[NB];
   int dstB[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    int c0 = (int)threadIdx.x + k * 512;
+    int c0 = (int)threadIdx.x + k * NT;
     c0 = c0 < 4 * 2 * CV3_NPX ? c0 : 4 * 2 * CV3_NPX - 1;        // surplus slots redo the last chunk (same data, same place)
     const int gg = c0 / (2 * CV3_NPX), c = c0 - gg * (2 * CV3_NPX);
-    const int g0 = (gg >> 1) * 4 + (gg & 1);
+    const int g0 = (gg >> 1) * GH + (gg & 1);
     const int cl = c < nchB ? c : nchB - 1;
     offB[k] = (unsigned)g0 * in_gstride + (unsigned)qin * 8u + (unsigned)cl * 4u;
     dstB[k] = g0 * GRP + c * 8;
@@ -251,9 +267,11 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
     *reinterpret_cast<uint2*>(smem + dstB[k] + PLANE) = s1;
     *reinterpret_cast<uint2*>(smem + dstB[k] + 2 * PLANE) = s2;
   }
-  // second phase: loads in flight during the first k-chunk's MFMAs
+  // second phase (Cin 64): loads in flight during the first k-chunk's MFMAs
+  if (NCC == 2) {
 #pragma unroll
-  for (int k = 0; k < NB; ++k) stB[k] = ld4(in + 2u * in_gstride + offB[k]);
+    for (int k = 0; k < NB; ++k) stB[k] = ld4(in + 2u * in_gstride + offB[k]);
+  }
   __syncthreads();
   if (DBG) t_pro = __builtin_amdgcn_s_memtime();
 
@@ -274,33 +292,35 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
 #pragma unroll
-  for (int cc = 0; cc < 2; ++cc) {
+  for (int cc = 0; cc < NCC; ++cc) {
     CV3_LOAD_B((cc * 9) & 1, cc * 9)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int u = cc * 9 + tap;
-      if (u + 2 < 18) { CV3_LOAD_A((u + 2) % 3, u + 2) }
+      if (u + 2 < NU) { CV3_LOAD_A((u + 2) % 3, u + 2) }
       if (tap + 1 < 9) { CV3_LOAD_B((u + 1) & 1, u + 1) }
       if (u == 0) {
-        split_patch_load<EPI>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, has_patch ? tile : 0);
+        split_patch_load<EPI, CIN, COUT>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, has_patch ? tile : 0);
         pt.valid = pt.valid && has_patch;
       }
       __builtin_amdgcn_sched_barrier(0);
       CV3_MFMA(u % 3, u & 1)
-      if (u == 4) split_patch_finish<EPI>(pt, out, HWp);
-      // second-phase staging, one slot per tap: its ~30 VALU ops and 3 LDS writes issue between this
-      // tap's MFMAs instead of in one MFMA-idle burst before the phase barrier
-      if (cc == 0 && tap >= 2 && tap - 2 < NB) {
-        const int k = tap - 2;
-        uint2 s0, s1, s2;
-        split3x4(stB[k], s0, s1, s2);
-        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k]) = s0;
-        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + PLANE) = s1;
-        *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + 2 * PLANE) = s2;
+      if (u == 4) split_patch_finish<EPI, CIN>(pt, out, HWp);
+      // second-phase staging spread over taps 2..8 (slot k at tap 2 + 7k/NB): its VALU ops and LDS writes
+      // issue between MFMAs instead of in one MFMA-idle burst before the phase barrier
+      if (cc == 0 && NCC == 2) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          if (2 + (7 * k) / NB != tap) continue;
+          uint2 s0, s1, s2;
+          split3x4(stB[k], s0, s1, s2);
+          *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k]) = s0;
+          *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + PLANE) = s1;
+          *reinterpret_cast<uint2*>(smem + 2 * GRP + dstB[k] + 2 * PLANE) = s2;
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(NB <= 7, "second-phase slots are spread over taps 2..8");
     if (DBG && cc == 0) t_mid0 = __builtin_amdgcn_s_memtime();
     __syncthreads();
     if (DBG && cc == 0) t_mid1 = __builtin_amdgcn_s_memtime();
@@ -314,7 +334,7 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
   // ---- sum the two K halves: wave kh keeps pixel tile nt = kh and hands the other one over ---------
   // (kh is wave-uniform: a scalar branch instead of 32 v_cndmask on the accumulators)
   {
-    float* red = smem_f + (((ph * 2 + ch) * 2) * 4) * 256 + lane * 4;   // [ph*2+ch][kh][4][64][4] floats (32 KB), tile LDS is dead
+    float* red = smem_f + (((ph * MT + ch) * 2) * 4) * 256 + lane * 4;  // [ph*MT+ch][kh][4][64][4] floats (<= 32 KB), tile LDS is dead
     const int m_base = ch * 32;
     if (__builtin_amdgcn_readfirstlane(kh))
       split_reduce_store<EPI>(acc[0], acc[1], red + 1024, red, true, out, bias, aux, HWp, poffn[1], m_base, h);
@@ -323,11 +343,11 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
   }
   // shapes with more remainder patches than blocks: the rest, round-robin (not on the headline shapes)
   for (int patch = tile + full_blocks; patch < npatch; patch += full_blocks) {
-    split_patch_load<EPI>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, patch);
-    split_patch_finish<EPI>(pt, out, HWp);
+    split_patch_load<EPI, CIN, COUT>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, patch);
+    split_patch_finish<EPI, CIN>(pt, out, HWp);
   }
   if (DBG && lane == 0) {           // census record, same format as conv3x3_mfma_v2_kernel
-    unsigned long long* r = dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+    unsigned long long* r = dbg + ((size_t)blockIdx.x * (NT / 64) + wave) * 8;
     r[0] = __builtin_amdgcn_s_getreg(63492);
     r[1] = __builtin_amdgcn_s_getreg(63508);
     r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = t_pro; r[5] = t_loop; r[6] = t_mid0; r[7] = t_mid1;
@@ -338,15 +358,17 @@ int conv_split_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
   rc = 0;
-#define OPTIN(EPI_, DBG_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<EPI_, DBG_>), hipFuncAttributeMaxDynamicSharedMemorySize, Cv3Cfg::SMEM_BYTES); if (e != hipSuccess) rc = (int)e; }
-  OPTIN(0, false) OPTIN(1, false) OPTIN(2, false) OPTIN(0, true)
+#define OPTIN(EPI_, CI_, CO_, DBG_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<EPI_, CI_, CO_, DBG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (Cv3Cfg<CI_, CO_>::SMEM_BYTES)); if (e != hipSuccess) rc = (int)e; }
+#define OPTIN3(CI_, CO_) OPTIN(0, CI_, CO_, false) OPTIN(1, CI_, CO_, false) OPTIN(2, CI_, CO_, false)
+  OPTIN3(64, 64) OPTIN3(64, 32) OPTIN3(32, 64) OPTIN3(32, 32) OPTIN(0, 64, 64, true)
+#undef OPTIN3
 #undef OPTIN
   return rc;
 }
 
 // shapes the split kernel takes; everything else stays on conv3x3_mfma_lds
 bool conv3x3_split_supported(int H, int W, int cin, int cout) {
-  if (cin != 64 || cout != 64 || H <= 0 || W <= 0) return false;
+  if ((cin != 32 && cin != 64) || (cout != 32 && cout != 64) || H <= 0 || W <= 0) return false;
   const long P = (long)H * W;
   const long full = P / 128;
   if (full < 1 || P > (1l << 24)) return false;
@@ -362,12 +384,17 @@ int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const f
   const uint4* w3v = reinterpret_cast<const uint4*>(w3);
   const unsigned wmagic = (unsigned)((1ull << 32) / (unsigned)W + 1);       // exact for p < 2^32 / W (P <= 2^24 checked)
   if (dbg) {
-    if (epi != 0) return LEMO_ERR_ARG;
-    hipLaunchKernelGGL((conv3x3_split_kernel<0, true>), dim3(full), dim3(512), (Cv3Cfg::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, dbg);
+    if (epi != 0 || cin != 64 || cout != 64) return LEMO_ERR_ARG;
+    hipLaunchKernelGGL((conv3x3_split_kernel<0, 64, 64, true>), dim3(full), dim3(512), (Cv3Cfg<64, 64>::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, dbg);
     return (int)hipGetLastError();
   }
-#define LAUNCH3(EPI_) hipLaunchKernelGGL((conv3x3_split_kernel<EPI_, false>), dim3(full), dim3(512), (Cv3Cfg::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, (unsigned long long*)nullptr)
-  if (epi == 0) LAUNCH3(0); else if (epi == 1) LAUNCH3(1); else LAUNCH3(2);
+#define LAUNCH3(EPI_, CI_, CO_) hipLaunchKernelGGL((conv3x3_split_kernel<EPI_, CI_, CO_, false>), dim3(full), dim3((Cv3Cfg<CI_, CO_>::NT)), (Cv3Cfg<CI_, CO_>::SMEM_BYTES), s, in, w3v, wt, bias, aux, out, H, W, wmagic, full, (unsigned long long*)nullptr)
+#define LAUNCH_E(CI_, CO_) { if (epi == 0) LAUNCH3(0, CI_, CO_); else if (epi == 1) LAUNCH3(1, CI_, CO_); else LAUNCH3(2, CI_, CO_); }
+  if (cin == 64 && cout == 64) LAUNCH_E(64, 64)
+  else if (cin == 64) LAUNCH_E(64, 32)
+  else if (cout == 64) LAUNCH_E(32, 64)
+  else LAUNCH_E(32, 32)
+#undef LAUNCH_E
 #undef LAUNCH3
   return (int)hipGetLastError();
 }

@@ -108,7 +108,7 @@ class EncWeights:
         self.keys = enc_layer_keys()
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
         self.w, self.b, self.wbwd, self.w2, self.wbwd2 = [], [], [], [], []
-        self.w3, self.wbwd3 = [], []                       # split-bf16 packs of the 64->64 layers (else None)
+        self.w3, self.wbwd3 = [], []                       # split-bf16 packs (layer 0: None)
         t16 = lambda a: torch.from_numpy(a.view(np.int16)).to(device)
         for li, k in enumerate(self.keys):
             w = np.asarray(state[k + '.weight'], np.float32)
@@ -124,9 +124,8 @@ class EncWeights:
                 self.wbwd.append(t(pack_conv3x3_bwd(w)))
                 self.w2.append(t(pack_conv3x3_gmajor(w)))
                 self.wbwd2.append(t(pack_conv3x3_bwd_gmajor(w)))
-                both64 = w.shape[0] == 64 and w.shape[1] == 64
-                self.w3.append(t16(pack_conv3x3_split(w)) if both64 else None)
-                self.wbwd3.append(t16(pack_conv3x3_bwd_split(w)) if both64 else None)
+                self.w3.append(t16(pack_conv3x3_split(w)))
+                self.wbwd3.append(t16(pack_conv3x3_bwd_split(w)))
             self.b.append(t(b))
 
 

@@ -49,19 +49,19 @@ def test_conv3x3_mfma_forward_and_backward_data(emu_lib, ci, co, variant):
         assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
 
 
-@pytest.mark.parametrize('H,W', [(7, 41), (36, 57)])
-def test_conv3x3_split_bf16_forward_and_backward_data(emu_lib, H, W):
+@pytest.mark.parametrize('H,W,ci,co', [(7, 41, 64, 64), (36, 57, 64, 64), (7, 41, 32, 64), (7, 41, 64, 32), (9, 30, 32, 32)])
+def test_conv3x3_split_bf16_forward_and_backward_data(emu_lib, H, W, ci, co):
     """conv variant 3 (fp32-exact 3-way bf16 operand split on the bf16 MFMA) against torch fp32 AND float64:
     its error must be of the size of the fp32 convolution's own rounding error, not a bf16-sized one.
     (7, 41): 2 blocks + 31 remainder pixels = 128 patches -> 64 patches per block (generic patch loop);
-    (36, 57): 16 blocks + 4 remainder pixels = one patch per block (the headline-shape code path)."""
+    (36, 57): 16 blocks + 4 remainder pixels = one patch per block (the headline-shape code path);
+    Cin / Cout 32: the one-phase (Cin 32) and 4-wave (Cout 32) instantiations."""
     from lemo_amd.priors import pack_conv3x3_split, pack_conv3x3_bwd_split, bf16_split3
-    ci = co = 64
-    g = torch.Generator().manual_seed(H * W)
+    g = torch.Generator().manual_seed(H * W + ci + 2 * co)
     x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
     hi, mid, lo = bf16_split3(w.numpy())
     assert np.abs(mid).max() <= 2.0 ** -8 * np.abs(w.numpy()).max() and np.abs(lo).max() <= 2.0 ** -16 * np.abs(w.numpy()).max()
-    assert emu_lib.conv3x3_split_supported(H, W, ci, co) == 1 and emu_lib.conv3x3_split_supported(H, W, 32, 64) == 0
+    assert emu_lib.conv3x3_split_supported(H, W, ci, co) == 1 and emu_lib.conv3x3_split_supported(H, W, 16, 64) == 0
     ref64 = F.leaky_relu(F.conv2d(x[None].double(), w.double(), b.double(), padding=1), 0.2)[0]
     ref32 = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
     xin, out = to_cg8p(x), cg8p_alloc(co, H, W, 'cpu')
