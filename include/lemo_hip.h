@@ -135,6 +135,10 @@ typedef struct lemo_vertex_set_bwd {
   const int *jcsr_start, *jcsr_u;
   const float* jcsr_w;
 } lemo_vertex_set_bwd;
+/* blend GEMM of lemo_lbs_verts_fwd: 1 (default) = bf16 matrix cores with exact fp32 operands (3-way bf16 split,
+ * 6 products, fp32 accumulate -- same error class as an fp32 GEMM, see lemo_conv3x3_mfma_split) ; 0 = fp32 MFMA.
+ * Process-wide; call before lemo_fit_create (a captured graph keeps the variant it was captured with). */
+int lemo_lbs_set_variant(int variant);
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 /* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */

@@ -23,6 +23,26 @@ __device__ __forceinline__ float lrelu_grad_from_out(float y) { return y > 0.f ?
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- exact fp32 -> 3 x bf16 operand split (conv_split_kernels.hip header has the error analysis) ---------
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// x = hi + mid + lo exactly: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)  (round-to-nearest-even)
+__device__ __forceinline__ void split3x4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = (__bf16)x[e];
+    float r = x[e] - (float)h[e];
+    m[e] = (__bf16)r;
+    r -= (float)m[e];
+    l[e] = (__bf16)r;
+  }
+  hi = __builtin_bit_cast(uint2, h);
+  mid = __builtin_bit_cast(uint2, m);
+  lo = __builtin_bit_cast(uint2, l);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

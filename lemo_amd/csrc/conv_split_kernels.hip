@@ -32,9 +32,6 @@
 
 namespace lemo {
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 #define CV3_NPX 408
 template <int CIN, int COUT> struct Cv3Cfg {
   static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "encoder layer shapes");
@@ -54,22 +51,6 @@ template <int CIN, int COUT> struct Cv3Cfg {
 // p / W for 0 <= p < 2^24 with magic = 2^32 / W + 1 (host): one v_mul_hi instead of the ~40-instruction
 // runtime division (the prologue had 13 of them per thread: 3.6k of its 6.9k cycles were address math)
 __device__ __forceinline__ int div_w(int p, unsigned magic) { return (int)__umulhi((unsigned)p, magic); }
-
-__device__ __forceinline__ void split3x4(float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  bf16x4 h, m, l;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    h[e] = (__bf16)x[e];
-    float r = x[e] - (float)h[e];
-    m[e] = (__bf16)r;
-    r -= (float)m[e];
-    l[e] = (__bf16)r;
-  }
-  hi = __builtin_bit_cast(uint2, h);
-  mid = __builtin_bit_cast(uint2, m);
-  lo = __builtin_bit_cast(uint2, l);
-}
 
 // One remainder patch = PPX px x 4 couts over K = 9 Cin, no LDS, no barrier: wave w owns pixel w>>1 and the
 // cout pair 2*(w&1), +1; lane l takes channel l of every tap (Cin 64; Cin 32: channel l&31 of the taps of

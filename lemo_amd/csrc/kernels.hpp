@@ -57,6 +57,7 @@ int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, c
 // ---------------- lbs_kernels.hip ----------------
 int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
+int lbs_set_variant(int v);         // 1 (default): split-bf16 blend GEMM ; 0: fp32-MFMA blend GEMM
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,

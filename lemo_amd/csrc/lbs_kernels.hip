@@ -28,7 +28,7 @@ static inline int lbs_smem_bytes(int nj) { const int b = (LBS_FR * LBS_PITCH + 2
 // 8 waves: wave w = (frame tile w&3, column-tile pair w>>2) -> 2 waves per SIMD.  Both GEMM operands go
 // through LDS (register-staged, double-buffered, all loads of a stage issued up front); operand
 // reads run one 2-group chunk ahead of the MFMAs that consume them.
-template <bool DBG>
+template <bool DBG, bool SPLIT>
 __global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
@@ -54,6 +54,81 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   const size_t b_off = (size_t)fr_s * 8 + 4 * shalf;
   const size_t dg_stride = (size_t)c.NC * 8, xg_stride = (size_t)Bp * 8;
   const int lds_dst = ((sg0 * 2 + shalf) * 128 + scol) * 4;     // + k * (2 groups) ; same for A and B tiles
+  f32x16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  if (SPLIT) {
+    // ---- blend GEMM on the bf16 matrix cores with exact fp32 operands (3-way bf16 split, 6 products per
+    // 16-deep k-chunk, fp32 accumulate: conv_split_kernels.hip has the error analysis).  The MFMA floor of
+    // the 128 x 128 x 512 tile drops from 65.5k to 24.6k cycles; D (64 MB, streamed once) is converted on
+    // the fly while it is staged, so HBM still sees 4 B per element.
+    // LDS per buffer: A [4 groups][3 pieces][128 cols][8 bf16] (24 KB) + B likewise over frames; 2 buffers.
+    constexpr int SG = 4, PL = 128 * 16, OPB = SG * 3 * PL, BUFB = 2 * OPB, NSTS = 64 / SG;
+    unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
+    const int dstb = scol * 16 + shalf * 8;                       // + (group * 3 + piece) * PL
+    // D streams from HBM (~2 us away under load) and one stage is only ~0.75 us of MFMA work: the global
+    // loads run TWO stages ahead (two register sets), the LDS image one stage ahead
+    float4 sa[2][2], sb[2][2];
+#define LBS_SPLIT_LOAD(SET, ST)                                                                    \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                \
+      sa[SET][k] = ld4(c.Dg + (size_t)((ST) * SG + sg0 + 2 * k) * dg_stride + a_off);              \
+      sb[SET][k] = ld4(Xg + (size_t)((ST) * SG + sg0 + 2 * k) * xg_stride + b_off);                \
+    }
+#define LBS_SPLIT_STORE(SET, BUF)                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                \
+      uint2 p0, p1, p2;                                                                            \
+      unsigned char* d = sm + (BUF) * BUFB + (sg0 + 2 * k) * 3 * PL + dstb;                        \
+      split3x4(sa[SET][k], p0, p1, p2);                                                            \
+      *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PL) = p1; *reinterpret_cast<uint2*>(d + 2 * PL) = p2; \
+      split3x4(sb[SET][k], p0, p1, p2);                                                            \
+      *reinterpret_cast<uint2*>(d + OPB) = p0; *reinterpret_cast<uint2*>(d + OPB + PL) = p1;       \
+      *reinterpret_cast<uint2*>(d + OPB + 2 * PL) = p2;                                            \
+    }
+    LBS_SPLIT_LOAD(0, 0)
+    LBS_SPLIT_LOAD(1, 1)
+    LBS_SPLIT_STORE(0, 0)
+    __syncthreads();
+    if (DBG) t_pro = __builtin_amdgcn_s_memtime();
+    const int a_rdb = (mp * 64 + j) * 16, b_rdb = OPB + (nt * 32 + j) * 16;
+#pragma unroll 2
+    for (int st = 0; st < NSTS; ++st) {
+      const int buf = st & 1;
+      // register set (st & 1) held stage st (already in LDS): refill it with stage st + 2
+      if (st + 2 < NSTS) { if (st & 1) { LBS_SPLIT_LOAD(1, st + 2) } else { LBS_SPLIT_LOAD(0, st + 2) } }
+      const unsigned char* base = sm + buf * BUFB + h * 3 * PL;   // lane half h takes group 2c + h of chunk c
+      uint4 ra[2][2][3], rb[2][3];                                // [set][m-tile][piece]
+#define LBS_SREAD(SET, C)                                                                          \
+      _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                           \
+        ra[SET][0][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb);   \
+        ra[SET][1][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb + 32 * 16); \
+        rb[SET][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + b_rdb);      \
+      }
+#define LBS_SMFMA1(SET, SA, SB)                                                                    \
+      _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                             \
+        acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[SET][m_][SA]), \
+                                                          __builtin_bit_cast(bf16x8, rb[SET][SB]), acc[m_], 0, 0, 0);
+#define LBS_SMFMA(SET) LBS_SMFMA1(SET, 0, 2) LBS_SMFMA1(SET, 2, 0) LBS_SMFMA1(SET, 1, 1)           \
+                       LBS_SMFMA1(SET, 0, 1) LBS_SMFMA1(SET, 1, 0) LBS_SMFMA1(SET, 0, 0)
+      LBS_SREAD(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      LBS_SREAD(1, 1)
+      __builtin_amdgcn_sched_barrier(0);
+      LBS_SMFMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      LBS_SMFMA(1)
+#undef LBS_SREAD
+#undef LBS_SMFMA1
+#undef LBS_SMFMA
+      // (running the two waves of a SIMD out of phase -- one converting while the other owns the MFMA pipe --
+      // measured slower: 49.9k vs 43.1k cycles)
+      if (st + 1 < NSTS) { if (st & 1) { LBS_SPLIT_STORE(0, 0) } else { LBS_SPLIT_STORE(1, 1) } }
+      __syncthreads();
+    }
+#undef LBS_SPLIT_STORE
+#undef LBS_SPLIT_LOAD
+  } else {
   float* As0 = smem;                                   // [2 buffers] of LBS_STAGE_FLOATS
   float* Bs0 = smem + 2 * LBS_STAGE_FLOATS;
   float4 sa[4], sb[4];
@@ -69,11 +144,6 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
   __syncthreads();
   if (DBG) t_pro = __builtin_amdgcn_s_memtime();
-  f32x16 acc[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   const int a_rd = (h * 128 + mp * 64 + j) * 4, b_rd = (h * 128 + nt * 32 + j) * 4;
   constexpr int NST = 64 / LBS_KC;
   for (int st = 0; st < NST; ++st) {
@@ -128,6 +198,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
       }
     }
     __syncthreads();
+  }
   }
   if (DBG) t_gemm = __builtin_amdgcn_s_memtime();
   // ---- hand the blend tile over through LDS (aliases the staging buffers: everyone is past the last read)
@@ -218,13 +289,16 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
 }
 
+static int g_lbs_variant = 1;       // 1: blend GEMM on the bf16 MFMA with split fp32 operands ; 0: fp32 MFMA
+int lbs_set_variant(int v) { if (v != 0 && v != 1) return LEMO_ERR_ARG; g_lbs_variant = v; return 0; }
+
 int lbs_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
-  rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
-  if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
+  rc = 0;
+#define OPTIN(DBG_, SPLIT_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, SPLIT_>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
+  OPTIN(false, false) OPTIN(true, false) OPTIN(false, true) OPTIN(true, true)
+#undef OPTIN
   return rc;
 }
 
@@ -235,8 +309,10 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
   if (nj > 64 || 3 * nj * 12 > 5 * 512) return LEMO_ERR_SHAPE;
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
-  if (dbg) hipLaunchKernelGGL(lbs_verts_fwd_kernel<true>, grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg);
-  else hipLaunchKernelGGL(lbs_verts_fwd_kernel<false>, grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg);
+#define LAUNCH(DBG_, SPLIT_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg)
+  if (g_lbs_variant == 1) { if (dbg) LAUNCH(true, true); else LAUNCH(false, true); }
+  else { if (dbg) LAUNCH(true, false); else LAUNCH(false, false); }
+#undef LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const 
   if (!c || !ws || !gi || !go || !gi->dA) return LEMO_ERR_ARG;
   return smplx_pose_bwd(*c, *ws, *gi, *go, B, S(stream));
 }
+int lemo_lbs_set_variant(int variant) { return lbs_set_variant(variant); }
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream) {
   if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;

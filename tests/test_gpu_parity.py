@@ -91,6 +91,21 @@ def test_smplx_module_full_size_vs_oracle(dev):
     assert out.vertices.shape == (119, 10475, 3) and out.joints.shape == (119, 127, 3)
     assert rel_err(out.vertices.cpu(), v_ref) < VERT_TOL
     assert rel_err(out.joints.cpu(), j_ref) < VERT_TOL
+    # blend GEMM variants: bf16 matrix cores with exactly split fp32 operands (default) vs fp32 MFMA -- the error
+    # against the (fp32, CPU) oracle must be of the same size
+    from lemo_amd import _hip
+    lib = _hip.get_lib()
+    e_split = rel_err(out.vertices.cpu(), v_ref)
+    try:
+        lib.check(lib.lbs_set_variant(0))
+        out0 = model(betas=p[:, 6:16].to(dev), global_orient=p[:, 3:6].to(dev), body_pose=body.to(dev),
+                     left_hand_pose=p[:, 48:60].to(dev), right_hand_pose=p[:, 60:].to(dev), transl=p[:, 0:3].to(dev))
+        e_f32 = rel_err(out0.vertices.cpu(), v_ref)
+        e_ab = rel_err(out.vertices.cpu(), out0.vertices.cpu())
+    finally:
+        lib.check(lib.lbs_set_variant(1))
+    print(f'\nvertices vs oracle: split-bf16 blend GEMM {e_split:.3e}, fp32-MFMA blend GEMM {e_f32:.3e}, A vs B {e_ab:.3e}')
+    assert e_split < 3 * e_f32 + 1e-6 and e_ab < 2e-6
 
 
 def test_split_bf16_conv_error_is_fp32_sized(dev):
@@ -204,19 +219,32 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
             assert rel_err(g[k].cpu(), ref) < 2e-4, k
         fits.append(fit)
     assert rel_err(fits[0].vertices().cpu(), verts.detach()) < VERT_TOL
-    # eager vs graph replay: identical kernels -> identical parameters
+    # Adam trajectories (eager launches and hipGraph replay) against the oracle.  One step must agree to fp32 rounding.
+    # Later steps may not: the contact term selects `x[x > thr]` (opt_amass_temp.py:429-443), so a velocity within an
+    # ulp of the threshold enters the mean on one side and not on the other, which changes a handful of gradient
+    # entries by ~1e-3 relative and, through lr = 1e-2, parameters by ~1e-4 (measured: which kernel family trips a
+    # flip is a matter of rounding pattern, tools/traj_check.py).  Hence: tight after 1 step, bounded after 5.
     s = torch.cuda.Stream(dev)
     for fit in fits:
         fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     with torch.cuda.stream(s):
-        fits[0].step(5, use_graph=False)
-        fits[1].step(5, use_graph=True)
+        fits[0].step(1, use_graph=False)
+        fits[1].step(1, use_graph=True)
     torch.cuda.synchronize()
     ofit.opt.zero_grad()
-    for _ in range(5):
+    ofit.step()
+    for fit in fits:
+        assert float((fit.params75().cpu() - ofit.params75()).abs().max()) < 2e-6
+    with torch.cuda.stream(s):
+        fits[0].step(4, use_graph=False)
+        fits[1].step(4, use_graph=True)
+    torch.cuda.synchronize()
+    for _ in range(4):
         ofit.step()
     for fit in fits:
-        assert float((fit.params75().cpu() - ofit.params75()).abs().max()) < 1e-4
+        d = (fit.params75().cpu() - ofit.params75()).abs()
+        print(f'\nparams after 5 Adam steps vs oracle: max {float(d.max()):.2e} mean {float(d.mean()):.2e}')
+        assert float(d.max()) < 2e-3 and float(d.mean()) < 5e-5
         assert int(fit.step_ctr.item()) == 5
 
 

@@ -204,10 +204,17 @@ def test_fit_iteration_vs_oracle(emu_lib, full):
         assert rel_err(g[k], ref) < 2e-4, k
     fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     ofit.opt.zero_grad()
-    for _ in range(3):
+    # One Adam step must agree to fp32 rounding.  Later steps may not: the contact term selects `x[x > thr]`
+    # (opt_amass_temp.py:429-443), so a velocity within an ulp of the threshold is in the mean on one side and out on
+    # the other; that moves a handful of gradient entries by ~1e-3 relative and parameters by ~1e-4 (lr = 1e-2).
+    ofit.step()
+    fit.step(1, use_graph=False)
+    assert float((fit.params75() - ofit.params75()).abs().max()) < 1e-6
+    for _ in range(2):
         ofit.step()
-    fit.step(3, use_graph=False)
-    assert float((fit.params75() - ofit.params75()).abs().max()) < 5e-5
+    fit.step(2, use_graph=False)
+    d = (fit.params75() - ofit.params75()).abs()
+    assert float(d.max()) < 1e-3 and float(d.mean()) < 2e-5, (float(d.max()), float(d.mean()))
     assert int(fit.step_ctr.item()) == 3
 
 
