@@ -324,6 +324,7 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
 //   kernel 2: dX[b][k] = sum_col Dk[k][col] dvp[b][col]        (fp32-MFMA NT GEMM)
 // ------------------------------------------------------------------------------------------------
 #define LBS_BWD_STAGE 1024          // vertex sets up to this size keep g / v_posed of the frame in LDS
+#define LBS_BWD_NNZ 4096            // ... and the joint-major CSR (vertex, weight) lists up to this many entries
 template <bool STAGE>
 __global__ void __launch_bounds__(256)
 lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
@@ -333,6 +334,8 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   __shared__ float gs[STAGE ? LBS_BWD_STAGE * 3 : 1];
   __shared__ float vs[STAGE ? LBS_BWD_STAGE * 3 : 1];
   __shared__ float As[STAGE ? 64 * 12 : 1];
+  __shared__ int cu[STAGE ? LBS_BWD_NNZ : 1];
+  __shared__ float cw[STAGE ? LBS_BWD_NNZ : 1];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
   const float* g = dverts + (size_t)b * u.n * 3;
@@ -340,6 +343,11 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     for (int i = t; i < u.n * 3; i += 256) gs[i] = g[i];
     for (int i = t; i < u.n * 3; i += 256) vs[i] = v_posed[((size_t)b * vp_rows + u.vp_row[i / 3]) * 3 + (i % 3)];
     for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
+    // the dA gather below walks one (vertex, weight) list per thread: from global memory that is a chain of
+    // ~170 dependent L1 round trips for the foot joints (the whole kernel took 20 us); from LDS, unrolled, it
+    // is a pipelined stream
+    const int nnz = u.jcsr_start[nj];
+    for (int i = t; i < nnz; i += 256) { cu[i] = u.jcsr_u[i]; cw[i] = u.jcsr_w[i]; }
     __syncthreads();
   }
   const float* gp = STAGE ? gs : g;
@@ -354,12 +362,22 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     for (int e = 0; e < 9; ++e) T[e] = 0.f;
     const int* wi = c.w_idx + (size_t)vid * c.KW;
     const float* wv = c.w_val + (size_t)vid * c.KW;
-    for (int k = 0; k < c.KW; ++k) {
-      const float w = wv[k];
-      const float* Aj = Ap + wi[k] * 12;
-      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
-      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
-      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+    for (int k0 = 0; k0 < c.KW; k0 += 4) {               // 4 (index, weight) pairs per round trip, not one
+      int ji[4]; float wk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int kk = k0 + k < c.KW ? k0 + k : c.KW - 1;
+        ji[k] = wi[kk];
+        wk[k] = k0 + k < c.KW ? wv[kk] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = wk[k];
+        const float* Aj = Ap + ji[k] * 12;
+        T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
+        T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
+        T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+      }
     }
     float* d = dvp + (size_t)b * u.NCs + 3 * s;
     d[0] = T[0] * gx + T[3] * gy + T[6] * gz;
@@ -372,11 +390,21 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   for (int w = t; w < nj * 12; w += 256) {
     const int jj = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
     float acc = 0.f;
-    for (int q = u.jcsr_start[jj]; q < u.jcsr_start[jj + 1]; ++q) {
-      const int s = u.jcsr_u[q];
-      const float gv = gp[3 * s + r] * u.jcsr_w[q];
-      if (cc < 3) acc += gv * (STAGE ? vs[3 * s + cc] : v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc]);
-      else acc += gv;
+    const int q0 = u.jcsr_start[jj], q1 = u.jcsr_start[jj + 1];
+    if (STAGE) {
+#pragma unroll 4
+      for (int q = q0; q < q1; ++q) {
+        const int s = cu[q];
+        const float gv = gs[3 * s + r] * cw[q];
+        acc += cc < 3 ? gv * vs[3 * s + cc] : gv;
+      }
+    } else {
+      for (int q = q0; q < q1; ++q) {
+        const int s = u.jcsr_u[q];
+        const float gv = gp[3 * s + r] * u.jcsr_w[q];
+        if (cc < 3) acc += gv * v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc];
+        else acc += gv;
+      }
     }
     dA[((size_t)b * nj) * 12 + w] = acc;
   }
@@ -390,7 +418,7 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
                   const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s) {
   if (u.n <= 0 || B <= 0 || (u.NCs % 16) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
   (void)Bp;
-  if (u.n <= LBS_BWD_STAGE && nj <= 64)
+  if (u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ)
     hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
   else
     hipLaunchKernelGGL((lbs_bwd_frame_kernel<false>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256)
 vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                               const float* __restrict__ contact, const float* __restrict__ shape,
                               const float* __restrict__ other, int B, double* __restrict__ accg) {
-  __shared__ float red[4];
+  __shared__ float red[4][12];
   const int b = blockIdx.x, t = threadIdx.x;
   float acc[12];
   for (int i = 0; i < 12; ++i) acc[i] = 0.f;
@@ -101,9 +101,18 @@ vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int 
   if (t < 32) { const float v = other[(size_t)b * 56 + t]; acc[9] = v * v; }
   else if (t >= 64 && t < 74) { const float v = shape[(size_t)b * 10 + (t - 64)]; acc[10] = v * v; }
   else if (t >= 128 && t < 152) { const float v = other[(size_t)b * 56 + 32 + (t - 128)]; acc[11] = v * v; }
-  for (int i = 0; i < 12; ++i) {
-    const float v = block_sum(acc[i], red);
-    if (t == 0 && v != 0.f) atomicAdd(accg + (b & 31) * 16 + (i < 9 ? i : i + 1), (double)v);
+  // 12 wave sums, ONE barrier, then 12 threads finish and publish in parallel (was: 12 block sums = 24 barriers,
+  // 12 serial atomics from thread 0); the order of the adds is fixed -> deterministic
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) red[t >> 6][i] = acc[i];
+  }
+  __syncthreads();
+  if (t < 12) {
+    const float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (v != 0.f) atomicAdd(accg + (b & 31) * 16 + (t < 9 ? t : t + 1), (double)v);
   }
 }
 

@@ -145,8 +145,19 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   __shared__ float Ts[MAXJ * 12];
   __shared__ float shp[32];
   __shared__ float gob[66];           // global_orient (3) | body_pose (63) of this frame
+  // Model constants that the loops below walk element by element (one dependent L2/L1 round trip per element
+  // when read from global memory: 20 per rest joint, 12 per hand component -- most of this kernel's 13 us) are
+  // staged through LDS with coalesced, independent loads first.
+  __shared__ float Jd[MAXJ * 3 * 32];  // J_dirs [np][nshape]
+  __shared__ float hcomp[2 * 45 * 45]; // hand PCA components [side][ncomp][45] (ncomp <= 45)
+  __shared__ float hcoef[2 * 45];
   const int b = blockIdx.x, t = threadIdx.x;
   const int nj = c.nj, np = nj * 3;
+  for (int i = t; i < np * c.nshape; i += 256) Jd[i] = c.J_dirs[i];
+  if (c.ncomp > 0) {
+    for (int i = t; i < c.ncomp * 45; i += 256) { hcomp[i] = c.lh_comp[i]; hcomp[45 * 45 + i] = c.rh_comp[i]; }
+    if (t < 2 * c.ncomp) hcoef[(t / c.ncomp) * 45 + t % c.ncomp] = (t < c.ncomp ? in.lh : in.rh)[(size_t)b * in.hand_stride + t % c.ncomp];
+  }
   // ---- per-iteration bookkeeping of the fitting engine (block 0 only)
   if (b == 0) {
     if (in.zero_f64) for (int i = t; i < in.n_zero; i += 256) in.zero_f64[i] = 0.0;
@@ -184,9 +195,9 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
       const int hidx = i - 75, side = hidx / 45, cc = hidx - side * 45;
       const float* hp = (side == 0 ? in.lh : in.rh) + (size_t)b * in.hand_stride;
       if (c.ncomp > 0) {
-        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
+        const float* comp = hcomp + side * 45 * 45;
         float a = 0.f;
-        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hp[k], comp[k * 45 + cc], a);
+        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hcoef[side * 45 + k], comp[k * 45 + cc], a);
         v = a;
       } else v = hp[cc];
     }
@@ -208,7 +219,7 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   // ---- rest joints  J = J_template + J_dirs . shape
   for (int i = t; i < np; i += 256) {
     float a = c.J_template[i];
-    for (int k = 0; k < c.nshape; ++k) a = fmaf(c.J_dirs[(size_t)i * c.nshape + k], shp[k], a);
+    for (int k = 0; k < c.nshape; ++k) a = fmaf(Jd[i * c.nshape + k], shp[k], a);
     Js[i] = a;
     ws.J[(size_t)b * np + i] = a;
   }
@@ -259,7 +270,7 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
 }
 
 int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s) {
-  if (c.nj > MAXJ || c.nshape > 32 || B <= 0 || B > ws.Bp) return LEMO_ERR_SHAPE;
+  if (c.nj > MAXJ || c.nshape > 32 || c.ncomp > 45 || B <= 0 || B > ws.Bp) return LEMO_ERR_SHAPE;
   if (c.nshape + (c.nj - 1) * 9 > 512) return LEMO_ERR_SHAPE;
   hipLaunchKernelGGL(smplx_pose_fwd_kernel, dim3(B), dim3(256), 0, s, c, in, ws);
   return (int)hipGetLastError();
@@ -278,8 +289,15 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   __shared__ float drel[MAXJ * 3];
   __shared__ float dRl[MAXJ * 9];
   __shared__ float dfp[MAXJ * 3];
+  // tree tables and hand PCA components: staged once (coalesced, independent loads) instead of being chased
+  // element by element through L2 inside the level loops / the 45-term component sums
+  __shared__ int cstart[MAXJ + 1], clist[MAXJ], par[MAXJ];
+  __shared__ float hcomp[2 * 45 * 45];
   const int b = blockIdx.x, t = threadIdx.x;
   const int nj = c.nj, np = nj * 3;
+  if (t <= nj) cstart[t] = c.child_start[t];
+  if (t < nj) { par[t] = c.parents[t]; if (t < nj - 1) clist[t] = c.child_list[t]; }
+  if (c.ncomp > 0) for (int i = t; i < c.ncomp * 45; i += 256) { hcomp[i] = c.lh_comp[i]; hcomp[45 * 45 + i] = c.rh_comp[i]; }
   for (int i = t; i < nj * 9; i += 256) Rs[i] = ws.R[(size_t)b * nj * 9 + i];
   for (int i = t; i < nj * 12; i += 256) Ts[i] = ws.T[(size_t)b * nj * 12 + i];
   for (int i = t; i < np; i += 256) Js[i] = ws.J[(size_t)b * np + i];
@@ -305,8 +323,8 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     for (int w = t; w < (s1 - s0) * 12; w += 256) {
       const int i = c.level_joints[s0 + w / 12], e = w % 12, r = e >> 2, cc = e & 3;
       float acc = 0.f;
-      for (int q = c.child_start[i]; q < c.child_start[i + 1]; ++q) {
-        const int ch = c.child_list[q];
+      for (int q = cstart[i]; q < cstart[i + 1]; ++q) {
+        const int ch = clist[q];
         const float* Gc = &G[12 * ch + 4 * r];
         if (cc < 3) {
           acc += Gc[0] * Rs[9 * ch + 3 * cc] + Gc[1] * Rs[9 * ch + 3 * cc + 1] + Gc[2] * Rs[9 * ch + 3 * cc + 2] +
@@ -320,7 +338,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   // local grads: dR_i = T_R[p]^T G_R[i] ; drel_i = T_R[p]^T G_t[i]
   for (int w = t; w < nj * 12; w += 256) {
     const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;     // (r,cc): element of dR_i (cc<3) or drel (cc==3 -> comp r)
-    const int p = c.parents[i];
+    const int p = par[i];
     float v;
     if (p < 0) v = G[12 * i + 4 * r + cc];
     else v = Ts[12 * p + r] * G[12 * i + cc] + Ts[12 * p + 4 + r] * G[12 * i + 4 + cc] + Ts[12 * p + 8 + r] * G[12 * i + 8 + cc];
@@ -335,7 +353,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   for (int w = t; w < np; w += 256) {
     const int i = w / 3, cc = w % 3;
     float v = dJ[w] + drel[w];
-    for (int q = c.child_start[i]; q < c.child_start[i + 1]; ++q) v -= drel[3 * c.child_list[q] + cc];
+    for (int q = cstart[i]; q < cstart[i + 1]; ++q) v -= drel[3 * clist[q] + cc];
     dJ[w] = v;
   }
   // Rodrigues backward
@@ -384,7 +402,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
       if (!dst) continue;
       float v;
       if (c.ncomp > 0) {
-        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
+        const float* comp = hcomp + side * 45 * 45;
         v = 0.f;
         for (int cc = 0; cc < 45; ++cc) v = fmaf(comp[k * 45 + cc], dfp[75 + side * 45 + cc], v);
       } else v = dfp[75 + side * 45 + k];
