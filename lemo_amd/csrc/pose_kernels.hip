@@ -145,19 +145,8 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   __shared__ float Ts[MAXJ * 12];
   __shared__ float shp[32];
   __shared__ float gob[66];           // global_orient (3) | body_pose (63) of this frame
-  // Model constants that the loops below walk element by element (one dependent L2/L1 round trip per element
-  // when read from global memory: 20 per rest joint, 12 per hand component -- most of this kernel's 13 us) are
-  // staged through LDS with coalesced, independent loads first.
-  __shared__ float Jd[MAXJ * 3 * 32];  // J_dirs [np][nshape]
-  __shared__ float hcomp[2 * 45 * 45]; // hand PCA components [side][ncomp][45] (ncomp <= 45)
-  __shared__ float hcoef[2 * 45];
   const int b = blockIdx.x, t = threadIdx.x;
   const int nj = c.nj, np = nj * 3;
-  for (int i = t; i < np * c.nshape; i += 256) Jd[i] = c.J_dirs[i];
-  if (c.ncomp > 0) {
-    for (int i = t; i < c.ncomp * 45; i += 256) { hcomp[i] = c.lh_comp[i]; hcomp[45 * 45 + i] = c.rh_comp[i]; }
-    if (t < 2 * c.ncomp) hcoef[(t / c.ncomp) * 45 + t % c.ncomp] = (t < c.ncomp ? in.lh : in.rh)[(size_t)b * in.hand_stride + t % c.ncomp];
-  }
   // ---- per-iteration bookkeeping of the fitting engine (block 0 only)
   if (b == 0) {
     if (in.zero_f64) for (int i = t; i < in.n_zero; i += 256) in.zero_f64[i] = 0.0;
@@ -195,9 +184,9 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
       const int hidx = i - 75, side = hidx / 45, cc = hidx - side * 45;
       const float* hp = (side == 0 ? in.lh : in.rh) + (size_t)b * in.hand_stride;
       if (c.ncomp > 0) {
-        const float* comp = hcomp + side * 45 * 45;
+        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
         float a = 0.f;
-        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hcoef[side * 45 + k], comp[k * 45 + cc], a);
+        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hp[k], comp[k * 45 + cc], a);
         v = a;
       } else v = hp[cc];
     }
@@ -219,7 +208,7 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   // ---- rest joints  J = J_template + J_dirs . shape
   for (int i = t; i < np; i += 256) {
     float a = c.J_template[i];
-    for (int k = 0; k < c.nshape; ++k) a = fmaf(Jd[i * c.nshape + k], shp[k], a);
+    for (int k = 0; k < c.nshape; ++k) a = fmaf(c.J_dirs[(size_t)i * c.nshape + k], shp[k], a);
     Js[i] = a;
     ws.J[(size_t)b * np + i] = a;
   }
