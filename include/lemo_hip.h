@@ -151,6 +151,15 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
                          const int* lmk_rows, const float* lmk_bary, int n_lmk, const float* transl, int B, float* joints,
                          void* stream);
 
+/* ---- marker-image decode / encode around the loop, one clip (T <= 256 frames) per call ----
+ * utils/utils.py:184-203 reconstruct_global_body: in [T][J+2][3] = (ignored reference slot, J local joints, trajectory
+ * (dx, dz, dr)); rot_0_pivot from the encode below; out [T][J][3] global positions. */
+int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_pivot, float* out, void* stream);
+/* utils/utils.py:209-265 get_local_markers_4chan: body [T][1+67][3] global pelvis + markers, contact [T][4] ->
+ * image [4][T-1][3*68+4] (local markers + contacts | dx | dz | dr repeated) and rot_0_pivot[1] (float64, device). */
+int lemo_local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot_0_pivot,
+                             void* stream);
+
 /* ---- motion-infilling autoencoder, models/AE.py:11-108 and its finetune step, opt_amass_temp.py:154-214 ----
  * (stride-1 convs / transposed convs run on lemo_conv3x3_mfma; these are the remaining layer types) */
 /* MaxPool2d(3,2,1): out is CG8P of ((H-1)/2+1) x ((W-1)/2+1); idx [C/8][Ho*Wo][8] winning tap (uint8) */

@@ -97,4 +97,8 @@ int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float*
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
               int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s);
 
+// ---------------- marker_kernels.hip ----------------
+int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s);
+int local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot0, hipStream_t s);
+
 }  // namespace lemo

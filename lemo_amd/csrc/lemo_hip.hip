@@ -141,6 +141,16 @@ int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int
   return sdf_sample(sdf, D, H, W, pts, N, gmin, gmax, val, dval, S(stream));
 }
 
+int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_pivot, float* out, void* stream) {
+  if (!in || !out) return LEMO_ERR_ARG;
+  return reconstruct_global_body(in, T, J, rot_0_pivot, out, S(stream));
+}
+int lemo_local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot_0_pivot,
+                             void* stream) {
+  if (!body || !contact || !image || !rot_0_pivot) return LEMO_ERR_ARG;
+  return local_markers_4chan(body, contact, T, M1, image, rot_0_pivot, S(stream));
+}
+
 // ------------------------------------------------------------------------------------------------
 // fitting engine
 // ------------------------------------------------------------------------------------------------

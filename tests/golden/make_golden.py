@@ -48,6 +48,34 @@ def small_model(V=640, seed=3):
     return m
 
 
+def synthetic_marker_clip(seed=11, T=120):
+    """pelvis + 67 markers of a body that walks a curved path and turns (SMPL-X axes: z up), + contact labels"""
+    rng = np.random.default_rng(seed)
+    t = np.arange(T) / 30.0
+    heading = 0.6 * np.sin(0.7 * t) + 0.4 * t                        # turning while walking
+    path = np.stack([np.cumsum(np.cos(heading)) * 0.03, np.cumsum(np.sin(heading)) * 0.03, np.zeros(T)], -1)
+    rest = rng.normal(0, 0.25, (68, 3)); rest[:, 2] = np.abs(rest[:, 2]) * 2.0 + 0.05      # offsets in the body frame
+    # give the four direction markers (26, 56 shoulders; 27, 57 hips -- utils.py:228) a left/right layout
+    for idx, (side, h) in {26: (+1, 1.4), 56: (-1, 1.4), 27: (+1, 0.9), 57: (-1, 0.9)}.items():
+        rest[idx + 1] = [0.0, 0.2 * side, h]
+    c, s_ = np.cos(heading), np.sin(heading)
+    R = np.stack([np.stack([c, -s_, np.zeros(T)], -1), np.stack([s_, c, np.zeros(T)], -1),
+                  np.stack([np.zeros(T), np.zeros(T), np.ones(T)], -1)], 1)                 # [T,3,3] about z
+    body = np.einsum('tij,mj->tmi', R, rest) + path[:, None] + rng.normal(0, 0.003, (T, 68, 3))
+    body[:, 0] = path + np.array([0, 0, 0.95])
+    contact = (rng.random((T, 4)) < 0.7).astype(np.float64)
+    return body, contact
+
+
+def decode_input_from_image(img):
+    """what opt_amass_temp.py:300-323 feeds reconstruct_global_body: [T, 1+68+1, 3] = zero reference slot, the local
+    pelvis + markers of channel 0, and the (dx, dz, dr) trajectory of channels 1-3"""
+    T = img.shape[1]
+    local = img[0, :, :-4].reshape(T, 68, 3)
+    traj = np.stack([img[1, :, 0], img[2, :, 0], img[3, :, 0]], -1)[:, None]
+    return np.concatenate([np.zeros((T, 1, 3)), local, traj], axis=1)
+
+
 def check_against_reference():
     report = {}
     # ---- lbs.py --------------------------------------------------------------------------
@@ -107,6 +135,21 @@ def check_against_reference():
     report['utils.convert_to_3D_rot'] = _rel(O.convert_to_3D_rot(x75), ref_utils.convert_to_3D_rot(x75))
     aa = torch.randn(16, 3, generator=g)
     report['utils.convert_to_6D_all'] = _rel(O.convert_to_6D_all(aa), ref_utils.convert_to_6D_all(aa))
+
+    # ---- utils/utils.py marker-image encode / decode around the loop --------------
+    from oracle import markers_oracle as MO
+    body, contact = synthetic_marker_clip(seed=11)
+    ref_img, ref_piv = ref_utils.get_local_markers_4chan(body.copy(), contact.copy())
+    o_img, o_piv = MO.get_local_markers_4chan(body, contact)
+    report['utils.get_local_markers_4chan'] = _rel(torch.from_numpy(o_img), torch.from_numpy(ref_img))
+    report['utils.get_local_markers_4chan.rot_0_pivot'] = float(np.abs(o_piv - ref_piv).max())
+    dec_in = decode_input_from_image(ref_img)
+    ref_glob = ref_utils.reconstruct_global_body(dec_in.copy(), ref_piv)
+    o_glob = MO.reconstruct_global_body(dec_in, ref_piv)
+    report['utils.reconstruct_global_body'] = _rel(torch.from_numpy(o_glob), torch.from_numpy(ref_glob))
+    np.savez_compressed(os.path.join(HERE, 'markers_decode.npz'), body=body.astype(np.float32), contact=contact.astype(np.float32),
+                        image=ref_img.astype(np.float32), rot_0_pivot=np.asarray(ref_piv, np.float64),
+                        decode_in=dec_in.astype(np.float32), global_body=ref_glob.astype(np.float32))
 
     # ---- VPoser.decode -------------------------------------------------------------------
     cfg = types.ModuleType('configer'); cfg.Configer = object

@@ -463,3 +463,18 @@ def test_infill_ae_full_size_golden_and_finetune(dev):
     dt = time.time() - t0
     print(f'infilling AE: 60 finetune steps + eval at [1,4,210,135]: {dt * 1e3:.1f} ms per clip ({dt / 61 * 1e3:.2f} ms per pass)')
     assert rec.shape == (1, 1, 208, 119) and torch.isfinite(rec).all()
+
+
+def test_marker_image_encode_decode_golden(dev):
+    """SURVEY N2 on the GPU: utils/utils.py::get_local_markers_4chan / reconstruct_global_body against the golden
+    vectors produced by the reference's own functions; device tensors in -> device tensors out."""
+    from lemo_amd.markers import get_local_markers_4chan, reconstruct_global_body
+    g = np.load(os.path.join(GOLDEN, 'markers_decode.npz'))
+    img, piv = get_local_markers_4chan(torch.from_numpy(g['body']).to(dev), torch.from_numpy(g['contact']).to(dev))
+    assert img.is_cuda and img.shape == (4, 119, 208) and piv.dtype == torch.float64
+    assert rel_err(img.cpu(), g['image']) < 1e-5
+    assert abs(float(piv[0]) - float(g['rot_0_pivot'][0])) < 1e-6
+    glob = reconstruct_global_body(torch.from_numpy(g['decode_in']).to(dev), piv)
+    assert rel_err(glob.cpu(), g['global_body']) < 1e-5
+    img_np, _ = get_local_markers_4chan(g['body'], g['contact'])          # numpy in -> float64 numpy out, like the reference
+    assert isinstance(img_np, np.ndarray) and img_np.dtype == np.float64
