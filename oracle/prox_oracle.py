@@ -212,3 +212,17 @@ class ProxFitOracle:
         ld = self.closure()
         self.opt.step()
         return {k: float(v) for k, v in ld.items()}
+
+
+def slide_index_oracle(n_frames: int, batch_size: int):
+    """temp_prox/data_parser_slide.py:199-212 restated literally on frame numbers (the reference runs it on image
+    paths): returns the concatenated frame list ``img_paths_slide``."""
+    img_paths = list(range(n_frames))
+    slide_window_size = int(batch_size * 0.7)
+    seq_n = (len(img_paths) - batch_size) - slide_window_size
+    out = img_paths[0:batch_size]
+    for i in range(int(seq_n) + 1):
+        start = slide_window_size * (i + 1)
+        end = min(start + batch_size, len(img_paths))
+        out += img_paths[start:end]
+    return out

@@ -1,0 +1,70 @@
+"""PROX sliding-window schedule and result-pkl wire format (host logic, CPU)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from lemo_amd import prox_windows as PW
+from oracle.prox_oracle import slide_index_oracle
+
+
+@pytest.mark.parametrize('n,b', [(100, 100), (169, 100), (170, 100), (171, 100), (240, 100), (1000, 100), (37, 10),
+                                 (10, 10), (5, 10), (311, 64)])
+def test_window_schedule_matches_reference_loop(n, b):
+    assert PW.slide_frame_index(n, b).tolist() == slide_index_oracle(n, b)
+    wins = PW.sliding_windows(n, b)
+    assert wins[0][0] == 0 and all(e - s <= b for s, e in wins)
+    assert all(wins[i + 1][0] - wins[i][0] == int(0.7 * b) for i in range(len(wins) - 1))
+
+
+def test_frozen_prefix():
+    assert PW.frozen_prefix(100, True) == 0 and PW.frozen_prefix(100, False) == 15 and PW.frozen_prefix(10, False) == 1
+
+
+def test_result_pkl_wire_format_and_overlap_init(tmp_path):
+    B = 10
+    rng = np.random.default_rng(0)
+    cam = {'rotation': rng.normal(size=(B, 3, 3)), 'translation': rng.normal(size=(B, 3))}
+    body = {k: rng.normal(size=(B, d)).astype(np.float32) for k, d in
+            dict(transl=3, global_orient=3, betas=10, left_hand_pose=12, right_hand_pose=12, jaw_pose=3, leye_pose=3,
+                 reye_pose=3, expression=10).items()}
+    emb, bp = rng.normal(size=(B, 32)).astype(np.float32), rng.normal(size=(B, 63)).astype(np.float32)
+    cur, prox = str(tmp_path / 'cur'), str(tmp_path / 'prox')
+    names = [f's001_frame_{i:05d}' for i in range(B)]
+    for i, fn in enumerate(names):                                          # the "PROX fit" every window can fall back to
+        PW.write_result_pkl(PW.result_path(prox, fn), cam, body, emb * 0, bp * 0, i)
+    d = PW.write_result_pkl(PW.result_path(cur, names[3]), cam, body, emb, bp, 3)
+    assert set(d) == {'camera_rotation', 'camera_translation', *body, 'pose_embedding', 'body_pose'}
+    with open(PW.result_path(cur, names[3]), 'rb') as f:
+        raw = f.read()
+    assert raw[:2] == b'\x80\x02'                                            # pickle protocol 2
+    back = pickle.loads(raw)
+    assert all(v.shape[0] == 1 for v in back.values()) and np.array_equal(back['body_pose'][0], bp[3])
+    init = PW.init_params_for_window(names, cur, prox)
+    assert set(init) == set(PW.BODY_PARAM_KEYS) and init['pose_embedding'].shape == (B, 32)
+    assert np.array_equal(init['pose_embedding'][3], emb[3]) and not init['pose_embedding'][4].any()   # newest result wins
+
+
+def test_run_recording_overwrites_the_overlap(tmp_path):
+    n, B = 24, 10
+    names = [f'f{i:03d}' for i in range(n)]
+    cur, prox = str(tmp_path / 'cur'), str(tmp_path / 'prox')
+    z = lambda d: np.zeros((n, d), np.float32)
+    body0 = {k: z(d) for k, d in dict(transl=3, global_orient=3, betas=10, left_hand_pose=12, right_hand_pose=12,
+                                      jaw_pose=3, leye_pose=3, reye_pose=3, expression=10).items()}
+    for i, fn in enumerate(names):
+        PW.write_result_pkl(PW.result_path(prox, fn), {}, body0, z(32), z(63), i)
+    calls = []
+
+    def fit_window(fns, init, first, n_frozen):
+        w = len(calls)
+        calls.append((fns[0], fns[-1], first, n_frozen, float(init['transl'][:, 0].max())))
+        body = {k: np.full((len(fns),) + v.shape[1:], w + 1, np.float32) for k, v in body0.items()}
+        return {}, body, np.zeros((len(fns), 32), np.float32), np.zeros((len(fns), 63), np.float32)
+
+    assert PW.run_recording(names, B, cur, prox, fit_window) == 3
+    assert calls[0][:4] == ('f000', 'f009', True, 0) and calls[1][:4] == ('f007', 'f016', False, 1)
+    assert calls[1][4] == 1.0 and calls[2][4] == 2.0            # a window starts from the previous window's overlap
+    assert PW.read_prox_pkl(PW.result_path(cur, 'f008'))['transl'][0] == 2.0    # later window overwrote the overlap
+    assert PW.read_prox_pkl(PW.result_path(cur, 'f023'))['transl'][0] == 3.0
