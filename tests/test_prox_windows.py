@@ -63,8 +63,9 @@ def test_run_recording_overwrites_the_overlap(tmp_path):
         body = {k: np.full((len(fns),) + v.shape[1:], w + 1, np.float32) for k, v in body0.items()}
         return {}, body, np.zeros((len(fns), 32), np.float32), np.zeros((len(fns), 63), np.float32)
 
-    assert PW.run_recording(names, B, cur, prox, fit_window) == 3
+    assert PW.run_recording(names, B, cur, prox, fit_window) == 4     # (0,10) (7,17) (14,24) and the short tail (21,24)
     assert calls[0][:4] == ('f000', 'f009', True, 0) and calls[1][:4] == ('f007', 'f016', False, 1)
     assert calls[1][4] == 1.0 and calls[2][4] == 2.0            # a window starts from the previous window's overlap
     assert PW.read_prox_pkl(PW.result_path(cur, 'f008'))['transl'][0] == 2.0    # later window overwrote the overlap
-    assert PW.read_prox_pkl(PW.result_path(cur, 'f023'))['transl'][0] == 3.0
+    assert PW.read_prox_pkl(PW.result_path(cur, 'f020'))['transl'][0] == 3.0
+    assert PW.read_prox_pkl(PW.result_path(cur, 'f023'))['transl'][0] == 4.0
