@@ -175,6 +175,9 @@ int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, i
                        float* partial, float* dw, float* db, void* stream);
 /* torch.optim.Adam (defaults) over a flat buffer; step is 1-based */
 int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream);
+/* same with the step count on the device (step_ctr[0] = completed steps; advanced by one after the update), so that a
+ * captured graph of a whole training step can be replayed */
+int lemo_adam_flat_ctr(float* p, const float* g, float* m, float* v, int n, float lr, int* step_ctr, void* stream);
 
 /* ---- PROX scene terms: F.grid_sample(sdf, verts, padding_mode='border') of temp_prox/fitting_temp_slide.py:685-739
  * sdf [D][H][W] device; pts [N][3] device world coordinates; gmin/gmax HOST float[3]; val [N]; dval [N][3] or NULL

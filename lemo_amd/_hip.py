@@ -140,6 +140,7 @@ _SIGS = {
     'lemo_conv3x3_wgrad_nslab': (C.c_int, [C.c_int, C.c_int]),
     'lemo_conv3x3_wgrad': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     'lemo_adam_flat': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
+    'lemo_adam_flat_ctr': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, vp, vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
     'lemo_fit_destroy': (None, [vp]),

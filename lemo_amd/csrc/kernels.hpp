@@ -79,7 +79,7 @@ int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, in
 int conv3x3_wgrad_nslab(int H, int W);
 int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
                   float* partial, float* dw, float* db, hipStream_t s);
-int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, hipStream_t s);
+int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, int* step_dev, hipStream_t s);
 
 // ---------------- loss_kernels.hip ----------------
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,

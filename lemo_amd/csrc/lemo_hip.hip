@@ -133,7 +133,11 @@ int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, i
 }
 int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream) {
   if (!p || !g || !m || !v) return LEMO_ERR_ARG;
-  return adam_flat(p, g, m, v, n, lr, step, S(stream));
+  return adam_flat(p, g, m, v, n, lr, step, nullptr, S(stream));
+}
+int lemo_adam_flat_ctr(float* p, const float* g, float* m, float* v, int n, float lr, int* step_ctr, void* stream) {
+  if (!p || !g || !m || !v || !step_ctr) return LEMO_ERR_ARG;
+  return adam_flat(p, g, m, v, n, lr, 0, step_ctr, S(stream));
 }
 int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
                     float* val, float* dval, void* stream) {

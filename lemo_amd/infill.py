@@ -251,6 +251,7 @@ class FlatAdam:
         dev = self.params[0].device
         self.flat = torch.cat([p.detach().reshape(-1).float() for p in self.params])
         self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)      # completed steps (device copy: graph replay)
 
     def zero_grad(self):
         for p in self.params:
@@ -260,8 +261,8 @@ class FlatAdam:
     def step(self):
         self.t += 1
         g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in self.params])
-        self.lib.check(self.lib.adam_flat(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), self.lr, self.t,
-                                          self.lib.stream(self.flat.device)), 'adam_flat')
+        self.lib.check(self.lib.adam_flat_ctr(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), self.lr,
+                                              ptr(self.step_ctr), self.lib.stream(self.flat.device)), 'adam_flat')
         o = 0
         for p in self.params:
             p.copy_(self.flat[o:o + p.numel()].view_as(p))
@@ -269,20 +270,47 @@ class FlatAdam:
 
 
 def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, train_mask: torch.Tensor, steps: int = 60,
-                        lr: float = 3e-6):
+                        lr: float = 3e-6, use_graph: Optional[bool] = None):
     """The per-clip block of opt_amass_temp.py:160-215: reload the pretrained weights, ``steps`` x [forward, L1 on
     ``train_mask`` (bool [d+2, T+16] over channel 0), backward, Adam], then one eval forward.  Returns
-    ``(clip_img_rec [1,1,d,T] un-padded, z)``."""
+    ``(clip_img_rec [1,1,d,T] un-padded, z)``.
+
+    ``use_graph`` (default: on a HIP device): the training step -- ~60 HIP kernels plus ~150 small packing ops -- is
+    host-launch bound when issued one by one (8 ms per step).  It is therefore captured ONCE per clip into a graph
+    (after 3 eager steps that also warm the allocator) and replayed; Adam's bias-correction step lives on the device
+    (``lemo_adam_flat_ctr``) so the replays advance it.  Same kernels, same order: results are identical."""
     model.load_state_dict(weights)
     opt = FlatAdam(list(model.parameters()), lr, model._lib_override)
     m = train_mask.to(clip_img_input.dtype)
     cnt = m.sum()
-    for _ in range(steps):
+
+    def train_step():
         opt.zero_grad()
         rec, _ = model(clip_img_input)
         loss = ((rec[0, 0] - clip_img_input[0, 0]).abs() * m).sum() / cnt
         loss.backward()
         opt.step()
+
+    if use_graph is None:
+        use_graph = clip_img_input.is_cuda
+    n_eager = min(3, steps) if use_graph else steps
+    if use_graph:
+        side = torch.cuda.Stream(clip_img_input.device)
+        side.wait_stream(torch.cuda.current_stream(clip_img_input.device))
+        with torch.cuda.stream(side):
+            for _ in range(n_eager):
+                train_step()
+        torch.cuda.current_stream(clip_img_input.device).wait_stream(side)
+        if steps > n_eager:
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad()
+            with torch.cuda.graph(g):
+                train_step()
+            for _ in range(steps - n_eager):          # capture records the step without running it
+                g.replay()
+    else:
+        for _ in range(n_eager):
+            train_step()
     with torch.no_grad():
         rec, z = model(clip_img_input)
     return rec[:, :, 1:-1, 8:-8], z

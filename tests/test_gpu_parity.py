@@ -461,8 +461,22 @@ def test_infill_ae_full_size_golden_and_finetune(dev):
     rec, zz = finetune_and_infill(ae, {k: v.to(dev) for k, v in w.items()}, x, mask.to(dev), steps=60, lr=3e-6)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(f'infilling AE: 60 finetune steps + eval at [1,4,210,135]: {dt * 1e3:.1f} ms per clip ({dt / 61 * 1e3:.2f} ms per pass)')
+    print(f'infilling AE (training step captured in a graph): 60 finetune steps + eval at [1,4,210,135]: {dt * 1e3:.1f} ms per clip ({dt / 61 * 1e3:.2f} ms per pass)')
     assert rec.shape == (1, 1, 208, 119) and torch.isfinite(rec).all()
+    # graph replay == eager launches: same kernels in the same order on the same data (12 steps each way)
+    wdev = {k: v.to(dev) for k, v in w.items()}
+    r_g, _ = finetune_and_infill(ae, wdev, x, mask.to(dev), steps=12, lr=3e-6, use_graph=True)
+    p_g = {k: v.detach().clone() for k, v in ae.state_dict().items()}
+    torch.cuda.synchronize()
+    t0 = time.time()
+    r_e, _ = finetune_and_infill(ae, wdev, x, mask.to(dev), steps=12, lr=3e-6, use_graph=False)
+    torch.cuda.synchronize()
+    print(f'eager launches: {(time.time() - t0) / 13 * 1e3:.2f} ms per pass')
+    assert torch.equal(r_g, r_e)
+    for k, v in ae.state_dict().items():
+        assert torch.equal(v, p_g[k]), k
+    moved = max(float((p_g[k] - wdev[k]).abs().max()) for k in p_g)
+    assert 1e-6 < moved < 1e-3                                    # 12 Adam steps of lr 3e-6 actually happened
 
 
 def test_marker_image_encode_decode_golden(dev):
