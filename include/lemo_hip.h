@@ -179,6 +179,14 @@ int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr
  * captured graph of a whole training step can be replayed */
 int lemo_adam_flat_ctr(float* p, const float* g, float* m, float* v, int n, float lr, int* step_ctr, void* stream);
 
+/* ---- stream capture helpers: record everything a host-side step enqueues on `stream` (HIP kernels of this library
+ * and the caller's own device work alike) into an executable graph, replay it with one call.  Relaxed capture mode;
+ * the caller guarantees that the step does not synchronise and that every buffer it touches outlives the replays. */
+int lemo_capture_begin(void* stream);
+int lemo_capture_end(void* stream, void** graph_exec);
+int lemo_graph_launch(void* graph_exec, void* stream);
+int lemo_graph_destroy(void* graph_exec);
+
 /* ---- PROX scene terms: F.grid_sample(sdf, verts, padding_mode='border') of temp_prox/fitting_temp_slide.py:685-739
  * sdf [D][H][W] device; pts [N][3] device world coordinates; gmin/gmax HOST float[3]; val [N]; dval [N][3] or NULL
  * (d val / d pts).  Grid axis order follows the reference's norm_vertices[:, :, [2,1,0]]. */

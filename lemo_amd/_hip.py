@@ -109,6 +109,10 @@ _SIGS = {
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_lbs_set_variant': (C.c_int, [C.c_int]),
+    'lemo_capture_begin': (C.c_int, [vp]),
+    'lemo_capture_end': (C.c_int, [vp, C.POINTER(C.c_void_p)]),
+    'lemo_graph_launch': (C.c_int, [vp, vp]),
+    'lemo_graph_destroy': (C.c_int, [vp]),
     'lemo_reconstruct_global_body': (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp]),
     'lemo_local_markers_4chan': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_conv3x3_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -139,6 +139,30 @@ int lemo_adam_flat_ctr(float* p, const float* g, float* m, float* v, int n, floa
   if (!p || !g || !m || !v || !step_ctr) return LEMO_ERR_ARG;
   return adam_flat(p, g, m, v, n, lr, 0, step_ctr, S(stream));
 }
+int lemo_capture_begin(void* stream) {
+  if (!stream) return LEMO_ERR_ARG;                      // the legacy default stream cannot be captured
+  return (int)hipStreamBeginCapture(S(stream), hipStreamCaptureModeRelaxed);
+}
+int lemo_capture_end(void* stream, void** graph_exec) {
+  if (!stream || !graph_exec) return LEMO_ERR_ARG;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(S(stream), &g);
+  if (e != hipSuccess || !g) return e != hipSuccess ? (int)e : LEMO_ERR_STATE;
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return (int)e;
+  *graph_exec = (void*)x;
+  return 0;
+}
+int lemo_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return LEMO_ERR_ARG;
+  return (int)hipGraphLaunch((hipGraphExec_t)graph_exec, S(stream));
+}
+int lemo_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return 0;
+  return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
 int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
                     float* val, float* dval, void* stream) {
   if (!sdf || !pts || !gmin || !gmax || !val) return LEMO_ERR_ARG;

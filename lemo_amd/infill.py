@@ -280,37 +280,68 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     (after 3 eager steps that also warm the allocator) and replayed; Adam's bias-correction step lives on the device
     (``lemo_adam_flat_ctr``) so the replays advance it.  Same kernels, same order: results are identical."""
     model.load_state_dict(weights)
-    opt = FlatAdam(list(model.parameters()), lr, model._lib_override)
+    lib = model._lib_override or _hip.get_lib()
     m = train_mask.to(clip_img_input.dtype)
     cnt = m.sum()
-
-    def train_step():
-        opt.zero_grad()
-        rec, _ = model(clip_img_input)
-        loss = ((rec[0, 0] - clip_img_input[0, 0]).abs() * m).sum() / cnt
-        loss.backward()
-        opt.step()
-
     if use_graph is None:
         use_graph = clip_img_input.is_cuda
-    n_eager = min(3, steps) if use_graph else steps
-    if use_graph:
-        side = torch.cuda.Stream(clip_img_input.device)
-        side.wait_stream(torch.cuda.current_stream(clip_img_input.device))
-        with torch.cuda.stream(side):
-            for _ in range(n_eager):
-                train_step()
-        torch.cuda.current_stream(clip_img_input.device).wait_stream(side)
-        if steps > n_eager:
-            g = torch.cuda.CUDAGraph()
-            opt.zero_grad()
-            with torch.cuda.graph(g):
-                train_step()
-            for _ in range(steps - n_eager):          # capture records the step without running it
-                g.replay()
+    use_graph = bool(use_graph) and steps > 3
+
+    def run(stream_ctx):
+        # The step trains fresh leaf copies of the parameters created on the stream the step runs on.  Autograd
+        # keeps one AccumulateGrad node per leaf for as long as ANY graph references it and pins it to the stream it
+        # was first used on: with the module's own parameters, a caller that still holds an output of an earlier
+        # forward (made on another stream) forces a cross-stream event wait into every backward -- fatal inside a
+        # stream capture (segfault in hipStreamEndCapture, tools/graph_repro.py).
+        with stream_ctx:
+            params = [p.detach().clone().requires_grad_(True) for p in model.ordered_parameters()]
+            opt = FlatAdam(params, lr, lib)
+
+            def train_step():
+                opt.zero_grad()
+                rec, _ = _AEFn.apply(lib, clip_img_input[0], *params)
+                loss = ((rec - clip_img_input[0, 0]).abs() * m).sum() / cnt
+                loss.backward()
+                opt.step()
+
+            if not use_graph:
+                for _ in range(steps):
+                    train_step()
+            else:
+                import ctypes as C
+                for _ in range(3):                           # eager: warms the allocator cache and every lazy init
+                    train_step()
+                # After three identical steps every allocation of the step is served from the caching allocator and
+                # everything runs on this one stream, so the recorded addresses stay valid and stream order protects
+                # their reuse.  Raw capture (lemo_capture_*): the step is ~60 HIP kernels + ~150 small torch ops.
+                opt.zero_grad()
+                sh = torch.cuda.current_stream(clip_img_input.device).cuda_stream
+                lib.check(lib.capture_begin(sh), 'capture_begin')
+                try:
+                    train_step()
+                finally:
+                    exe = C.c_void_p()
+                    rc = lib.capture_end(sh, C.byref(exe))
+                lib.check(rc, 'capture_end')
+                try:
+                    for _ in range(steps - 3):               # capture records the step without running it
+                        lib.check(lib.graph_launch(exe, sh), 'graph_launch')
+                    torch.cuda.current_stream(clip_img_input.device).synchronize()
+                finally:
+                    lib.check(lib.graph_destroy(exe), 'graph_destroy')
+            with torch.no_grad():
+                for p, q in zip(model.ordered_parameters(), params):
+                    p.copy_(q)
+
+    if clip_img_input.is_cuda:
+        dev = clip_img_input.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        run(torch.cuda.stream(side))
+        torch.cuda.current_stream(dev).wait_stream(side)
     else:
-        for _ in range(n_eager):
-            train_step()
+        import contextlib
+        run(contextlib.nullcontext())
     with torch.no_grad():
         rec, z = model(clip_img_input)
     return rec[:, :, 1:-1, 8:-8], z
