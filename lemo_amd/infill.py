@@ -275,10 +275,12 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     ``train_mask`` (bool [d+2, T+16] over channel 0), backward, Adam], then one eval forward.  Returns
     ``(clip_img_rec [1,1,d,T] un-padded, z)``.
 
-    ``use_graph`` (default: on a HIP device): the training step -- ~60 HIP kernels plus ~150 small packing ops -- is
-    host-launch bound when issued one by one (8 ms per step).  It is therefore captured ONCE per clip into a graph
-    (after 3 eager steps that also warm the allocator) and replayed; Adam's bias-correction step lives on the device
-    (``lemo_adam_flat_ctr``) so the replays advance it.  Same kernels, same order: results are identical."""
+    ``use_graph`` (default: on a HIP device): the training step -- ~70 HIP kernels plus ~300 small packing ops -- is
+    captured ONCE per clip into a graph (after 3 eager steps that also warm the allocator) and replayed, which takes
+    the host out of the loop; Adam's bias-correction step lives on the device (``lemo_adam_flat_ctr``) so the replays
+    advance it.  Same kernels, same order: results are bit-identical to eager launches (tested).  The step itself is
+    GPU-bound (5.0 ms: 19 weight-gradient kernels 1.5 ms, 27 convolutions of the 128/256-channel layers at 27x17 ..
+    14x9 pixels 1.9 ms -- too few tiles to fill the chip -- and 1.1 ms of packing ops; tools/ae_prof.py)."""
     model.load_state_dict(weights)
     lib = model._lib_override or _hip.get_lib()
     m = train_mask.to(clip_img_input.dtype)
