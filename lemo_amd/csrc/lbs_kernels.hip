@@ -245,6 +245,18 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
   const int* wi = c.w_idx + (size_t)vid * c.KW;
   const float* wv = c.w_val + (size_t)vid * c.KW;
+  // the vertex's (joint, weight) pairs are read ONCE, up front and all together (they were re-read from global memory
+  // inside every 12-frame chunk: KW dependent L1 round trips x 11 chunks per thread); rows beyond KW carry weight 0
+  constexpr int KWR = 8;
+  int jk[KWR];
+  float wk[KWR];
+#pragma unroll
+  for (int k = 0; k < KWR; ++k) {
+    const int kk = k < c.KW ? k : c.KW - 1;
+    jk[k] = wi[kk] * 12;
+    wk[k] = k < c.KW ? wv[kk] : 0.f;
+  }
+  const int kwr = c.KW < KWR ? c.KW : KWR;
   LBS_ALOAD(0)
   LBS_ASTORE(0)
   __syncthreads();
@@ -259,14 +271,18 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
 #pragma unroll
       for (int e = 0; e < 12; ++e) T[e] = 0.f;
       const float* Af = Ab + buf * 12 * fpf + fg * fpf;
-      for (int k = 0; k < c.KW; ++k) {
-        const float w = wv[k];
-        const float* Aj = Af + wi[k] * 12;
-        const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);
-        T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
-        T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
-        T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
-      }
+#define LBS_SKIN_K(W_, AJ_) {                                                                     \
+        const float w = (W_);                                                                     \
+        const float* Aj = (AJ_);                                                                  \
+        const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);                            \
+        T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);   \
+        T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);   \
+        T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]); }
+#pragma unroll
+      for (int k = 0; k < KWR; ++k)
+        if (k < kwr) LBS_SKIN_K(wk[k], Af + jk[k])
+      for (int k = KWR; k < c.KW; ++k) LBS_SKIN_K(wv[k], Af + wi[k] * 12)     // models with more than 8 weights per vertex
+#undef LBS_SKIN_K
       float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
       float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
       float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
