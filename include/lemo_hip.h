@@ -50,6 +50,25 @@ int lemo_conv3x3_mfma_split(const float* in, const void* w3, const float* wt, co
                             float* out, int H, int W, int cin, int cout, int epi, void* stream);
 int lemo_conv3x3_mfma_split_census(const float* in, const void* w3, const float* wt, const float* bias, float* out,
                                    int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
+/* Persistent chain of up to LEMO_CHAIN_MAX consecutive 64 -> 64 layers in ONE launch (layer l reads what layer l-1
+ * wrote: in[l] == out[l-1]); results are bit-identical to n calls of lemo_conv3x3_mfma_split.  One workgroup per CU
+ * keeps its tile through all layers and waits on per-tile flags of its neighbours instead of a kernel boundary, so
+ * every workgroup must be resident at once: lemo_conv3x3_split_chain_supported() checks H*W/128 <= #CUs.
+ * sync: device ints, lemo_conv3x3_split_chain_sync_ints(H, W, n) of them, zeroed once by the caller and then owned
+ * by this (shape, n); sync[1] != 0 after a launch means a bounded wait timed out (results invalid). */
+#define LEMO_CHAIN_MAX 8
+typedef struct lemo_conv_chain {
+  int n;
+  const float* in[LEMO_CHAIN_MAX];
+  const void* w3[LEMO_CHAIN_MAX];
+  const float* wt[LEMO_CHAIN_MAX];
+  const float* bias[LEMO_CHAIN_MAX];   /* epi 0 / 2 */
+  const float* aux[LEMO_CHAIN_MAX];    /* epi 1 */
+  float* out[LEMO_CHAIN_MAX];
+} lemo_conv_chain;
+int lemo_conv3x3_split_chain_supported(int H, int W);
+int lemo_conv3x3_split_chain_sync_ints(int H, int W, int n);
+int lemo_conv3x3_split_chain(const lemo_conv_chain* c, int H, int W, int epi, int* sync, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
@@ -220,6 +239,8 @@ typedef struct lemo_fit_desc {
   const float* enc_wbwd2[10];
   const void* enc_w3[10];         /* split-bf16 packs for conv_variant 3 (layer 0: NULL) */
   const void* enc_wbwd3[10];
+  int* conv_chain_sync[2];        /* forward / backward encoder chains (lemo_conv3x3_split_chain), or NULL: one launch
+                                   * per layer.  Sized for n = 7 layers each, zeroed by the caller. */
   /* sequence data */
   const float* target;            /* [B][n67][3]  markers_rec */
   const float* contact;           /* [B][4] */

@@ -70,6 +70,15 @@ class FitConst(C.Structure):
                            'u_foot_mask', 'Xstd', 'Xmean')]
 
 
+CHAIN_MAX = 8
+
+
+class ConvChain(C.Structure):
+    """lemo_conv_chain"""
+    _fields_ = [('n', C.c_int), ('inp', vp * CHAIN_MAX), ('w3', vp * CHAIN_MAX), ('wt', vp * CHAIN_MAX), ('bias', vp * CHAIN_MAX),
+                ('aux', vp * CHAIN_MAX), ('out', vp * CHAIN_MAX)]
+
+
 class FitDesc(C.Structure):
     _fields_ = [
         ('B', C.c_int), ('Bp', C.c_int), ('V', C.c_int), ('nrows', C.c_int), ('full_vertices', C.c_int),
@@ -77,7 +86,7 @@ class FitDesc(C.Structure):
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
         ('fwd_ids', vp),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
-        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10),
+        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10), ('conv_chain_sync', vp * 2),
         ('target', vp), ('contact', vp), ('weights', vp), ('weights_host', C.c_float * 6),
         ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
         ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
@@ -115,6 +124,9 @@ _SIGS = {
     'lemo_graph_destroy': (C.c_int, [vp]),
     'lemo_reconstruct_global_body': (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp]),
     'lemo_local_markers_4chan': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    'lemo_conv3x3_split_chain_supported': (C.c_int, [C.c_int, C.c_int]),
+    'lemo_conv3x3_split_chain_sync_ints': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'lemo_conv3x3_split_chain': (C.c_int, [C.POINTER(ConvChain), C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'lemo_conv3x3_mfma_split': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_split_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

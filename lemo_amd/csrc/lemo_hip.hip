@@ -35,6 +35,12 @@ int lemo_conv3x3_mfma_split_census(const float* in, const void* w3, const float*
   if (!in || !w3 || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
   return conv3x3_mfma_split(in, w3, wt, bias, nullptr, out, H, W, cin, cout, 0, S(stream), dbg);
 }
+int lemo_conv3x3_split_chain_supported(int H, int W) { return conv3x3_split_chain_supported(H, W) ? 1 : 0; }
+int lemo_conv3x3_split_chain_sync_ints(int H, int W, int n) { return conv3x3_split_chain_sync_ints(H, W, n); }
+int lemo_conv3x3_split_chain(const lemo_conv_chain* c, int H, int W, int epi, int* sync, void* stream) {
+  if (!c) return LEMO_ERR_ARG;
+  return conv3x3_split_chain(*c, H, W, epi, sync, false, S(stream));
+}
 int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
                                  int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
   if (!in || !wt || !wt2 || !out || !bias || !dbg) return LEMO_ERR_ARG;
@@ -182,6 +188,8 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 // ------------------------------------------------------------------------------------------------
 // fitting engine
 // ------------------------------------------------------------------------------------------------
+static const int CHAIN_LAYERS = 7;    // 64 -> 64 layers of the encoder (models/AE_sep.py:77-89): what conv_chain_sync is sized for
+
 struct FitEngine {
   lemo_fit_desc d;
   hipGraph_t graph = nullptr;
@@ -208,13 +216,26 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
   CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
   CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
-  for (int l = 1; l < 10; ++l) {
+  // runs of 64 -> 64 layers go out as ONE persistent chain launch when the caller provided the sync buffer and
+  // every workgroup fits on the device at once; everything else one launch per layer
+  const bool chain_f = d.conv_variant == 3 && d.conv_chain_sync[0] && conv3x3_split_chain_supported(H, W);
+  for (int l = 1; l < 10;) {
+    if (chain_f && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_w3[l]) {
+      lemo_conv_chain c{};
+      while (l < 10 && c.n < LEMO_CHAIN_MAX && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_w3[l]) {
+        c.in[c.n] = d.act[l]; c.w3[c.n] = d.enc_w3[l]; c.wt[c.n] = d.enc_w[l]; c.bias[c.n] = d.enc_b[l]; c.out[c.n] = d.act[l + 1];
+        ++c.n; ++l;
+      }
+      if (c.n == CHAIN_LAYERS) { CHK(conv3x3_split_chain(c, H, W, 0, d.conv_chain_sync[0], false, s)); continue; }
+      l -= c.n;                                       // the sync buffer is sized for CHAIN_LAYERS: fall through
+    }
     if (d.conv_variant == 3 && d.enc_w3[l] && conv3x3_split_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1]))
       CHK(conv3x3_mfma_split(d.act[l], d.enc_w3[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
     else if (d.conv_variant >= 2)
       CHK(conv3x3_mfma_lds(d.act[l], d.enc_w[l], d.enc_w2[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
     else
       CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, d.conv_variant, s));
+    ++l;
   }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
@@ -229,7 +250,18 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
-  for (int l = 9; l >= 1; --l) {   // d(pre-act of layer l+1) -> d(pre-act of layer l)
+  const bool chain_b = d.conv_variant == 3 && d.conv_chain_sync[1] && conv3x3_split_chain_supported(H, W);
+  for (int l = 9; l >= 1;) {       // d(pre-act of layer l+1) -> d(pre-act of layer l)
+    if (chain_b && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_wbwd3[l]) {
+      lemo_conv_chain c{};
+      int cc = cur;
+      while (l >= 1 && c.n < LEMO_CHAIN_MAX && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_wbwd3[l]) {
+        c.in[c.n] = d.dact[cc]; c.w3[c.n] = d.enc_wbwd3[l]; c.wt[c.n] = d.enc_wbwd[l]; c.aux[c.n] = d.act[l]; c.out[c.n] = d.dact[1 - cc];
+        cc = 1 - cc; ++c.n; --l;
+      }
+      if (c.n == CHAIN_LAYERS) { CHK(conv3x3_split_chain(c, H, W, 1, d.conv_chain_sync[1], false, s)); cur = cc; continue; }
+      l += c.n;
+    }
     if (d.conv_variant == 3 && d.enc_wbwd3[l] && conv3x3_split_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l]))
       CHK(conv3x3_mfma_split(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
     else if (d.conv_variant >= 2)
@@ -237,6 +269,7 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
     else
       CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, d.conv_variant, s));
     cur = 1 - cur;
+    --l;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
   CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s));

@@ -33,7 +33,7 @@ class AmassTemporalFitter:
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
-                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None,
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None, use_conv_chain: Optional[bool] = None,
                  lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
@@ -118,6 +118,12 @@ class AmassTemporalFitter:
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
         d.fwd_ids = ptr(I['fwd_ids'])
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
+        # persistent encoder chains (7 x 64->64 forward, 7 backward-data): flags + counters, zeroed once
+        nsync = self.lib.conv3x3_split_chain_sync_ints(H, W, 7)
+        self.chain_sync = [torch.zeros(max(nsync, 1), dtype=torch.int32, device=dev) for _ in range(2)]
+        use_chain = bool(use_conv_chain)           # default off: measured 18.8 vs 16.6 us per layer (conv_split_kernels.hip)
+        for i in range(2):
+            d.conv_chain_sync[i] = ptr(self.chain_sync[i]) if (use_chain and nsync > 0 and not self.lib.is_emu) else None
         for l in range(10):
             d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
             d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
@@ -181,6 +187,13 @@ class AmassTemporalFitter:
         stream, so call inside ``with torch.cuda.stream(s):``."""
         self.lib.check(self.lib.fit_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()),
                        'fit_step')
+
+    def check_chains(self):
+        """raises if a bounded wait of the persistent encoder kernels timed out (call after a synchronisation)"""
+        for i, name in enumerate(('forward', 'backward')):
+            if int(self.chain_sync[i][1].item()) != 0:
+                raise _hip.LemoHipError(f'{name} encoder chain: a neighbour-tile wait timed out (are all {self.H * self.W // 128} '
+                                        'workgroups resident at once?)')
 
     # -- results -------------------------------------------------------------------------------
     def losses(self) -> Dict[str, float]:

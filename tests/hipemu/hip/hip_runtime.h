@@ -337,6 +337,33 @@ static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (floa
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 
+// ---- buffer resources / cache-policy loads & stores / scoped atomics (plain memory on the host) ------------
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// (workgroups run one after another here: multi-layer chains cannot make progress -- the CPU tests use n = 1)
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 1 << 20; return hipSuccess; }
+struct hipemu_rsrc { char* p; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int, int) { return hipemu_rsrc{(char*)p}; }
+static inline hipemu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  hipemu_u32x4 v; memcpy(&v, r.p + voff + soff, 16); return v;
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int) {
+  unsigned v; memcpy(&v, r.p + voff + soff, 4); return v;
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) { memcpy(r.p + voff + soff, &v, 16); }
+static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) { memcpy(r.p + voff + soff, &v, 8); }
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) { memcpy(r.p + voff + soff, &v, 4); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+template <typename T> static inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add((p), (v))
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
+
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // only ever applied to wave-uniform values in the kernels

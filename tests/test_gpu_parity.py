@@ -492,3 +492,42 @@ def test_marker_image_encode_decode_golden(dev):
     assert rel_err(glob.cpu(), g['global_body']) < 1e-5
     img_np, _ = get_local_markers_4chan(g['body'], g['contact'])          # numpy in -> float64 numpy out, like the reference
     assert isinstance(img_np, np.ndarray) and img_np.dtype == np.float64
+
+
+def test_conv_chain_is_bit_identical_to_per_layer_launches(dev):
+    """persistent 7-layer encoder chain (neighbour-tile flags, coherent activation accesses) == 7 launches, bit for bit,
+    for the forward epilogue and for the backward-data epilogue with ping-pong buffers; and through the fitting engine."""
+    import ctypes as C
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import EncWeights, cg8p_alloc, to_cg8p
+    lib = _hip.get_lib()
+    H, W = 245, 134
+    if not lib.conv3x3_split_chain_supported(H, W):
+        pytest.skip('fewer CUs than tiles: the chain kernel cannot keep every workgroup resident')
+    enc = EncWeights(load_assets()['enc_w'], dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator().manual_seed(1)
+    x = to_cg8p(torch.randn(64, H, W, generator=g).abs() * 0.3).to(dev)
+    auxs = [to_cg8p(torch.randn(64, H, W, generator=g)).to(dev) for _ in range(7)]
+    for epi in (0, 1):
+        outs = []
+        for chain in (False, True):
+            layers = list(range(3, 10)) if epi == 0 else list(range(9, 2, -1))
+            pp = [x.clone(), cg8p_alloc(64, H, W, dev)]
+            c = _hip.ConvChain(); c.n = 7
+            for i, l in enumerate(layers):
+                c.inp[i], c.out[i] = ptr(pp[i & 1]), ptr(pp[1 - (i & 1)])
+                c.w3[i], c.wt[i] = (ptr(enc.w3[l]), ptr(enc.w[l])) if epi == 0 else (ptr(enc.wbwd3[l]), ptr(enc.wbwd[l]))
+                if epi == 0: c.bias[i] = ptr(enc.b[l])
+                else: c.aux[i] = ptr(auxs[i])
+            sync = torch.zeros(lib.conv3x3_split_chain_sync_ints(H, W, 7), dtype=torch.int32, device=dev)
+            if chain:
+                lib.check(lib.conv3x3_split_chain(C.byref(c), H, W, epi, ptr(sync), s))
+            else:
+                for i in range(7):
+                    lib.check(lib.conv3x3_mfma_split(c.inp[i], c.w3[i], c.wt[i], c.bias[i], c.aux[i], c.out[i], H, W, 64, 64, epi, s))
+            torch.cuda.synchronize()
+            assert int(sync[1]) == 0
+            outs.append(pp[1].clone())
+        assert torch.equal(outs[0], outs[1]), epi

@@ -236,3 +236,33 @@ def test_contact_term_empty_selection_is_exactly_zero(emu_lib):
     fit.load_sequence(prob['seq']['init_params'], markers, np.zeros_like(prob['seq']['contact_lbl']))
     fit.forward()
     assert fit.losses()['contact'] == 0.0                # no contact labels at all
+
+
+def test_conv_chain_single_layer_coherent_path(emu_lib):
+    """the persistent chain kernel's code path (coherent buffer accesses, patch after the K loop, flag publication)
+    with n = 1 layer -- the emulator runs workgroups one after another, so multi-layer chains are GPU-only tests"""
+    import ctypes as C
+    from lemo_amd import _hip
+    from lemo_amd.priors import pack_conv3x3_split
+    H, W = 36, 57
+    g = torch.Generator().manual_seed(7)
+    x, w, b = torch.randn(64, H, W, generator=g), torch.randn(64, 64, 3, 3, generator=g) * 0.1, torch.randn(64, generator=g)
+    ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    xin, out = to_cg8p(x), cg8p_alloc(64, H, W, 'cpu')
+    wt, w3 = torch.from_numpy(pack_conv3x3(w.numpy())), torch.from_numpy(pack_conv3x3_split(w.numpy()).view(np.int16))
+    n = emu_lib.conv3x3_split_chain_sync_ints(H, W, 1)
+    assert n == 3 + 1 + (H * W) // 128
+    sync = torch.zeros(n, dtype=torch.int32)
+    c = _hip.ConvChain()
+    c.n = 1
+    c.inp[0], c.w3[0], c.wt[0], c.bias[0], c.out[0] = ptr(xin), ptr(w3), ptr(wt), ptr(b), ptr(out)
+    for epoch in (1, 2):                                               # a second launch reuses the sync buffer
+        out.zero_()
+        assert emu_lib.conv3x3_split_chain(C.byref(c), H, W, 0, ptr(sync), None) == 0
+        assert rel_err(from_cg8p(out, H, W), ref) < 2e-6
+        nb = (H * W) // 128
+        assert int(sync[0]) == epoch and int(sync[1]) == 0 and int(sync[2]) == epoch * nb and int(sync[3]) == epoch * nb
+        assert (sync[4:] == epoch).all()
+    one = cg8p_alloc(64, H, W, 'cpu')
+    assert emu_lib.conv3x3_mfma_split(ptr(xin), ptr(w3), ptr(wt), ptr(b), None, ptr(one), H, W, 64, 64, 0, None) == 0
+    assert torch.equal(one, out)                                       # bit-identical to the per-layer kernel
