@@ -35,8 +35,9 @@ def full_problem(dev):
     g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
     model = synthetic.make_synthetic_smplx(seed=0)
     seq = synthetic.make_synthetic_sequence(0, B=119)
-    mk = lambda full, variant=None: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'],
-                                                        119, dev, full_vertices=full, conv_variant=variant)
+    mk = lambda full, variant=None, chain=None: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'],
+                                                                    A['Xstd'], 119, dev, full_vertices=full, conv_variant=variant,
+                                                                    use_conv_chain=chain)
     return dict(A=A, g=g, model=model, seq=seq, make=mk)
 
 
@@ -492,6 +493,27 @@ def test_marker_image_encode_decode_golden(dev):
     assert rel_err(glob.cpu(), g['global_body']) < 1e-5
     img_np, _ = get_local_markers_4chan(g['body'], g['contact'])          # numpy in -> float64 numpy out, like the reference
     assert isinstance(img_np, np.ndarray) and img_np.dtype == np.float64
+
+
+def test_fit_engine_with_conv_chain_matches_per_layer(full_problem, dev):
+    """the fitting engine with the opt-in persistent encoder chains: same losses and parameters after 3 graph-replayed
+    steps as with one launch per layer (identical arithmetic -> identical bits)"""
+    from lemo_amd import _hip
+    if not _hip.get_lib().conv3x3_split_chain_supported(245, 134):
+        pytest.skip('fewer CUs than tiles')
+    g, seq = full_problem['g'], full_problem['seq']
+    res = []
+    for chain in (False, True):
+        fit = full_problem['make'](False, 3, chain)
+        fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+        s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            fit.step(3, use_graph=True)
+        torch.cuda.synchronize()
+        fit.check_chains()
+        fit.forward(); torch.cuda.synchronize()
+        res.append((fit.params75().clone(), fit.losses()))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
 
 
 def test_conv_chain_is_bit_identical_to_per_layer_launches(dev):
