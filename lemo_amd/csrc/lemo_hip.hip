@@ -190,12 +190,31 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 // ------------------------------------------------------------------------------------------------
 static const int CHAIN_LAYERS = 7;    // 64 -> 64 layers of the encoder (models/AE_sep.py:77-89): what conv_chain_sync is sized for
 
+// a replay costs ~8 us of device idle time around the graph (tools/ubench/launch_ubench.hip) on top of its nodes:
+// FIT_UNROLL iterations are captured into one graph and the remainder runs on a one-iteration graph
+static const int FIT_UNROLL = 5;
+
 struct FitEngine {
   lemo_fit_desc d;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  hipGraphExec_t exec = nullptr;        // 1 iteration
+  hipGraphExec_t exec_u = nullptr;      // FIT_UNROLL iterations
   hipStream_t graph_stream = nullptr;
 };
+
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s);
+
+static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s);
+  const int ec = (int)hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  CHK(ec);
+  const int ic = (int)hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  return ic;
+}
 
 static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   const int B = d.B, nj = d.body.nj;
@@ -304,7 +323,7 @@ void lemo_fit_destroy(void* h) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return;
   if (e->exec) (void)hipGraphExecDestroy(e->exec);
-  if (e->graph) (void)hipGraphDestroy(e->graph);
+  if (e->exec_u) (void)hipGraphExecDestroy(e->exec_u);
   delete e;
 }
 
@@ -328,18 +347,16 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
     for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s));
     return 0;
   }
-  if (!e->exec || e->graph_stream != s) {
+  if (e->graph_stream != s) {
     if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-    CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    const int rc = fit_iteration(e->d, s);
-    const int ec = (int)hipStreamEndCapture(s, &e->graph);
-    if (rc) return rc;
-    CHK(ec);
-    CHK((int)hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    if (e->exec_u) { (void)hipGraphExecDestroy(e->exec_u); e->exec_u = nullptr; }
     e->graph_stream = s;
   }
-  for (int i = 0; i < n; ++i) CHK((int)hipGraphLaunch(e->exec, s));
+  if (n >= FIT_UNROLL && !e->exec_u) CHK(capture_iterations(e, s, FIT_UNROLL, &e->exec_u));
+  if (n % FIT_UNROLL && !e->exec) CHK(capture_iterations(e, s, 1, &e->exec));
+  int i = 0;
+  for (; i + FIT_UNROLL <= n; i += FIT_UNROLL) CHK((int)hipGraphLaunch(e->exec_u, s));
+  for (; i < n; ++i) CHK((int)hipGraphLaunch(e->exec, s));
   return 0;
 }
 
