@@ -116,14 +116,21 @@ class ProxTemporalFitter:
         self.contact_lbl_rec = None if contact_lbl_rec is None else f(contact_lbl_rec)
         self.first_batch_flag = first_batch_flag
         self.params = [p for n, p in self.body_model.named_parameters() if p.requires_grad] + [self.pose_embedding]
-        self.optimizer = torch.optim.Adam(self.params, lr=lr)            # optim_factory.py:43-46
+        # optim_factory.py:43-46.  capturable: the step count lives on the device so that a captured step can be replayed
+        self.optimizer = torch.optim.Adam(self.params, lr=lr, capturable=self.pose_embedding.is_cuda)
         self._comp = None
+        # small constants as device tensors, made once: a host -> device tensor construction inside an iteration is a
+        # synchronous copy (and illegal while the iteration is being captured)
+        self._cam_f = torch.tensor([self.cam['fx'], self.cam['fy']], device=dev).view(1, 1, 2)
+        self._cam_c = torch.tensor([self.cam['cx'], self.cam['cy']], device=dev).view(1, 1, 2)
+        self._angle_idx = torch.tensor([55, 58, 12, 15], device=dev) - 3
+        self._angle_sgn = torch.tensor([1., -1., -1., -1.], device=dev)
+        self._z_axis = torch.tensor([0., 0., 1.], device=dev)
 
     # temp_prox/camera.py:88-116 with the fixed identity camera pose of the PROX configs
     def camera(self, points: torch.Tensor) -> torch.Tensor:
         xy = points[:, :, :2] / points[:, :, 2:3]
-        f = torch.tensor([self.cam['fx'], self.cam['fy']], device=points.device).view(1, 1, 2)
-        c = torch.tensor([self.cam['cx'], self.cam['cy']], device=points.device).view(1, 1, 2)
+        f, c = self._cam_f, self._cam_c
         return xy * f + c
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
@@ -142,8 +149,7 @@ class ProxTemporalFitter:
         # ---- priors
         pprior = self.pose_embedding.pow(2).sum() * w['body_pose_weight'] ** 2
         shape_loss = torch.sum(out.betas ** 2) * w['shape_weight'] ** 2
-        idx = torch.tensor([55, 58, 12, 15], device=self.device) - 3
-        sgn = torch.tensor([1., -1., -1., -1.], device=self.device)
+        idx, sgn = self._angle_idx, self._angle_sgn
         angle = torch.sum(torch.exp(out.full_pose[:, 3:66][:, idx] * sgn)) * w['bending_prior_weight'] ** 2
         lhand = torch.sum(out.left_hand_pose ** 2) * w['hand_prior_weight'] ** 2
         rhand = torch.sum(out.right_hand_pose ** 2) * w['hand_prior_weight'] ** 2
@@ -186,7 +192,7 @@ class ProxTemporalFitter:
         x_axis = j0[2] - j0[1]
         x_axis = torch.cat([x_axis[:2], torch.zeros(1, device=self.device)])
         x_axis = x_axis / torch.norm(x_axis)
-        z_axis = torch.tensor([0., 0., 1.], device=self.device)
+        z_axis = self._z_axis
         y_axis = torch.linalg.cross(z_axis, x_axis)
         y_axis = y_axis / torch.norm(y_axis)
         R0 = torch.stack([x_axis, y_axis, z_axis], dim=1)
@@ -215,9 +221,48 @@ class ProxTemporalFitter:
                     p.grad[0:erase_n, :] = 0
         return ld
 
-    def step(self, n: int = 1) -> Dict[str, torch.Tensor]:
-        ld = None
-        for _ in range(n):
+    def step(self, n: int = 1, use_graph: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """n Adam iterations; returns the ``loss_dict`` of the last one (detached).
+
+        ``use_graph`` (default: on a HIP device when n > 4): an iteration is ~60 HIP kernels plus ~250 small torch ops
+        of loss algebra and is host-launch bound when issued one by one.  It is captured once (raw stream capture,
+        ``lemo_capture_*``; three eager iterations first warm the allocator) and replayed n - 3 times on a private
+        stream, inside this call.  The returned tensors are the captured iteration's outputs after the last replay."""
+        lib = _hip.get_lib() if self.pose_embedding.is_cuda else None
+        if use_graph is None:
+            use_graph = lib is not None and n > 4
+
+        def one():
             ld = self.closure()
             self.optimizer.step()
+            return {k: v.detach() for k, v in ld.items()}       # no autograd graph survives the iteration
+
+        if not use_graph:
+            ld = None
+            for _ in range(n):
+                ld = one()
+            return ld
+        import ctypes as C
+        dev = self.pose_embedding.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                ld = one()
+            del ld
+            self.optimizer.zero_grad()
+            lib.check(lib.capture_begin(side.cuda_stream), 'capture_begin')
+            try:
+                ld = one()
+            finally:
+                exe = C.c_void_p()
+                rc = lib.capture_end(side.cuda_stream, C.byref(exe))
+            lib.check(rc, 'capture_end')
+            try:
+                for _ in range(n - 3):                           # capture records the iteration without running it
+                    lib.check(lib.graph_launch(exe, side.cuda_stream), 'graph_launch')
+                side.synchronize()
+            finally:
+                lib.check(lib.graph_destroy(exe), 'graph_destroy')
+        torch.cuda.current_stream(dev).wait_stream(side)
         return ld
