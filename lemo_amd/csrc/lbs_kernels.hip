@@ -430,13 +430,85 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   }
 }
 
+// ---- dense variant (large vertex sets, e.g. the PROX window whose scene terms touch all 10475 vertices) ------------
+// lbs_bwd_frame_kernel walks each frame with ONE block: 41 vertices per thread and joint lists of ~760 entries per
+// thread -> 1.3 ms per launch at n = 10475.  Here a block takes a chunk of 512 vertices of one frame: vertex-major,
+// dA accumulated in LDS with float atomics and added to global dA with one atomic per entry (order of the adds is
+// not fixed: results vary in the last bits between runs, like the torch scatter ops of the same path).
+#define LBS_DENSE_CHUNK 512
+__global__ void __launch_bounds__(256)
+lbs_bwd_zero_kernel(float* __restrict__ dvp, int NCs, int n3, float* __restrict__ dA, int na, float* __restrict__ dtransl) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < na; i += 256) dA[(size_t)b * na + i] = 0.f;
+  for (int i = n3 + t; i < NCs; i += 256) dvp[(size_t)b * NCs + i] = 0.f;       // padding columns of the GEMM operand
+  if (dtransl && t < 3) dtransl[(size_t)b * 3 + t] = 0.f;
+}
+__global__ void __launch_bounds__(256)
+lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj, const float* __restrict__ v_posed,
+                     int vp_rows, const float* __restrict__ dverts, float* __restrict__ dvp, float* __restrict__ dA,
+                     float* __restrict__ dtransl) {
+  __shared__ float As[64 * 12];
+  __shared__ float dAs[64 * 12];
+  __shared__ float red[4];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const float* Af = A + (size_t)b * nj * 12;
+  for (int i = t; i < nj * 12; i += 256) { As[i] = Af[i]; dAs[i] = 0.f; }
+  __syncthreads();
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  const int s_end = min((int)(blockIdx.x + 1) * LBS_DENSE_CHUNK, u.n);
+  for (int s = blockIdx.x * LBS_DENSE_CHUNK + t; s < s_end; s += 256) {
+    const int vid = u.ids[s];
+    const float* g = dverts + ((size_t)b * u.n + s) * 3;
+    const float* vp = v_posed + ((size_t)b * vp_rows + u.vp_row[s]) * 3;
+    const float gx = g[0], gy = g[1], gz = g[2];
+    const float vx = vp[0], vy = vp[1], vz = vp[2];
+    sx += gx; sy += gy; sz += gz;
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+    const int* wi = c.w_idx + (size_t)vid * c.KW;
+    const float* wv = c.w_val + (size_t)vid * c.KW;
+    for (int k = 0; k < c.KW; ++k) {
+      const float w = wv[k];
+      if (w == 0.f) continue;                                  // ELL padding
+      const int j = wi[k];
+      const float* Aj = As + j * 12;
+      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
+      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
+      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+      float* d = dAs + j * 12;
+      const float wx = w * gx, wy = w * gy, wz = w * gz;       // dA[j][r][:] += w g_r (x) [v, 1]
+      atomicAdd(d + 0, wx * vx); atomicAdd(d + 1, wx * vy); atomicAdd(d + 2, wx * vz); atomicAdd(d + 3, wx);
+      atomicAdd(d + 4, wy * vx); atomicAdd(d + 5, wy * vy); atomicAdd(d + 6, wy * vz); atomicAdd(d + 7, wy);
+      atomicAdd(d + 8, wz * vx); atomicAdd(d + 9, wz * vy); atomicAdd(d + 10, wz * vz); atomicAdd(d + 11, wz);
+    }
+    float* d = dvp + (size_t)b * u.NCs + 3 * s;
+    d[0] = T[0] * gx + T[3] * gy + T[6] * gz;
+    d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
+    d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
+  }
+  __syncthreads();
+  for (int i = t; i < nj * 12; i += 256) {
+    const float v = dAs[i];
+    if (v != 0.f) atomicAdd(dA + (size_t)b * nj * 12 + i, v);
+  }
+  if (dtransl) {
+    const float tx = block_sum(sx, red), ty = block_sum(sy, red), tz = block_sum(sz, red);
+    if (t == 0) { atomicAdd(dtransl + (size_t)b * 3, tx); atomicAdd(dtransl + (size_t)b * 3 + 1, ty); atomicAdd(dtransl + (size_t)b * 3 + 2, tz); }
+  }
+}
+
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s) {
   if (u.n <= 0 || B <= 0 || (u.NCs % 16) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
   (void)Bp;
   if (u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ)
     hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
-  else
+  else if (nj <= 64) {
+    hipLaunchKernelGGL(lbs_bwd_zero_kernel, dim3(B), dim3(256), 0, s, dvp, u.NCs, 3 * u.n, dA, nj * 12, dtransl);
+    hipLaunchKernelGGL(lbs_bwd_dense_kernel, dim3((u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK, B), dim3(256), 0, s, c, u, A, nj,
+                       v_posed, vp_rows, dverts, dvp, dA, dtransl);
+  } else
     hipLaunchKernelGGL((lbs_bwd_frame_kernel<false>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
   int e = (int)hipGetLastError();
   if (e) return e;
