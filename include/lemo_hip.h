@@ -33,6 +33,10 @@ int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const
                       int H, int W, int cin, int cout, int epi, int variant, void* stream);
 /* LDS-tiled variant (the engine's default): additionally takes the channel-group-major pack
  * wt2[Cin/8][tap][Cout][8]; W must satisfy 127 + 2*(127/W+1) + 2*(W+2) + 3 <= 416 (W <= 139) */
+/* variant 0 with the K = 9 Cin reduction split over `ks` slices (grid.z) + a combine pass; for layers with few pixels
+ * and many channels (too few tiles to fill the chip).  partial: ks * (cout/8) * (H+2)*(W+2) * 8 floats of scratch. */
+int lemo_conv3x3_mfma_splitk(const float* in, const float* wt, const float* bias, const float* aux, float* out,
+                             float* partial, int ks, int H, int W, int cin, int cout, int epi, void* stream);
 int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux,
                           float* out, int H, int W, int cin, int cout, int epi, void* stream);
 /* diagnostics: same launch (epi 0, Cout % 64 == 0) that also records, per wave, {HW_ID, XCC_ID, start, end}

@@ -116,6 +116,7 @@ class LemoHipError(RuntimeError):
 _SIGS = {
     'lemo_abi_version': (C.c_int, []),
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma_splitk': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_lbs_set_variant': (C.c_int, [C.c_int]),
     'lemo_capture_begin': (C.c_int, [vp]),

@@ -50,16 +50,22 @@ conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  const int nit = 9 * cin_g;
+  // split-K: grid.z slices the 9 * Cin/8 (tap, channel group) steps; EPI 3 writes raw partial sums of slice z to
+  // out + z * (Cout/8 * HWp * 8) and conv_splitk_combine_kernel finishes (layers with few pixels and many channels
+  // -- the infilling AE at 27x17 .. 14x9 -- have too few tiles to fill the chip otherwise: one wave would run
+  // 1152 fp32 MFMAs = 70 us)
+  const int nit_all = 9 * cin_g;
+  const int it_lo = (int)((long)nit_all * blockIdx.z / gridDim.z), nit = (int)((long)nit_all * (blockIdx.z + 1) / gridDim.z);
+  if (EPI == 3) out += (size_t)blockIdx.z * ((size_t)(cout >> 3) * HWp * 8);
+  int tap = it_lo / cin_g, g = it_lo - tap * cin_g;
   float4 a_cur[MT], b_cur;
   {
-    const int tapoff = -Wp - 1;
-    b_cur = ld4(in_l + (std::ptrdiff_t)tapoff * 8);
+    const int dy0 = tap / 3 - 1, dx0 = tap - (tap / 3) * 3 - 1;
+    b_cur = ld4(in_l + (std::ptrdiff_t)(dy0 * Wp + dx0) * 8 + (size_t)g * in_gstride);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[m] = ld4(wt_l + (size_t)m * 256);
+    for (int m = 0; m < MT; ++m) a_cur[m] = ld4(wt_l + (size_t)it_lo * wt_itstride + (size_t)m * 256);
   }
-  int tap = 0, g = 0;
-  for (int it = 0; it < nit; ++it) {
+  for (int it = it_lo; it < nit; ++it) {
     float4 a_nxt[MT], b_nxt;
     int g2 = g + 1, tap2 = tap;
     if (g2 == cin_g) { g2 = 0; tap2 = tap + 1; }
@@ -96,7 +102,8 @@ conv3x3_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
         const int c0 = m_base + m * 32 + q * 8 + 4 * h;          // first of 4 consecutive couts
         const size_t o = ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7);
         float4 v = make_float4(acc[m][4 * q + 0], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]);
-        if (EPI == 0 || EPI == 2) {
+        if (EPI == 3) {
+        } else if (EPI == 0 || EPI == 2) {
           const float4 bb = ld4(bias + c0);
           v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
           if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
@@ -512,6 +519,44 @@ int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const f
   if (cpb == 64) { if (epi == 0) LAUNCH2(0, 512); else if (epi == 1) LAUNCH2(1, 512); else LAUNCH2(2, 512); }
   else           { if (epi == 0) LAUNCH2(0, 256); else if (epi == 1) LAUNCH2(1, 256); else LAUNCH2(2, 256); }
 #undef LAUNCH2
+  return (int)hipGetLastError();
+}
+
+// out = epilogue(sum_z partial[z]) over the interior pixels (slices summed in a fixed order)
+template <int EPI>
+__global__ void __launch_bounds__(256)
+conv_splitk_combine_kernel(const float* __restrict__ partial, int ks, const float* __restrict__ bias, const float* __restrict__ aux,
+                           float* __restrict__ out, int H, int W, int cout) {
+  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * (cout >> 3) * 2) return;
+  const int half = idx & 1, rest = idx >> 1;
+  const int g = rest / P, p = rest - g * P;
+  const int y = p / W, x = p - y * W;
+  const size_t o = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8 + 4 * half;
+  const size_t slice = (size_t)(cout >> 3) * HWp * 8;
+  float4 v = ld4(partial + o);
+  for (int z = 1; z < ks; ++z) {
+    const float4 t = ld4(partial + z * slice + o);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  conv_store4<EPI>(out, bias, aux, o, g * 8 + 4 * half, v);
+}
+
+int conv3x3_mfma_splitk(const float* in, const float* wt, const float* bias, const float* aux, float* out, float* partial, int ks,
+                        int H, int W, int cin, int cout, int epi, hipStream_t s) {
+  if (cin % 8 || cout % 32 || H <= 0 || W <= 0 || epi < 0 || epi > 2 || ks < 1 || ks > 9 * (cin / 8) || !partial) return LEMO_ERR_SHAPE;
+  const int P = H * W;
+  const int mt = (cout % 64 == 0) ? 2 : 1;
+  dim3 grid((P + 127) / 128, cout / (mt * 32), ks);
+  if (mt == 2) hipLaunchKernelGGL((conv3x3_mfma_kernel<2, 3>), grid, dim3(256), 0, s, in, wt, bias, aux, partial, H, W, cin / 8, cout);
+  else hipLaunchKernelGGL((conv3x3_mfma_kernel<1, 3>), grid, dim3(256), 0, s, in, wt, bias, aux, partial, H, W, cin / 8, cout);
+  int e = (int)hipGetLastError();
+  if (e) return e;
+  const int nthr = P * (cout / 8) * 2;
+#define COMBINE(EPI_) hipLaunchKernelGGL((conv_splitk_combine_kernel<EPI_>), dim3((nthr + 255) / 256), dim3(256), 0, s, partial, ks, bias, aux, out, H, W, cout)
+  if (epi == 0) COMBINE(0); else if (epi == 1) COMBINE(1); else COMBINE(2);
+#undef COMBINE
   return (int)hipGetLastError();
 }
 

@@ -9,6 +9,8 @@ namespace lemo {
 // ---------------- conv_kernels.hip ----------------
 int conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
                  int H, int W, int cin, int cout, int epi, int variant, hipStream_t s);
+int conv3x3_mfma_splitk(const float* in, const float* wt, const float* bias, const float* aux, float* out, float* partial, int ks,
+                        int H, int W, int cin, int cout, int epi, hipStream_t s);
 int conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux, float* out,
                      int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
 int conv_lds_init();

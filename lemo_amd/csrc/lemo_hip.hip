@@ -19,6 +19,11 @@ int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const
   if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma(in, wt, bias, aux, out, H, W, cin, cout, epi, variant, S(stream));
 }
+int lemo_conv3x3_mfma_splitk(const float* in, const float* wt, const float* bias, const float* aux, float* out,
+                             float* partial, int ks, int H, int W, int cin, int cout, int epi, void* stream) {
+  if (!in || !wt || !out || !partial || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
+  return conv3x3_mfma_splitk(in, wt, bias, aux, out, partial, ks, H, W, cin, cout, epi, S(stream));
+}
 int lemo_conv3x3_mfma_lds(const float* in, const float* wt, const float* wt2, const float* bias, const float* aux,
                           float* out, int H, int W, int cin, int cout, int epi, void* stream) {
   if (!in || !wt || !wt2 || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;

@@ -79,6 +79,15 @@ def _layers() -> List[_Layer]:
 
 
 def _conv(lib, x, wt, bias, aux, out, H, W, cin, cout, epi, s):
+    # one wave owns a 32 px x (32|64) cout tile over the whole K = 9 Cin: layers with few pixels and many channels have
+    # too few tiles for the chip (256 x 256 at 27 x 17: 64 waves running 1152 fp32 MFMAs each = 70 us) -> split K
+    waves = ((H * W + 31) // 32) * (cout // (64 if cout % 64 == 0 else 32))
+    ks = min(8, 9 * (cin // 8), max(1, 1024 // max(waves, 1)))
+    if ks >= 2:
+        part = torch.empty(ks * (cout // 8) * (H + 2) * (W + 2) * 8, dtype=torch.float32, device=out.device)
+        lib.check(lib.conv3x3_mfma_splitk(ptr(x), ptr(wt), ptr(bias), ptr(aux), ptr(out), ptr(part), ks, H, W, cin, cout, epi, s),
+                  'conv3x3_mfma_splitk')
+        return
     lib.check(lib.conv3x3_mfma(ptr(x), ptr(wt), ptr(bias), ptr(aux), ptr(out), H, W, cin, cout, epi, 0, s), 'conv3x3_mfma')
 
 

@@ -292,3 +292,24 @@ def test_dense_vertex_backward_large_set(emu_lib):
     assert rel_err(out.vertices.detach(), v_ref.detach()) < 1e-4
     for k in p:
         assert rel_err(p[k].grad, q[k].grad) < 1e-4, k
+
+
+@pytest.mark.parametrize('ci,co,ks', [(64, 64, 4), (40, 32, 7), (128, 64, 8)])
+def test_conv3x3_splitk_matches_reference(emu_lib, ci, co, ks):
+    """variant 0 with the K reduction split over ks grid slices + the combine pass (uneven slice sizes included),
+    forward and backward-data epilogues"""
+    g = torch.Generator().manual_seed(ci + co + ks)
+    H, W = 9, 17
+    x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
+    ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    xin, out, wt = to_cg8p(x), cg8p_alloc(co, H, W, 'cpu'), torch.from_numpy(pack_conv3x3(w.numpy()))
+    part = torch.full((ks * (co // 8) * (H + 2) * (W + 2) * 8,), float('nan'))
+    assert emu_lib.conv3x3_mfma_splitk(ptr(xin), ptr(wt), ptr(b), None, ptr(out), ptr(part), ks, H, W, ci, co, 0, None) == 0
+    assert rel_err(from_cg8p(out, H, W), ref) < 2e-6
+    assert float(out.reshape(co // 8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0
+    aux = torch.randn(co, H, W, generator=g)
+    auxb = to_cg8p(aux)
+    assert emu_lib.conv3x3_mfma_splitk(ptr(xin), ptr(wt), None, ptr(auxb), ptr(out), ptr(part), ks, H, W, ci, co, 1, None) == 0
+    ref1 = F.conv2d(x[None], w, None, padding=1)[0] * torch.where(aux > 0, 1.0, 0.2)
+    assert rel_err(from_cg8p(out, H, W), ref1) < 2e-6
+    assert emu_lib.conv3x3_mfma_splitk(ptr(xin), ptr(wt), ptr(b), None, ptr(out), ptr(part), 9 * (ci // 8) + 1, H, W, ci, co, 0, None) != 0
