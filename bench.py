@@ -87,7 +87,7 @@ def pmc_traffic(conv_variant):
     profiles/r01_pmc_summary.json): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
     the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled."""
     path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    name = {2: 'lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>', 3: 'lemo::conv3x3_split_kernel<0, false>'}.get(conv_variant)
+    name = {2: 'lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>', 3: 'lemo::conv3x3_split_kernel<0, 64, 64, false>'}.get(conv_variant)
     if name is None or not os.path.exists(path):
         return None
     d = json.load(open(path)).get(name)
