@@ -19,6 +19,7 @@
 // accumulator map (col=l&31 -> pixel, row=(r&3)+8*(r>>2)+4*(l>>5) -> cout) makes the epilogue a
 // dwordx4 store per (lane, 8-cout group): 1 KiB contiguous per wave again.
 #include "conv_common.hpp"
+#include "loss_device.hpp"
 
 namespace lemo {
 
@@ -654,46 +655,11 @@ int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, 
   return (int)hipGetLastError();
 }
 
-// ---- latent smoothness loss (opt_amass_temp.py:390-391) + its gradient, fused ------------------
-//   loss = mean_{c,y,x<W-1} (z[c,y,x+1]-z[c,y,x])^2
-//   dpre[c,y,x] = coef * 2 * ((z[x]-z[x-1])[x>=1] - (z[x+1]-z[x])[x<=W-2]) * lrelu'(z[c,y,x])
-// with coef = weight / (C*H*(W-1)).  Per-block partial sums of the squared differences go to
-// `partial[blockIdx.x]` (fixed-order final reduction elsewhere -> deterministic).
+// (body: loss_device.hpp)
 __global__ void __launch_bounds__(256)
 smooth_loss_kernel(const float* __restrict__ z, float* __restrict__ dpre, float* __restrict__ partial,
                    int H, int W, int C, float coef2, double* __restrict__ acc) {
-  __shared__ float red[4];
-  const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = P * (C >> 3) * 2;                                   // one thread per float4
-  float sq = 0.f;
-  if (idx < n) {
-    const int half = idx & 1, rest = idx >> 1;
-    const int g = rest / P, p = rest - g * P;
-    const int y = p / W, x = p - y * W;
-    const size_t o = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8 + 4 * half;
-    const float4 c = ld4(z + o);
-    float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 1) {
-      const float4 l = ld4(z + o - 8);
-      gr.x += c.x - l.x; gr.y += c.y - l.y; gr.z += c.z - l.z; gr.w += c.w - l.w;
-    }
-    if (x <= W - 2) {
-      const float4 r = ld4(z + o + 8);
-      const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
-      sq = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-      gr.x -= d0; gr.y -= d1; gr.z -= d2; gr.w -= d3;
-    }
-    st4(dpre + o, make_float4(coef2 * gr.x * lrelu_grad_from_out(c.x), coef2 * gr.y * lrelu_grad_from_out(c.y),
-                              coef2 * gr.z * lrelu_grad_from_out(c.z), coef2 * gr.w * lrelu_grad_from_out(c.w)));
-  }
-  const float s = block_sum(sq, red);
-  if (threadIdx.x == 0) {
-    // f64 accumulation (order effects ~1e-16, invisible after the f32 cast), spread over 32 slots of 16
-    // doubles: 2000+ blocks on ONE address serialise in L2 (measured 28 us)
-    if (acc) atomicAdd(acc + (blockIdx.x & 31) * 16, (double)s);
-    else partial[blockIdx.x] = s;
-  }
+  smooth_loss_body((int)blockIdx.x, z, dpre, partial, H, W, C, coef2, acc);
 }
 
 int smooth_loss_blocks(int H, int W, int C) { return (H * W * (C / 8) * 2 + 255) / 256; }

@@ -92,6 +92,9 @@ int marker_feature(const FitConst& fc, const float* verts, int nrows, const floa
                    float* x0, float* canon, hipStream_t s);
 // acc (f64[16], zeroed at the start of the iteration): [0] marker L1 sum, [1..4] contact sums, [5..8] contact
 // counts, [9] smoothness sum of squares, [10] sum z^2, [11] sum betas^2, [12] sum hands^2
+int fit_losses(const float* z, float* dpre, int H, int W, int C, float coef2, double* sm_acc, const FitConst& fc, const float* verts,
+               int nrows, const float* target, const float* contact, const float* shape, const float* other, int B, double* acc,
+               hipStream_t s);
 int vertex_loss_accumulate(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
                            const float* shape, const float* other, int B, double* acc, hipStream_t s);
 int loss_finalize(const double* acc, int B, int n67, double smooth_count, const float* weights, float* losses, hipStream_t s);

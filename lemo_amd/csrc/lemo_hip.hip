@@ -263,8 +263,8 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
-  CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 9));
-  CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
+  CHK(fit_losses(d.act[10], d.dact[0], H, W, d.enc_ch[10], coef2, d.loss_acc + 9, d.fit, d.verts, d.nrows, d.target, d.contact,
+                 d.shape, d.other, B, d.loss_acc, s));
   if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, cnt, d.weights, d.losses, s));
   return 0;
 }

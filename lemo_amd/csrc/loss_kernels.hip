@@ -2,7 +2,7 @@
 // w.r.t. the vertices that carry loss, and the Adam update (opt_amass_temp.py:342-352,454-455).
 // All data-dependent branches of the reference (`.item()` host syncs at :431-443) are evaluated on
 // the device: counts go through a tiny finalize kernel, nothing ever returns to the host.
-#include "kernels.hpp"
+#include "loss_device.hpp"
 
 namespace lemo {
 
@@ -67,53 +67,33 @@ int marker_feature(const FitConst& fc, const float* verts, int nrows, const floa
   return (int)hipGetLastError();
 }
 
-// Loss accumulators (f64 [32 slots][16], zeroed at the start of every iteration by the pose-stage kernel;
-// a block adds to slot blockIdx & 31 to keep the L2 atomics from serialising on one address):
-//   [0] marker L1 sum ; [1+k] contact-velocity sum, [5+k] count (k = 4 foot sets) ; [9] smoothness sum of
-//   squares ; [10] sum z^2 ; [11] sum betas^2 ; [12] sum hands^2.
-// Accumulating f32 block sums into f64 with atomics is order-dependent only at ~1e-16 relative, far
-// below the f32 value that is finally reported.
+// (bodies: loss_device.hpp)
 __global__ void __launch_bounds__(256)
 vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                               const float* __restrict__ contact, const float* __restrict__ shape,
                               const float* __restrict__ other, int B, double* __restrict__ accg) {
-  __shared__ float red[4][12];
-  const int b = blockIdx.x, t = threadIdx.x;
-  float acc[12];
-  for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-  for (int w = t; w < fc.n67 * 3; w += 256) {
-    const int m = w / 3, c = w % 3;
-    acc[0] += fabsf(verts[((size_t)b * nrows + fc.row67[m]) * 3 + c] - target[((size_t)b * fc.n67 + m) * 3 + c]);
-  }
-  if (b < B - 1) {
-    for (int k = 0; k < 4; ++k) {
-      if (contact[(size_t)b * 4 + k] != 1.f) continue;
-      for (int q = fc.foot_start[k] + t; q < fc.foot_start[k + 1]; q += 256) {
-        const float* v0 = verts + ((size_t)b * nrows + fc.foot_row[q]) * 3;
-        const float* v1 = v0 + (size_t)nrows * 3;
-        const float vx = (v1[0] - v0[0]) * 30.f, vy = (v1[1] - v0[1]) * 30.f, vz = (v1[2] - v0[2]) * 30.f;
-        const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
-        if (sp - 0.1f > 0.f) { acc[1 + k] += sp; acc[5 + k] += 1.f; }
-      }
-    }
-  }
-  // L2 priors of this frame (opt_amass_temp.py:397-404): z (32), betas (10), hands (24)
-  if (t < 32) { const float v = other[(size_t)b * 56 + t]; acc[9] = v * v; }
-  else if (t >= 64 && t < 74) { const float v = shape[(size_t)b * 10 + (t - 64)]; acc[10] = v * v; }
-  else if (t >= 128 && t < 152) { const float v = other[(size_t)b * 56 + 32 + (t - 128)]; acc[11] = v * v; }
-  // 12 wave sums, ONE barrier, then 12 threads finish and publish in parallel (was: 12 block sums = 24 barriers,
-  // 12 serial atomics from thread 0); the order of the adds is fixed -> deterministic
-#pragma unroll
-  for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
-  if ((t & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) red[t >> 6][i] = acc[i];
-  }
-  __syncthreads();
-  if (t < 12) {
-    const float v = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-    if (v != 0.f) atomicAdd(accg + (b & 31) * 16 + (t < 9 ? t : t + 1), (double)v);
-  }
+  vertex_loss_body((int)blockIdx.x, fc, verts, nrows, target, contact, shape, other, B, accg);
+}
+
+// both post-encoder loss kernels in one launch: blocks [0, nsm) = smoothness loss + d(pre-activation), the rest =
+// per-frame vertex losses and priors
+__global__ void __launch_bounds__(256)
+fit_losses_kernel(int nsm, const float* __restrict__ z, float* __restrict__ dpre, int H, int W, int C, float coef2, double* __restrict__ sm_acc,
+                  FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
+                              const float* __restrict__ contact, const float* __restrict__ shape,
+                              const float* __restrict__ other, int B, double* __restrict__ accg) {
+  if ((int)blockIdx.x < nsm) smooth_loss_body((int)blockIdx.x, z, dpre, nullptr, H, W, C, coef2, sm_acc);
+  else vertex_loss_body((int)blockIdx.x - nsm, fc, verts, nrows, target, contact, shape, other, B, accg);
+}
+
+int fit_losses(const float* z, float* dpre, int H, int W, int C, float coef2, double* sm_acc, const FitConst& fc, const float* verts,
+               int nrows, const float* target, const float* contact, const float* shape, const float* other, int B, double* acc,
+               hipStream_t s) {
+  if (C % 8 || !sm_acc) return LEMO_ERR_SHAPE;
+  const int nsm = smooth_loss_blocks(H, W, C);
+  hipLaunchKernelGGL(fit_losses_kernel, dim3(nsm + B), dim3(256), 0, s, nsm, z, dpre, H, W, C, coef2, sm_acc, fc, verts, nrows, target,
+                     contact, shape, other, B, acc);
+  return (int)hipGetLastError();
 }
 
 int vertex_loss_accumulate(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
