@@ -365,6 +365,7 @@ static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 // only ever applied to wave-uniform values in the kernels
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
