@@ -155,6 +155,7 @@ typedef struct lemo_vertex_set_bwd {
   int n, NCs;
   const int *ids, *vp_row;
   const float* Dk;          /* [512][NCs] */
+  const float* DkT;         /* [NCs][512]: the same directions feature-contiguous (forward over the set), or NULL */
   const int *jcsr_start, *jcsr_u;
   const float* jcsr_w;
 } lemo_vertex_set_bwd;
@@ -167,6 +168,10 @@ int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const 
 /* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */
 int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                               int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream);
+/* forward over a small vertex set U only: verts / v_posed [B][u->n][3] in U's order, identical arithmetic
+ * per vertex up to the summation order of the blend GEMM; blend: [B][u->NCs] floats of scratch; needs u->DkT */
+int lemo_lbs_verts_fwd_active(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* Xg, int Bp, const float* A,
+                              int nj, const float* transl, int B, float* blend, float* verts, float* v_posed, void* stream);
 int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
                        int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
                        void* stream);

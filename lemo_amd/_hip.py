@@ -61,7 +61,7 @@ class SkinConst(C.Structure):
 
 class VertexSetBwd(C.Structure):
     _fields_ = [('n', C.c_int), ('NCs', C.c_int)] + \
-        [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'jcsr_start', 'jcsr_u', 'jcsr_w')]
+        [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'DkT', 'jcsr_start', 'jcsr_u', 'jcsr_w')]
 
 
 class FitConst(C.Structure):
@@ -119,6 +119,7 @@ _SIGS = {
     'lemo_conv3x3_mfma_splitk': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_lbs_set_variant': (C.c_int, [C.c_int]),
+    'lemo_lbs_verts_fwd_active': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
     'lemo_capture_begin': (C.c_int, [vp]),
     'lemo_capture_end': (C.c_int, [vp, C.POINTER(C.c_void_p)]),
     'lemo_graph_launch': (C.c_int, [vp, vp]),

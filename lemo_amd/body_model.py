@@ -140,7 +140,10 @@ class BodyModelData:
         for j in range(self.nj):
             u, k = np.nonzero((wi == j) & (wv != 0))
             ju.append(u.astype(np.int32)); jw.append(wv[u, k].astype(np.float32)); js.append(js[-1] + u.shape[0])
-        return dict(n=n, NCs=NCs, ids=ids.astype(np.int32),
+        extra = {}
+        if n <= 4096:          # small sets also get the feature-contiguous copy used by the small-set FORWARD
+            extra['DkT'] = np.ascontiguousarray(Dk.T)
+        return dict(n=n, NCs=NCs, ids=ids.astype(np.int32), **extra,
                     vp_row=(ids if vp_row is None else np.asarray(vp_row)).astype(np.int32), Dk=Dk,
                     jcsr_start=np.asarray(js, np.int32),
                     jcsr_u=np.concatenate(ju + [np.zeros(1, np.int32)]), jcsr_w=np.concatenate(jw + [np.zeros(1, np.float32)]))
@@ -169,6 +172,7 @@ class DeviceBody:
             s = self.data.vertex_set(ids, vp_row)
             tt = {k: torch.from_numpy(v).to(self.device) for k, v in s.items() if isinstance(v, np.ndarray)}
             st = _hip.VertexSetBwd(s['n'], s['NCs'], ptr(tt['ids']), ptr(tt['vp_row']), ptr(tt['Dk']),
+                                   ptr(tt['DkT']) if 'DkT' in tt else None,
                                    ptr(tt['jcsr_start']), ptr(tt['jcsr_u']), ptr(tt['jcsr_w']))
             self._sets[key] = (st, tt)
         return self._sets[key]

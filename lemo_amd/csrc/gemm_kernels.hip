@@ -16,7 +16,8 @@ namespace lemo {
 template <int EPI>
 __global__ void __launch_bounds__(256)
 gemm_nt16_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K,
-                 float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ aux, int ldaux) {
+                 float* __restrict__ C, int ldc, const float* __restrict__ bias, const float* __restrict__ aux, int ldaux,
+                 int b_kg8 /* 0: B row-major [N][ldb] ; else B in KG8 layout [K/8][b_kg8 rows][8] (the pose stage's Xg) */) {
   __shared__ __attribute__((aligned(16))) float red[4][64][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -24,7 +25,11 @@ gemm_nt16_kernel(const float* __restrict__ Am, int lda, const float* __restrict_
   const int mt = blockIdx.x % mtiles, nt = blockIdx.x / mtiles;
   const int nrow = nt * 16 + i;
   const float* ap = Am + (size_t)(mt * 16 + i) * lda + 4 * q;
-  const float* bp = Bm + (size_t)(nrow < N ? nrow : N - 1) * ldb + 4 * q;
+  // KG8: element (n, k) sits at ((k >> 3) * rows + n) * 8 + (k & 7); lane quarter q reads k = 16 c + 4 q .. + 3,
+  // i.e. group 2 c + (q >> 1), floats 4 (q & 1) ..: affine in the chunk index c with step 16 * rows
+  const int nclamp = nrow < N ? nrow : N - 1;
+  const float* bp = b_kg8 ? Bm + ((size_t)(q >> 1) * b_kg8 + nclamp) * 8 + 4 * (q & 1) : Bm + (size_t)nclamp * ldb + 4 * q;
+  const int bstep = b_kg8 ? 16 * b_kg8 : 16;
   const int k16 = K >> 4, per = (k16 + 3) >> 2;
   const int c0 = wave * per, c1 = (c0 + per < k16) ? c0 + per : k16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -34,7 +39,7 @@ gemm_nt16_kernel(const float* __restrict__ Am, int lda, const float* __restrict_
     for (int u = 0; u < GEMM_MAXCH; ++u) {
       const int c = (cb + u < c1) ? cb + u : c1 - 1;             // clamp: unconditional loads
       a[u] = ld4(ap + c * 16);
-      b[u] = ld4(bp + c * 16);
+      b[u] = ld4(bp + (size_t)c * bstep);
     }
     __builtin_amdgcn_sched_barrier(0);                           // all loads in flight before the MFMA chain
 #pragma unroll
@@ -76,9 +81,18 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
   if ((epi == 1 || epi == 2) && !bias) return LEMO_ERR_ARG;
   if (epi == 3 && (!aux || (ldaux & 3))) return LEMO_ERR_ARG;
   const dim3 grid((M >> 4) * ((N + 15) >> 4));
-#define GL(E) hipLaunchKernelGGL((gemm_nt16_kernel<E>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, C, ldc, bias, aux, ldaux)
+#define GL(E) hipLaunchKernelGGL((gemm_nt16_kernel<E>), grid, dim3(256), 0, s, A, lda, B, ldb, M, N, K, C, ldc, bias, aux, ldaux, 0)
   if (epi == 0) GL(0); else if (epi == 1) GL(1); else if (epi == 2) GL(2); else if (epi == 3) GL(3); else return LEMO_ERR_ARG;
 #undef GL
+  return (int)hipGetLastError();
+}
+
+// C[n][m] = sum_k A[m][k] * X(n, k) with X in the KG8 layout [K/8][rows][8]
+int gemm_nt16_kg8(const float* A, int lda, const float* Xg, int rows, int M, int N, int K, float* C, int ldc, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M & 15) || (K & 15) || (lda & 3) || (ldc & 3) || N > rows) return LEMO_ERR_SHAPE;
+  const dim3 grid((M >> 4) * ((N + 15) >> 4));
+  hipLaunchKernelGGL((gemm_nt16_kernel<0>), grid, dim3(256), 0, s, A, lda, Xg, 0, M, N, K, C, ldc, (const float*)nullptr,
+                     (const float*)nullptr, 0, rows);
   return (int)hipGetLastError();
 }
 

@@ -35,6 +35,8 @@ int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C
 int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
               const float* bias, const float* aux, int ldaux, int epi, hipStream_t s);
 
+int gemm_nt16_kg8(const float* A, int lda, const float* Xg, int rows, int M, int N, int K, float* C, int ldc, hipStream_t s);
+
 // ---------------- pose_kernels.hip ----------------
 typedef lemo_vposer_w VPoserW;
 typedef lemo_body_const BodyConst;
@@ -63,6 +65,8 @@ int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, c
 // ---------------- lbs_kernels.hip ----------------
 int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
+int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
+                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s);
 int lbs_set_variant(int v);         // 1 (default): split-bf16 blend GEMM ; 0: fp32-MFMA blend GEMM
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);

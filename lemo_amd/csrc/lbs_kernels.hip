@@ -333,6 +333,64 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward restricted to a small vertex set U (the AMASS losses touch 253 of 10475 vertices).  The tiled
+// kernel above is built for all vertices (42-vertex tiles x the full K on one CU each: 7 busy CUs and ~37 us for
+// n = 253); here the blend is a small MFMA GEMM over U's compact transposed directions DkT [3n -> NCs][512]
+// (384 workgroups, split-K inside each) followed by a thread-per-(frame, vertex) skinning pass.
+//   blend [B][NCs] scratch (the engine passes its d(v_posed) buffer, free during the forward pass)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+lbs_skin_active_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ blend, const float* __restrict__ A, int nj,
+                       const float* __restrict__ transl, int B, float* __restrict__ verts, float* __restrict__ v_posed) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * u.n) return;
+  const int b = idx / u.n, s = idx - b * u.n;
+  const int vid = u.ids[s];
+  const float* bl = blend + (size_t)b * u.NCs + 3 * s;
+  const float px = bl[0] + c.v_template[(size_t)vid * 3], py = bl[1] + c.v_template[(size_t)vid * 3 + 1],
+              pz = bl[2] + c.v_template[(size_t)vid * 3 + 2];
+  const int* wi = c.w_idx + (size_t)vid * c.KW;
+  const float* wv = c.w_val + (size_t)vid * c.KW;
+  const float* Af = A + (size_t)b * nj * 12;
+  float T[12];
+#pragma unroll
+  for (int e = 0; e < 12; ++e) T[e] = 0.f;
+  for (int k0 = 0; k0 < c.KW; k0 += 4) {                       // 4 (joint, weight) pairs per round trip
+    int ji[4]; float wk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int kk = k0 + k < c.KW ? k0 + k : c.KW - 1;
+      ji[k] = wi[kk];
+      wk[k] = k0 + k < c.KW ? wv[kk] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float w = wk[k];
+      const float* Aj = Af + ji[k] * 12;
+      const float4 r0 = ld4(Aj), r1 = ld4(Aj + 4), r2 = ld4(Aj + 8);
+      T[0] = fmaf(w, r0.x, T[0]); T[1] = fmaf(w, r0.y, T[1]); T[2] = fmaf(w, r0.z, T[2]); T[3] = fmaf(w, r0.w, T[3]);
+      T[4] = fmaf(w, r1.x, T[4]); T[5] = fmaf(w, r1.y, T[5]); T[6] = fmaf(w, r1.z, T[6]); T[7] = fmaf(w, r1.w, T[7]);
+      T[8] = fmaf(w, r2.x, T[8]); T[9] = fmaf(w, r2.y, T[9]); T[10] = fmaf(w, r2.z, T[10]); T[11] = fmaf(w, r2.w, T[11]);
+    }
+  }
+  float ox = T[0] * px + T[1] * py + T[2] * pz + T[3];
+  float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+  float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+  if (transl) { ox += transl[(size_t)b * 3]; oy += transl[(size_t)b * 3 + 1]; oz += transl[(size_t)b * 3 + 2]; }
+  float* o = verts + ((size_t)b * u.n + s) * 3;
+  o[0] = ox; o[1] = oy; o[2] = oz;
+  if (v_posed) { float* q = v_posed + ((size_t)b * u.n + s) * 3; q[0] = px; q[1] = py; q[2] = pz; }
+}
+
+int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
+                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s) {
+  if (u.n <= 0 || B <= 0 || B > Bp || (u.NCs % 16) || u.NCs < 3 * u.n || !u.DkT || !blend) return LEMO_ERR_SHAPE;
+  if (int e = gemm_nt16_kg8(u.DkT, 512, Xg, Bp, u.NCs, B, 512, blend, u.NCs, s)) return e;
+  hipLaunchKernelGGL(lbs_skin_active_kernel, dim3((B * u.n + 255) / 256), dim3(256), 0, s, c, u, blend, A, nj, transl, B, verts, v_posed);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward over a vertex set U (all vertices, or only those that carry gradient: the AMASS losses
 // touch 81 markers + 172 heel/toe vertices, opt_amass_temp.py:359,366,414-425 -- every other row of
 // d(verts) is exactly zero, so restricting the backward to U is exact).

@@ -98,6 +98,11 @@ int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const 
   return smplx_pose_bwd(*c, *ws, *gi, *go, B, S(stream));
 }
 int lemo_lbs_set_variant(int variant) { return lbs_set_variant(variant); }
+int lemo_lbs_verts_fwd_active(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* Xg, int Bp, const float* A,
+                              int nj, const float* transl, int B, float* blend, float* verts, float* v_posed, void* stream) {
+  if (!c || !u || !Xg || !A || !blend || !verts) return LEMO_ERR_ARG;
+  return lbs_verts_fwd_active(*c, *u, Xg, Bp, A, nj, transl, B, blend, verts, v_posed, S(stream));
+}
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream) {
   if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;
@@ -237,6 +242,8 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
+  else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
+    CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
   CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
   CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
