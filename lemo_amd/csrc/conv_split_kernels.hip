@@ -243,6 +243,9 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in_p, cons
   CV3_MFMA1(0, SETA, 2, SETB) CV3_MFMA1(2, SETA, 0, SETB) CV3_MFMA1(1, SETA, 1, SETB)              \
   CV3_MFMA1(0, SETA, 1, SETB) CV3_MFMA1(1, SETA, 0, SETB) CV3_MFMA1(0, SETA, 0, SETB)
 
+  // the first two weight fragments are requested before anything else (nothing depends on them)
+  CV3_LOAD_A(0, 0)
+  CV3_LOAD_A(1, 1)
 
   // ---- remainder patch of this block: PPX px x 4 couts ---------------------------------------------
   const int rem0 = full_blocks * 128;
@@ -291,11 +294,6 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in_p, cons
   float4 stB[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) stB[k] = in.ld4(offB[k]);
-  // The staging loads go out FIRST: the activations were just written by the previous kernel and come from the fabric
-  // (~2k cycles), the weight fragments are L2-warm and not needed before the first MFMA -- they follow, pinned behind.
-  __builtin_amdgcn_sched_barrier(0);
-  CV3_LOAD_A(0, 0)
-  CV3_LOAD_A(1, 1)
 
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
