@@ -243,7 +243,9 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in_p, cons
   CV3_MFMA1(0, SETA, 2, SETB) CV3_MFMA1(2, SETA, 0, SETB) CV3_MFMA1(1, SETA, 1, SETB)              \
   CV3_MFMA1(0, SETA, 1, SETB) CV3_MFMA1(1, SETA, 0, SETB) CV3_MFMA1(0, SETA, 0, SETB)
 
-  // the first two weight fragments are requested before anything else (nothing depends on them)
+  // the first two weight fragments are requested before anything else (nothing depends on them; issuing the staging
+  // loads first instead shortens the prologue in isolation but measured 0.5 % slower inside the engine, and moving
+  // the remainder patch's loads into the prologue 1.5 % slower: same-box A/B with tools/gpu_ab_bench.sh)
   CV3_LOAD_A(0, 0)
   CV3_LOAD_A(1, 1)
 
