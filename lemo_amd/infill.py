@@ -54,11 +54,11 @@ class _Layer:
     def __init__(self, name, cin, cout, deconv, cin_pad, cout_pad):
         self.name, self.cin, self.cout, self.deconv, self.cin_pad, self.cout_pad = name, cin, cout, deconv, cin_pad, cout_pad
 
-    def conv_weight(self, w: torch.Tensor) -> torch.Tensor:
+    def conv_weight(self, w: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
         """parameter -> padded conv weight [cout_pad][cin_pad][3][3]"""
         if self.deconv:                                            # ConvTranspose2d weight is [in][out][kh][kw]
             w = w.flip(2, 3).transpose(0, 1)
-        out = torch.zeros(self.cout_pad, self.cin_pad, 3, 3, dtype=torch.float32, device=w.device)
+        out = torch.full((self.cout_pad, self.cin_pad, 3, 3), fill, dtype=torch.float32, device=w.device)
         out[:self.cout, :self.cin] = w
         return out
 
@@ -91,22 +91,85 @@ def _conv(lib, x, wt, bias, aux, out, H, W, cin, cout, epi, s):
     lib.check(lib.conv3x3_mfma(ptr(x), ptr(wt), ptr(bias), ptr(aux), ptr(out), H, W, cin, cout, epi, 0, s), 'conv3x3_mfma')
 
 
+class _FlatTables:
+    """Gather indices between the FLAT parameter vector (weights and biases in `_layers()` order, each in the
+    parameter's own layout, plus one trailing zero) and the packed operands of the kernels.  Built once per device by
+    running the packing code on index tensors, so a training step needs three gathers instead of ~250 small
+    zero / copy / flip / permute launches:
+        packed forward weights  = flat[idx_fwd]      (all 20 layers back to back, views per layer)
+        padded biases           = flat[idx_bias]
+        packed backward weights = flat[idx_bwd]
+        flat gradient           = dwdb[idx_grad]     (dwdb = conv-layout weight grads + bias grads of all layers)"""
+    _cache: Dict[str, '_FlatTables'] = {}
+
+    def __init__(self, device):
+        L = _layers()
+        self.L = L
+        offs, o = [], 0
+        for l in L:
+            nw = l.cout * l.cin * 9
+            offs.append((o, o + nw))                            # weight start, bias start
+            o += nw + l.cout
+        self.n_param = o
+        Z = o                                                   # index of the trailing zero
+        fwd, bwd, bias, self.sl_fwd, self.sl_bwd, self.sl_bias = [], [], [], [], [], []
+        # position of every conv-layout gradient entry in dwdb, and the inverse map flat-param -> dwdb
+        grad_idx = torch.empty(self.n_param, dtype=torch.int64)
+        self.dw_off, self.db_off, g = [], [], 0
+        for l, (ow, ob) in zip(L, offs):
+            pshape = (l.cin, l.cout, 3, 3) if l.deconv else (l.cout, l.cin, 3, 3)
+            idx = (ow + torch.arange(l.cout * l.cin * 9, dtype=torch.float32)).reshape(pshape)
+            assert ob < 2 ** 24                                 # float32 carries the indices exactly through the packers
+            cw = l.conv_weight(idx, fill=float(Z))
+            for lst, sl, packer in ((fwd, self.sl_fwd, _pack_fwd), (bwd, self.sl_bwd, _pack_bwd)):
+                pk = packer(cw).reshape(-1).long()
+                sl.append((sum(t.numel() for t in lst), pk.numel(), pk.numel()))
+                lst.append(pk)
+            bi = torch.full((l.cout_pad,), Z, dtype=torch.int64)
+            bi[:l.cout] = ob + torch.arange(l.cout)
+            self.sl_bias.append((sum(t.numel() for t in bias), l.cout_pad))
+            bias.append(bi)
+            # gradients: the kernel writes dw in conv layout [cout][cin][3][3]; the parameter wants param_grad(dw)
+            self.dw_off.append(g)
+            didx = (g + torch.arange(l.cout * l.cin * 9, dtype=torch.float32)).reshape(l.cout, l.cin, 3, 3)
+            grad_idx[ow:ob] = l.param_grad(didx).reshape(-1).long()
+            g += l.cout * l.cin * 9
+            self.db_off.append(g)
+            grad_idx[ob:ob + l.cout] = g + torch.arange(l.cout)
+            g += l.cout
+        self.n_dwdb = g
+        dev = torch.device(device)
+        self.idx_fwd, self.idx_bwd = torch.cat(fwd).to(dev), torch.cat(bwd).to(dev)
+        self.idx_bias, self.idx_grad = torch.cat(bias).to(dev), grad_idx.to(dev)
+
+    @classmethod
+    def get(cls, device) -> '_FlatTables':
+        k = str(device)
+        if k not in cls._cache:
+            cls._cache[k] = cls(device)
+        return cls._cache[k]
+
+
+def flatten_params(params) -> torch.Tensor:
+    """weights and biases in `_layers()` order -> one flat vector (differentiable: autograd splits the gradient back)"""
+    return torch.cat([p.reshape(-1).float() for p in params])
+
+
 class _AEFn(torch.autograd.Function):
-    """(x [4,H,W], *parameters in _layers() order: weight, bias, ...) -> (out [H,W], z [256,h,w])"""
+    """(x [4,H,W], flat parameter vector, see `flatten_params`) -> (out [H,W], z [256,h,w])"""
 
     @staticmethod
-    def forward(ctx, lib, x, *params):
+    def forward(ctx, lib, x, flat):
         x = x.contiguous().float()
         _hip.check_device(lib, x)
         dev, s = x.device, lib.stream(x.device)
-        L = _layers()
-        W_ = [L[i].conv_weight(params[2 * i].detach().float()) for i in range(20)]
-        B_ = []
-        for i in range(20):
-            b = torch.zeros(L[i].cout_pad, dtype=torch.float32, device=dev)
-            b[:L[i].cout] = params[2 * i + 1].detach().float()
-            B_.append(b)
-        Wf = [_pack_fwd(w) for w in W_]
+        T = _FlatTables.get(dev)
+        L = T.L
+        assert flat.numel() == T.n_param
+        flatz = torch.cat([flat.detach().float(), torch.zeros(1, dtype=torch.float32, device=dev)])
+        wf_all, b_all = flatz[T.idx_fwd], flatz[T.idx_bias]
+        Wf = [wf_all[o:o + n] for o, n, _ in T.sl_fwd]
+        B_ = [b_all[o:o + n] for o, n in T.sl_bias]
         H, Wd = x.shape[1:]
         xin = torch.zeros(8, H, Wd, dtype=torch.float32, device=dev)
         xin[:4] = x
@@ -140,29 +203,28 @@ class _AEFn(torch.autograd.Function):
             cur, curH, curW = b2, tH, tW
         out = from_cg8p(cur, H, Wd)[0]
         z = from_cg8p(z_buf, zH, zW)[:256]
-        ctx.lib, ctx.L, ctx.W_, ctx.enc_rec, ctx.dec_rec, ctx.shape = lib, L, W_, enc_rec, dec_rec, (H, Wd, zH, zW)
-        ctx.need_w = any(p.requires_grad for p in params)
+        ctx.lib, ctx.T, ctx.flatz, ctx.enc_rec, ctx.dec_rec, ctx.shape = lib, T, flatz, enc_rec, dec_rec, (H, Wd, zH, zW)
         return out, z
 
     @staticmethod
     def backward(ctx, dout, dz):
-        lib, L, W_ = ctx.lib, ctx.L, ctx.W_
+        lib, T = ctx.lib, ctx.T
+        L = T.L
         H, Wd, zH, zW = ctx.shape
-        dev = W_[0].device
+        dev = ctx.flatz.device
         s = lib.stream(dev)
-        Wb = {i: _pack_bwd(W_[i]) for i in range(1, 20)}              # layer 0 needs no backward-data
-        grads: List[Optional[torch.Tensor]] = [None] * 40
+        wb_all = ctx.flatz[T.idx_bwd]
+        Wb = {i: wb_all[T.sl_bwd[i][0]:T.sl_bwd[i][0] + T.sl_bwd[i][1]] for i in range(1, 20)}   # layer 0 needs no backward-data
+        dwdb = torch.empty(T.n_dwdb, dtype=torch.float32, device=dev)     # every layer's dw (conv layout) and db
         zeros_bias = torch.zeros(256, dtype=torch.float32, device=dev)
         nsl = lambda h, w: lib.conv3x3_wgrad_nslab(h, w)
 
         def wgrad(i, dpre, xin, h, w):
             l = L[i]
             part = torch.empty(nsl(h, w) * 9 * l.cout_pad * l.cin_pad, dtype=torch.float32, device=dev)
-            dw = torch.empty(l.cout, l.cin, 3, 3, dtype=torch.float32, device=dev)
-            db = torch.empty(l.cout, dtype=torch.float32, device=dev)
+            dw, db = dwdb[T.dw_off[i]:T.db_off[i]], dwdb[T.db_off[i]:T.db_off[i] + l.cout]
             lib.check(lib.conv3x3_wgrad(ptr(dpre), ptr(xin), h, w, l.cin_pad, l.cout_pad, l.cin, l.cout, ptr(part), ptr(dw),
                                         ptr(db), s), 'conv3x3_wgrad')
-            grads[2 * i], grads[2 * i + 1] = l.param_grad(dw), db
 
         # ---- decoder, last block first.  dpre = d(pre-activation of the block's deconv2 output)
         d = torch.zeros(32, H, Wd, dtype=torch.float32, device=dev)
@@ -200,7 +262,7 @@ class _AEFn(torch.autograd.Function):
                 dprev = cg8p_alloc(L[i0].cin_pad, h, w, dev)
                 _conv(lib, dpre0, Wb[i0], zeros_bias, None, dprev, h, w, L[i0].cout_pad, L[i0].cin_pad, 2, s)
                 dpre = dprev
-        return (None, None) + tuple(grads)
+        return None, None, dwdb[T.idx_grad]
 
 
 class _Conv(nn.Module):
@@ -246,7 +308,7 @@ class AE(nn.Module):
     def forward(self, x):
         assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 4, 'the infilling prior is fed [1,4,d,T] clips'
         lib = self._lib_override or _hip.get_lib()
-        out, z = _AEFn.apply(lib, x[0], *self.ordered_parameters())
+        out, z = _AEFn.apply(lib, x[0], flatten_params(self.ordered_parameters()))
         return out[None, None], z[None]
 
 
@@ -258,7 +320,9 @@ class FlatAdam:
         self.params, self.lr, self.lib, self.t = [p for p in params if p.requires_grad], lr, lib or _hip.get_lib(), 0
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.cat([p.detach().reshape(-1).float() for p in self.params])
+        # a single flat fp32 leaf is updated in place (no gather of gradients, no copy back)
+        self.inplace = len(self.params) == 1 and self.params[0].dim() == 1 and self.params[0].dtype == torch.float32
+        self.flat = self.params[0].data if self.inplace else torch.cat([p.detach().reshape(-1).float() for p in self.params])
         self.m, self.v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
         self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)      # completed steps (device copy: graph replay)
 
@@ -269,6 +333,11 @@ class FlatAdam:
     @torch.no_grad()
     def step(self):
         self.t += 1
+        if self.inplace:
+            g = self.params[0].grad.contiguous()
+            self.lib.check(self.lib.adam_flat_ctr(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), self.lr,
+                                                  ptr(self.step_ctr), self.lib.stream(self.flat.device)), 'adam_flat')
+            return
         g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in self.params])
         self.lib.check(self.lib.adam_flat_ctr(ptr(self.flat), ptr(g), ptr(self.m), ptr(self.v), self.flat.numel(), self.lr,
                                               ptr(self.step_ctr), self.lib.stream(self.flat.device)), 'adam_flat')
@@ -299,18 +368,18 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     use_graph = bool(use_graph) and steps > 3
 
     def run(stream_ctx):
-        # The step trains fresh leaf copies of the parameters created on the stream the step runs on.  Autograd
+        # The step trains ONE fresh flat leaf copy of the parameters created on the stream the step runs on.  Autograd
         # keeps one AccumulateGrad node per leaf for as long as ANY graph references it and pins it to the stream it
         # was first used on: with the module's own parameters, a caller that still holds an output of an earlier
         # forward (made on another stream) forces a cross-stream event wait into every backward -- fatal inside a
         # stream capture (segfault in hipStreamEndCapture, tools/graph_repro.py).
         with stream_ctx:
-            params = [p.detach().clone().requires_grad_(True) for p in model.ordered_parameters()]
-            opt = FlatAdam(params, lr, lib)
+            flat = flatten_params([p.detach() for p in model.ordered_parameters()]).clone().requires_grad_(True)
+            opt = FlatAdam([flat], lr, lib)
 
             def train_step():
                 opt.zero_grad()
-                rec, _ = _AEFn.apply(lib, clip_img_input[0], *params)
+                rec, _ = _AEFn.apply(lib, clip_img_input[0], flat)
                 loss = ((rec - clip_img_input[0, 0]).abs() * m).sum() / cnt
                 loss.backward()
                 opt.step()
@@ -341,8 +410,10 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
                 finally:
                     lib.check(lib.graph_destroy(exe), 'graph_destroy')
             with torch.no_grad():
-                for p, q in zip(model.ordered_parameters(), params):
-                    p.copy_(q)
+                o = 0
+                for p in model.ordered_parameters():
+                    p.copy_(flat[o:o + p.numel()].view_as(p))
+                    o += p.numel()
 
     if clip_img_input.is_cuda:
         dev = clip_img_input.device
