@@ -474,9 +474,11 @@ def test_infill_ae_full_size_golden_and_finetune(dev):
     (O.ae_forward(wr2, xs)[0][0, 0] * ws).sum().backward()
     for k, p in ae2.named_parameters():
         assert rel_err(p.grad.cpu(), wr2[k].grad) < 1e-4, k
+    wdev0 = {k: v.to(dev) for k, v in w.items()}
+    finetune_and_infill(ae, wdev0, x, mask.to(dev), steps=8, lr=3e-6)       # one-time: gather tables, LDS opt-ins, allocator
     torch.cuda.synchronize()
     t0 = time.time()
-    rec, zz = finetune_and_infill(ae, {k: v.to(dev) for k, v in w.items()}, x, mask.to(dev), steps=60, lr=3e-6)
+    rec, zz = finetune_and_infill(ae, wdev0, x, mask.to(dev), steps=60, lr=3e-6)
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f'infilling AE (training step captured in a graph): 60 finetune steps + eval at [1,4,210,135]: {dt * 1e3:.1f} ms per clip ({dt / 61 * 1e3:.2f} ms per pass)')
