@@ -4,7 +4,7 @@ Reference: ``opt_amass_temp.py::optimize`` -- per-clip setup :332-345, the 100-s
 :349-455 (the hot path), result :457-458.  One :class:`AmassTemporalFitter` owns every device
 buffer of one sequence (parameters, Adam state, ~0.5 GB of workspace for B=119) and hands raw
 pointers to ``liblemo_hip.so`` once (``lemo_fit_create``); an iteration is then a single C call
-(``lemo_fit_step``) that replays a captured hipGraph of 36 kernels -- no host sync, no ``.item()``
+(``lemo_fit_step``) that replays a captured hipGraph (35 kernels per iteration) -- no host sync, no ``.item()``
 (the reference has 4 per iteration, :431-443), SMPL-X evaluated once instead of twice (:357,:364).
 """
 from __future__ import annotations
