@@ -11,6 +11,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LEMO_DYN_SMEM(var) extern __shared__ __attribute__((aligned(16))) float var[]
 #endif
 
+
+#ifdef LEMO_CENSUS
+static __device__ unsigned long long* g_lemo_census = nullptr;   // one copy per translation unit
+#define CENSUS_SETTER(NAME) extern "C" int NAME(unsigned long long* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lemo_census), &buf, sizeof(buf)); }          // [kernel 4][32 stamps], block 60 thread 0
+#define CENSUS_DECL(K) int cz_ = 0; const bool cz_on_ = g_lemo_census && blockIdx.x == 60 && threadIdx.x == 0; unsigned long long* cz_p_ = g_lemo_census + (K) * 32;
+#define CENSUS() if (cz_on_ && cz_ < 32) cz_p_[cz_++] = __builtin_amdgcn_s_memtime();
+#else
+#define CENSUS_DECL(K)
+#define CENSUS()
+#define CENSUS_SETTER(NAME)
+#endif
+
 #define LEMO_WAVE 64
 #define LEMO_LRELU_SLOPE 0.2f
 
@@ -43,10 +55,30 @@ __device__ __forceinline__ void split3x4(float4 v, uint2& hi, uint2& mid, uint2&
   lo = __builtin_bit_cast(uint2, l);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Reductions over DPP rows: v_add_f32 with a DPP source runs at full VALU rate; __shfl_xor compiles to ds_bpermute,
+// one LDS-crossbar round trip (~100+ cycles) per step, which dominated the short latency-bound kernels that reduce.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a row, bitwise identical in every lane of the row (xor-1, xor-2 butterflies via quad_perm,
+// then half-row and row mirrors: the mirrored partner holds the same value as the xor-4 / xor-8 partner)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);             // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);             // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);            // row_half_mirror
+  v += dpp_move<0x140>(v);            // row_mirror
   return v;
+}
+// sum over the 64 lanes of a full wave, same value in every lane (all 64 lanes must be active)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // Deterministic block sum (fixed tree order).  `red` must hold blockDim.x/64 floats.  All threads

@@ -404,25 +404,57 @@ __global__ void __launch_bounds__(256)
 lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
                      const float* __restrict__ v_posed, int vp_rows, const float* __restrict__ dverts,
                      float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
-  __shared__ float red[4];
+  CENSUS_DECL(2)
+  CENSUS()
   __shared__ float gs[STAGE ? LBS_BWD_STAGE * 3 : 1];
   __shared__ float vs[STAGE ? LBS_BWD_STAGE * 3 : 1];
   __shared__ float As[STAGE ? 64 * 12 : 1];
   __shared__ int cu[STAGE ? LBS_BWD_NNZ : 1];
   __shared__ float cw[STAGE ? LBS_BWD_NNZ : 1];
+  __shared__ int js[STAGE ? 65 : 1];   // jcsr_start (nj <= 64: the host checks)
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
   const float* g = dverts + (size_t)b * u.n * 3;
   if (STAGE) {                        // coalesced / gathered once, then every inner loop reads LDS
-    for (int i = t; i < u.n * 3; i += 256) gs[i] = g[i];
-    for (int i = t; i < u.n * 3; i += 256) vs[i] = v_posed[((size_t)b * vp_rows + u.vp_row[i / 3]) * 3 + (i % 3)];
-    for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
-    // the dA gather below walks one (vertex, weight) list per thread: from global memory that is a chain of
-    // ~170 dependent L1 round trips for the foot joints (the whole kernel took 20 us); from LDS, unrolled, it
-    // is a pipelined stream
-    const int nnz = u.jcsr_start[nj];
-    for (int i = t; i < nnz; i += 256) { cu[i] = u.jcsr_u[i]; cw[i] = u.jcsr_w[i]; }
-    __syncthreads();
+    // loads are issued in batches of 4 per thread with clamped (never predicated) addresses so that they are all in
+    // flight together; with one load -> one LDS store per loop trip the prologue was a chain of ~20 L2 round trips
+    const int n3 = u.n * 3, na = nj * 12, nnz = u.jcsr_start[nj];
+    for (int i0 = 0; i0 < n3; i0 += 1024) {
+      float a[4], v[4]; int row[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + t + 256 * k, n3 - 1);
+        a[k] = g[i];
+        row[k] = u.vp_row[i / 3];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + t + 256 * k, n3 - 1);
+        v[k] = v_posed[((size_t)b * vp_rows + row[k]) * 3 + (i % 3)];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + t + 256 * k;
+        if (i < n3) { gs[i] = a[k]; vs[i] = v[k]; }
+      }
+    }
+    for (int i0 = 0; i0 < nnz; i0 += 1024) {
+      int cu4[4]; float cw4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = min(i0 + t + 256 * k, nnz - 1);
+        cu4[k] = u.jcsr_u[i];
+        cw4[k] = u.jcsr_w[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + t + 256 * k;
+        if (i < nnz) { cu[i] = cu4[k]; cw[i] = cw4[k]; }
+      }
+    }
+    for (int i = t; i < na; i += 256) As[i] = Af[i];
+    if (t <= nj) js[t] = u.jcsr_start[t];
+    __syncthreads(); CENSUS()
   }
   const float* gp = STAGE ? gs : g;
   const float* Ap = STAGE ? As : Af;
@@ -458,34 +490,54 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
     d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
   }
+  CENSUS()
   // zero the padding columns of this frame's dvp row
   for (int cidx = 3 * u.n + t; cidx < u.NCs; cidx += 256) dvp[(size_t)b * u.NCs + cidx] = 0.f;
   // dA via the joint-major CSR (deterministic gather)
-  for (int w = t; w < nj * 12; w += 256) {
-    const int jj = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
-    float acc = 0.f;
-    const int q0 = u.jcsr_start[jj], q1 = u.jcsr_start[jj + 1];
-    if (STAGE) {
-#pragma unroll 4
-      for (int q = q0; q < q1; ++q) {
-        const int s = cu[q];
-        const float gv = gs[3 * s + r] * cw[q];
-        acc += cc < 3 ? gv * vs[3 * s + cc] : gv;
+  if (STAGE) {
+    // the lists are very uneven (the heel / toe vertices hang ~170 entries on each foot joint, most joints have a
+    // handful): one (joint, element) list per thread left 250 threads waiting for the 4 longest walks (23 k cycles).
+    // Here a wave takes a joint; lane = 16 * row + segment walks every 16th entry for one row of dA (4 outputs),
+    // and the 16 segments are combined with a fixed DPP tree -> deterministic, ~16x shorter critical path.
+    const int wave = t >> 6, lane = t & 63, seg = lane & 15, r = lane >> 4;
+    for (int jj = wave; jj < nj; jj += 4) {
+      const int q0 = js[jj], q1 = js[jj + 1];
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (r < 3) {
+#pragma unroll 2
+        for (int q = q0 + seg; q < q1; q += 16) {
+          const int sv = cu[q];
+          const float gv = gs[3 * sv + r] * cw[q];
+          a0 = fmaf(gv, vs[3 * sv], a0); a1 = fmaf(gv, vs[3 * sv + 1], a1); a2 = fmaf(gv, vs[3 * sv + 2], a2);
+          a3 += gv;
+        }
       }
-    } else {
+      a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2); a3 = row16_sum(a3);
+      if (seg == 0 && r < 3) st4(dA + ((size_t)b * nj + jj) * 12 + 4 * r, make_float4(a0, a1, a2, a3));
+    }
+  } else {
+    for (int w = t; w < nj * 12; w += 256) {
+      const int jj = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
+      float acc = 0.f;
+      const int q0 = u.jcsr_start[jj], q1 = u.jcsr_start[jj + 1];
       for (int q = q0; q < q1; ++q) {
-        const int s = u.jcsr_u[q];
-        const float gv = gp[3 * s + r] * u.jcsr_w[q];
-        if (cc < 3) acc += gv * v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + cc];
+        const int sv = u.jcsr_u[q];
+        const float gv = gp[3 * sv + r] * u.jcsr_w[q];
+        if (cc < 3) acc += gv * v_posed[((size_t)b * vp_rows + u.vp_row[sv]) * 3 + cc];
         else acc += gv;
       }
+      dA[((size_t)b * nj) * 12 + w] = acc;
     }
-    dA[((size_t)b * nj) * 12 + w] = acc;
   }
-  if (dtransl) {
-    const float tx = block_sum(sx, red), ty = block_sum(sy, red), tz = block_sum(sz, red);
-    if (t == 0) { dtransl[(size_t)b * 3] = tx; dtransl[(size_t)b * 3 + 1] = ty; dtransl[(size_t)b * 3 + 2] = tz; }
+  CENSUS()
+  if (dtransl) {                      // one barrier pair for the three sums (fixed order: wave tree, then waves 0..3)
+    __shared__ float red3[12];
+    sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+    if ((t & 63) == 0) { red3[3 * (t >> 6)] = sx; red3[3 * (t >> 6) + 1] = sy; red3[3 * (t >> 6) + 2] = sz; }
+    __syncthreads();
+    if (t < 3) dtransl[(size_t)b * 3 + t] = ((red3[t] + red3[3 + t]) + red3[6 + t]) + red3[9 + t];
   }
+  CENSUS()
 }
 
 // ---- dense variant (large vertex sets, e.g. the PROX window whose scene terms touch all 10475 vertices) ------------
@@ -607,3 +659,5 @@ int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, con
 }
 
 }  // namespace lemo
+
+CENSUS_SETTER(lemo_census_set_lbs)

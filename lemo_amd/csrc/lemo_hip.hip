@@ -179,6 +179,11 @@ int lemo_graph_destroy(void* graph_exec) {
   if (!graph_exec) return 0;
   return (int)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
 }
+#ifdef LEMO_CENSUS
+extern "C" int lemo_census_set_pose(unsigned long long*);
+extern "C" int lemo_census_set_lbs(unsigned long long*);
+extern "C" int lemo_census_set(unsigned long long* buf) { return lemo_census_set_pose(buf) | lemo_census_set_lbs(buf); }
+#endif
 int lemo_sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, const float* gmin, const float* gmax,
                     float* val, float* dval, void* stream) {
   if (!sdf || !pts || !gmin || !gmax || !val) return LEMO_ERR_ARG;

@@ -139,66 +139,100 @@ int rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float
 
 __global__ void __launch_bounds__(256)
 smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
+  CENSUS_DECL(0)
+  CENSUS()
   __shared__ float fp[MAXJ * 3];
   __shared__ float Rs[MAXJ * 9];
   __shared__ float Js[MAXJ * 3];
   __shared__ float Ts[MAXJ * 12];
   __shared__ float shp[32];
   __shared__ float gob[66];           // global_orient (3) | body_pose (63) of this frame
+  __shared__ float Jd[MAXJ * 3 * 32];
+  __shared__ int par[MAXJ];
   const int b = blockIdx.x, t = threadIdx.x;
   const int nj = c.nj, np = nj * 3;
+  if (t >= 192 && t - 192 < nj) par[t - 192] = c.parents[t - 192];
   // ---- per-iteration bookkeeping of the fitting engine (block 0 only)
   if (b == 0) {
     if (in.zero_f64) for (int i = t; i < in.n_zero; i += 256) in.zero_f64[i] = 0.0;
     if (in.step_cur && t == 0) *in.step_cur = *in.step_ctr;
   }
-  // ---- global_orient / body_pose: given, or derived from the 6-D rotation / VPoser out layer
-  if (in.rot6d) {
-    if (t == 0) {
-      float x6[6], R[9], a3[3];
-      for (int k = 0; k < 6; ++k) x6[k] = in.rot6d[(size_t)b * 6 + k];
-      rot6d_fwd(x6, R);
-      rotmat_to_aa_fwd(R, a3);
-      for (int k = 0; k < 3; ++k) { gob[k] = a3[k]; if (in.go_out) in.go_out[(size_t)b * 3 + k] = a3[k]; }
-    }
-  } else if (t < 3) gob[t] = in.global_orient[(size_t)b * 3 + t];
-  if (in.vposer_o) {
-    if (t >= 64 && t < 64 + VP_NJ) {
-      const int jn = t - 64;
-      float o6[6], R[9], a3[3];
-      for (int k = 0; k < 6; ++k) o6[k] = in.vposer_o[(size_t)b * 128 + 6 * jn + k];
-      rot6d_fwd(o6, R);
-      rotmat_to_aa_fwd(R, a3);
-      for (int k = 0; k < 3; ++k) gob[3 + 3 * jn + k] = a3[k];
-    }
-  } else if (t >= 64 && t < 64 + 63) gob[3 + t - 64] = in.body_pose[(size_t)b * 63 + (t - 64)];
-  __syncthreads();
-  // ---- full pose (SMPLX.forward: cat[go, body, jaw, leye, reye, lhand45, rhand45] + pose_mean)
-  for (int i = t; i < np; i += 256) {
-    float v;
-    if (i < 66) v = gob[i];
-    else if (i < 69) v = in.jaw ? in.jaw[(size_t)b * 3 + (i - 66)] : 0.f;
-    else if (i < 72) v = in.leye ? in.leye[(size_t)b * 3 + (i - 69)] : 0.f;
-    else if (i < 75) v = in.reye ? in.reye[(size_t)b * 3 + (i - 72)] : 0.f;
-    else {
-      const int hidx = i - 75, side = hidx / 45, cc = hidx - side * 45;
-      const float* hp = (side == 0 ? in.lh : in.rh) + (size_t)b * in.hand_stride;
-      if (c.ncomp > 0) {
-        const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
-        float a = 0.f;
-        for (int k = 0; k < c.ncomp; ++k) a = fmaf(hp[k], comp[k * 45 + cc], a);
-        v = a;
-      } else v = hp[cc];
-    }
-    v += c.pose_mean[i];
-    fp[i] = v;
-    ws.full_pose[(size_t)b * np + i] = v;
+  // ---- every global read of the kernel is issued here, before the first barrier, with clamped (never predicated)
+  // addresses; the phases below only touch registers and LDS.  (Read where they were consumed, three phases in a
+  // row began with an exposed L2 round trip: ~12 k of the kernel's 20 k cycles.)
+  float r6[6], o6[6];                 // operands of the rotation conversions first: they gate the longest chain
+  if (in.rot6d) for (int k = 0; k < 6; ++k) r6[k] = in.rot6d[(size_t)b * 6 + k];
+  const int jn = min(max(t - 64, 0), VP_NJ - 1);
+  if (in.vposer_o) for (int k = 0; k < 6; ++k) o6[k] = in.vposer_o[(size_t)b * 128 + 6 * jn + k];
+  const int ic = min(t, np - 1);      // thread t owns full_pose[t] (np <= 192)
+  float r_own;                        // its entry of [global_orient | body_pose | jaw | leye | reye] when read directly
+  {
+    const float* q = nullptr;
+    if (ic < 3) q = in.rot6d ? nullptr : in.global_orient + (size_t)b * 3 + ic;
+    else if (ic < 66) q = in.vposer_o ? nullptr : in.body_pose + (size_t)b * 63 + (ic - 3);
+    else if (ic < 69) q = in.jaw ? in.jaw + (size_t)b * 3 + (ic - 66) : nullptr;
+    else if (ic < 72) q = in.leye ? in.leye + (size_t)b * 3 + (ic - 69) : nullptr;
+    else if (ic < 75) q = in.reye ? in.reye + (size_t)b * 3 + (ic - 72) : nullptr;
+    r_own = q ? *q : 0.f;
   }
+  const float r_pm = c.pose_mean[ic];
+  float r_shp = 0.f;
   if (t < c.nshape) {
     const int nb = c.nshape / 2;
-    shp[t] = t < nb ? in.betas[(size_t)b * in.betas_stride + t] : (in.expr ? in.expr[(size_t)b * nb + (t - nb)] : 0.f);
+    r_shp = t < nb ? in.betas[(size_t)b * in.betas_stride + t] : (in.expr ? in.expr[(size_t)b * nb + (t - nb)] : 0.f);
   }
-  __syncthreads();
+  const float rJt = c.J_template[ic];
+  // J_dirs [np][nshape]: read coalesced (a row per lane is one cache line per lane and instruction) and staged flat
+  float rJd[24];
+  const int njd = np * c.nshape;      // <= 192 * 32
+#pragma unroll
+  for (int m = 0; m < 24; ++m) rJd[m] = c.J_dirs[min(t + 256 * m, njd - 1)];
+  // ---- global_orient / body_pose derived from the 6-D rotation / VPoser out layer: every lane runs the conversion
+  // (same cost as one lane; keeps the loads above out of a divergent branch), the owning lanes publish it
+  if (in.rot6d) {
+    float R[9], a3[3];
+    rot6d_fwd(r6, R);
+    rotmat_to_aa_fwd(R, a3);
+    if (t == 0) for (int k = 0; k < 3; ++k) { gob[k] = a3[k]; if (in.go_out) in.go_out[(size_t)b * 3 + k] = a3[k]; }
+  }
+  if (in.vposer_o) {
+    float R[9], a3[3];
+    rot6d_fwd(o6, R);
+    rotmat_to_aa_fwd(R, a3);
+    if (t >= 64 && t < 64 + VP_NJ) for (int k = 0; k < 3; ++k) gob[3 + 3 * jn + k] = a3[k];
+  }
+  // ---- hand pose of lane t = 75 + 45 side + cc (PCA components -> 45 axis-angle values per hand)
+  float vh = 0.f;
+  if (np > 75) {
+    const int hidx = min(max(t - 75, 0), 89), side = hidx >= 45 ? 1 : 0, cc = hidx - 45 * side;
+    const float* hp = (side == 0 ? in.lh : in.rh) + (size_t)b * in.hand_stride;
+    if (c.ncomp > 0) {
+      const float* comp = side == 0 ? c.lh_comp : c.rh_comp;
+      for (int k0 = 0; k0 < c.ncomp; k0 += 12) {
+        float h[12], cm[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) { const int kk = min(k0 + k, c.ncomp - 1); h[k] = hp[kk]; cm[k] = comp[kk * 45 + cc]; }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) vh = fmaf(k0 + k < c.ncomp ? h[k] : 0.f, cm[k], vh);
+      }
+    } else vh = hp[cc];
+  }
+  if (t < c.nshape) shp[t] = r_shp;
+#pragma unroll
+  for (int m = 0; m < 24; ++m) if (t + 256 * m < njd) Jd[t + 256 * m] = rJd[m];
+  __syncthreads(); CENSUS()
+  // ---- full pose (SMPLX.forward: cat[go, body, jaw, leye, reye, lhand45, rhand45] + pose_mean)
+  if (t < np) {
+    float v;
+    if (t < 3) v = in.rot6d ? gob[t] : r_own;
+    else if (t < 66) v = in.vposer_o ? gob[t] : r_own;
+    else if (t < 75) v = r_own;
+    else v = vh;
+    v += r_pm;
+    fp[t] = v;
+    ws.full_pose[(size_t)b * np + t] = v;
+  }
+  __syncthreads(); CENSUS()
   // ---- Rodrigues
   if (t < nj) {
     float R[9];
@@ -206,13 +240,13 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
     for (int i = 0; i < 9; ++i) { Rs[9 * t + i] = R[i]; ws.R[((size_t)b * nj + t) * 9 + i] = R[i]; }
   }
   // ---- rest joints  J = J_template + J_dirs . shape
-  for (int i = t; i < np; i += 256) {
-    float a = c.J_template[i];
-    for (int k = 0; k < c.nshape; ++k) a = fmaf(c.J_dirs[(size_t)i * c.nshape + k], shp[k], a);
-    Js[i] = a;
-    ws.J[(size_t)b * np + i] = a;
+  if (t < np) {
+    float a = rJt;
+    for (int k = 0; k < c.nshape; ++k) a = fmaf(Jd[t * c.nshape + k], shp[k], a);
+    Js[t] = a;
+    ws.J[(size_t)b * np + t] = a;
   }
-  __syncthreads();
+  __syncthreads(); CENSUS()
   // ---- GEMM features, KG8 layout: Xg[k>>3][b][k&7]; k < nshape: shape coefs; then (R[1:] - I)
   {
     const int nfeat = c.nshape + (nj - 1) * 9;
@@ -226,24 +260,36 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
       ws.Xg[((size_t)(k >> 3) * ws.Bp + b) * 8 + (k & 7)] = v;
     }
   }
-  // ---- kinematic chain, level-synchronous: T[i] = T[parent] * [R_i | J_i - J_parent]
-  for (int lev = 0; lev < c.nlev; ++lev) {
-    const int s0 = c.level_start[lev], s1 = c.level_start[lev + 1];
-    for (int w = t; w < (s1 - s0) * 12; w += 256) {
-      const int i = c.level_joints[s0 + w / 12], e = w % 12, r = e >> 2, cc = e & 3;
-      const int p = c.parents[i];
-      float v;
-      if (p < 0) v = cc < 3 ? Rs[9 * i + 3 * r + cc] : Js[3 * i + r];
-      else {
-        const float* Tp = &Ts[12 * p + 4 * r];
-        if (cc < 3) v = Tp[0] * Rs[9 * i + cc] + Tp[1] * Rs[9 * i + 3 + cc] + Tp[2] * Rs[9 * i + 6 + cc];
-        else v = Tp[0] * (Js[3 * i] - Js[3 * p]) + Tp[1] * (Js[3 * i + 1] - Js[3 * p + 1]) +
-                 Tp[2] * (Js[3 * i + 2] - Js[3 * p + 2]) + Tp[3];
-      }
-      Ts[12 * i + e] = v;
+  // ---- kinematic chain: T[i] = L[root] * ... * L[parent(i)] * L[i],  L[j] = [R_j | J_j - J_parent(j)]
+  // Four threads per joint (one column of T each) walk up the ancestor list and left-multiply as they go.  The
+  // level-synchronous form (T[i] = T[parent] * L[i], one barrier per tree level) spent 11 x 1250 cycles on barriers
+  // and dependent table loads for ~40 FMAs of work per thread; the walk is <= 10 steps of one LDS round trip each.
+  if (t < nj * 4) {
+    const int i = t >> 2, cc = t & 3;
+    int p = par[i];
+    float x, y, z;
+    if (cc < 3) { x = Rs[9 * i + cc]; y = Rs[9 * i + 3 + cc]; z = Rs[9 * i + 6 + cc]; }
+    else {
+      x = Js[3 * i]; y = Js[3 * i + 1]; z = Js[3 * i + 2];
+      if (p >= 0) { x -= Js[3 * p]; y -= Js[3 * p + 1]; z -= Js[3 * p + 2]; }
     }
-    __syncthreads();
+    while (p >= 0) {
+      const int pp = par[p];
+      const float* R = &Rs[9 * p];
+      float nx = R[0] * x + R[1] * y + R[2] * z;
+      float ny = R[3] * x + R[4] * y + R[5] * z;
+      float nz = R[6] * x + R[7] * y + R[8] * z;
+      if (cc == 3) {
+        float tx = Js[3 * p], ty = Js[3 * p + 1], tz = Js[3 * p + 2];
+        if (pp >= 0) { tx -= Js[3 * pp]; ty -= Js[3 * pp + 1]; tz -= Js[3 * pp + 2]; }
+        nx += tx; ny += ty; nz += tz;
+      }
+      x = nx; y = ny; z = nz;
+      p = pp;
+    }
+    Ts[12 * i + cc] = x; Ts[12 * i + 4 + cc] = y; Ts[12 * i + 8 + cc] = z;
   }
+  __syncthreads(); CENSUS()
   // ---- relative transforms A = [T_R | T_t - T_R J], posed joints
   for (int w = t; w < nj * 12; w += 256) {
     const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
@@ -256,6 +302,7 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
     ws.A[((size_t)b * nj + i) * 12 + e] = v;
     ws.T[((size_t)b * nj + i) * 12 + e] = Ti[cc];
   }
+  CENSUS()
 }
 
 int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B, hipStream_t s) {
@@ -270,7 +317,10 @@ int smplx_pose_fwd(const BodyConst& c, const PoseIn& in, const PoseWs& ws, int B
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
-  __shared__ float G[MAXJ * 12];      // d(global transform) [dT_R | dT_t]
+  CENSUS_DECL(1)
+  CENSUS()
+  __shared__ __attribute__((aligned(16))) float G[MAXJ * 12];      // d(global transform) [dT_R | dT_t]
+  __shared__ __attribute__((aligned(16))) float Cb[MAXJ * 12];     // what each joint adds to its parent's G
   __shared__ float Rs[MAXJ * 9];
   __shared__ float Ts[MAXJ * 12];
   __shared__ float Js[MAXJ * 3];
@@ -278,52 +328,105 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   __shared__ float drel[MAXJ * 3];
   __shared__ float dRl[MAXJ * 9];
   __shared__ float dfp[MAXJ * 3];
+  __shared__ float dAs[MAXJ * 12], dJt[MAXJ * 3], fps[MAXJ * 3], dXs[512], o6s[128], x6s[8], part[8 * 32];
   // tree tables and hand PCA components: staged once (coalesced, independent loads) instead of being chased
   // element by element through L2 inside the level loops / the 45-term component sums
-  __shared__ int cstart[MAXJ + 1], clist[MAXJ], par[MAXJ];
+  __shared__ int cstart[MAXJ + 1], clist[MAXJ], par[MAXJ], lvl[MAXJ];
   __shared__ float hcomp[2 * 45 * 45];
   const int b = blockIdx.x, t = threadIdx.x;
-  const int nj = c.nj, np = nj * 3;
-  if (t <= nj) cstart[t] = c.child_start[t];
-  if (t < nj) { par[t] = c.parents[t]; if (t < nj - 1) clist[t] = c.child_list[t]; }
-  if (c.ncomp > 0) for (int i = t; i < c.ncomp * 45; i += 256) { hcomp[i] = c.lh_comp[i]; hcomp[45 * 45 + i] = c.rh_comp[i]; }
-  for (int i = t; i < nj * 9; i += 256) Rs[i] = ws.R[(size_t)b * nj * 9 + i];
-  for (int i = t; i < nj * 12; i += 256) Ts[i] = ws.T[(size_t)b * nj * 12 + i];
-  for (int i = t; i < np; i += 256) Js[i] = ws.J[(size_t)b * np + i];
-  __syncthreads();
-  // own terms: A_R = T_R ; A_t = T_t - T_R J ; Jtr = T_t
-  for (int w = t; w < nj * 12; w += 256) {
-    const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;
-    const float* dAi = gi.dA + ((size_t)b * nj + i) * 12;
-    float v;
-    if (cc < 3) v = dAi[4 * r + cc] - dAi[4 * r + 3] * Js[3 * i + cc];
-    else v = dAi[4 * r + 3] + (gi.dJtr ? gi.dJtr[((size_t)b * nj + i) * 3 + r] : 0.f);
-    G[w] = v;
+  const int nj = c.nj, np = nj * 3, n9 = nj * 9, n12 = nj * 12;
+  // ---- every global read of the kernel is issued here, before the first barrier, with clamped (never predicated)
+  // addresses: the loads of one thread are all in flight together and the later phases only touch LDS.  (Issued
+  // where they were consumed, each phase started with an exposed L2 round trip: 37 k cycles per block, of which
+  // ~15 k were load latency.)
+  float rR[3], rT[3], rA[3], rX[2], rJd[24];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rR[k] = ws.R[(size_t)b * n9 + min(t + 256 * k, n9 - 1)];
+    rT[k] = ws.T[(size_t)b * n12 + min(t + 256 * k, n12 - 1)];
+    rA[k] = gi.dA[(size_t)b * n12 + min(t + 256 * k, n12 - 1)];
   }
+  const int tc = min(t, np - 1);
+  const float rJ = ws.J[(size_t)b * np + tc], rF = ws.full_pose[(size_t)b * np + tc];
+  const float rJt = gi.dJtr ? gi.dJtr[(size_t)b * np + tc] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) rX[k] = gi.dX ? gi.dX[(size_t)b * 512 + t + 256 * k] : 0.f;
+  const float rO = go.d_vposer_o ? go.vposer_o[(size_t)b * 128 + (t & 127)] : 0.f;
+  const float r6 = go.d_rot6d ? go.rot6d[(size_t)b * 6 + min(t, 5)] : 0.f;
+  const int tj = min(t, nj - 1);
+  const int rcs = c.child_start[min(t, nj)], rpar = c.parents[tj], rcl = nj > 1 ? c.child_list[min(t, nj - 2)] : 0;
+  const int rlj = c.level_joints[tj];                  // joint at position t of the level-ordered list
+  int rlev = 0;                                        // ... and its level: #{l : level_start[l + 1] <= t}
+  for (int l = 1; l < c.nlev; ++l) rlev += c.level_start[l] <= t ? 1 : 0;
+  // J_dirs^T dJ at the end of the kernel: thread (k = t & 31, group = t >> 5) owns rows group, group + 8, ...
+  const int sk = max(min(t & 31, c.nshape - 1), 0), sg = t >> 5;
+#pragma unroll
+  for (int m = 0; m < 24; ++m) rJd[m] = c.J_dirs[(size_t)min(sg + 8 * m, np - 1) * c.nshape + sk];
+  if (c.ncomp > 0) {
+    const int nh = c.ncomp * 45;
+    for (int i0 = 0; i0 < nh; i0 += 1024) {
+      float hl[4], hr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int i = min(i0 + t + 256 * k, nh - 1); hl[k] = c.lh_comp[i]; hr[k] = c.rh_comp[i]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const int i = i0 + t + 256 * k; if (i < nh) { hcomp[i] = hl[k]; hcomp[45 * 45 + i] = hr[k]; } }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = t + 256 * k;
+    if (i < n9) Rs[i] = rR[k];
+    if (i < n12) { Ts[i] = rT[k]; dAs[i] = rA[k]; }
+  }
+  if (t < np) { Js[t] = rJ; fps[t] = rF; dJt[t] = rJt; }
+  dXs[t] = rX[0]; dXs[t + 256] = rX[1];
+  if (t < 128) o6s[t] = rO;
+  if (t < 6) x6s[t] = r6;
+  if (t <= nj) cstart[t] = rcs;
+  if (t < nj) { par[t] = rpar; lvl[rlj] = rlev; if (t < nj - 1) clist[t] = rcl; }
+  __syncthreads(); CENSUS()
   for (int w = t; w < np; w += 256) {          // dJ_i = -T_R^T dA_t
     const int i = w / 3, cc = w % 3;
-    const float* dAi = gi.dA + ((size_t)b * nj + i) * 12;
+    const float* dAi = dAs + 12 * i;
     dJ[w] = -(Ts[12 * i + cc] * dAi[3] + Ts[12 * i + 4 + cc] * dAi[7] + Ts[12 * i + 8 + cc] * dAi[11]);
   }
-  __syncthreads();
-  // reverse levels: G[p] += sum_children [G_R[ch] R_ch^T + G_t[ch] (x) rel_ch | G_t[ch]]
-  for (int lev = c.nlev - 2; lev >= 0; --lev) {
-    const int s0 = c.level_start[lev], s1 = c.level_start[lev + 1];
-    for (int w = t; w < (s1 - s0) * 12; w += 256) {
-      const int i = c.level_joints[s0 + w / 12], e = w % 12, r = e >> 2, cc = e & 3;
-      float acc = 0.f;
-      for (int q = cstart[i]; q < cstart[i + 1]; ++q) {
-        const int ch = clist[q];
-        const float* Gc = &G[12 * ch + 4 * r];
-        if (cc < 3) {
-          acc += Gc[0] * Rs[9 * ch + 3 * cc] + Gc[1] * Rs[9 * ch + 3 * cc + 1] + Gc[2] * Rs[9 * ch + 3 * cc + 2] +
-                 Gc[3] * (Js[3 * ch + cc] - Js[3 * i + cc]);
-        } else acc += Gc[3];
+  // G = d(global transforms).  Own terms (A_R = T_R ; A_t = T_t - T_R J ; Jtr = T_t), then children into parents,
+  // deepest level first:  G[p] += sum_children [G_R[ch] R_ch^T + G_t[ch] (x) rel_ch | G_t[ch]],  rel_ch = J_ch - J_p.
+  // Row r of G[p] only needs row r of the children, so wave r carries row r of every joint (lane = joint) and the
+  // levels are ordered by the wave's own program order -- no block barrier per level.  (The block-wide form, one
+  // barrier and ~6 dependent LDS reads per level, took 10 x 1.0-1.6 k cycles.)
+  if (t < 192) {
+    const int r = t >> 6, i = min(t & 63, nj - 1);
+    const float* dAi = dAs + 12 * i + 4 * r;
+    const float jx = Js[3 * i], jy = Js[3 * i + 1], jz = Js[3 * i + 2];
+    float g0 = dAi[0] - dAi[3] * jx, g1 = dAi[1] - dAi[3] * jy, g2 = dAi[2] - dAi[3] * jz;
+    float g3 = dAi[3] + dJt[3 * i + r];
+    const int mylev = (t & 63) < nj ? lvl[i] : -1, q0 = cstart[i], q1 = cstart[i + 1], p = par[i];
+    // what this lane hands to its parent is a function of its own finished row and its own R / rel (in registers);
+    // the parent only adds the published 4-vectors of its children: one LDS write -> read per level
+    float Rc[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rc[e] = Rs[9 * i + e];
+    const int pc = max(p, 0);
+    const float rx = jx - Js[3 * pc], ry = jy - Js[3 * pc + 1], rz = jz - Js[3 * pc + 2];
+    int ch[5];                          // SMPL-X: at most 5 children (the wrists); longer lists take the loop below
+#pragma unroll
+    for (int k = 0; k < 5; ++k) ch[k] = clist[min(q0 + k, max(nj - 2, 0))];
+    for (int lev = c.nlev - 1; lev >= 0; --lev) {
+      if (mylev == lev) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (q0 + k < q1) { const float4 cv = ld4(&Cb[12 * ch[k] + 4 * r]); g0 += cv.x; g1 += cv.y; g2 += cv.z; g3 += cv.w; }
+        for (int q = q0 + 5; q < q1; ++q) { const float4 cv = ld4(&Cb[12 * clist[q] + 4 * r]); g0 += cv.x; g1 += cv.y; g2 += cv.z; g3 += cv.w; }
+        st4(&G[12 * i + 4 * r], make_float4(g0, g1, g2, g3));
+        st4(&Cb[12 * i + 4 * r], make_float4(g0 * Rc[0] + g1 * Rc[1] + g2 * Rc[2] + g3 * rx,
+                                              g0 * Rc[3] + g1 * Rc[4] + g2 * Rc[5] + g3 * ry,
+                                              g0 * Rc[6] + g1 * Rc[7] + g2 * Rc[8] + g3 * rz, g3));
       }
-      G[12 * i + e] += acc;
+      __builtin_amdgcn_wave_barrier();    // (emulation: lanes of the wave rendezvous; hardware: lockstep, scheduling fence)
     }
-    __syncthreads();
   }
+  __syncthreads(); CENSUS()
   // local grads: dR_i = T_R[p]^T G_R[i] ; drel_i = T_R[p]^T G_t[i]
   for (int w = t; w < nj * 12; w += 256) {
     const int i = w / 12, e = w % 12, r = e >> 2, cc = e & 3;     // (r,cc): element of dR_i (cc<3) or drel (cc==3 -> comp r)
@@ -333,11 +436,11 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     else v = Ts[12 * p + r] * G[12 * i + cc] + Ts[12 * p + 4 + r] * G[12 * i + 4 + cc] + Ts[12 * p + 8 + r] * G[12 * i + 8 + cc];
     if (cc < 3) {
       float d = v;
-      if (i >= 1 && gi.dX) d += gi.dX[(size_t)b * 512 + c.nshape + (i - 1) * 9 + 3 * r + cc];
+      if (i >= 1) d += dXs[c.nshape + (i - 1) * 9 + 3 * r + cc];
       dRl[9 * i + 3 * r + cc] = d;
     } else drel[3 * i + r] = v;
   }
-  __syncthreads();
+  __syncthreads(); CENSUS()
   // dJ: J_i enters rel_i (+) and rel_children (-)
   for (int w = t; w < np; w += 256) {
     const int i = w / 3, cc = w % 3;
@@ -348,15 +451,15 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   // Rodrigues backward
   if (t < nj) {
     float fp3[3], d3[3];
-    for (int k = 0; k < 3; ++k) fp3[k] = ws.full_pose[(size_t)b * np + 3 * t + k];
+    for (int k = 0; k < 3; ++k) fp3[k] = fps[3 * t + k];
     rodrigues_bwd(fp3, &dRl[9 * t], d3);
     for (int k = 0; k < 3; ++k) dfp[3 * t + k] = d3[k];
   }
-  __syncthreads();
+  __syncthreads(); CENSUS()
   // fused consumers: d(global_orient) -> d(rot6d) ; d(body_pose) -> d(VPoser out layer)
   if (go.d_rot6d && t == 0) {
     float x6[6], R[9], dR[9], d6[6];
-    for (int k = 0; k < 6; ++k) x6[k] = go.rot6d[(size_t)b * 6 + k];
+    for (int k = 0; k < 6; ++k) x6[k] = x6s[k];
     rot6d_fwd(x6, R);
     rotmat_to_aa_bwd(R, &dfp[0], dR);
     rot6d_bwd(x6, dR, d6);
@@ -367,7 +470,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     if (jn == VP_NJ) { go.d_vposer_o[(size_t)b * 128 + 126] = 0.f; go.d_vposer_o[(size_t)b * 128 + 127] = 0.f; }
     else {
       float o6[6], R[9], dR[9], d6[6];
-      for (int k = 0; k < 6; ++k) o6[k] = go.vposer_o[(size_t)b * 128 + 6 * jn + k];
+      for (int k = 0; k < 6; ++k) o6[k] = o6s[6 * jn + k];
       rot6d_fwd(o6, R);
       rotmat_to_aa_bwd(R, &dfp[3 + 3 * jn], dR);
       rot6d_bwd(o6, dR, d6);
@@ -398,14 +501,26 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
       dst[(size_t)b * go.hand_stride + k] = v;
     }
   }
-  // d(shape coefs) = dX[:nshape] + J_dirs^T dJ
+  // d(shape coefs) = dX[:nshape] + J_dirs^T dJ   (8 row groups x 32 coefficients, combined in fixed order)
+  {
+    float a = 0.f;
+#pragma unroll
+    for (int m = 0; m < 24; ++m) {
+      const int i = sg + 8 * m;
+      a = fmaf(rJd[m], i < np ? dJ[min(i, np - 1)] : 0.f, a);
+    }
+    part[t] = a;
+  }
+  __syncthreads();
   if (t < c.nshape && (go.d_betas || go.d_expr)) {
-    float v = gi.dX ? gi.dX[(size_t)b * 512 + t] : 0.f;
-    for (int i = 0; i < np; ++i) v = fmaf(c.J_dirs[(size_t)i * c.nshape + t], dJ[i], v);
+    float v = dXs[t];
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) v += part[32 * gq + t];
     const int nb = c.nshape / 2;
     if (t < nb) { if (go.d_betas) go.d_betas[(size_t)b * nb + t] = v; }
     else { if (go.d_expr) go.d_expr[(size_t)b * nb + (t - nb)] = v; }
   }
+  CENSUS()
 }
 
 int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, const PoseGradOut& go, int B, hipStream_t s) {
@@ -415,3 +530,5 @@ int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, c
 }
 
 }  // namespace lemo
+
+CENSUS_SETTER(lemo_census_set_pose)

@@ -273,6 +273,19 @@ static inline unsigned long long __ballot(int pred) {
   return m;
 }
 
+// DPP row operations used by the reductions (common.hpp): quad_perm, row_mirror, row_half_mirror, row_ror
+static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, bool) {
+  const int lane = hipemu::me().lane;
+  int from = lane;
+  if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15));
+  else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));
+  else if (ctrl > 0x120 && ctrl <= 0x12F) from = (lane & ~15) | ((lane - (ctrl - 0x120)) & 15);
+  else abort();
+  return hipemu_exchange(src, from);
+}
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_exchange(v, lane); }
+
 // ---- MFMA (f32 in / f32 acc) ----------------------------------------------------------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
@@ -364,6 +377,7 @@ template <typename T> static inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::barrier(hipemu::mywave().g); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
