@@ -23,6 +23,11 @@ static __device__ unsigned long long* g_lemo_census = nullptr;   // one copy per
 #define CENSUS_SETTER(NAME)
 #endif
 
+// keep a loaded value where it was loaded: hipcc sinks a load whose only use sits in a later branch into that branch
+#ifndef LEMO_PIN
+#define LEMO_PIN(x) asm volatile("" : "+v"(x))
+#endif
+
 #define LEMO_WAVE 64
 #define LEMO_LRELU_SLOPE 0.2f
 

@@ -415,10 +415,13 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
   const float* g = dverts + (size_t)b * u.n * 3;
+  int vid0 = 0, ji0[4] = {0, 0, 0, 0};
+  float wk0[4] = {0.f, 0.f, 0.f, 0.f};
   if (STAGE) {                        // coalesced / gathered once, then every inner loop reads LDS
     // loads are issued in batches of 4 per thread with clamped (never predicated) addresses so that they are all in
     // flight together; with one load -> one LDS store per loop trip the prologue was a chain of ~20 L2 round trips
     const int n3 = u.n * 3, na = nj * 12, nnz = u.jcsr_start[nj];
+    vid0 = u.ids[min(t, u.n - 1)];   // first vertex of the dvp loop below: its (index, weight) reads ride along
     for (int i0 = 0; i0 < n3; i0 += 1024) {
       float a[4], v[4]; int row[4];
 #pragma unroll
@@ -431,6 +434,14 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       for (int k = 0; k < 4; ++k) {
         const int i = min(i0 + t + 256 * k, n3 - 1);
         v[k] = v_posed[((size_t)b * vp_rows + row[k]) * 3 + (i % 3)];
+      }
+      if (i0 == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int kk = min(k, c.KW - 1);
+          ji0[k] = c.w_idx[(size_t)vid0 * c.KW + kk];
+          wk0[k] = k < c.KW ? c.w_val[(size_t)vid0 * c.KW + kk] : 0.f;
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -460,7 +471,8 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   const float* Ap = STAGE ? As : Af;
   float sx = 0.f, sy = 0.f, sz = 0.f;
   for (int s = t; s < u.n; s += 256) {
-    const int vid = u.ids[s];
+    const bool pre = STAGE && s == t;                    // block-uniform: the first trip uses the prefetched reads
+    const int vid = pre ? vid0 : u.ids[s];
     const float gx = gp[3 * s], gy = gp[3 * s + 1], gz = gp[3 * s + 2];
     sx += gx; sy += gy; sz += gz;
     float T[9];
@@ -470,11 +482,16 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     const float* wv = c.w_val + (size_t)vid * c.KW;
     for (int k0 = 0; k0 < c.KW; k0 += 4) {               // 4 (index, weight) pairs per round trip, not one
       int ji[4]; float wk[4];
+      if (pre && k0 == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int kk = k0 + k < c.KW ? k0 + k : c.KW - 1;
-        ji[k] = wi[kk];
-        wk[k] = k0 + k < c.KW ? wv[kk] : 0.f;
+        for (int k = 0; k < 4; ++k) { ji[k] = ji0[k]; wk[k] = wk0[k]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int kk = k0 + k < c.KW ? k0 + k : c.KW - 1;
+          ji[k] = wi[kk];
+          wk[k] = k0 + k < c.KW ? wv[kk] : 0.f;
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -499,21 +516,65 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     // handful): one (joint, element) list per thread left 250 threads waiting for the 4 longest walks (23 k cycles).
     // Here a wave takes a joint; lane = 16 * row + segment walks every 16th entry for one row of dA (4 outputs),
     // and the 16 segments are combined with a fixed DPP tree -> deterministic, ~16x shorter critical path.
-    const int wave = t >> 6, lane = t & 63, seg = lane & 15, r = lane >> 4;
-    for (int jj = wave; jj < nj; jj += 4) {
-      const int q0 = js[jj], q1 = js[jj + 1];
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (r < 3) {
-#pragma unroll 2
-        for (int q = q0 + seg; q < q1; q += 16) {
-          const int sv = cu[q];
-          const float gv = gs[3 * sv + r] * cw[q];
-          a0 = fmaf(gv, vs[3 * sv], a0); a1 = fmaf(gv, vs[3 * sv + 1], a1); a2 = fmaf(gv, vs[3 * sv + 2], a2);
-          a3 += gv;
+    // Four joints of the wave are in flight at a time: one joint after
+    // the other is a chain of ~4 dependent LDS round trips + the reduction per joint, 14 times per wave.
+    const int wave = t >> 6, lane = t & 63, seg = lane & 15, r = lane >> 4, rr = min(r, 2);
+    const int qmax = max(js[nj] - 1, 0);
+    // list bounds of the wave's joints wave, wave + 4, ...: lane L holds joint wave + 4 L, handed out by v_readlane
+    // (wave-uniform q0 / q1 in scalar registers; one LDS round trip instead of one per joint)
+    const int jl = min(wave + 4 * (lane & 15), nj - 1);
+    const int js_lo = js[jl], js_hi = wave + 4 * (lane & 15) < nj ? js[jl + 1] : js_lo;
+    const bool b0 = seg & 1, b1 = seg & 2, b2 = seg & 4, b3 = seg & 8;
+    for (int j0 = wave, m0 = 0; j0 < nj; j0 += 16, m0 += 4) {
+      int q0[4], q1[4], sv[4];
+      float wq[4], acc[16];             // acc[4 k + e]: joint j0 + 4 k, element e of row r
+      int len = 0;                      // wave-uniform: the longest of the four lists
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        q0[k] = __builtin_amdgcn_readlane(js_lo, m0 + k);
+        q1[k] = __builtin_amdgcn_readlane(js_hi, m0 + k);
+        len = max(len, q1[k] - q0[k]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      for (int base = 0; base < len; base += 16) {      // every trip: 4 joints x (index, weight) -> (g, v) reads in flight
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int q = q0[k] + base + seg, qc = min(q, qmax);
+          sv[k] = cu[qc];
+          wq[k] = q < q1[k] ? cw[qc] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gv = gs[3 * sv[k] + rr] * wq[k];
+          acc[4 * k] = fmaf(gv, vs[3 * sv[k]], acc[4 * k]); acc[4 * k + 1] = fmaf(gv, vs[3 * sv[k] + 1], acc[4 * k + 1]);
+          acc[4 * k + 2] = fmaf(gv, vs[3 * sv[k] + 2], acc[4 * k + 2]);
+          acc[4 * k + 3] += gv;
         }
       }
-      a0 = row16_sum(a0); a1 = row16_sum(a1); a2 = row16_sum(a2); a3 = row16_sum(a3);
-      if (seg == 0 && r < 3) st4(dA + ((size_t)b * nj + jj) * 12 + 4 * r, make_float4(a0, a1, a2, a3));
+      // 16 values x 16 segments -> lane seg ends with the row sum of value seg: each butterfly level keeps the half of
+      // the values selected by one bit of the lane index (17 DPP moves instead of 64 for 16 separate row sums)
+      float w8[8], x4[4], y2[2];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float keep = b0 ? acc[2 * m + 1] : acc[2 * m], send = b0 ? acc[2 * m] : acc[2 * m + 1];
+        w8[m] = keep + dpp_move<0xB1>(send);                              // lane ^ 1
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const float keep = b1 ? w8[2 * m + 1] : w8[2 * m], send = b1 ? w8[2 * m] : w8[2 * m + 1];
+        x4[m] = keep + dpp_move<0x4E>(send);                              // lane ^ 2
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float keep = b2 ? x4[2 * m + 1] : x4[2 * m], send = b2 ? x4[2 * m] : x4[2 * m + 1];
+        const float dn = dpp_move<0x124>(send), up = dpp_move<0x12C>(send);   // row_ror 4 / 12: from lane - 4 / lane + 4
+        y2[m] = keep + (b2 ? dn : up);                                    // lane ^ 4
+      }
+      const float keep = b3 ? y2[1] : y2[0], send = b3 ? y2[0] : y2[1];
+      const float tot = keep + dpp_move<0x128>(send);                     // row_ror 8: lane ^ 8
+      const int jj = j0 + 4 * (seg >> 2);
+      if (r < 3 && jj < nj) dA[((size_t)b * nj + jj) * 12 + 4 * r + (seg & 3)] = tot;
     }
   } else {
     for (int w = t; w < nj * 12; w += 256) {

@@ -188,18 +188,21 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
 #pragma unroll
   for (int m = 0; m < 24; ++m) rJd[m] = c.J_dirs[min(t + 256 * m, njd - 1)];
   // ---- global_orient / body_pose derived from the 6-D rotation / VPoser out layer: every lane runs the conversion
-  // (same cost as one lane; keeps the loads above out of a divergent branch), the owning lanes publish it
-  if (in.rot6d) {
+  // (same cost as one lane); LEMO_PIN keeps the loads above from being sunk into these branches
+  // (the pins sit after every load has been issued: an asm operand is a use, and waits for its load)
+  if (in.rot6d) for (int k = 0; k < 6; ++k) LEMO_PIN(r6[k]);
+  if (in.vposer_o) for (int k = 0; k < 6; ++k) LEMO_PIN(o6[k]);
+  if (in.rot6d && (t >> 6) == 2) {    // wave 2 (wave-uniform branch): the two conversions run side by side
     float R[9], a3[3];
     rot6d_fwd(r6, R);
     rotmat_to_aa_fwd(R, a3);
-    if (t == 0) for (int k = 0; k < 3; ++k) { gob[k] = a3[k]; if (in.go_out) in.go_out[(size_t)b * 3 + k] = a3[k]; }
+    if (t == 128) for (int k = 0; k < 3; ++k) { gob[k] = a3[k]; if (in.go_out) in.go_out[(size_t)b * 3 + k] = a3[k]; }
   }
-  if (in.vposer_o) {
+  if (in.vposer_o && (t >> 6) == 1) {
     float R[9], a3[3];
     rot6d_fwd(o6, R);
     rotmat_to_aa_fwd(R, a3);
-    if (t >= 64 && t < 64 + VP_NJ) for (int k = 0; k < 3; ++k) gob[3 + 3 * jn + k] = a3[k];
+    if (t < 64 + VP_NJ) for (int k = 0; k < 3; ++k) gob[3 + 3 * jn + k] = a3[k];
   }
   // ---- hand pose of lane t = 75 + 45 side + cc (PCA components -> 45 axis-angle values per hand)
   float vh = 0.f;
@@ -414,9 +417,14 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     for (int k = 0; k < 5; ++k) ch[k] = clist[min(q0 + k, max(nj - 2, 0))];
     for (int lev = c.nlev - 1; lev >= 0; --lev) {
       if (mylev == lev) {
+        float4 cv[5];                     // five independent reads, then selects: no branch (and wait) per child
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-          if (q0 + k < q1) { const float4 cv = ld4(&Cb[12 * ch[k] + 4 * r]); g0 += cv.x; g1 += cv.y; g2 += cv.z; g3 += cv.w; }
+        for (int k = 0; k < 5; ++k) cv[k] = ld4(&Cb[12 * ch[k] + 4 * r]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const bool on = q0 + k < q1;
+          g0 += on ? cv[k].x : 0.f; g1 += on ? cv[k].y : 0.f; g2 += on ? cv[k].z : 0.f; g3 += on ? cv[k].w : 0.f;
+        }
         for (int q = q0 + 5; q < q1; ++q) { const float4 cv = ld4(&Cb[12 * clist[q] + 4 * r]); g0 += cv.x; g1 += cv.y; g2 += cv.z; g3 += cv.w; }
         st4(&G[12 * i + 4 * r], make_float4(g0, g1, g2, g3));
         st4(&Cb[12 * i + 4 * r], make_float4(g0 * Rc[0] + g1 * Rc[1] + g2 * Rc[2] + g3 * rx,

@@ -32,6 +32,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
 #define __shared__ static
+#define LEMO_PIN(x) ((void)0)
 #define __launch_bounds__(...)
 #define __constant__ static
 
