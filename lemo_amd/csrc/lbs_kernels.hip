@@ -399,8 +399,11 @@ int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float*
 // ------------------------------------------------------------------------------------------------
 #define LBS_BWD_STAGE 1024          // vertex sets up to this size keep g / v_posed of the frame in LDS
 #define LBS_BWD_NNZ 4096            // ... and the joint-major CSR (vertex, weight) lists up to this many entries
+// The staged variant runs 1024 threads per frame: every phase is a short dependent chain (global -> LDS -> LDS), and
+// with one wave per SIMD each of its ~100 VALU instructions and each LDS round trip is fully exposed; four waves per
+// SIMD overlap them (the joint loop below becomes one batch per wave).
 template <bool STAGE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(STAGE ? 1024 : 256)
 lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
                      const float* __restrict__ v_posed, int vp_rows, const float* __restrict__ dverts,
                      float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
@@ -412,6 +415,7 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   __shared__ int cu[STAGE ? LBS_BWD_NNZ : 1];
   __shared__ float cw[STAGE ? LBS_BWD_NNZ : 1];
   __shared__ int js[STAGE ? 65 : 1];   // jcsr_start (nj <= 64: the host checks)
+  constexpr int NT = STAGE ? 1024 : 256, NW = NT / 64;
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
   const float* g = dverts + (size_t)b * u.n * 3;
@@ -422,17 +426,17 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     // flight together; with one load -> one LDS store per loop trip the prologue was a chain of ~20 L2 round trips
     const int n3 = u.n * 3, na = nj * 12, nnz = u.jcsr_start[nj];
     vid0 = u.ids[min(t, u.n - 1)];   // first vertex of the dvp loop below: its (index, weight) reads ride along
-    for (int i0 = 0; i0 < n3; i0 += 1024) {
+    for (int i0 = 0; i0 < n3; i0 += 4 * NT) {
       float a[4], v[4]; int row[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + 256 * k, n3 - 1);
+        const int i = min(i0 + t + NT * k, n3 - 1);
         a[k] = g[i];
         row[k] = u.vp_row[i / 3];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + 256 * k, n3 - 1);
+        const int i = min(i0 + t + NT * k, n3 - 1);
         v[k] = v_posed[((size_t)b * vp_rows + row[k]) * 3 + (i % 3)];
       }
       if (i0 == 0) {
@@ -445,32 +449,32 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = i0 + t + 256 * k;
+        const int i = i0 + t + NT * k;
         if (i < n3) { gs[i] = a[k]; vs[i] = v[k]; }
       }
     }
-    for (int i0 = 0; i0 < nnz; i0 += 1024) {
+    for (int i0 = 0; i0 < nnz; i0 += 4 * NT) {
       int cu4[4]; float cw4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + 256 * k, nnz - 1);
+        const int i = min(i0 + t + NT * k, nnz - 1);
         cu4[k] = u.jcsr_u[i];
         cw4[k] = u.jcsr_w[i];
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = i0 + t + 256 * k;
+        const int i = i0 + t + NT * k;
         if (i < nnz) { cu[i] = cu4[k]; cw[i] = cw4[k]; }
       }
     }
-    for (int i = t; i < na; i += 256) As[i] = Af[i];
+    for (int i = t; i < na; i += NT) As[i] = Af[i];
     if (t <= nj) js[t] = u.jcsr_start[t];
     __syncthreads(); CENSUS()
   }
   const float* gp = STAGE ? gs : g;
   const float* Ap = STAGE ? As : Af;
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int s = t; s < u.n; s += 256) {
+  for (int s = t; s < u.n; s += NT) {
     const bool pre = STAGE && s == t;                    // block-uniform: the first trip uses the prefetched reads
     const int vid = pre ? vid0 : u.ids[s];
     const float gx = gp[3 * s], gy = gp[3 * s + 1], gz = gp[3 * s + 2];
@@ -509,7 +513,7 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   }
   CENSUS()
   // zero the padding columns of this frame's dvp row
-  for (int cidx = 3 * u.n + t; cidx < u.NCs; cidx += 256) dvp[(size_t)b * u.NCs + cidx] = 0.f;
+  for (int cidx = 3 * u.n + t; cidx < u.NCs; cidx += NT) dvp[(size_t)b * u.NCs + cidx] = 0.f;
   // dA via the joint-major CSR (deterministic gather)
   if (STAGE) {
     // the lists are very uneven (the heel / toe vertices hang ~170 entries on each foot joint, most joints have a
@@ -520,14 +524,14 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     // the other is a chain of ~4 dependent LDS round trips + the reduction per joint, 14 times per wave.
     const int wave = t >> 6, lane = t & 63, seg = lane & 15, r = lane >> 4, rr = min(r, 2);
     const int qmax = max(js[nj] - 1, 0);
-    // list bounds of the wave's joints wave, wave + 4, ...: lane L holds joint wave + 4 L, handed out by v_readlane
+    // list bounds of the wave's joints wave, wave + NW, ...: lane L holds joint wave + NW L, handed out by v_readlane
     // (wave-uniform q0 / q1 in scalar registers; one LDS round trip instead of one per joint)
-    const int jl = min(wave + 4 * (lane & 15), nj - 1);
-    const int js_lo = js[jl], js_hi = wave + 4 * (lane & 15) < nj ? js[jl + 1] : js_lo;
+    const int jl = min(wave + NW * (lane & 15), nj - 1);
+    const int js_lo = js[jl], js_hi = wave + NW * (lane & 15) < nj ? js[jl + 1] : js_lo;
     const bool b0 = seg & 1, b1 = seg & 2, b2 = seg & 4, b3 = seg & 8;
-    for (int j0 = wave, m0 = 0; j0 < nj; j0 += 16, m0 += 4) {
+    for (int j0 = wave, m0 = 0; j0 < nj; j0 += 4 * NW, m0 += 4) {
       int q0[4], q1[4], sv[4];
-      float wq[4], acc[16];             // acc[4 k + e]: joint j0 + 4 k, element e of row r
+      float wq[4], acc[16];             // acc[4 k + e]: joint j0 + NW k, element e of row r
       int len = 0;                      // wave-uniform: the longest of the four lists
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -573,7 +577,7 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       }
       const float keep = b3 ? y2[1] : y2[0], send = b3 ? y2[0] : y2[1];
       const float tot = keep + dpp_move<0x128>(send);                     // row_ror 8: lane ^ 8
-      const int jj = j0 + 4 * (seg >> 2);
+      const int jj = j0 + NW * (seg >> 2);
       if (r < 3 && jj < nj) dA[((size_t)b * nj + jj) * 12 + 4 * r + (seg & 3)] = tot;
     }
   } else {
@@ -591,12 +595,16 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     }
   }
   CENSUS()
-  if (dtransl) {                      // one barrier pair for the three sums (fixed order: wave tree, then waves 0..3)
-    __shared__ float red3[12];
+  if (dtransl) {                      // one barrier pair for the three sums (fixed order: wave tree, then the waves in order)
+    __shared__ float red3[3 * NW];
     sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
     if ((t & 63) == 0) { red3[3 * (t >> 6)] = sx; red3[3 * (t >> 6) + 1] = sy; red3[3 * (t >> 6) + 2] = sz; }
     __syncthreads();
-    if (t < 3) dtransl[(size_t)b * 3 + t] = ((red3[t] + red3[3 + t]) + red3[6 + t]) + red3[9 + t];
+    if (t < 3) {
+      float a = red3[t];
+      for (int w = 1; w < NW; ++w) a += red3[3 * w + t];
+      dtransl[(size_t)b * 3 + t] = a;
+    }
   }
   CENSUS()
 }
@@ -674,7 +682,7 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
   if (u.n <= 0 || B <= 0 || (u.NCs % 16) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
   (void)Bp;
   if (u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ)
-    hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+    hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
   else if (nj <= 64) {
     hipLaunchKernelGGL(lbs_bwd_zero_kernel, dim3(B), dim3(256), 0, s, dvp, u.NCs, 3 * u.n, dA, nj * 12, dtransl);
     hipLaunchKernelGGL(lbs_bwd_dense_kernel, dim3((u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK, B), dim3(256), 0, s, c, u, A, nj,
