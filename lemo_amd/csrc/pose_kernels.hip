@@ -276,17 +276,16 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
       x = Js[3 * i]; y = Js[3 * i + 1]; z = Js[3 * i + 2];
       if (p >= 0) { x -= Js[3 * p]; y -= Js[3 * p + 1]; z -= Js[3 * p + 2]; }
     }
-    while (p >= 0) {
-      const int pp = par[p];
+    const float tsel = cc == 3 ? 1.f : 0.f;
+    while (p >= 0) {                    // every lane reads the translation too (x 0 for the rotation columns): a
+      const int pp = par[p], pq = max(pp, 0);   // branch on the column would put a second LDS round trip in each step
       const float* R = &Rs[9 * p];
-      float nx = R[0] * x + R[1] * y + R[2] * z;
-      float ny = R[3] * x + R[4] * y + R[5] * z;
-      float nz = R[6] * x + R[7] * y + R[8] * z;
-      if (cc == 3) {
-        float tx = Js[3 * p], ty = Js[3 * p + 1], tz = Js[3 * p + 2];
-        if (pp >= 0) { tx -= Js[3 * pp]; ty -= Js[3 * pp + 1]; tz -= Js[3 * pp + 2]; }
-        nx += tx; ny += ty; nz += tz;
-      }
+      const float rs = pp >= 0 ? tsel : 0.f;
+      const float tx = tsel * Js[3 * p] - rs * Js[3 * pq], ty = tsel * Js[3 * p + 1] - rs * Js[3 * pq + 1],
+                  tz = tsel * Js[3 * p + 2] - rs * Js[3 * pq + 2];
+      const float nx = R[0] * x + R[1] * y + R[2] * z + tx;
+      const float ny = R[3] * x + R[4] * y + R[5] * z + ty;
+      const float nz = R[6] * x + R[7] * y + R[8] * z + tz;
       x = nx; y = ny; z = nz;
       p = pp;
     }
@@ -486,7 +485,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     }
   }
   // scatter d(full_pose)
-  for (int i = t; i < 75; i += 256) {
+  for (int i = t - 192; i >= 0 && i < 75; i += 64) {      // wave 3 (waves 0 / 1 are busy with the conversions above)
     const float v = dfp[i];
     if (i < 3) { if (go.d_global_orient) go.d_global_orient[(size_t)b * 3 + i] = v; }
     else if (i < 66) { if (go.d_body_pose) go.d_body_pose[(size_t)b * 63 + (i - 3)] = v; }
@@ -496,7 +495,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
   }
   {
     const int nh = c.ncomp > 0 ? c.ncomp : 45;
-    for (int w = t; w < 2 * nh; w += 256) {
+    for (int w = t - 128; w >= 0 && w < 2 * nh; w += 128) { // waves 2 and 3
       const int side = w / nh, k = w - side * nh;
       float* dst = side == 0 ? go.d_lh : go.d_rh;
       if (!dst) continue;
