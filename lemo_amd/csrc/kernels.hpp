@@ -47,6 +47,13 @@ typedef lemo_pose_grad_out PoseGradOut;
 typedef lemo_skin_const SkinConst;
 typedef lemo_vertex_set_bwd VertexSetBwd;
 typedef lemo_fit_const FitConst;
+// inputs of d(total)/d(verts) (loss_device.hpp::dverts_vertex)
+struct DvertsIn {
+  const float* verts; int nrows; const float* target; const float* contact; const float* dx0; const float* canon;
+  const float* weights; int B;
+};
+// the fitting engine's LBS backward computes d(verts) itself instead of reading it (one launch less per iteration)
+struct FitFuse { FitConst fc; DvertsIn in; const double* acc; double smooth_count; float* losses_out; };
 
 // z: [B] rows with stride z_stride floats.  Saves h1,h2 [B][512], o [B][128] for backward.
 int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, float* h1, float* h2, float* o,
@@ -70,9 +77,10 @@ int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float*
 int lbs_set_variant(int v);         // 1 (default): split-bf16 blend GEMM ; 0: fp32-MFMA blend GEMM
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);
+bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj);
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts /*[B][n][3]*/, int B, int Bp, float* dvp /*[B][NCs] scratch*/,
-                  float* dA /*[B][nj][12]*/, float* dtransl /*[B][3] or null*/, float* dX /*[B][512]*/, hipStream_t s);
+                  float* dA /*[B][nj][12]*/, float* dtransl /*[B][3] or null*/, float* dX /*[B][512]*/, hipStream_t s, const FitFuse* fuse = nullptr);
 int joints_assemble(const float* Jtr, int nj, const float* verts, int vrows, const int* extra_rows, int n_extra,
                     const int* lmk_rows /*[n_lmk][3]*/, const float* lmk_bary, int n_lmk, const float* transl,
                     int B, float* joints /*[B][nj+n_extra+n_lmk][3]*/, hipStream_t s);

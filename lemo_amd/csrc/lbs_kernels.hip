@@ -11,6 +11,7 @@
 // through HBM between the blend and the skinning: the GEMM tile is handed over through LDS.
 // Skinning weights are held as ELL (<= KW non-zeros per vertex; real SMPL-X rows are sparse).
 #include "kernels.hpp"
+#include "loss_device.hpp"
 
 namespace lemo {
 
@@ -402,11 +403,15 @@ int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float*
 // The staged variant runs 1024 threads per frame: every phase is a short dependent chain (global -> LDS -> LDS), and
 // with one wave per SIMD each of its ~100 VALU instructions and each LDS round trip is fully exposed; four waves per
 // SIMD overlap them (the joint loop below becomes one batch per wave).
-template <bool STAGE>
+// FUSED (fitting engine): d(verts) of the frame is computed here (loss_device.hpp::dverts_vertex) by the first four
+// waves, straight into the LDS copy the other phases read, while the other twelve stage the frame -- the separate
+// dverts_assemble launch (one cold dependent chain + a dispatch, ~9 us) and the global round trip of d(verts) go.
+template <bool STAGE, bool FUSED>
 __global__ void __launch_bounds__(STAGE ? 1024 : 256)
 lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj,
                      const float* __restrict__ v_posed, int vp_rows, const float* __restrict__ dverts,
-                     float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
+                     float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl, FitFuse ff) {
+  static_assert(STAGE || !FUSED, "the fused variant stages the frame in LDS");
   CENSUS_DECL(2)
   CENSUS()
   __shared__ float gs[STAGE ? LBS_BWD_STAGE * 3 : 1];
@@ -418,58 +423,91 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   constexpr int NT = STAGE ? 1024 : 256, NW = NT / 64;
   const int b = blockIdx.x, t = threadIdx.x;
   const float* Af = A + (size_t)b * nj * 12;
-  const float* g = dverts + (size_t)b * u.n * 3;
+  const float* g = FUSED ? nullptr : dverts + (size_t)b * u.n * 3;
   int vid0 = 0, ji0[4] = {0, 0, 0, 0};
   float wk0[4] = {0.f, 0.f, 0.f, 0.f};
   if (STAGE) {                        // coalesced / gathered once, then every inner loop reads LDS
     // loads are issued in batches of 4 per thread with clamped (never predicated) addresses so that they are all in
     // flight together; with one load -> one LDS store per loop trip the prologue was a chain of ~20 L2 round trips
+    constexpr int DV = FUSED ? 256 : 0, NS = NT - DV;    // threads [0, DV): loss record + d(verts); the rest stage
+    __shared__ float losses[FUSED ? 12 : 1];
+    __shared__ double tots[FUSED ? 13 : 1];
+    const int ts = t - DV;
+    DvIdx ix0 = {0, -1, 0, -1};
     const int n3 = u.n * 3, na = nj * 12, nnz = u.jcsr_start[nj];
     vid0 = u.ids[min(t, u.n - 1)];   // first vertex of the dvp loop below: its (index, weight) reads ride along
-    for (int i0 = 0; i0 < n3; i0 += 4 * NT) {
-      float a[4], v[4]; int row[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + NT * k, n3 - 1);
-        a[k] = g[i];
-        row[k] = u.vp_row[i / 3];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + NT * k, n3 - 1);
-        v[k] = v_posed[((size_t)b * vp_rows + row[k]) * 3 + (i % 3)];
-      }
-      if (i0 == 0) {
+    if (!FUSED || t >= DV) {
+      for (int i0 = 0; i0 < n3; i0 += 4 * NS) {
+        float a[4], v[4]; int row[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int kk = min(k, c.KW - 1);
-          ji0[k] = c.w_idx[(size_t)vid0 * c.KW + kk];
-          wk0[k] = k < c.KW ? c.w_val[(size_t)vid0 * c.KW + kk] : 0.f;
+          const int i = min(i0 + ts + NS * k, n3 - 1);
+          a[k] = FUSED ? 0.f : g[i];
+          row[k] = u.vp_row[i / 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = min(i0 + ts + NS * k, n3 - 1);
+          v[k] = v_posed[((size_t)b * vp_rows + row[k]) * 3 + (i % 3)];
+        }
+        if (i0 == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int kk = min(k, c.KW - 1);
+            ji0[k] = c.w_idx[(size_t)vid0 * c.KW + kk];
+            wk0[k] = k < c.KW ? c.w_val[(size_t)vid0 * c.KW + kk] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + ts + NS * k;
+          if (i < n3) { if (!FUSED) gs[i] = a[k]; vs[i] = v[k]; }
         }
       }
+      for (int i0 = 0; i0 < nnz; i0 += 4 * NS) {
+        int cu4[4]; float cw4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = min(i0 + ts + NS * k, nnz - 1);
+          cu4[k] = u.jcsr_u[i];
+          cw4[k] = u.jcsr_w[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + ts + NS * k;
+          if (i < nnz) { cu[i] = cu4[k]; cw[i] = cw4[k]; }
+        }
+      }
+      for (int i = ts; i < na; i += NS) As[i] = Af[i];
+      if (ts <= nj) js[ts] = u.jcsr_start[ts];
+    } else {
+      // loss record: 13 lanes of wave 0 total the accumulator slots, lane 0 finalises (same wave: program order is
+      // enough between the LDS write and the read); every block does it, block 0 publishes
+      ix0 = dverts_indices(ff.fc, min(t, u.n - 1));       // indices of this lane's first vertex: in flight with the rest
+      if (t < 13) tots[t] = loss_slot_total(ff.acc, t);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int i = i0 + t + NT * k;
-        if (i < n3) { gs[i] = a[k]; vs[i] = v[k]; }
+        const int kk = min(k, c.KW - 1);
+        ji0[k] = c.w_idx[(size_t)vid0 * c.KW + kk];
+        wk0[k] = k < c.KW ? c.w_val[(size_t)vid0 * c.KW + kk] : 0.f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (t == 0) {
+        finalize_losses(tots, ff.in.B, ff.fc.n67, ff.smooth_count, ff.in.weights, losses);
+        if (b == 0) for (int i = 0; i < 12; ++i) ff.losses_out[i] = losses[i];
       }
     }
-    for (int i0 = 0; i0 < nnz; i0 += 4 * NT) {
-      int cu4[4]; float cw4[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = min(i0 + t + NT * k, nnz - 1);
-        cu4[k] = u.jcsr_u[i];
-        cw4[k] = u.jcsr_w[i];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int i = i0 + t + NT * k;
-        if (i < nnz) { cu[i] = cu4[k]; cw[i] = cw4[k]; }
-      }
+    __syncthreads();
+    if (FUSED) {
+      if (t < DV)
+        for (int uu = t; uu < u.n; uu += DV) {
+          float gx, gy, gz;
+          dverts_vertex(ff.fc, ff.in, losses, b, uu == t ? ix0 : dverts_indices(ff.fc, uu), gx, gy, gz);
+          gs[3 * uu] = gx; gs[3 * uu + 1] = gy; gs[3 * uu + 2] = gz;
+        }
+      __syncthreads();
     }
-    for (int i = t; i < na; i += NT) As[i] = Af[i];
-    if (t <= nj) js[t] = u.jcsr_start[t];
-    __syncthreads(); CENSUS()
+    CENSUS()
   }
   const float* gp = STAGE ? gs : g;
   const float* Ap = STAGE ? As : Af;
@@ -677,18 +715,29 @@ lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   }
 }
 
+// the staged (frame in LDS) kernel takes the set; only that one has the fused d(verts) form
+bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj) {
+  return u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ;
+}
+
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
-                  const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s) {
+                  const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX, hipStream_t s,
+                  const FitFuse* fuse) {
   if (u.n <= 0 || B <= 0 || (u.NCs % 16) || u.NCs < 3 * u.n) return LEMO_ERR_SHAPE;
   (void)Bp;
-  if (u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ)
-    hipLaunchKernelGGL((lbs_bwd_frame_kernel<true>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+  if (fuse && (!lbs_verts_bwd_fusable(c, u, nj) || fuse->fc.n != u.n)) return LEMO_ERR_SHAPE;
+  if (!fuse && !dverts) return LEMO_ERR_ARG;
+  if (lbs_verts_bwd_fusable(c, u, nj))
+    {
+    if (fuse) hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, true>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, *fuse);
+    else hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, false>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, FitFuse{});
+  }
   else if (nj <= 64) {
     hipLaunchKernelGGL(lbs_bwd_zero_kernel, dim3(B), dim3(256), 0, s, dvp, u.NCs, 3 * u.n, dA, nj * 12, dtransl);
     hipLaunchKernelGGL(lbs_bwd_dense_kernel, dim3((u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK, B), dim3(256), 0, s, c, u, A, nj,
                        v_posed, vp_rows, dverts, dvp, dA, dtransl);
   } else
-    hipLaunchKernelGGL((lbs_bwd_frame_kernel<false>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl);
+    hipLaunchKernelGGL((lbs_bwd_frame_kernel<false, false>), dim3(B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, FitFuse{});
   int e = (int)hipGetLastError();
   if (e) return e;
   // dX[b][k] = sum_col Dk[k][col] dvp[b][col]  : A = Dk (M = 512 features), B = dvp (N = B frames)

@@ -308,8 +308,14 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
     --l;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
-  CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s));
-  CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
+  if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
+    // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two
+    const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B}, d.loss_acc, cnt, d.losses};
+    CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, nullptr, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s, &ff));
+  } else {
+    CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s));
+    CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
+  }
   lemo_pose_grad_in gi{d.dA, nullptr, d.dX};
   lemo_pose_grad_out go{};
   go.d_lh = d.g_other + 32; go.d_rh = d.g_other + 44; go.hand_stride = 56;

@@ -95,4 +95,165 @@ __device__ __forceinline__ void vertex_loss_body(int b, FitConst fc, const float
   }
 }
 
+// ---- d(total)/d(verts) pieces (opt_amass_temp.py:359-425 differentiated by hand) --------------------------------
+// losses[0..6] = marker, vposer, shape, hand, contact, smooth, total ; losses[8..11] = 1/count per foot set
+// weights[0..5] = rec_markers, vposer, shape, hand, contact_vel, smooth   (opt_amass_temp.py:47-52)
+__device__ __forceinline__ void finalize_losses(const double* tot, int B, int n67, double smooth_count,
+                                                const float* weights, float* losses) {
+  const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
+  float l_contact = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    const double cnt = tot[5 + k];
+    const float part = cnt >= 1.0 ? (float)(tot[1 + k] / cnt) : 0.f;
+    l_contact = l_contact + part;
+    losses[8 + k] = cnt >= 1.0 ? (float)(1.0 / cnt) : 0.f;
+  }
+  const float l_smooth = (float)(tot[9] / smooth_count);
+  const float l_vposer = (float)(tot[10] / ((double)B * 32));
+  const float l_shape = (float)(tot[11] / ((double)B * 10));
+  const float l_hand = (float)(tot[12] / ((double)B * 24));
+  float total = weights[0] * l_marker + weights[1] * l_vposer;
+  total = total + weights[2] * l_shape;
+  total = total + weights[3] * l_hand;
+  total = total + weights[4] * l_contact;
+  total = total + weights[5] * l_smooth;
+  losses[0] = l_marker; losses[1] = l_vposer; losses[2] = l_shape; losses[3] = l_hand;
+  losses[4] = l_contact; losses[5] = l_smooth; losses[6] = total; losses[7] = 0.f;
+}
+
+
+// total of accumulator `i` over its 32 slots
+__device__ __forceinline__ double loss_slot_total(const double* __restrict__ acc, int i) {
+  double v = 0.0;
+  for (int sl = 0; sl < 32; ++sl) v += acc[sl * 16 + i];
+  return v;
+}
+
+
+// gradient of the weighted total w.r.t. vertex u of the active set, frame b.  `losses` = the finalised record
+// (losses[8 + k] = 1 / count of foot set k).
+// Every global read is issued up front with clamped addresses and the terms are switched by selects: written the
+// natural way (a load inside each `if`), the function was a chain of 5-6 dependent cold round trips (~7 us per block).
+struct DvIdx { int row, m67, fm, m81; };
+__device__ __forceinline__ DvIdx dverts_indices(const FitConst& fc, int u) {
+  DvIdx ix;
+  ix.row = fc.u_row[u]; ix.m67 = fc.u_m67[u]; ix.fm = fc.u_foot_mask[u]; ix.m81 = fc.u_m81[u];
+  return ix;
+}
+
+__device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn& in, const float* losses, int b, const DvIdx ix,
+                                              float& gx_out, float& gy_out, float& gz_out) {
+  const float* __restrict__ verts = in.verts; const float* __restrict__ target = in.target;
+  const float* __restrict__ contact = in.contact; const float* __restrict__ dx0 = in.dx0;
+  const float* __restrict__ canon = in.canon; const float* __restrict__ weights = in.weights;
+  const int nrows = in.nrows, B = in.B;
+  const int D = 3 * fc.n81, W = B - 1 + 16, nd = B - 1;
+  const int row = ix.row, m67 = ix.m67, fm = ix.fm, m81 = ix.m81;
+  // ---- reads
+  const int bn = min(b + 1, B - 1), bp = max(b - 1, 0), bc = max(min(b, B - 2), 0);
+  const float* v = verts + ((size_t)b * nrows + row) * 3;
+  const float* v1 = verts + ((size_t)bn * nrows + row) * 3;
+  const float* vm = verts + ((size_t)bp * nrows + row) * 3;
+  const float* tg = target + ((size_t)b * fc.n67 + max(m67, 0)) * 3;
+  float p[3], pn[3], pm[3], tgv[3], xstd[3], ct[4], ctm[4], cn[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { p[c] = v[c]; pn[c] = v1[c]; pm[c] = vm[c]; tgv[c] = tg[c]; xstd[c] = fc.Xstd[3 * max(m81, 0) + c]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { ct[k] = contact[(size_t)bc * 4 + k]; ctm[k] = contact[(size_t)bp * 4 + k]; }
+#pragma unroll
+  for (int e = 0; e < 9; ++e) cn[e] = canon[e];
+  const float wm = weights[0] / ((float)B * fc.n67 * 3), wc = weights[4];
+  // smoothness-image gradient: feature row d = 3 m81 + c is read by padded rows y = d + 1 (+ one reflected copy for
+  // d == 1 or d == D - 2) and, for each of the two time differences, padded columns t' + 8 (+ one reflected copy near
+  // either end).  2 x 2 x 2 candidate reads per component, absent ones point at the main one and are switched off.
+  const bool fast = D >= 5 && nd >= 18;          // the reflected copies are then mutually exclusive
+  float dx[3][2][4];
+  bool on[3][2][4];
+  if (fast) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int d = 3 * max(m81, 0) + c;
+      const int yA = d + 1, yB = d == 1 ? 0 : (d == D - 2 ? D + 1 : -1);
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const int tp = side == 0 ? b - 1 : b;
+        const bool tv = tp >= 0 && tp <= nd - 1;
+        const int tq = min(max(tp, 0), nd - 1);
+        const int xA = tq + 8, xB = (tq >= 1 && tq <= 8) ? 8 - tq : ((tq >= nd - 9 && tq <= nd - 2) ? 2 * (nd - 1) - tq + 8 : -1);
+        on[c][side][0] = tv;               on[c][side][1] = tv && xB >= 0;
+        on[c][side][2] = tv && yB >= 0;    on[c][side][3] = tv && yB >= 0 && xB >= 0;
+        const int yb = yB >= 0 ? yB : yA, xb = xB >= 0 ? xB : xA;
+        dx[c][side][0] = dx0[(size_t)yA * W + xA]; dx[c][side][1] = dx0[(size_t)yA * W + xb];
+        dx[c][side][2] = dx0[(size_t)yb * W + xA]; dx[c][side][3] = dx0[(size_t)yb * W + xb];
+      }
+    }
+  }
+  // ---- marker term: d|v - target| (opt_amass_temp.py:359)
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (m67 >= 0) {
+    const float d0 = p[0] - tgv[0], d1 = p[1] - tgv[1], d2 = p[2] - tgv[2];
+    gx += wm * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
+    gy += wm * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+    gz += wm * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+  }
+  // ---- contact-velocity term (:414-425): speeds above 0.1 of the foot sets in contact, both neighbours
+  if (fm) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!((fm >> k) & 1)) continue;
+      const float coef = wc * losses[8 + k] * 30.f;
+      if (b < B - 1 && ct[k] == 1.f) {
+        const float vx = (pn[0] - p[0]) * 30.f, vy = (pn[1] - p[1]) * 30.f, vz = (pn[2] - p[2]) * 30.f;
+        const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (sp - 0.1f > 0.f) { const float q = coef / sp; gx -= q * vx; gy -= q * vy; gz -= q * vz; }
+      }
+      if (b >= 1 && ctm[k] == 1.f) {
+        const float vx = (p[0] - pm[0]) * 30.f, vy = (p[1] - pm[1]) * 30.f, vz = (p[2] - pm[2]) * 30.f;
+        const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
+        if (sp - 0.1f > 0.f) { const float q = coef / sp; gx += q * vx; gy += q * vy; gz += q * vz; }
+      }
+    }
+  }
+  // ---- smoothness term through the marker image (:376-391)
+  if (m81 >= 0) {
+    float dg[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int d = 3 * m81 + c;
+      float acc = 0.f;
+      if (fast) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {             // side 0: difference t' = b - 1 (+), side 1: t' = b (-)
+          float sv = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sv += on[c][side][q] ? dx[c][side][q] : 0.f;
+          acc += side == 0 ? sv : -sv;
+        }
+      } else {
+        int ys[3]; int ny = 0;
+        ys[ny++] = d + 1;
+        if (d == 1) ys[ny++] = 0;
+        if (d == D - 2) ys[ny++] = D + 1;
+        for (int side = 0; side < 2; ++side) {
+          const int tp = side == 0 ? b - 1 : b;
+          if (tp < 0 || tp > nd - 1) continue;
+          int xs[3]; int nx = 0;
+          xs[nx++] = tp + 8;
+          if (tp >= 1 && tp <= 8) xs[nx++] = 8 - tp;
+          if (tp >= nd - 9 && tp <= nd - 2) xs[nx++] = 2 * (nd - 1) - tp + 8;
+          float sv = 0.f;
+          for (int iy = 0; iy < ny; ++iy)
+            for (int jx = 0; jx < nx; ++jx) sv += dx0[(size_t)ys[iy] * W + xs[jx]];
+          acc += side == 0 ? sv : -sv;
+        }
+      }
+      dg[c] = acc / xstd[c];
+    }
+    gx += cn[0] * dg[0] + cn[1] * dg[1] + cn[2] * dg[2];
+    gy += cn[3] * dg[0] + cn[4] * dg[1] + cn[5] * dg[2];
+    gz += cn[6] * dg[0] + cn[7] * dg[1] + cn[8] * dg[2];
+  }
+  gx_out = gx; gy_out = gy; gz_out = gz;
+}
+
 }  // namespace lemo

@@ -102,31 +102,6 @@ int vertex_loss_accumulate(const FitConst& fc, const float* verts, int nrows, co
   return (int)hipGetLastError();
 }
 
-// losses[0..6] = marker, vposer, shape, hand, contact, smooth, total ; losses[8..11] = 1/count per foot set
-// weights[0..5] = rec_markers, vposer, shape, hand, contact_vel, smooth   (opt_amass_temp.py:47-52)
-__device__ __forceinline__ void finalize_losses(const double* tot, int B, int n67, double smooth_count,
-                                                const float* weights, float* losses) {
-  const float l_marker = (float)(tot[0] / ((double)B * n67 * 3));
-  float l_contact = 0.f;
-  for (int k = 0; k < 4; ++k) {
-    const double cnt = tot[5 + k];
-    const float part = cnt >= 1.0 ? (float)(tot[1 + k] / cnt) : 0.f;
-    l_contact = l_contact + part;
-    losses[8 + k] = cnt >= 1.0 ? (float)(1.0 / cnt) : 0.f;
-  }
-  const float l_smooth = (float)(tot[9] / smooth_count);
-  const float l_vposer = (float)(tot[10] / ((double)B * 32));
-  const float l_shape = (float)(tot[11] / ((double)B * 10));
-  const float l_hand = (float)(tot[12] / ((double)B * 24));
-  float total = weights[0] * l_marker + weights[1] * l_vposer;
-  total = total + weights[2] * l_shape;
-  total = total + weights[3] * l_hand;
-  total = total + weights[4] * l_contact;
-  total = total + weights[5] * l_smooth;
-  losses[0] = l_marker; losses[1] = l_vposer; losses[2] = l_shape; losses[3] = l_hand;
-  losses[4] = l_contact; losses[5] = l_smooth; losses[6] = total; losses[7] = 0.f;
-}
-
 __global__ void loss_finalize_kernel(const double* __restrict__ acc, int B, int n67, double smooth_count,
                                      const float* __restrict__ weights, float* __restrict__ losses) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -141,91 +116,28 @@ int loss_finalize(const double* acc, int B, int n67, double smooth_count, const 
   return (int)hipGetLastError();
 }
 
-// d(total)/d(verts) on the active vertex set U (block per frame).
+// d(total)/d(verts) on the active vertex set U (block per frame; bodies in loss_device.hpp, shared with the fused
+// LBS backward of the fitting engine).
 __global__ void __launch_bounds__(256)
 dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                        const float* __restrict__ contact, const float* __restrict__ dx0, const float* __restrict__ canon,
                        const float* __restrict__ weights, const double* __restrict__ acc, double smooth_count,
                        float* __restrict__ losses_out, int B, float* __restrict__ dverts) {
   __shared__ float losses[12];
-  const int b = blockIdx.x;
   __shared__ double tots[13];
-  if (threadIdx.x < 13) {             // every block finalises the (tiny) loss record itself; block 0 publishes it
-    double v = 0.0;
-    for (int sl = 0; sl < 32; ++sl) v += acc[sl * 16 + threadIdx.x];
-    tots[threadIdx.x] = v;
-  }
+  const int b = blockIdx.x;
+  // every block finalises the (tiny) loss record itself; block 0 publishes it
+  if (threadIdx.x < 13) tots[threadIdx.x] = loss_slot_total(acc, threadIdx.x);
   __syncthreads();
   if (threadIdx.x == 0) {
-    double tot[13];
-    for (int i = 0; i < 13; ++i) tot[i] = tots[i];
-    finalize_losses(tot, B, fc.n67, smooth_count, weights, losses);
+    finalize_losses(tots, B, fc.n67, smooth_count, weights, losses);
     if (b == 0) for (int i = 0; i < 12; ++i) losses_out[i] = losses[i];
   }
   __syncthreads();
-  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, nd = B - 1;
-  (void)H;
-  const float wm = weights[0] / ((float)B * fc.n67 * 3), wc = weights[4];
+  const DvertsIn in = {verts, nrows, target, contact, dx0, canon, weights, B};
   for (int u = threadIdx.x; u < fc.n; u += 256) {
-    const int row = fc.u_row[u];
-    const float* v = verts + ((size_t)b * nrows + row) * 3;
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    const int m67 = fc.u_m67[u];
-    if (m67 >= 0) {
-      const float* tg = target + ((size_t)b * fc.n67 + m67) * 3;
-      const float d0 = v[0] - tg[0], d1 = v[1] - tg[1], d2 = v[2] - tg[2];
-      gx += wm * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
-      gy += wm * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-      gz += wm * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
-    }
-    const int fm = fc.u_foot_mask[u];
-    if (fm) {
-      for (int k = 0; k < 4; ++k) {
-        if (!((fm >> k) & 1)) continue;
-        const float coef = wc * losses[8 + k] * 30.f;
-        if (b < B - 1 && contact[(size_t)b * 4 + k] == 1.f) {
-          const float* v1 = v + (size_t)nrows * 3;
-          const float vx = (v1[0] - v[0]) * 30.f, vy = (v1[1] - v[1]) * 30.f, vz = (v1[2] - v[2]) * 30.f;
-          const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
-          if (sp - 0.1f > 0.f) { const float q = coef / sp; gx -= q * vx; gy -= q * vy; gz -= q * vz; }
-        }
-        if (b >= 1 && contact[(size_t)(b - 1) * 4 + k] == 1.f) {
-          const float* vm = v - (size_t)nrows * 3;
-          const float vx = (v[0] - vm[0]) * 30.f, vy = (v[1] - vm[1]) * 30.f, vz = (v[2] - vm[2]) * 30.f;
-          const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
-          if (sp - 0.1f > 0.f) { const float q = coef / sp; gx += q * vx; gy += q * vy; gz += q * vz; }
-        }
-      }
-    }
-    const int m81 = fc.u_m81[u];
-    if (m81 >= 0) {
-      float dg[3];
-      for (int c = 0; c < 3; ++c) {
-        const int d = 3 * m81 + c;
-        // rows of the padded image that read feature row d : y = d+1, plus the reflected copies
-        int ys[3]; int ny = 0;
-        ys[ny++] = d + 1;
-        if (d == 1) ys[ny++] = 0;
-        if (d == D - 2) ys[ny++] = D + 1;
-        float acc = 0.f;
-        for (int side = 0; side < 2; ++side) {               // side 0: difference t'=b-1 (+), side 1: t'=b (-)
-          const int tp = side == 0 ? b - 1 : b;
-          if (tp < 0 || tp > nd - 1) continue;
-          int xs[3]; int nx = 0;
-          xs[nx++] = tp + 8;
-          if (tp >= 1 && tp <= 8) xs[nx++] = 8 - tp;
-          if (tp >= nd - 9 && tp <= nd - 2) xs[nx++] = 2 * (nd - 1) - tp + 8;
-          float sv = 0.f;
-          for (int iy = 0; iy < ny; ++iy)
-            for (int ix = 0; ix < nx; ++ix) sv += dx0[(size_t)ys[iy] * W + xs[ix]];
-          acc += side == 0 ? sv : -sv;
-        }
-        dg[c] = acc / fc.Xstd[d];
-      }
-      gx += canon[0] * dg[0] + canon[1] * dg[1] + canon[2] * dg[2];
-      gy += canon[3] * dg[0] + canon[4] * dg[1] + canon[5] * dg[2];
-      gz += canon[6] * dg[0] + canon[7] * dg[1] + canon[8] * dg[2];
-    }
+    float gx, gy, gz;
+    dverts_vertex(fc, in, losses, b, dverts_indices(fc, u), gx, gy, gz);
     float* o = dverts + ((size_t)b * fc.n + u) * 3;
     o[0] = gx; o[1] = gy; o[2] = gz;
   }

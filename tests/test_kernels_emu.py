@@ -218,6 +218,28 @@ def test_fit_iteration_vs_oracle(emu_lib, full):
     assert int(fit.step_ctr.item()) == 3
 
 
+@pytest.mark.timeout(900)
+def test_fit_gradient_long_clip_vs_oracle(emu_lib):
+    """B = 20 (> 18 difference columns): dverts_vertex takes its prefetched form, where the reflected copies of the
+    smoothness image are mutually exclusive (loss_device.hpp); the 14-frame problem above takes the generic loop."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem(B=20)
+    ofit, markers = ge.oracle_for(prob)
+    total, parts, _, _ = ofit.losses()
+    total.backward()
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                              prob['B'], 'cpu', full_vertices=False, lib=emu_lib)
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    fit.forward()
+    fit.backward()
+    L = fit.losses()
+    assert abs(L['total'] - float(total)) <= 1e-5 * float(total)
+    g = fit.grads_with_priors()
+    for k, ref in (('transl', ofit.transl.grad), ('rot6d', ofit.rot6d.grad), ('other', ofit.other.grad)):
+        assert rel_err(g[k], ref) < 2e-4, k
+
+
 def test_contact_term_empty_selection_is_exactly_zero(emu_lib):
     """K15: `x[x>thr].mean()` with an empty selection must be exactly 0 (opt_amass_temp.py:429-443)."""
     import __graft_entry__ as ge
