@@ -434,6 +434,7 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     __shared__ double tots[FUSED ? 13 : 1];
     const int ts = t - DV;
     DvIdx ix0 = {0, -1, 0, -1};
+    DvRegs dv0;
     const int n3 = u.n * 3, na = nj * 12, nnz = u.jcsr_start[nj];
     vid0 = u.ids[min(t, u.n - 1)];   // first vertex of the dvp loop below: its (index, weight) reads ride along
     if (!FUSED || t >= DV) {
@@ -484,25 +485,34 @@ lbs_bwd_frame_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       // loss record: 13 lanes of wave 0 total the accumulator slots, lane 0 finalises (same wave: program order is
       // enough between the LDS write and the read); every block does it, block 0 publishes
       ix0 = dverts_indices(ff.fc, min(t, u.n - 1));       // indices of this lane's first vertex: in flight with the rest
-      if (t < 13) tots[t] = loss_slot_total(ff.acc, t);
+      // loss record: d(verts) only needs 1 / count of the four foot sets (accumulators 5..8): lanes 5..8 total their
+      // slots and divide, in parallel.  The full record (a dozen f64 divisions on one lane, ~4 k cycles) is only for
+      // reporting: block 0 totals all 13 and an otherwise idle staging wave finalises it after the barrier.
+      if (t < 13 && (b == 0 || (t >= 5 && t < 9))) {
+        const double tot = loss_slot_total(ff.acc, t);
+        tots[t] = tot;
+        if (t >= 5 && t < 9) losses[8 + (t - 5)] = tot >= 1.0 ? (float)(1.0 / tot) : 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int kk = min(k, c.KW - 1);
         ji0[k] = c.w_idx[(size_t)vid0 * c.KW + kk];
         wk0[k] = k < c.KW ? c.w_val[(size_t)vid0 * c.KW + kk] : 0.f;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (t == 0) {
-        finalize_losses(tots, ff.in.B, ff.fc.n67, ff.smooth_count, ff.in.weights, losses);
-        if (b == 0) for (int i = 0; i < 12; ++i) ff.losses_out[i] = losses[i];
-      }
+      dverts_load(ff.fc, ff.in, b, ix0, dv0);               // second-level reads of the first vertex, before the barrier
     }
     __syncthreads();
     if (FUSED) {
+      if (b == 0 && t == DV) {
+        float rec[12];
+        finalize_losses(tots, ff.in.B, ff.fc.n67, ff.smooth_count, ff.in.weights, rec);
+        for (int i = 0; i < 12; ++i) ff.losses_out[i] = rec[i];
+      }
       if (t < DV)
         for (int uu = t; uu < u.n; uu += DV) {
           float gx, gy, gz;
-          dverts_vertex(ff.fc, ff.in, losses, b, uu == t ? ix0 : dverts_indices(ff.fc, uu), gx, gy, gz);
+          if (uu == t) dverts_compute(ff.fc, ff.in, losses, b, dv0, gx, gy, gz);
+          else dverts_vertex(ff.fc, ff.in, losses, b, dverts_indices(ff.fc, uu), gx, gy, gz);
           gs[3 * uu] = gx; gs[3 * uu + 1] = gy; gs[3 * uu + 2] = gz;
         }
       __syncthreads();

@@ -141,8 +141,17 @@ __device__ __forceinline__ DvIdx dverts_indices(const FitConst& fc, int u) {
   return ix;
 }
 
-__device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn& in, const float* losses, int b, const DvIdx ix,
-                                              float& gx_out, float& gy_out, float& gz_out) {
+// everything dverts_compute reads from global memory, loaded by dverts_load (so a caller can put a barrier -- the
+// loss record -- between the two without exposing the reads behind it)
+struct DvRegs {
+  float p[3], pn[3], pm[3], tgv[3], xstd[3], ct[4], ctm[4], cn[9], wm, wc;
+  float dx[3][2][4];
+  bool on[3][2][4];
+  bool fast;
+  int m67, fm, m81;
+};
+
+__device__ __forceinline__ void dverts_load(const FitConst& fc, const DvertsIn& in, int b, const DvIdx ix, DvRegs& r) {
   const float* __restrict__ verts = in.verts; const float* __restrict__ target = in.target;
   const float* __restrict__ contact = in.contact; const float* __restrict__ dx0 = in.dx0;
   const float* __restrict__ canon = in.canon; const float* __restrict__ weights = in.weights;
@@ -155,21 +164,19 @@ __device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn
   const float* v1 = verts + ((size_t)bn * nrows + row) * 3;
   const float* vm = verts + ((size_t)bp * nrows + row) * 3;
   const float* tg = target + ((size_t)b * fc.n67 + max(m67, 0)) * 3;
-  float p[3], pn[3], pm[3], tgv[3], xstd[3], ct[4], ctm[4], cn[9];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { p[c] = v[c]; pn[c] = v1[c]; pm[c] = vm[c]; tgv[c] = tg[c]; xstd[c] = fc.Xstd[3 * max(m81, 0) + c]; }
+  for (int c = 0; c < 3; ++c) { r.p[c] = v[c]; r.pn[c] = v1[c]; r.pm[c] = vm[c]; r.tgv[c] = tg[c]; r.xstd[c] = fc.Xstd[3 * max(m81, 0) + c]; }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { ct[k] = contact[(size_t)bc * 4 + k]; ctm[k] = contact[(size_t)bp * 4 + k]; }
+  for (int k = 0; k < 4; ++k) { r.ct[k] = contact[(size_t)bc * 4 + k]; r.ctm[k] = contact[(size_t)bp * 4 + k]; }
 #pragma unroll
-  for (int e = 0; e < 9; ++e) cn[e] = canon[e];
-  const float wm = weights[0] / ((float)B * fc.n67 * 3), wc = weights[4];
+  for (int e = 0; e < 9; ++e) r.cn[e] = canon[e];
+  r.wm = weights[0] / ((float)B * fc.n67 * 3); r.wc = weights[4];
   // smoothness-image gradient: feature row d = 3 m81 + c is read by padded rows y = d + 1 (+ one reflected copy for
   // d == 1 or d == D - 2) and, for each of the two time differences, padded columns t' + 8 (+ one reflected copy near
   // either end).  2 x 2 x 2 candidate reads per component, absent ones point at the main one and are switched off.
-  const bool fast = D >= 5 && nd >= 18;          // the reflected copies are then mutually exclusive
-  float dx[3][2][4];
-  bool on[3][2][4];
-  if (fast) {
+  r.fast = D >= 5 && nd >= 18;                   // the reflected copies are then mutually exclusive
+  r.m67 = m67; r.fm = fm; r.m81 = m81;
+  if (r.fast) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int d = 3 * max(m81, 0) + c;
@@ -180,18 +187,27 @@ __device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn
         const bool tv = tp >= 0 && tp <= nd - 1;
         const int tq = min(max(tp, 0), nd - 1);
         const int xA = tq + 8, xB = (tq >= 1 && tq <= 8) ? 8 - tq : ((tq >= nd - 9 && tq <= nd - 2) ? 2 * (nd - 1) - tq + 8 : -1);
-        on[c][side][0] = tv;               on[c][side][1] = tv && xB >= 0;
-        on[c][side][2] = tv && yB >= 0;    on[c][side][3] = tv && yB >= 0 && xB >= 0;
+        r.on[c][side][0] = tv;               r.on[c][side][1] = tv && xB >= 0;
+        r.on[c][side][2] = tv && yB >= 0;    r.on[c][side][3] = tv && yB >= 0 && xB >= 0;
         const int yb = yB >= 0 ? yB : yA, xb = xB >= 0 ? xB : xA;
-        dx[c][side][0] = dx0[(size_t)yA * W + xA]; dx[c][side][1] = dx0[(size_t)yA * W + xb];
-        dx[c][side][2] = dx0[(size_t)yb * W + xA]; dx[c][side][3] = dx0[(size_t)yb * W + xb];
+        r.dx[c][side][0] = dx0[(size_t)yA * W + xA]; r.dx[c][side][1] = dx0[(size_t)yA * W + xb];
+        r.dx[c][side][2] = dx0[(size_t)yb * W + xA]; r.dx[c][side][3] = dx0[(size_t)yb * W + xb];
       }
     }
   }
+}
+
+__device__ __forceinline__ void dverts_compute(const FitConst& fc, const DvertsIn& in, const float* losses, int b, const DvRegs& r,
+                                               float& gx_out, float& gy_out, float& gz_out) {
+  const float* __restrict__ dx0 = in.dx0;
+  const int B = in.B, D = 3 * fc.n81, W = B - 1 + 16, nd = B - 1;
+  const int m67 = r.m67, fm = r.fm, m81 = r.m81;
+  const float wm = r.wm, wc = r.wc;
+  const bool fast = r.fast;
   // ---- marker term: d|v - target| (opt_amass_temp.py:359)
   float gx = 0.f, gy = 0.f, gz = 0.f;
   if (m67 >= 0) {
-    const float d0 = p[0] - tgv[0], d1 = p[1] - tgv[1], d2 = p[2] - tgv[2];
+    const float d0 = r.p[0] - r.tgv[0], d1 = r.p[1] - r.tgv[1], d2 = r.p[2] - r.tgv[2];
     gx += wm * (d0 > 0.f ? 1.f : (d0 < 0.f ? -1.f : 0.f));
     gy += wm * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
     gz += wm * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
@@ -202,13 +218,13 @@ __device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn
     for (int k = 0; k < 4; ++k) {
       if (!((fm >> k) & 1)) continue;
       const float coef = wc * losses[8 + k] * 30.f;
-      if (b < B - 1 && ct[k] == 1.f) {
-        const float vx = (pn[0] - p[0]) * 30.f, vy = (pn[1] - p[1]) * 30.f, vz = (pn[2] - p[2]) * 30.f;
+      if (b < B - 1 && r.ct[k] == 1.f) {
+        const float vx = (r.pn[0] - r.p[0]) * 30.f, vy = (r.pn[1] - r.p[1]) * 30.f, vz = (r.pn[2] - r.p[2]) * 30.f;
         const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
         if (sp - 0.1f > 0.f) { const float q = coef / sp; gx -= q * vx; gy -= q * vy; gz -= q * vz; }
       }
-      if (b >= 1 && ctm[k] == 1.f) {
-        const float vx = (p[0] - pm[0]) * 30.f, vy = (p[1] - pm[1]) * 30.f, vz = (p[2] - pm[2]) * 30.f;
+      if (b >= 1 && r.ctm[k] == 1.f) {
+        const float vx = (r.p[0] - r.pm[0]) * 30.f, vy = (r.p[1] - r.pm[1]) * 30.f, vz = (r.p[2] - r.pm[2]) * 30.f;
         const float sp = sqrtf(vx * vx + vy * vy + vz * vz);
         if (sp - 0.1f > 0.f) { const float q = coef / sp; gx += q * vx; gy += q * vy; gz += q * vz; }
       }
@@ -226,7 +242,7 @@ __device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn
         for (int side = 0; side < 2; ++side) {             // side 0: difference t' = b - 1 (+), side 1: t' = b (-)
           float sv = 0.f;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sv += on[c][side][q] ? dx[c][side][q] : 0.f;
+          for (int q = 0; q < 4; ++q) sv += r.on[c][side][q] ? r.dx[c][side][q] : 0.f;
           acc += side == 0 ? sv : -sv;
         }
       } else {
@@ -247,13 +263,20 @@ __device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn
           acc += side == 0 ? sv : -sv;
         }
       }
-      dg[c] = acc / xstd[c];
+      dg[c] = acc / r.xstd[c];
     }
-    gx += cn[0] * dg[0] + cn[1] * dg[1] + cn[2] * dg[2];
-    gy += cn[3] * dg[0] + cn[4] * dg[1] + cn[5] * dg[2];
-    gz += cn[6] * dg[0] + cn[7] * dg[1] + cn[8] * dg[2];
+    gx += r.cn[0] * dg[0] + r.cn[1] * dg[1] + r.cn[2] * dg[2];
+    gy += r.cn[3] * dg[0] + r.cn[4] * dg[1] + r.cn[5] * dg[2];
+    gz += r.cn[6] * dg[0] + r.cn[7] * dg[1] + r.cn[8] * dg[2];
   }
   gx_out = gx; gy_out = gy; gz_out = gz;
+}
+
+__device__ __forceinline__ void dverts_vertex(const FitConst& fc, const DvertsIn& in, const float* losses, int b, const DvIdx ix,
+                                              float& gx_out, float& gy_out, float& gz_out) {
+  DvRegs r;
+  dverts_load(fc, in, b, ix, r);
+  dverts_compute(fc, in, losses, b, r, gx_out, gy_out, gz_out);
 }
 
 }  // namespace lemo
