@@ -40,22 +40,26 @@ __global__ void __launch_bounds__(256)
 marker_feature_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ Jtr, int nj,
                       const float* __restrict__ transl, int B, float* __restrict__ x0, float* __restrict__ canon_out) {
   __shared__ float cn[12];
+  // this thread's reads first (they do not depend on the canonical frame): they are in flight while thread 0 walks
+  // its own index -> vertex -> joint chain below
+  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, Wp = W + 2;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, pc = min(p, H * W - 1);
+  const int y = pc / W, x = pc - y * W;
+  const int d = reflect_idx(y - 1, D), tp = reflect_idx(x - 8, B - 1);
+  const int m = d / 3, c = d - 3 * m;
+  const float* v0 = verts + ((size_t)tp * nrows + fc.row81[m]) * 3;
+  const float* v1 = v0 + (size_t)nrows * 3;
+  const float a0 = v0[0], a1 = v0[1], a2 = v0[2], b0 = v1[0], b1 = v1[1], b2 = v1[2];
+  const float xm = fc.Xmean[d], xs = fc.Xstd[d];
   if (threadIdx.x == 0) {
     canonical_frame(verts, nrows, fc.row81, Jtr, nj, transl, cn);
     if (blockIdx.x == 0) for (int i = 0; i < 12; ++i) canon_out[i] = cn[i];
   }
   __syncthreads();
-  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, Wp = W + 2;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= H * W) return;
-  const int y = p / W, x = p - y * W;
-  const int d = reflect_idx(y - 1, D), tp = reflect_idx(x - 8, B - 1);
-  const int m = d / 3, c = d - 3 * m;
-  const float* v0 = verts + ((size_t)tp * nrows + fc.row81[m]) * 3;
-  const float* v1 = v0 + (size_t)nrows * 3;
-  const float g0 = (v0[0] - cn[9]) * cn[c] + (v0[1] - cn[10]) * cn[3 + c] + (v0[2] - cn[11]) * cn[6 + c];
-  const float g1 = (v1[0] - cn[9]) * cn[c] + (v1[1] - cn[10]) * cn[3 + c] + (v1[2] - cn[11]) * cn[6 + c];
-  const float n0 = (g0 - fc.Xmean[d]) / fc.Xstd[d], n1 = (g1 - fc.Xmean[d]) / fc.Xstd[d];
+  const float g0 = (a0 - cn[9]) * cn[c] + (a1 - cn[10]) * cn[3 + c] + (a2 - cn[11]) * cn[6 + c];
+  const float g1 = (b0 - cn[9]) * cn[c] + (b1 - cn[10]) * cn[3 + c] + (b2 - cn[11]) * cn[6 + c];
+  const float n0 = (g0 - xm) / xs, n1 = (g1 - xm) / xs;
   x0[(size_t)(y + 1) * Wp + (x + 1)] = n1 - n0;
 }
 
