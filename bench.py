@@ -220,7 +220,7 @@ def main():
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',
                      'peak_note': peak_note,
-                     'kernel': kname + ' 64->64ch 245x134, 14 of the 35 launches/iteration',
+                     'kernel': kname + ' 64->64ch 245x134, 14 of the 34 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
