@@ -662,7 +662,7 @@ smooth_loss_kernel(const float* __restrict__ z, float* __restrict__ dpre, float*
   smooth_loss_body((int)blockIdx.x, z, dpre, partial, H, W, C, coef2, acc);
 }
 
-int smooth_loss_blocks(int H, int W, int C) { return (H * W * (C / 8) * 2 + 255) / 256; }
+int smooth_loss_blocks(int H, int W, int C) { return (H * W * (C / 8) * 2 + 256 * LEMO_SMOOTH_ITEMS - 1) / (256 * LEMO_SMOOTH_ITEMS); }
 
 int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C, float coef2, hipStream_t s, double* acc) {
   if (C % 8 || (!partial && !acc)) return LEMO_ERR_SHAPE;

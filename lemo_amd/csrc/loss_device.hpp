@@ -11,32 +11,43 @@ namespace lemo {
 //   dpre[c,y,x] = coef * 2 * ((z[x]-z[x-1])[x>=1] - (z[x+1]-z[x])[x<=W-2]) * lrelu'(z[c,y,x])
 // with coef = weight / (C*H*(W-1)).  Per-block partial sums of the squared differences go to
 // `partial[blockIdx.x]` (fixed-order final reduction elsewhere -> deterministic).
+#define LEMO_SMOOTH_ITEMS 4          // float4s per thread: all 12 loads of a thread are issued before the first use
 __device__ __forceinline__ void smooth_loss_body(int blk, const float* __restrict__ z, float* __restrict__ dpre, float* __restrict__ partial,
                                                  int H, int W, int C, float coef2, double* __restrict__ acc) {
   __shared__ float red[4];
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
-  const int idx = blk * blockDim.x + threadIdx.x;
-  const int n = P * (C >> 3) * 2;                                   // one thread per float4
+  const int n = P * (C >> 3) * 2;                                   // one item per float4
   float sq = 0.f;
-  if (idx < n) {
-    const int half = idx & 1, rest = idx >> 1;
+  float4 cv[LEMO_SMOOTH_ITEMS], lv[LEMO_SMOOTH_ITEMS], rv[LEMO_SMOOTH_ITEMS];
+  size_t ov[LEMO_SMOOTH_ITEMS];
+  bool hasl[LEMO_SMOOTH_ITEMS], hasr[LEMO_SMOOTH_ITEMS], valid[LEMO_SMOOTH_ITEMS];
+#pragma unroll
+  for (int k = 0; k < LEMO_SMOOTH_ITEMS; ++k) {
+    const int idx = (blk * LEMO_SMOOTH_ITEMS + k) * (int)blockDim.x + (int)threadIdx.x;
+    valid[k] = idx < n;
+    const int ic = valid[k] ? idx : n - 1;
+    const int half = ic & 1, rest = ic >> 1;
     const int g = rest / P, p = rest - g * P;
     const int y = p / W, x = p - y * W;
-    const size_t o = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8 + 4 * half;
-    const float4 c = ld4(z + o);
+    ov[k] = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8 + 4 * half;
+    hasl[k] = x >= 1; hasr[k] = x <= W - 2;
+    cv[k] = ld4(z + ov[k]);
+    lv[k] = ld4(z + ov[k] - 8);                                     // x = 0 / W-1: the zero border column, switched off below
+    rv[k] = ld4(z + ov[k] + 8);
+  }
+#pragma unroll
+  for (int k = 0; k < LEMO_SMOOTH_ITEMS; ++k) {
+    const float4 c = cv[k], l = lv[k], r = rv[k];
     float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (x >= 1) {
-      const float4 l = ld4(z + o - 8);
-      gr.x += c.x - l.x; gr.y += c.y - l.y; gr.z += c.z - l.z; gr.w += c.w - l.w;
-    }
-    if (x <= W - 2) {
-      const float4 r = ld4(z + o + 8);
+    if (hasl[k]) { gr.x += c.x - l.x; gr.y += c.y - l.y; gr.z += c.z - l.z; gr.w += c.w - l.w; }
+    if (hasr[k]) {
       const float d0 = r.x - c.x, d1 = r.y - c.y, d2 = r.z - c.z, d3 = r.w - c.w;
-      sq = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+      if (valid[k]) sq += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
       gr.x -= d0; gr.y -= d1; gr.z -= d2; gr.w -= d3;
     }
-    st4(dpre + o, make_float4(coef2 * gr.x * lrelu_grad_from_out(c.x), coef2 * gr.y * lrelu_grad_from_out(c.y),
-                              coef2 * gr.z * lrelu_grad_from_out(c.z), coef2 * gr.w * lrelu_grad_from_out(c.w)));
+    if (valid[k])
+      st4(dpre + ov[k], make_float4(coef2 * gr.x * lrelu_grad_from_out(c.x), coef2 * gr.y * lrelu_grad_from_out(c.y),
+                                    coef2 * gr.z * lrelu_grad_from_out(c.z), coef2 * gr.w * lrelu_grad_from_out(c.w)));
   }
   const float s = block_sum(sq, red);
   if (threadIdx.x == 0) {

@@ -79,15 +79,18 @@ vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int 
   vertex_loss_body((int)blockIdx.x, fc, verts, nrows, target, contact, shape, other, B, accg);
 }
 
-// both post-encoder loss kernels in one launch: blocks [0, nsm) = smoothness loss + d(pre-activation), the rest =
-// per-frame vertex losses and priors
+// both post-encoder loss kernels in one launch: blocks [0, B) = per-frame vertex losses and priors, the rest =
+// smoothness loss + d(pre-activation)
 __global__ void __launch_bounds__(256)
 fit_losses_kernel(int nsm, const float* __restrict__ z, float* __restrict__ dpre, int H, int W, int C, float coef2, double* __restrict__ sm_acc,
                   FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                               const float* __restrict__ contact, const float* __restrict__ shape,
                               const float* __restrict__ other, int B, double* __restrict__ accg) {
-  if ((int)blockIdx.x < nsm) smooth_loss_body((int)blockIdx.x, z, dpre, nullptr, H, W, C, coef2, sm_acc);
-  else vertex_loss_body((int)blockIdx.x - nsm, fc, verts, nrows, target, contact, shape, other, B, accg);
+  // the per-frame blocks are a chain of dependent gathers (index -> vertex rows): first in the grid, so that the
+  // streaming smoothness blocks run under their latency instead of the other way round
+  if ((int)blockIdx.x < B) vertex_loss_body((int)blockIdx.x, fc, verts, nrows, target, contact, shape, other, B, accg);
+  else smooth_loss_body((int)blockIdx.x - B, z, dpre, nullptr, H, W, C, coef2, sm_acc);
+  (void)nsm;
 }
 
 int fit_losses(const float* z, float* dpre, int H, int W, int C, float coef2, double* sm_acc, const FitConst& fc, const float* verts,
