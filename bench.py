@@ -171,6 +171,8 @@ def main():
 
     with torch.cuda.stream(stream):
         fit.step(args.warmup, use_graph=use_graph)
+        if use_graph:
+            fit.prepare(args.steps)         # record the graphs of the timed call (nothing runs): capture is not a step
     torch.cuda.synchronize(device)
     barrier()
     torch.cuda.synchronize(device)
@@ -220,7 +222,7 @@ def main():
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',
                      'peak_note': peak_note,
-                     'kernel': kname + ' 64->64ch 245x134, 14 of the 34 launches/iteration',
+                     'kernel': kname + ' 64->64ch 245x134, 14 of the 33 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

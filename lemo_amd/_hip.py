@@ -165,6 +165,7 @@ _SIGS = {
     'lemo_fit_forward': (C.c_int, [vp, vp]),
     'lemo_fit_backward': (C.c_int, [vp, vp]),
     'lemo_fit_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    'lemo_fit_prepare': (C.c_int, [vp, C.c_int, vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

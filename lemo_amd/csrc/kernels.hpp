@@ -100,6 +100,8 @@ int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int co
 int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, int* step_dev, hipStream_t s);
 
 // ---------------- loss_kernels.hip ----------------
+int marker_c1(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
+              const float* w, const float* bias, float* x0, float* canon, float* out, int cout, hipStream_t s);
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);
 // acc (f64[16], zeroed at the start of the iteration): [0] marker L1 sum, [1..4] contact sums, [5..8] contact

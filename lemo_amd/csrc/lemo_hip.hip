@@ -206,13 +206,14 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 static const int CHAIN_LAYERS = 7;    // 64 -> 64 layers of the encoder (models/AE_sep.py:77-89): what conv_chain_sync is sized for
 
 // a replay costs ~8 us of device idle time around the graph (tools/ubench/launch_ubench.hip) on top of its nodes:
-// FIT_UNROLL iterations are captured into one graph and the remainder runs on a one-iteration graph
-static const int FIT_UNROLL = 5;
+// up to FIT_UNROLL[0] iterations are captured into one graph; remainders run on the smaller graphs
+static const int FIT_LEVELS = 3;
+static const int FIT_UNROLL[FIT_LEVELS] = {20, 5, 1};   // iterations per graph, tried largest first (20: 372.4 vs 374.4 us
+                                                          // per iteration with 5 only, same box; 100-step fits = 5 replays)
 
 struct FitEngine {
   lemo_fit_desc d;
-  hipGraphExec_t exec = nullptr;        // 1 iteration
-  hipGraphExec_t exec_u = nullptr;      // FIT_UNROLL iterations
+  hipGraphExec_t exec[FIT_LEVELS] = {nullptr, nullptr, nullptr};   // FIT_UNROLL[l] iterations each, captured on first use
   hipStream_t graph_stream = nullptr;
 };
 
@@ -229,6 +230,21 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
   const int ic = (int)hipGraphInstantiate(out, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   return ic;
+}
+
+// n iterations as replays of the 20 / 5 / 1-iteration graphs (largest first); launch = false only captures what is missing
+static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
+  if (e->graph_stream != s) {
+    for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) { (void)hipGraphExecDestroy(e->exec[l]); e->exec[l] = nullptr; }
+    e->graph_stream = s;
+  }
+  int left = n;
+  for (int l = 0; l < FIT_LEVELS; ++l) {
+    if (left < FIT_UNROLL[l]) continue;
+    if (!e->exec[l]) CHK(capture_iterations(e, s, FIT_UNROLL[l], &e->exec[l]));
+    for (; left >= FIT_UNROLL[l]; left -= FIT_UNROLL[l]) if (launch) CHK((int)hipGraphLaunch(e->exec[l], s));
+  }
+  return 0;
 }
 
 static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
@@ -250,8 +266,8 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
     CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
-  CHK(marker_feature(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.x0, d.canon, s));
-  CHK(conv3x3_c1(d.x0, d.enc_w[0], d.enc_b[0], d.act[1], H, W, d.enc_ch[1], s));
+  // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
+  CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
   // runs of 64 -> 64 layers go out as ONE persistent chain launch when the caller provided the sync buffer and
   // every workgroup fits on the device at once; everything else one launch per layer
   const bool chain_f = d.conv_variant == 3 && d.conv_chain_sync[0] && conv3x3_split_chain_supported(H, W);
@@ -345,8 +361,7 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
 void lemo_fit_destroy(void* h) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return;
-  if (e->exec) (void)hipGraphExecDestroy(e->exec);
-  if (e->exec_u) (void)hipGraphExecDestroy(e->exec_u);
+  for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
   delete e;
 }
 
@@ -370,17 +385,14 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
     for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s));
     return 0;
   }
-  if (e->graph_stream != s) {
-    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-    if (e->exec_u) { (void)hipGraphExecDestroy(e->exec_u); e->exec_u = nullptr; }
-    e->graph_stream = s;
-  }
-  if (n >= FIT_UNROLL && !e->exec_u) CHK(capture_iterations(e, s, FIT_UNROLL, &e->exec_u));
-  if (n % FIT_UNROLL && !e->exec) CHK(capture_iterations(e, s, 1, &e->exec));
-  int i = 0;
-  for (; i + FIT_UNROLL <= n; i += FIT_UNROLL) CHK((int)hipGraphLaunch(e->exec_u, s));
-  for (; i < n; ++i) CHK((int)hipGraphLaunch(e->exec, s));
-  return 0;
+  CHK(fit_graphs(e, s, n, false));
+  return fit_graphs(e, s, n, true);
+}
+
+int lemo_fit_prepare(void* h, int n, void* stream) {
+  FitEngine* e = (FitEngine*)h;
+  if (!e || n < 0) return LEMO_ERR_ARG;
+  return fit_graphs(e, S(stream), n, false);
 }
 
 }  // extern "C"

@@ -71,6 +71,97 @@ int marker_feature(const FitConst& fc, const float* verts, int nrows, const floa
   return (int)hipGetLastError();
 }
 
+// ---- marker image + first encoder layer in one launch (fitting engine) ---------------------------------------
+// marker_feature_kernel writes the single-channel image x0 and conv3x3_c1_kernel (conv_kernels.hip) reads it back nine
+// times per output: two launches of ~5 us whose work is a few microseconds of latency.  Here a block owns a tile of
+// MC_TY feature rows x MC_TX time columns: it computes the tile of x0 with its one-pixel halo into LDS (same formula,
+// same order of operations as marker_feature_kernel), publishes the interior to the global x0 (kept for the parity
+// tests and the C-ABI contract of the engine's buffers), and applies the 1 -> cout 3x3 layer from LDS.  The layer's
+// weights are uniform across the block (every thread loops over all channel groups): scalar loads.
+#define MC_TX 32
+#define MC_TY 8
+#define MC_PITCH (MC_TX + 2)
+__global__ void __launch_bounds__(MC_TX * MC_TY)
+marker_c1_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ Jtr, int nj,
+                 const float* __restrict__ transl, int B, const float* __restrict__ w, const float* __restrict__ bias,
+                 float* __restrict__ x0, float* __restrict__ canon_out, float* __restrict__ out, int cout) {
+  __shared__ float cn[12];
+  __shared__ float xs[(MC_TY + 2) * MC_PITCH];
+  constexpr int NT = MC_TX * MC_TY, NH = (MC_TY + 2) * MC_PITCH;     // 256 threads, 340 halo-tile values
+  const int D = 3 * fc.n81, H = D + 2, W = B - 1 + 16, Wp = W + 2, HWp = (H + 2) * Wp;
+  const int t = threadIdx.x;
+  const int x00 = blockIdx.x * MC_TX, y00 = blockIdx.y * MC_TY;      // tile origin (image coordinates)
+  // ---- reads of this thread's (up to two) halo-tile values, before anything that waits
+  float a[2][3], b[2][3], xm[2], xsd[2];
+  int cc[2];
+  bool inside[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = min(t + NT * k, NH - 1);
+    const int yy = y00 + i / MC_PITCH - 1, xx = x00 + i % MC_PITCH - 1;   // image coordinates of the value (-1 .. H / W)
+    inside[k] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+    const int d = reflect_idx(yc - 1, D), tp = reflect_idx(xc - 8, B - 1);
+    const int m = d / 3;
+    cc[k] = d - 3 * m;
+    const float* v0 = verts + ((size_t)tp * nrows + fc.row81[m]) * 3;
+    const float* v1 = v0 + (size_t)nrows * 3;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { a[k][e] = v0[e]; b[k][e] = v1[e]; }
+    xm[k] = fc.Xmean[d]; xsd[k] = fc.Xstd[d];
+  }
+  if (t == 0) {
+    canonical_frame(verts, nrows, fc.row81, Jtr, nj, transl, cn);
+    if (blockIdx.x == 0 && blockIdx.y == 0) for (int i = 0; i < 12; ++i) canon_out[i] = cn[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = t + NT * k;
+    if (i < NH) {
+      const int c = cc[k];
+      const float g0 = (a[k][0] - cn[9]) * cn[c] + (a[k][1] - cn[10]) * cn[3 + c] + (a[k][2] - cn[11]) * cn[6 + c];
+      const float g1 = (b[k][0] - cn[9]) * cn[c] + (b[k][1] - cn[10]) * cn[3 + c] + (b[k][2] - cn[11]) * cn[6 + c];
+      const float n0 = (g0 - xm[k]) / xsd[k], n1 = (g1 - xm[k]) / xsd[k];
+      const float v = inside[k] ? n1 - n0 : 0.f;                      // outside the image: the zero border of the padded x0
+      xs[i] = v;
+      const int ly = i / MC_PITCH, lx = i % MC_PITCH;
+      if (inside[k] && ly >= 1 && ly <= MC_TY && lx >= 1 && lx <= MC_TX)   // the tile's own pixels
+        x0[(size_t)(y00 + ly) * Wp + (x00 + lx)] = v;
+    }
+  }
+  __syncthreads();
+  const int ly = t / MC_TX, lx = t % MC_TX, y = y00 + ly, x = x00 + lx;
+  if (y >= H || x >= W) return;
+  float xin[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) xin[tp] = xs[(ly + tp / 3) * MC_PITCH + lx + tp % 3];
+  const int poff = (y + 1) * Wp + (x + 1);
+  for (int g = 0; g < (cout >> 3); ++g) {
+    float r[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* wc = w + (size_t)(g * 8 + c) * 9;
+      float acc = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc = fmaf(wc[tp], xin[tp], acc);
+      r[c] = lrelu(acc + bias[g * 8 + c]);
+    }
+    float* o = out + ((size_t)g * HWp + poff) * 8;
+    st4(o, make_float4(r[0], r[1], r[2], r[3]));
+    st4(o + 4, make_float4(r[4], r[5], r[6], r[7]));
+  }
+}
+
+int marker_c1(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
+              const float* w, const float* bias, float* x0, float* canon, float* out, int cout, hipStream_t s) {
+  if (B < 10 || (cout % 8)) return LEMO_ERR_SHAPE;
+  const int H = 3 * fc.n81 + 2, W = B - 1 + 16;
+  hipLaunchKernelGGL(marker_c1_kernel, dim3((W + MC_TX - 1) / MC_TX, (H + MC_TY - 1) / MC_TY), dim3(MC_TX * MC_TY), 0, s, fc, verts, nrows,
+                     Jtr, nj, transl, B, w, bias, x0, canon, out, cout);
+  return (int)hipGetLastError();
+}
+
 // (bodies: loss_device.hpp)
 __global__ void __launch_bounds__(256)
 vertex_loss_accumulate_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,

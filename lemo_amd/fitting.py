@@ -4,7 +4,7 @@ Reference: ``opt_amass_temp.py::optimize`` -- per-clip setup :332-345, the 100-s
 :349-455 (the hot path), result :457-458.  One :class:`AmassTemporalFitter` owns every device
 buffer of one sequence (parameters, Adam state, ~0.5 GB of workspace for B=119) and hands raw
 pointers to ``liblemo_hip.so`` once (``lemo_fit_create``); an iteration is then a single C call
-(``lemo_fit_step``) that replays a captured hipGraph (35 kernels per iteration) -- no host sync, no ``.item()``
+(``lemo_fit_step``) that replays captured hipGraphs (34 kernels per iteration) -- no host sync, no ``.item()``
 (the reference has 4 per iteration, :431-443), SMPL-X evaluated once instead of twice (:357,:364).
 """
 from __future__ import annotations
@@ -187,6 +187,11 @@ class AmassTemporalFitter:
         stream, so call inside ``with torch.cuda.stream(s):``."""
         self.lib.check(self.lib.fit_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()),
                        'fit_step')
+
+    def prepare(self, n: int) -> None:
+        """capture (without running) the hipGraphs an ``n``-iteration :meth:`step` on the current stream replays."""
+        if not self.lib.is_emu:
+            self.lib.check(self.lib.fit_prepare(self.handle, int(n), self._s()), 'fit_prepare')
 
     def check_chains(self):
         """raises if a bounded wait of the persistent encoder kernels timed out (call after a synchronisation)"""

@@ -15,7 +15,7 @@ def _declared():
 def test_header_declares_expected_entry_points():
     names = _declared()
     for need in ('lemo_conv3x3_mfma', 'lemo_vposer_decode_fwd', 'lemo_smplx_pose_fwd', 'lemo_lbs_verts_fwd',
-                 'lemo_lbs_verts_bwd', 'lemo_fit_create', 'lemo_fit_step'):
+                 'lemo_lbs_verts_bwd', 'lemo_fit_create', 'lemo_fit_step', 'lemo_fit_prepare'):
         assert need in names
 
 

@@ -293,6 +293,23 @@ def test_fit_full_size_golden(full_problem, dev, conv_variant):
     assert abs(fit.losses()['total'] - float(g['total_hist'][9])) < 1e-3 * float(g['total_hist'][9])
 
 
+def test_fused_marker_image_and_first_layer(full_problem, dev):
+    """the engine's one-launch marker image + first encoder layer (marker_c1_kernel) against the stand-alone layer
+    (C-ABI lemo_conv3x3_c1) applied to the image it published: identical activations, at the full 245 x 134 size."""
+    from lemo_amd.priors import ENC_CHANNELS
+    g, seq = full_problem['g'], full_problem['seq']
+    fit = full_problem['make'](True)
+    fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    fit.forward()
+    ref1 = torch.zeros_like(fit.act[1])
+    lib = fit.lib
+    lib.check(lib.conv3x3_c1(ptr(fit.ws['x0']), ptr(fit.enc.w[0]), ptr(fit.enc.b[0]), ptr(ref1), fit.H, fit.W, ENC_CHANNELS[1],
+                             lib.stream(dev)))
+    torch.cuda.synchronize()
+    assert float(fit.ws['x0'].abs().max()) > 0
+    assert torch.equal(ref1, fit.act[1])
+
+
 def test_active_vertex_forward_is_identical(full_problem, dev):
     """forwarding only the 253 vertices the losses read gives the same losses and gradients."""
     g, seq = full_problem['g'], full_problem['seq']

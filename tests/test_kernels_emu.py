@@ -192,6 +192,12 @@ def test_fit_iteration_vs_oracle(emu_lib, full):
                               prob['B'], 'cpu', full_vertices=full, lib=emu_lib)
     fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     fit.forward()
+    # the engine builds the marker image and applies the first encoder layer in one launch (marker_c1_kernel); the
+    # stand-alone layer (C-ABI lemo_conv3x3_c1) on the image it published must give the same activations bit for bit
+    from lemo_amd.priors import ENC_CHANNELS
+    ref1 = torch.zeros_like(fit.act[1])
+    assert emu_lib.conv3x3_c1(ptr(fit.ws['x0']), ptr(fit.enc.w[0]), ptr(fit.enc.b[0]), ptr(ref1), fit.H, fit.W, ENC_CHANNELS[1], None) == 0
+    assert float(fit.ws['x0'].abs().max()) > 0 and torch.equal(ref1, fit.act[1])
     fit.backward()
     L = fit.losses()
     for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
