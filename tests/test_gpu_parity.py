@@ -296,6 +296,7 @@ def test_fit_full_size_golden(full_problem, dev, conv_variant):
 def test_fused_marker_image_and_first_layer(full_problem, dev):
     """the engine's one-launch marker image + first encoder layer (marker_c1_kernel) against the stand-alone layer
     (C-ABI lemo_conv3x3_c1) applied to the image it published: identical activations, at the full 245 x 134 size."""
+    from lemo_amd._hip import ptr
     from lemo_amd.priors import ENC_CHANNELS
     g, seq = full_problem['g'], full_problem['seq']
     fit = full_problem['make'](True)
