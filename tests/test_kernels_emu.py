@@ -246,6 +246,30 @@ def test_fit_gradient_long_clip_vs_oracle(emu_lib):
         assert rel_err(g[k], ref) < 2e-4, k
 
 
+@pytest.mark.timeout(900)
+def test_fit_gradient_large_vertex_set_vs_oracle(emu_lib):
+    """a loss-carrying set of more than 256 vertices: the fused d(verts) stage of the LBS backward (256 lanes) and the
+    1024-thread staging loops take more than one trip per lane."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem(B=12, foot=75)
+    ofit, markers = ge.oracle_for(prob)
+    total, parts, _, _ = ofit.losses()
+    total.backward()
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                              prob['B'], 'cpu', full_vertices=True, lib=emu_lib)
+    assert fit.n > 256
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    fit.forward()
+    fit.backward()
+    L = fit.losses()
+    for k in ('marker', 'contact', 'smooth'):
+        assert abs(L[k] - float(parts[k])) <= 1e-5 * abs(float(parts[k])), (k, L[k], float(parts[k]))
+    g = fit.grads_with_priors()
+    for k, ref in (('transl', ofit.transl.grad), ('rot6d', ofit.rot6d.grad), ('other', ofit.other.grad)):
+        assert rel_err(g[k], ref) < 2e-4, k
+
+
 def test_contact_term_empty_selection_is_exactly_zero(emu_lib):
     """K15: `x[x>thr].mean()` with an empty selection must be exactly 0 (opt_amass_temp.py:429-443)."""
     import __graft_entry__ as ge
