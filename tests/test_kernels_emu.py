@@ -247,18 +247,20 @@ def test_fit_gradient_long_clip_vs_oracle(emu_lib):
 
 
 @pytest.mark.timeout(900)
-def test_fit_gradient_large_vertex_set_vs_oracle(emu_lib):
-    """a loss-carrying set of more than 256 vertices: the fused d(verts) stage of the LBS backward (256 lanes) and the
-    1024-thread staging loops take more than one trip per lane."""
+@pytest.mark.parametrize('V,foot,nmin', [(640, 75, 256), (1300, 262, 1024)])
+def test_fit_gradient_large_vertex_set_vs_oracle(emu_lib, V, foot, nmin):
+    """a loss-carrying set of more than 256 vertices: the fused d(verts) stage of the LBS backward (256 lanes) takes
+    more than one trip per lane; more than 1024: the set no longer fits the staged kernel, and the engine falls back
+    to dverts_assemble + the dense LBS backward."""
     import __graft_entry__ as ge
     from lemo_amd.fitting import AmassTemporalFitter
-    prob = ge.small_problem(B=12, foot=75)
+    prob = ge.small_problem(B=12, V=V, foot=foot)
     ofit, markers = ge.oracle_for(prob)
     total, parts, _, _ = ofit.losses()
     total.backward()
     fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
                               prob['B'], 'cpu', full_vertices=True, lib=emu_lib)
-    assert fit.n > 256
+    assert fit.n > nmin
     fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     fit.forward()
     fit.backward()
