@@ -311,6 +311,32 @@ def test_fused_marker_image_and_first_layer(full_problem, dev):
     assert torch.equal(ref1, fit.act[1])
 
 
+def test_compat_lbs_function(dev):
+    """smplx.lbs.lbs served by lemo_amd.compat on the GPU library: vertices, joints and gradients vs the oracle's lbs
+    (pinned to the reference's lbs.py), SMPL-X-sized model (V = 10475), 16 shape coefficients."""
+    from lemo_amd.compat.smplx.lbs import lbs
+    from oracle import lemo_oracle as O
+    m = synthetic.make_synthetic_smplx(seed=0)
+    so = O.SmplxOracle(m, extra_joint_ids=[0])
+    sd = torch.cat([so.shapedirs, so.expr_dirs], dim=-1)[:, :, :16].contiguous()
+    a = dict(v_template=so.v_template, shapedirs=sd, posedirs=so.posedirs, J_regressor=so.J_regressor,
+             parents=so.parents, lbs_weights=so.lbs_weights)
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    betas, pose = torch.randn(B, 16, generator=g) * 0.5, torch.randn(B, 165, generator=g) * 0.2
+    bc, pc = betas.clone().requires_grad_(True), pose.clone().requires_grad_(True)
+    v_ref, j_ref = O.lbs(bc, pc, **a)
+    wv = torch.randn(v_ref.shape, generator=g)
+    (v_ref * wv).sum().backward()
+    bd, pd = betas.to(dev).requires_grad_(True), pose.to(dev).requires_grad_(True)
+    ad = {k: v.to(dev) for k, v in a.items()}
+    verts, joints = lbs(bd, pd, ad['v_template'], ad['shapedirs'], ad['posedirs'], ad['J_regressor'], ad['parents'],
+                        ad['lbs_weights'])
+    assert rel_err(verts.detach().cpu(), v_ref.detach()) < 1e-4 and rel_err(joints.detach().cpu(), j_ref.detach()) < 1e-4
+    (verts * wv.to(dev)).sum().backward()
+    assert rel_err(bd.grad.cpu(), bc.grad) < 1e-4 and rel_err(pd.grad.cpu(), pc.grad) < 1e-4
+
+
 def test_active_vertex_forward_is_identical(full_problem, dev):
     """forwarding only the 253 vertices the losses read gives the same losses and gradients."""
     g, seq = full_problem['g'], full_problem['seq']
