@@ -1,0 +1,58 @@
+"""Static check of the compiled hot kernels (hipcc cross-compiles gfx950 without a GPU): register budgets that the
+launch shapes rely on, and no scratch (a spilled accumulator turns an MFMA loop into a memory loop)."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'lemo_amd', 'csrc')
+HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+
+# kernel-name fragment -> (file, max VGPRs, threads per block that budget comes from)
+BUDGETS = {
+    'conv3x3_split_kernelILi0ELi64ELi64ELb0E': ('conv_split_kernels.hip', 256, 512),   # one 8-wave block per CU: 2 waves per SIMD, 512 / 2 registers
+    'conv3x3_split_kernelILi1ELi64ELi64ELb0E': ('conv_split_kernels.hip', 256, 512),
+    'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
+    'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
+    'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),
+    'smplx_pose_fwd_kernel': ('pose_kernels.hip', 256, 256),
+    'smplx_pose_bwd_kernel': ('pose_kernels.hip', 256, 256),
+    'fit_losses_kernel': ('loss_kernels.hip', 128, 256),
+    'marker_c1_kernel': ('loss_kernels.hip', 128, 256),
+}
+
+
+def _usage(fname):
+    out = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
+                          '-Wno-unused-function', '-Rpass-analysis=kernel-resource-usage', '-c', fname, '-o', os.devnull],
+                         cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r'remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)', line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return res
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+@pytest.mark.timeout(1200)
+def test_hot_kernels_fit_their_register_budget_without_scratch():
+    files = sorted({f for f, _, _ in BUDGETS.values()})
+    with ThreadPoolExecutor(len(files)) as ex:
+        usage = dict(zip(files, ex.map(_usage, files)))
+    for frag, (fname, max_vgpr, _) in BUDGETS.items():
+        hits = {k: v for k, v in usage[fname].items() if frag in k}
+        assert hits, (frag, sorted(usage[fname])[:5])
+        for name, u in hits.items():
+            assert u.get('ScratchSize [bytes/lane]', 0) == 0 and u.get('VGPRs Spill', 0) == 0, (name, u)
+            assert u['VGPRs'] <= max_vgpr, (name, u)
+            assert u.get('LDS Size [bytes/block]', 0) <= 160 * 1024, (name, u)
