@@ -24,6 +24,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
 REF = '/root/reference'
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 
 from oracle import lemo_oracle as O                      # noqa: E402
 from lemo_amd import synthetic                           # noqa: E402
@@ -264,23 +265,133 @@ def emit_amass_iteration():
     print('amass iteration:', {k: (float(v) if np.ndim(v) == 0 else np.shape(v)) for k, v in out.items()})
 
 
-def emit_prox_iteration():
-    """(7) one PROX S3 / S2 iteration on the reduced seeded window of __graft_entry__.prox_small_problem: the 14
-    loss_dict entries and grads w.r.t. pose_embedding / transl / global_orient with and without the erase."""
+def _flat_clip_image(seed=11):
+    """normalised [1,4,208,119] clip image of the synthetic marker clip (what the AMASS loader hands over,
+    loader/optimize_loader_amass_new.py:371-377) + its rot_0_pivot"""
+    from oracle import markers_oracle as MO
+    stats = dict(np.load(os.path.join(ROOT, 'lemo_amd/assets/stats_infill.npz')))
+    body, contact = synthetic_marker_clip(seed=seed)
+    img, piv = MO.get_local_markers_4chan(body, contact)
+    clip = torch.from_numpy(img).float().unsqueeze(0)
+    f = lambda k: torch.from_numpy(np.asarray(stats[k])).float()
+    clip[:, 0] = (clip[:, 0] - f('Xmean_local')) / f('Xstd_local')
+    clip[:, 1:3] = (clip[:, 1:3] - f('Xmean_global_xy')) / f('Xstd_global_xy')
+    clip[:, 3] = (clip[:, 3] - f('Xmean_global_r')) / f('Xstd_global_r')
+    return clip.permute(0, 1, 3, 2).contiguous(), piv, stats
+
+
+def pin_amass_loop_and_clip(report):
+    """Run the reference's own TEXT (opt_amass_temp.py:355-453 loop body, :159-214 mask + finetune, :256-329 decode)
+    and compare with the oracle's restatements.  Emits tests/golden/amass_clip.npz (fixture of the per-clip setup)."""
+    import ref_harness as RH
+    from oracle import pipeline_oracle as PO
+    from lemo_amd.assets import load_assets
+    A = load_assets()
+    # ---- loop body at the golden-(6) inputs: B = 119, V = 10475, real markers / encoder weights -------------
+    m = synthetic.make_synthetic_smplx(seed=0)
+    so = O.SmplxOracle(m)
+    vw = O.make_vposer_weights(seed=2)
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    gold = np.load(os.path.join(HERE, 'amass_iter.npz'))
+    r = RH.run_amass_loop_body(so, vw, A['ids'], A['Xmean'], A['Xstd'], seq['init_params'], gold['markers_rec'],
+                               seq['contact_lbl'], steps=2)
+    relf = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
+    for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
+        report['amass_loop.' + k] = relf(float(gold['loss_' + k]), r[k])
+    report['amass_loop.total'] = relf(float(gold['total']), r['total'])
+    for k in ('g_transl', 'g_rot6d', 'g_other'):
+        report['amass_loop.' + k] = _rel(torch.from_numpy(gold[k]), torch.from_numpy(r[k]))
+    report['amass_loop.p75_after1'] = _rel(torch.from_numpy(gold['p75_after1']), torch.from_numpy(r['p75_hist'][0]))
+    # ---- per-clip setup: mask + 60-step finetune + eval forward, then decode -------------------------------
+    clip, piv, stats = _flat_clip_image()
+    ae_w = {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
+    xin_r, rec_r, rows, loss_r = RH.run_amass_finetune_text(ae_w, clip, finetune_steps=60)
+    xin_o, mask = PO.amass_mask_input(clip)
+    _, rec_o = PO.finetune(ae_w, xin_o, mask, steps=60)
+    report['amass_clip.masked_input'] = _rel(xin_o, xin_r)
+    report['amass_clip.train_rows'] = 0.0 if sorted(rows[:-5]) == torch.nonzero(mask[:, 0]).flatten().tolist() else 1.0
+    report['amass_clip.finetuned_rec'] = _rel(rec_o, rec_r)
+    lbl_r, mk_r = RH.run_amass_decode_text(rec_r, clip, piv)
+    lbl_o, mk_o = PO.decode_markers(rec_o[0, 0], clip[0], piv, stats)
+    report['amass_clip.contact_lbl_rec'] = float((lbl_r - lbl_o).abs().max())
+    report['amass_clip.markers_rec'] = _rel(torch.from_numpy(mk_o).float(), mk_r)
+    # the decode statements on an image with mixed contact logits (a seeded-random AE emits one sign only)
+    g = torch.Generator().manual_seed(5)
+    rnd = rec_r + torch.randn(rec_r.shape, generator=g) * 0.5
+    lbl_r2, mk_r2 = RH.run_amass_decode_text(rnd, clip, piv)
+    lbl_o2, mk_o2 = PO.decode_markers(rnd[0, 0], clip[0], piv, stats)
+    report['amass_clip.decode_mixed.contact_lbl_rec'] = float((lbl_r2 - lbl_o2).abs().max())
+    report['amass_clip.decode_mixed.markers_rec'] = _rel(torch.from_numpy(mk_o2).float(), mk_r2)
+    assert 0 < float(lbl_r2.sum()) < lbl_r2.numel()
+    np.savez_compressed(os.path.join(HERE, 'amass_clip.npz'), clip_img=clip.numpy(), rot_0_pivot=np.asarray(piv, np.float64),
+                        clip_img_input=xin_r.numpy(), train_mask=mask.numpy(), clip_img_rec=rec_r.numpy(),
+                        finetune_last_loss=np.float64(loss_r), contact_lbl_rec=lbl_r.numpy(), markers_rec=mk_r.numpy(),
+                        rec_mixed=rnd.numpy(), contact_lbl_mixed=lbl_r2.numpy(), markers_mixed=mk_r2.numpy())
+
+
+def pin_prox_and_emit(report):
+    """(7) Drive the reference's OWN SMPLifyLoss / FittingMonitor closure / PerspectiveCamera / L2Prior /
+    SMPLifyAnglePrior / JointMapper / optim_factory (imported under module stubs, tests/golden/ref_harness.py) on the
+    seeded window ``__graft_entry__.prox_small_problem(real_markers=True)`` for S2 / S3 x first / later window,
+    compare the 14 loss_dict entries, three gradients and the parameters after 3 Adam steps with
+    oracle/prox_oracle.py, and write tests/golden/prox_iter.npz FROM THE REFERENCE RUN.  Also pins the
+    ``opt_step == 0`` block (:776-941) against oracle/pipeline_oracle.py and writes prox_setup.npz."""
     import __graft_entry__ as ge
-    from oracle.prox_oracle import LOSS_KEYS
+    import ref_harness as RH
+    from oracle import pipeline_oracle as PO
+    from oracle.prox_oracle import LOSS_KEYS, PARAM_NAMES
     out = {}
+    relf = lambda a, b: (abs(a - b) / max(abs(b), 1e-30)) if a != b else 0.0
     for stage in ('S3', 'S2'):
         for first in (False, True):
-            of = ge.prox_oracle_for(ge.prox_small_problem(stage=stage), first_batch_flag=first)
-            ld = of.closure()
+            prob = ge.prox_small_problem(stage=stage, real_markers=True)
+            of = ge.prox_oracle_for(prob, first_batch_flag=first)
+            rw = RH.RefProxWindow(prob, first_batch_flag=first)
             tag = f'{stage}_{"first" if first else "later"}'
-            out[tag + '_loss'] = np.asarray([float(ld[k]) for k in LOSS_KEYS])
-            out[tag + '_g_pose_embedding'] = of.pose_embedding.grad.numpy().copy()
-            out[tag + '_g_transl'] = of.p['transl'].grad.numpy().copy()
-            out[tag + '_g_global_orient'] = of.p['global_orient'].grad.numpy().copy()
+            h = rw.iterate(1)[0]
+            go = of.closure()
+            out[tag + '_loss'] = np.asarray([h[k] for k in LOSS_KEYS])
+            report[f'prox.{tag}.loss_dict'] = max(relf(float(go[k]), h[k]) for k in LOSS_KEYS)
+            g = rw.grads()
+            for k, og in (('pose_embedding', of.pose_embedding.grad), ('transl', of.p['transl'].grad),
+                          ('global_orient', of.p['global_orient'].grad)):
+                out[f'{tag}_g_{k}'] = g[k]
+                report[f'prox.{tag}.g_{k}'] = _rel(og, torch.from_numpy(g[k]))
+            of.opt.step()
+            for _ in range(2):
+                of.step()
+            rw.iterate(2)
+            worst = max(float((getattr(rw.body_model, k).detach() - of.p[k].detach()).abs().max()) for k in PARAM_NAMES)
+            worst = max(worst, float((rw.pose_embedding.detach() - of.pose_embedding.detach()).abs().max()))
+            report[f'prox.{tag}.params_after3'] = worst
+            out[tag + '_pose_embedding_after3'] = rw.pose_embedding.detach().numpy().copy()
+            out[tag + '_transl_after3'] = rw.body_model.transl.detach().numpy().copy()
+            out[tag + '_global_orient_after3'] = rw.body_model.global_orient.detach().numpy().copy()
     np.savez(os.path.join(HERE, 'prox_iter.npz'), **out)
-    print('prox iteration:', {k: v.shape for k, v in out.items()})
+    # ---- opt_step == 0: per-window infill setup ------------------------------------------------------------
+    stats = dict(np.load(os.path.join(ROOT, 'lemo_amd/assets/stats_infill.npz')))
+    ae_w = {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
+    prob = ge.prox_small_problem(stage='S3', real_markers=True)
+    mask = prob['infill']['marker_mask']
+    prob['infill'] = dict(marker_mask=mask)
+    rw = RH.RefProxWindow(prob, first_batch_flag=False, ae_weights=ae_w)
+    rw.closure()
+    of = ge.prox_oracle_for(dict(prob, infill={}), first_batch_flag=False)
+    with torch.no_grad():
+        verts, _, _ = of._body(True)
+        _, sj, _ = of._body(False)
+        vw = torch.matmul(of.R, verts.permute(0, 2, 1)).permute(0, 2, 1) + of.t
+        jw = torch.matmul(of.R, sj.permute(0, 2, 1)).permute(0, 2, 1) + of.t
+    s = PO.prox_window_setup(vw, jw, torch.from_numpy(mask), ae_w, stats, prob['ids']['markers67'])
+    report['prox_setup.body_markers_rec'] = _rel(s['body_markers_rec'], rw.loss.body_markers_rec)
+    report['prox_setup.contact_lbl_rec'] = float((s['contact_lbl_rec'] - rw.loss.contact_lbl_rec).abs().max())
+    report['prox_setup.motion_infill_loss'] = 0.0 if np.isfinite(float(rw.loss_dict['motion_infill_loss'])) else 1.0
+    np.savez_compressed(os.path.join(HERE, 'prox_setup.npz'), vertices_world=vw.numpy(), smplx_joints_world=jw.numpy(),
+                        marker_mask=mask, body_markers_rec=rw.loss.body_markers_rec.numpy(),
+                        contact_lbl_rec=rw.loss.contact_lbl_rec.numpy(), clip_img_input=s['clip_img_input'].numpy(),
+                        train_mask=s['train_mask'].numpy(), clip_img_rec=s['clip_img_rec'].numpy(),
+                        motion_infill_loss=np.float64(float(rw.loss_dict['motion_infill_loss'])))
+    print('prox fixtures:', {k: v.shape for k, v in out.items()})
 
 
 if __name__ == '__main__':
@@ -297,6 +408,15 @@ if __name__ == '__main__':
     assert not bad, 'oracle disagrees with the reference'
     emit_golden(ae_sd)
     emit_amass_iteration()
-    emit_prox_iteration()
+    pins = {}
+    pin_amass_loop_and_clip(pins)
+    pin_prox_and_emit(pins)
+    print('loop bodies and pipelines vs the text and classes of the reference itself (max rel err):')
+    with open(os.path.join(HERE, 'oracle_vs_reference.txt'), 'a') as f:
+        for k, v in pins.items():
+            print(f'  {k:44s} {v}')
+            f.write(f'{k}\t{v}\n')
+            bad = bad or not (v <= 2e-6)
+    assert not bad, 'oracle disagrees with the reference'
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -20,6 +20,16 @@ def test_pinning_report_all_exact():
     names = {r[0] for r in rows}
     for need in ('lbs.verts', 'lbs.joints', 'Enc.z', 'AE.out', 'utils.convert_to_3D_rot', 'VPoser.decode.aa'):
         assert need in names
+    # round 2: the loop bodies / per-clip pipelines, run from the reference's own text and classes (ref_harness.py)
+    need = ['amass_loop.' + k for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total', 'g_transl', 'g_rot6d',
+                                        'g_other', 'p75_after1')]
+    need += ['amass_clip.' + k for k in ('masked_input', 'train_rows', 'finetuned_rec', 'contact_lbl_rec', 'markers_rec',
+                                         'decode_mixed.contact_lbl_rec', 'decode_mixed.markers_rec')]
+    need += [f'prox.{s}_{w}.{k}' for s in ('S2', 'S3') for w in ('first', 'later')
+             for k in ('loss_dict', 'g_pose_embedding', 'g_transl', 'g_global_orient', 'params_after3')]
+    need += ['prox_setup.body_markers_rec', 'prox_setup.contact_lbl_rec']
+    for n in need:
+        assert n in names, n
     assert all(float(r[1]) <= 2e-6 for r in rows)
 
 
@@ -123,11 +133,12 @@ def test_amass_iteration_golden():
 
 
 def test_prox_iteration_golden():
-    """golden (7): PROX S2/S3 iteration of the oracle (14 loss_dict entries + three gradients, +/- erase)."""
+    """golden (7): PROX S2/S3 iteration (14 loss_dict entries + three gradients, +/- erase, 3 Adam steps).  The fixture
+    was written from a run of the reference's own SMPLifyLoss / closure / camera / priors (make_golden.py)."""
     import __graft_entry__ as ge
     from oracle.prox_oracle import LOSS_KEYS
     g = np.load(os.path.join(GOLDEN, 'prox_iter.npz'))
-    of = ge.prox_oracle_for(ge.prox_small_problem(stage='S3'), first_batch_flag=False)
+    of = ge.prox_oracle_for(ge.prox_small_problem(stage='S3', real_markers=True), first_batch_flag=False)
     ld = of.closure()
     got = np.asarray([float(ld[k]) for k in LOSS_KEYS])
     assert np.allclose(got, g['S3_later_loss'], rtol=2e-6, atol=1e-12)
@@ -135,3 +146,30 @@ def test_prox_iteration_golden():
     assert rel_err(of.pose_embedding.grad, g['S3_later_g_pose_embedding']) < 1e-4
     assert float(np.abs(g['S3_later_g_transl'][:2]).max()) == 0.0 and float(np.abs(g['S3_first_g_transl'][:2]).max()) > 0
     assert np.allclose(g['S2_later_loss'][LOSS_KEYS.index('motion_infill_loss')], 0.0)
+    of.opt.step()
+    of.step(); of.step()
+    assert float(np.abs(of.pose_embedding.detach().numpy() - g['S3_later_pose_embedding_after3']).max()) < 1e-6
+
+
+def test_pipeline_oracle_vs_reference_fixture():
+    """amass_clip.npz / prox_setup.npz hold what the REFERENCE's text produced (opt_amass_temp.py:159-214, :256-329;
+    fitting_temp_slide.py:776-941); the restatement in oracle/pipeline_oracle.py reproduces the cheap stages here
+    (the 60-step finetune is re-run against the fixture by the GPU suite)."""
+    from oracle import pipeline_oracle as PO
+    stats = dict(np.load(os.path.join(os.path.dirname(GOLDEN), '..', 'lemo_amd', 'assets', 'stats_infill.npz')))
+    g = np.load(os.path.join(GOLDEN, 'amass_clip.npz'))
+    clip = torch.from_numpy(g['clip_img'])
+    x_in, m = PO.amass_mask_input(clip)
+    assert torch.equal(x_in, torch.from_numpy(g['clip_img_input'])) and np.array_equal(m.numpy(), g['train_mask'])
+    assert int(m[:, 0].sum()) == 210 - 66 - 5          # 22 markers x 3 rows masked, last 5 (contact + pad) excluded
+    for rec_k, lbl_k, mk_k in (('clip_img_rec', 'contact_lbl_rec', 'markers_rec'), ('rec_mixed', 'contact_lbl_mixed', 'markers_mixed')):
+        lbl, mk = PO.decode_markers(torch.from_numpy(g[rec_k])[0, 0], clip[0], g['rot_0_pivot'], stats)
+        assert np.array_equal(lbl.numpy(), g[lbl_k])
+        assert np.abs(mk.astype(np.float32) - g[mk_k]).max() == 0.0
+    assert 0 < g['contact_lbl_mixed'].sum() < g['contact_lbl_mixed'].size
+    # two finetune steps move the reconstruction towards the fixture's 60-step result
+    ae_w = {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
+    _, rec0 = PO.finetune(ae_w, x_in, m, steps=0)
+    _, rec2 = PO.finetune(ae_w, x_in, m, steps=2)
+    tgt = torch.from_numpy(g['clip_img_rec'])
+    assert float((rec2 - tgt).abs().mean()) < float((rec0 - tgt).abs().mean())
