@@ -8,9 +8,14 @@ losses, Adam), one independent sequence per GPU.
 
 A "step" is ONE full Adam iteration (forward incl. all 10475 vertices/frame, backward, update).
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (64->64 3x3 fp32-MFMA conv): algorithmic FLOP / measured duration
+  roofline     -- dominant kernel (64->64 3x3 conv, fp32-exact operands on the bf16 matrix cores): algorithmic FLOP /
+                  launch duration measured live with HIP events on the engine's stream; ``roofline.hbm`` = the same
+                  for the vertex stage (lbs_verts_fwd, HBM-bound side, SURVEY 8(d) "report both")
   cpu_baseline -- the oracle (faithful restatement, two SMPL-X forwards like the reference) timed on
                   this node's host cores on a bounded sample (N=1, rank 0 only).
+Before the W warm-up steps the graphs of the run are captured and uploaded, and the dominant kernel is replayed on
+scratch buffers for ``--ramp-ms`` so that the short timed region (20 steps = 8 ms in the driver's call) runs at the
+clocks a real 100-step fit sees; the ramp is not a fitting step and touches no fit state.
 """
 import argparse
 import ctypes as C
@@ -28,6 +33,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 MFMA (guide: ~2.5 PF; AMD's 5 PF headline is 2:1 sparse)
+PEAK_HBM_TBS = 8.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC_FILE = os.path.join('profiles', 'r02_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
 
 
 def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
@@ -52,9 +59,8 @@ def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
                      seq=seq, markers=markers)
 
 
-def time_dominant_kernel(fit, stream, reps=50):
-    """Average duration of the 64->64 conv3x3 fp32-MFMA launch (layer 10's shape) on `stream`,
-    measured with HIP events around back-to-back launches on the engine's own buffers."""
+def conv_launcher(fit, stream):
+    """closure that launches the engine's 64->64 conv (layer 10's shape, the engine's own buffers / scratch output)"""
     from lemo_amd._hip import ptr
     lib = fit.lib
     H, W = fit.H, fit.W
@@ -67,33 +73,82 @@ def time_dominant_kernel(fit, stream, reps=50):
     else:
         fn = lib.conv3x3_mfma
         args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0, fit.conv_variant)
+    return lambda: lib.check(fn(*args, stream.cuda_stream))
+
+
+def events_ms(stream, launch, reps):
     with torch.cuda.stream(stream):
         for _ in range(5):
-            lib.check(fn(*args, stream.cuda_stream))
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):
-            lib.check(fn(*args, stream.cuda_stream))
+            launch()
         e1.record(stream)
     e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def time_dominant_kernel(fit, stream, reps=50):
+    """Average duration of the 64->64 conv3x3 launch (layer 10's shape) on `stream`, measured with HIP events
+    around back-to-back launches on the engine's own buffers."""
+    ms = events_ms(stream, conv_launcher(fit, stream), reps)
     fit.dact[1].zero_()                    # scratch again (border must stay zero; interior rewritten each step)
-    ms = e0.elapsed_time(e1) / reps
-    flops = 2.0 * H * W * 64 * 64 * 9
-    return ms, flops
+    return ms, 2.0 * fit.H * fit.W * 64 * 64 * 9
 
 
-def pmc_traffic(conv_variant):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass (tools/gpu_pmc.sh ->
-    profiles/r01_pmc_summary.json): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half
-    the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    name = {2: 'lemo::conv3x3_mfma_v2_kernel<0, 512, 2, false>', 3: 'lemo::conv3x3_split_kernel<0, 64, 64, false>'}.get(conv_variant)
-    if name is None or not os.path.exists(path):
+def clock_ramp(fit, stream, ms):
+    """keep the matrix cores busy for ~ms before the warm-up (no fit state is touched: scratch output only)"""
+    if ms <= 0:
+        return
+    launch = conv_launcher(fit, stream)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(200):
+                launch()
+            stream.synchronize()
+    fit.dact[1].zero_()
+
+
+def time_vertex_stage(fit, stream, reps=30):
+    """HBM side of the roofline: lbs_verts_fwd over all V vertices x B frames.  Algorithmic bytes per
+    launch: blend directions 3V x 506 x 4 (streamed once) + verts and v_posed written (2 x B x V x 12)."""
+    from lemo_amd._hip import ptr
+    if not fit.full:
         return None
-    d = json.load(open(path)).get(name)
-    if not d or 'FETCH_SIZE' not in d or 'WRITE_SIZE' not in d:
+    lib, d = fit.lib, fit.data
+    t = fit._pose_t
+    args = (C.byref(fit.dev.skin), ptr(t['Xg']), fit.Bp, ptr(t['A']), d.nj, ptr(fit.P['transl']), None, d.V, fit.B,
+            ptr(fit.ws['verts']), ptr(fit.ws['v_posed']))
+    ms = events_ms(stream, lambda: lib.check(lib.lbs_verts_fwd(*args, stream.cuda_stream)), reps)
+    nbytes = 3.0 * d.V * 506 * 4 + 2.0 * fit.B * d.V * 12
+    flops = 2.0 * 128 * 3 * d.V * 512
+    return ms, nbytes, flops
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC passes of this round (tools/gpu_pmc.sh -> PMC_FILE;
+    counters cannot be read from inside the process): FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports
+    half the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled.  None when the file
+    of this round has not been produced yet."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
         return None
-    return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+    for name, d in json.load(open(path)).items():
+        if name.startswith(kernel_prefix) and 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            return (2.0 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024.0
+    return None
+
+
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
 
 
 def cpu_baseline(prob, B, budget_s=20.0):
@@ -105,6 +160,7 @@ def cpu_baseline(prob, B, budget_s=20.0):
         cores = psutil.cpu_count(logical=False) or cores
     except Exception:
         pass
+    physical = int(cores)
     so = O.SmplxOracle(prob['model'])
     vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
     ew = {k: torch.from_numpy(v) for k, v in prob['enc_w'].items()}
@@ -130,8 +186,20 @@ def cpu_baseline(prob, B, budget_s=20.0):
         fit.step()
         n += 1
     dt = time.time() - t0
-    return dict(value=n / dt, unit='fitting-iterations/s', cores=int(cores), kind='port',
-                sample=f'{n} iterations of oracle.AmassFitOracle(faithful=True), B={B}, V=10475, after 2 warm-up')
+    # single-forward variant: the same oracle evaluating SMPL-X once per iteration
+    fit1 = O.AmassFitOracle(so, vw, ew, prob['ids'], prob['Xmean'], prob['Xstd'], prob['seq']['init_params'],
+                            prob['markers'], prob['seq']['contact_lbl'], faithful=False)
+    fit1.step()
+    n1, t1 = 0, time.time()
+    while n1 < 10 and (time.time() - t1 < 4.0 or n1 < 3):
+        fit1.step()
+        n1 += 1
+    single = n1 / (time.time() - t1)
+    return dict(value=n / dt, unit='fitting-iterations/s', cores=int(cores), threads=int(cores), physical_cores=physical,
+                logical_cpus=os.cpu_count(), cpu_model=cpu_model_name(), kind='port', single_forward_value=single,
+                thread_sweep='torch.set_num_threads over {8,16,32,64,all physical}; the fastest is used and reported as cores/threads',
+                sample=f'{n} iterations of oracle.AmassFitOracle(faithful=True), B={B}, V=10475, after 2 warm-up; '
+                       f'single_forward_value: {n1} iterations with one SMPL-X forward per iteration')
 
 
 def main():
@@ -145,6 +213,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--conv-variant', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ramp-ms', type=float, default=300.0, help='clock ramp before the warm-up steps (0 = off)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -170,9 +239,12 @@ def main():
             dist.barrier()
 
     with torch.cuda.stream(stream):
+        if use_graph:                       # record + upload the graphs of both calls (nothing runs): capture is not a step
+            fit.prepare(args.warmup)
+            fit.prepare(args.steps)
+    clock_ramp(fit, stream, args.ramp_ms)
+    with torch.cuda.stream(stream):
         fit.step(args.warmup, use_graph=use_graph)
-        if use_graph:
-            fit.prepare(args.steps)         # record the graphs of the timed call (nothing runs): capture is not a step
     torch.cuda.synchronize(device)
     barrier()
     torch.cuda.synchronize(device)
@@ -180,19 +252,32 @@ def main():
     with torch.cuda.stream(stream):
         fit.step(args.steps, use_graph=use_graph)
         stream.synchronize()
-    gathered = gather_fitted_params(fit.params72()[None])          # the path's one collective
+    local72 = fit.params72()
+    gathered = gather_fitted_params(local72[None])                 # the path's one collective
     torch.cuda.synchronize(device)
     barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    dt_local = time.perf_counter() - t0
+    tmax = torch.tensor([dt_local], dtype=torch.float64, device=device)
+    per_rank = None
     if world > 1:
+        allt = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(allt, tmax)
+        per_rank = [args.steps / float(t.item()) for t in allt]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # self-check of the sharded run: every rank fitted ITS OWN sequence (rows differ between ranks) and the gathered
+    # block of this rank is bit-identical to what it contributed
     assert gathered.shape == (world, B, 72)
+    assert torch.equal(gathered[rank], local72), 'all_gather returned a different block for this rank'
+    for r in range(world):
+        if r != rank:
+            assert not torch.equal(gathered[r], local72), f'rank {r} returned the same fit as rank {rank}: sequences not sharded'
+    assert bool(torch.isfinite(gathered).all()) and fit.nonfinite_step() == 0
     losses = fit.losses()
 
     kern_ms, kern_flops = time_dominant_kernel(fit, stream)
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12
+    vs = time_vertex_stage(fit, stream)
     if fit.conv_variant == 3:
         # every fp32 multiply-accumulate is 6 bf16 MFMA products (exact 3-way operand split, fp32 accumulate):
         # the pipe that bounds the kernel is the bf16 matrix pipe at 1/6 of its dense peak
@@ -218,13 +303,24 @@ def main():
                    'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': pmc_traffic(fit.conv_variant),
+                     'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant == 3
+                                                                         else 'lemo::conv3x3_mfma_v2_kernel<0'),
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',
                      'peak_note': peak_note,
                      'kernel': kname + ' 64->64ch 245x134, 14 of the 33 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
+    if vs is not None:
+        vms, vbytes, vflops = vs
+        out['roofline']['hbm'] = {
+            'kernel': 'lbs_verts_fwd_kernel (blend-shape GEMM 128 x 3V x 512 + skinning, all V = 10475 vertices x B frames; 1 launch/iteration)',
+            'bound': 'hbm', 'achieved': vbytes / (vms * 1e-3) / 1e12, 'peak': PEAK_HBM_TBS, 'unit': 'TB/s',
+            'frac': vbytes / (vms * 1e-3) / 1e12 / PEAK_HBM_TBS, 'kernel_ms': vms, 'bytes_per_launch': vbytes,
+            'traffic': pmc_traffic('lemo::lbs_verts_fwd_kernel'),
+            'mfma_frac': vflops / (vms * 1e-3) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS / 6.0), 'flop_per_launch': vflops}
+    if per_rank is not None:
+        out['per_rank_iterations_per_s'] = per_rank
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(prob, B)
         out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

@@ -123,6 +123,7 @@ typedef struct lemo_pose_in {
   int n_zero;
   const int* step_ctr;
   int* step_cur;
+  int* nonfinite;            /* optional [2]: block 0 latches nonfinite[1] = nonfinite[0] (see lemo_fit_desc.nonfinite) */
 } lemo_pose_in;
 typedef struct lemo_pose_ws {
   float *full_pose, *R, *J, *T, *A, *Jtr, *Xg;
@@ -146,6 +147,9 @@ int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const 
 /* ---- SMPL-X vertex stage (blend shapes + skinning + transl): lbs.py:81,94-99,108-117 ------------ */
 typedef struct lemo_skin_const {
   int V, NC, KW;
+  int blend_fp32;           /* blend GEMM of lemo_lbs_verts_fwd: 0 (default) = bf16 matrix cores with exact fp32 operands
+                             * (3-way bf16 split, 6 products, fp32 accumulate -- same error class as an fp32 GEMM, see
+                             * lemo_conv3x3_mfma_split) ; 1 = fp32-input MFMA.  Per model constant: no process-wide state */
   const float* Dg;          /* [64][NC][8]  blend directions (shape | pose), K padded to 512 */
   const float* v_template;  /* [V][3] */
   const int* w_idx;         /* [V][KW] ELL skinning weights */
@@ -159,10 +163,6 @@ typedef struct lemo_vertex_set_bwd {
   const int *jcsr_start, *jcsr_u;
   const float* jcsr_w;
 } lemo_vertex_set_bwd;
-/* blend GEMM of lemo_lbs_verts_fwd: 1 (default) = bf16 matrix cores with exact fp32 operands (3-way bf16 split,
- * 6 products, fp32 accumulate -- same error class as an fp32 GEMM, see lemo_conv3x3_mfma_split) ; 0 = fp32 MFMA.
- * Process-wide; call before lemo_fit_create (a captured graph keeps the variant it was captured with). */
-int lemo_lbs_set_variant(int variant);
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 /* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */
@@ -272,6 +272,19 @@ typedef struct lemo_fit_desc {
   double* loss_acc;               /* [32][16] per-iteration loss accumulators (f64 atomics, 32 slots) */
   int* step_cur;                  /* [1] step index latched at the start of the iteration */
   float *g_transl, *g_rot6d, *g_other, *g_go, *g_body;
+  /* ---- round-2 additions (appended: earlier offsets unchanged; all optional / zero = previous behaviour) ---- */
+  float* snap;                    /* [B*65] or NULL: every Adam update first stores the PRE-update parameters here
+                                   * (transl [B][3] | rot6d [B][6] | other [B][56]): with go_aa of the same iteration's
+                                   * forward this is the reference's body_params_opt_t_72 (opt_amass_temp.py:457) */
+  int* nonfinite;                 /* [2] or NULL, zeroed by the caller.  [0]: 1-based index of the first iteration whose
+                                   * total loss was NaN / Inf (0 = none), written by the Adam kernel; [1]: its copy latched at
+                                   * the start of the next iteration.  Once latched, parameter updates are skipped: the device
+                                   * side of FittingMonitor.run_fitting's "NaN/Inf loss -> stop" (fitting_temp_slide.py:198-204);
+                                   * like there, the update of the offending iteration itself has already been applied. */
+  int per_frame;                  /* 1: opt_amass_perframe.py:324-351 -- marker L1 + the three L2 priors only (no smoothness
+                                   * encoder, no contact term), any B >= 1 */
+  float lr2;                      /* third learning-rate level: lr = lr2 when step > lr_switch2 > 0 (opt_amass_perframe.py:316-321) */
+  int lr_switch2;
 } lemo_fit_desc;
 
 /* Opaque engine: holds a copy of the descriptor (pointers only) and, optionally, a captured hipGraph. */

@@ -37,7 +37,7 @@ class PoseIn(C.Structure):
     _fields_ = [(n, vp) for n in ('global_orient', 'body_pose', 'jaw', 'leye', 'reye', 'lh', 'rh')] + \
         [('hand_stride', C.c_int), ('betas', vp), ('betas_stride', C.c_int), ('expr', vp),
          ('rot6d', vp), ('vposer_o', vp), ('go_out', vp), ('zero_f64', vp), ('n_zero', C.c_int),
-         ('step_ctr', vp), ('step_cur', vp)]
+         ('step_ctr', vp), ('step_cur', vp), ('nonfinite', vp)]
 
 
 class PoseWs(C.Structure):
@@ -55,7 +55,7 @@ class PoseGradOut(C.Structure):
 
 
 class SkinConst(C.Structure):
-    _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int)] + \
+    _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int), ('blend_fp32', C.c_int)] + \
         [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val')]
 
 
@@ -98,6 +98,7 @@ class FitDesc(C.Structure):
         ('dx0', vp), ('spartial', vp), ('vpartial', vp), ('losses', vp), ('dverts', vp), ('dvp', vp),
         ('dA', vp), ('dX', vp), ('loss_acc', vp), ('step_cur', vp),
         ('g_transl', vp), ('g_rot6d', vp), ('g_other', vp), ('g_go', vp), ('g_body', vp),
+        ('snap', vp), ('nonfinite', vp), ('per_frame', C.c_int), ('lr2', C.c_float), ('lr_switch2', C.c_int),
     ]
 
 
@@ -118,7 +119,6 @@ _SIGS = {
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_splitk': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    'lemo_lbs_set_variant': (C.c_int, [C.c_int]),
     'lemo_lbs_verts_fwd_active': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
     'lemo_capture_begin': (C.c_int, [vp]),
     'lemo_capture_end': (C.c_int, [vp, C.POINTER(C.c_void_p)]),

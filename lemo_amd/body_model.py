@@ -163,7 +163,7 @@ class DeviceBody:
                                    ptr(T['level_joints']), ptr(T['child_start']), ptr(T['child_list']),
                                    ptr(T['J_template']), ptr(T['J_dirs']), ptr(T['pose_mean']),
                                    ptr(T['lh_comp']), ptr(T['rh_comp']))
-        self.skin = _hip.SkinConst(d.V, d.NC, d.KW, ptr(T['Dg']), ptr(T['v_template']), ptr(T['w_idx']), ptr(T['w_val']))
+        self.skin = _hip.SkinConst(d.V, d.NC, d.KW, 0, ptr(T['Dg']), ptr(T['v_template']), ptr(T['w_idx']), ptr(T['w_val']))
         self._sets = {}
 
     def vertex_set(self, key, ids: np.ndarray, vp_row=None):

@@ -74,7 +74,6 @@ int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
 int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
                          const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s);
-int lbs_set_variant(int v);         // 1 (default): split-bf16 blend GEMM ; 0: fp32-MFMA blend GEMM
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);
 bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj);
@@ -118,7 +117,8 @@ int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const flo
                     float* losses, int B, float* dverts, hipStream_t s);
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
-              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s);
+              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s, float lr2 = 0.f,
+              int lr_switch2 = 0, float* snap = nullptr, int* nonfinite = nullptr, const float* losses = nullptr);
 
 // ---------------- marker_kernels.hip ----------------
 int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s);

@@ -306,9 +306,6 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
 }
 
-static int g_lbs_variant = 1;       // 1: blend GEMM on the bf16 MFMA with split fp32 operands ; 0: fp32 MFMA
-int lbs_set_variant(int v) { if (v != 0 && v != 1) return LEMO_ERR_ARG; g_lbs_variant = v; return 0; }
-
 int lbs_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
@@ -327,7 +324,7 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
 #define LAUNCH(DBG_, SPLIT_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg)
-  if (g_lbs_variant == 1) { if (dbg) LAUNCH(true, true); else LAUNCH(false, true); }
+  if (!c.blend_fp32) { if (dbg) LAUNCH(true, true); else LAUNCH(false, true); }
   else { if (dbg) LAUNCH(true, false); else LAUNCH(false, false); }
 #undef LAUNCH
   return (int)hipGetLastError();

@@ -97,7 +97,6 @@ int lemo_smplx_pose_bwd(const lemo_body_const* c, const lemo_pose_ws* ws, const 
   if (!c || !ws || !gi || !go || !gi->dA) return LEMO_ERR_ARG;
   return smplx_pose_bwd(*c, *ws, *gi, *go, B, S(stream));
 }
-int lemo_lbs_set_variant(int variant) { return lbs_set_variant(variant); }
 int lemo_lbs_verts_fwd_active(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* Xg, int Bp, const float* A,
                               int nj, const float* transl, int B, float* blend, float* verts, float* v_posed, void* stream) {
   if (!c || !u || !Xg || !A || !blend || !verts) return LEMO_ERR_ARG;
@@ -229,6 +228,7 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
   CHK(ec);
   const int ic = (int)hipGraphInstantiate(out, g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
+  if (!ic) (void)hipGraphUpload(*out, s);       // the first replay then does not pay for the upload (lemo_fit_prepare)
   return ic;
 }
 
@@ -261,11 +261,17 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   in.lh = d.other + 32; in.rh = d.other + 44; in.hand_stride = 56;
   in.betas = d.shape; in.betas_stride = 10;
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
+  in.nonfinite = d.nonfinite;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
     CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
+  if (d.per_frame) {       // opt_amass_perframe.py:324-351: marker L1 + the three L2 priors, nothing temporal
+    CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
+    if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, 1.0, d.weights, d.losses, s));
+    return 0;
+  }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
   CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
   // runs of 64 -> 64 layers go out as ONE persistent chain launch when the caller provided the sync buffer and
@@ -300,8 +306,10 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
 static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
-  const double cnt = (double)d.enc_ch[10] * H * (W - 1);
+  const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
+  if (d.per_frame) goto vertex_stage;           // no encoder: d.fit.u_m81 is all -1, dx0 is never read
+  {
   const bool chain_b = d.conv_variant == 3 && d.conv_chain_sync[1] && conv3x3_split_chain_supported(H, W);
   for (int l = 9; l >= 1;) {       // d(pre-act of layer l+1) -> d(pre-act of layer l)
     if (chain_b && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_wbwd3[l]) {
@@ -324,6 +332,8 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
     --l;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  }
+vertex_stage:
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
     // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two
     const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B}, d.loss_acc, cnt, d.losses};
@@ -346,12 +356,13 @@ static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
   CHK(fit_forward(d, s, false));
   CHK(fit_backward(d, s));
   CHK(adam_step(d.transl, d.g_transl, d.adam_m[0], d.adam_v[0], d.rot6d, d.g_rot6d, d.adam_m[1], d.adam_v[1], d.other,
-                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.step_cur, d.lr0, d.lr1, d.lr_switch, s));
+                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.step_cur, d.lr0, d.lr1, d.lr_switch, s,
+                d.lr2, d.lr_switch2, d.snap, d.nonfinite, d.losses));
   return 0;
 }
 
 void* lemo_fit_create(const lemo_fit_desc* d) {
-  if (!d || d->B < 10 || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
+  if (!d || d->B < (d->per_frame ? 1 : 10) || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
   if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
   FitEngine* e = new (std::nothrow) FitEngine();
   if (e) e->d = *d;

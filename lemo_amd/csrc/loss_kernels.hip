@@ -254,14 +254,30 @@ int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const flo
 struct AdamGroup { float* p; const float* g; float* m; float* v; int n; };
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __restrict__ weights, int* __restrict__ step_ctr,
-            const int* __restrict__ step_cur, float lr0, float lr1, int lr_switch) {
+            const int* __restrict__ step_cur, float lr0, float lr1, int lr_switch, float lr2, int lr_switch2,
+            float* __restrict__ snap, int* __restrict__ nonfinite, const float* __restrict__ losses) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // 0-based index of this iteration, latched into step_cur at the start of the iteration (every thread
   // reads the latch; one thread advances the counter -> no read/write race, no extra launch)
   const int step = *step_cur;
   if (i == 0) *step_ctr = step + 1;
+  // non-finite total loss (FittingMonitor.run_fitting, fitting_temp_slide.py:198-204): thread 0 records the first
+  // offending iteration in nonfinite[0]; every thread reads nonfinite[1], the copy latched by the pose-stage kernel at
+  // the START of this iteration (written one kernel boundary ago: no race), and skips its update once it is set
+  bool frozen = false;
+  if (nonfinite) {
+    frozen = nonfinite[1] != 0;
+    if (i == 0 && nonfinite[0] == 0) {
+      const float tot = losses[6];
+      if (!(fabsf(tot) <= 3.402823466e38f)) nonfinite[0] = step + 1;
+    }
+  }
   const int ntot = g0.n + g1.n + g2.n;
-  if (i < ntot) {
+  if (i < ntot && snap) {
+    const float* src = i < g0.n ? g0.p + i : (i < g0.n + g1.n ? g1.p + (i - g0.n) : g2.p + (i - g0.n - g1.n));
+    snap[i] = *src;
+  }
+  if (i < ntot && !frozen) {
     AdamGroup G = g0; int k = i;
     if (k >= g0.n) { k -= g0.n; G = g1; if (k >= g1.n) { k -= g1.n; G = g2; } }
     float grad = G.g[k];
@@ -270,7 +286,7 @@ adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __rest
       const float pv = G.p[k];
       grad += col < 32 ? weights[1] * 2.f * pv / ((float)B * 32.f) : weights[3] * 2.f * pv / ((float)B * 24.f);
     }
-    const float lr = step > lr_switch ? lr1 : lr0;
+    const float lr = (lr_switch2 > 0 && step > lr_switch2) ? lr2 : (step > lr_switch ? lr1 : lr0);
     const double t1 = (double)(step + 1);
     const float bc1 = (float)(1.0 - pow(0.9, t1));
     const float bc2s = (float)sqrt(1.0 - pow(0.999, t1));
@@ -283,10 +299,13 @@ adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __rest
 }
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
-              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s) {
+              int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s, float lr2, int lr_switch2,
+              float* snap, int* nonfinite, const float* losses) {
   AdamGroup a{transl, g_transl, m0, v0, B * 3}, b{rot6d, g_rot, m1, v1, B * 6}, c{other, g_other, m2, v2, B * 56};
   const int n = B * 65;
-  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr0, lr1, lr_switch);
+  if (nonfinite && !losses) return LEMO_ERR_ARG;
+  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr0, lr1, lr_switch,
+                     lr2, lr_switch2, snap, nonfinite, losses);
   return (int)hipGetLastError();
 }
 

@@ -156,6 +156,7 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
   if (b == 0) {
     if (in.zero_f64) for (int i = t; i < in.n_zero; i += 256) in.zero_f64[i] = 0.0;
     if (in.step_cur && t == 0) *in.step_cur = *in.step_ctr;
+    if (in.nonfinite && t == 1) in.nonfinite[1] = in.nonfinite[0];
   }
   // ---- every global read of the kernel is issued here, before the first barrier, with clamped (never predicated)
   // addresses; the phases below only touch registers and LDS.  (Read where they were consumed, three phases in a

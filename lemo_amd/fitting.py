@@ -4,8 +4,11 @@ Reference: ``opt_amass_temp.py::optimize`` -- per-clip setup :332-345, the 100-s
 :349-455 (the hot path), result :457-458.  One :class:`AmassTemporalFitter` owns every device
 buffer of one sequence (parameters, Adam state, ~0.5 GB of workspace for B=119) and hands raw
 pointers to ``liblemo_hip.so`` once (``lemo_fit_create``); an iteration is then a single C call
-(``lemo_fit_step``) that replays captured hipGraphs (34 kernels per iteration) -- no host sync, no ``.item()``
-(the reference has 4 per iteration, :431-443), SMPL-X evaluated once instead of twice (:357,:364).
+(``lemo_fit_step``) that replays captured hipGraphs (one node per kernel of the iteration) -- no host sync, no
+``.item()`` (the reference has 4 per iteration, :431-443), SMPL-X evaluated once instead of twice (:357,:364).
+
+:class:`PerFrameFitter` is the stage-1 twin (``opt_amass_perframe.py:293-355``, BASELINE configs[0]): B = 1, marker
+L1 + the three L2 priors, frames fitted one after the other, each warm-started from the previous one.
 """
 from __future__ import annotations
 
@@ -34,6 +37,7 @@ class AmassTemporalFitter:
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
                  lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None, use_conv_chain: Optional[bool] = None,
+                 lbs_blend_fp32: bool = False, per_frame: bool = False, lr2: float = 0.0, lr_switch2: int = 0,
                  lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
@@ -44,6 +48,7 @@ class AmassTemporalFitter:
         assert data.ncomp == 12, 'the AMASS parameter vector carries 12 PCA coefficients per hand'
         self.data = data
         self.dev = DeviceBody(data, self.device)
+        self.dev.skin.blend_fp32 = int(bool(lbs_blend_fp32))     # 0: split-bf16 blend GEMM (default); 1: fp32 MFMA
         dev = self.device
         ti = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
         tf = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
@@ -63,6 +68,11 @@ class AmassTemporalFitter:
         for k, f in enumerate(foot):
             for v in f: u_mask[slot[int(v)]] |= (1 << k)
         assert len(set(m67.tolist())) == len(m67) and len(set(m81.tolist())) == len(m81), 'duplicate marker ids'
+        for k, f in zip(FOOT_SETS, foot):    # a repeated id would count twice in the loss but once in the gradient mask
+            assert len(set(f.tolist())) == len(f), f'duplicate vertex id in foot set {k}'
+        self.per_frame = bool(per_frame)
+        if self.per_frame:
+            u_m81[:] = -1                      # no smoothness term: the gradient kernels never touch the marker image
         foot_start = np.cumsum([0] + [len(f) for f in foot]).astype(np.int32)
         self._idx = dict(row67=ti([row_of(v) for v in m67]), row81=ti([row_of(v) for v in m81]),
                          foot_start=ti(foot_start), foot_row=ti([row_of(v) for f in foot for v in f]),
@@ -140,6 +150,11 @@ class AmassTemporalFitter:
             setattr(d, k, ptr(self.ws[k]))
         d.pose = pose_ws
         d.loss_acc, d.step_cur = ptr(self.loss_acc), ptr(self.step_cur)
+        self.snap = z(B * 65)                                            # pre-update parameters of the last Adam step
+        self.nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)   # first iteration with a NaN / Inf total loss
+        d.snap, d.nonfinite = ptr(self.snap), ptr(self.nonfinite)
+        d.per_frame, d.lr2, d.lr_switch2 = int(self.per_frame), float(lr2), int(lr_switch2)
+        self._stepped = False
         for l in range(1, 11): d.act[l] = ptr(self.act[l])
         d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
         self.desc = d
@@ -165,9 +180,17 @@ class AmassTemporalFitter:
         self.P['other'].copy_(p[:, 16:])
         self.target.copy_(torch.as_tensor(np.asarray(markers_rec, np.float32), device=self.device))
         self.contact.copy_(torch.as_tensor(np.asarray(contact_lbl, np.float32), device=self.device))
+        self.reset_optimizer()
+
+    @torch.no_grad()
+    def reset_optimizer(self):
+        """a fresh ``optim.Adam`` (opt_amass_temp.py:343, opt_amass_perframe.py:312): moments, step count and the
+        non-finite-loss latch"""
         for t in self.adam_m + self.adam_v:
             t.zero_()
         self.step_ctr.zero_()
+        self.nonfinite.zero_()
+        self._stepped = False
 
     # -- execution ---------------------------------------------------------------------------
     def _s(self):
@@ -177,6 +200,7 @@ class AmassTemporalFitter:
 
     def forward(self) -> None:
         self.lib.check(self.lib.fit_forward(self.handle, self._s()), 'fit_forward')
+        self._stepped = False
 
     def backward(self) -> None:
         self.lib.check(self.lib.fit_backward(self.handle, self._s()), 'fit_backward')
@@ -187,6 +211,13 @@ class AmassTemporalFitter:
         stream, so call inside ``with torch.cuda.stream(s):``."""
         self.lib.check(self.lib.fit_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()),
                        'fit_step')
+        self._stepped = self._stepped or n > 0
+
+    def nonfinite_step(self) -> int:
+        """1-based index of the first iteration (since the last ``load_sequence`` / ``reset_optimizer``) whose total loss
+        was NaN or Inf, 0 if none (synchronises).  From the following iteration on the engine skipped every update --
+        the ``break`` of ``FittingMonitor.run_fitting`` (fitting_temp_slide.py:198-204) inside a replayed graph."""
+        return int(self.nonfinite[0].item())
 
     def prepare(self, n: int) -> None:
         """capture (without running) the hipGraphs an ``n``-iteration :meth:`step` on the current stream replays."""
@@ -221,9 +252,16 @@ class AmassTemporalFitter:
         return torch.cat([self.P['transl'], self.P['rot6d'], self.P['shape'], self.P['other']], dim=-1)
 
     def params72(self) -> torch.Tensor:
-        """[transl, global_orient aa, betas, z, hands] of the LAST forward (what the reference saves,
-        opt_amass_temp.py:457-458)."""
-        return torch.cat([self.P['transl'], self.ws['go_aa'], self.P['shape'], self.P['other']], dim=-1)
+        """``body_params_opt_t_72`` of the LAST forward: [transl, global_orient aa, betas, z, hands] -- what the
+        reference saves (opt_amass_temp.py:457-458: the parameters the last iteration's forward saw, i.e. after
+        n - 1 updates).  After ``step(n)`` every column comes from that iteration: ``go_aa`` from its forward and the
+        pre-update snapshot the Adam kernel took; after a bare ``forward()`` the live parameters are those values."""
+        if self._stepped:
+            B = self.B
+            tr, ot = self.snap[:3 * B].view(B, 3), self.snap[9 * B:].view(B, 56)
+        else:
+            tr, ot = self.P['transl'], self.P['other']
+        return torch.cat([tr, self.ws['go_aa'], self.P['shape'], ot], dim=-1)
 
     def vertices(self) -> torch.Tensor:
         return self.ws['verts']
@@ -231,3 +269,48 @@ class AmassTemporalFitter:
     def posed_joints(self) -> torch.Tensor:
         """the 55 posed skeleton joints + transl of the last forward, [B,55,3]."""
         return self._pose_t['Jtr'] + self.P['transl'][:, None, :]
+
+
+class PerFrameFitter:
+    """Stage 1 of LEMO on AMASS (``opt_amass_perframe.py:293-355``, BASELINE configs[0]): every frame of a clip is
+    fitted on its own -- B = 1, 100 Adam steps on ``weight_loss_rec_markers * L1(markers) + vposer / shape / hand L2
+    priors`` -- and frame t starts from the result of frame t - 1 (the parameter tensors live on across the loop,
+    :297-310) with a fresh optimiser (lr 0.1 for the first frame, 0.01 after; 0.01 from step 61, 0.003 from step 81,
+    :312-321).  Same engine as :class:`AmassTemporalFitter` (``lemo_fit_desc.per_frame``)."""
+
+    INIT_TRANSL = (0.0, 0.4, 1.0)         # :300-301
+    INIT_ORIENT = (0.0, 1.6, 3.14)        # :303-304
+
+    def __init__(self, body, vposer_weights, enc_state, ids, Xmean, Xstd, device, weights: Optional[dict] = None,
+                 lib: Optional[_hip.HipLib] = None):
+        w = dict(LOSS_WEIGHTS if weights is None else weights, contact_vel=0.0, smooth=0.0)
+        mk = lambda lr0: AmassTemporalFitter(body, vposer_weights, enc_state, ids, Xmean, Xstd, 1, device, weights=w,
+                                             lr0=lr0, lr1=0.01, lr_switch=60, lr2=0.003, lr_switch2=80, per_frame=True, lib=lib)
+        self.first, self.rest = mk(0.1), mk(0.01)
+        self.device = self.first.device
+
+    @torch.no_grad()
+    def fit_clip(self, markers_rec: np.ndarray, betas: np.ndarray, steps: int = 100, use_graph: bool = True) -> torch.Tensor:
+        """markers_rec [T,67,3], betas [10] (fixed, ``beta_gt``) -> ``body_params_opt_cur_clip`` [T,72]"""
+        mr = torch.as_tensor(np.asarray(markers_rec, np.float32), device=self.device)
+        T = mr.shape[0]
+        out = torch.empty(T, 72, device=self.device)
+        init = np.zeros((1, 72), np.float32)
+        init[0, 0:3], init[0, 3:6], init[0, 6:16] = self.INIT_TRANSL, self.INIT_ORIENT, np.asarray(betas, np.float32)
+        zero_lbl = np.zeros((1, 4), np.float32)
+        prev = None
+        for t in range(T):
+            fit = self.first if t == 0 else self.rest
+            if t == 0:
+                fit.load_sequence(init, mr[0:1].cpu().numpy(), zero_lbl)
+            else:
+                if t == 1:                                      # hand the running parameters to the lr-0.01 engine
+                    for k in ('transl', 'rot6d', 'other', 'shape'):
+                        fit.P[k].copy_(prev.P[k])
+                    fit.contact.zero_()
+                fit.target.copy_(mr[t:t + 1])
+                fit.reset_optimizer()
+            fit.step(steps, use_graph=use_graph)
+            out[t] = fit.params72()[0]
+            prev = fit
+        return out

@@ -173,3 +173,46 @@ def prox_window_setup(vertices_world: torch.Tensor, smplx_joints_world: torch.Te
     out = torch.matmul(out, torch.inverse(R0)) + j0[0]
     return dict(body_markers_rec=out, contact_lbl_rec=lbl_rec, clip_img_input=x_in, train_mask=train_mask,
                 clip_img_rec=rec, contact_lbls_in=lbls, rot_0_pivot=rot_0_pivot)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-frame fit (stage 1): opt_amass_perframe.py:291-363
+# ------------------------------------------------------------------------------------------------------------------
+def perframe_fit(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec: np.ndarray, betas: np.ndarray, steps: int = 100,
+                 weights: Optional[dict] = None):
+    """Returns ``body_params_opt_cur_clip`` [T,72] (p72 of each frame's LAST forward) and the per-frame final loss."""
+    w = dict(O.LOSS_WEIGHTS if weights is None else weights)
+    ids = torch.as_tensor(np.asarray(markers67_ids, np.int64))
+    T = markers_rec.shape[0]
+    shape_t = torch.from_numpy(np.asarray(betas, np.float32)).view(1, 10)
+    out, last = [], []
+    transl = rot6d = other = None
+    for t in range(T):
+        tgt = torch.from_numpy(np.asarray(markers_rec[t:t + 1], np.float32))
+        if t == 0:                                                                           # :298-310
+            transl = torch.tensor([[0.0, 0.4, 1.0]])
+            rot6d = O.convert_to_6D_all(torch.tensor([[0.0, 1.6, 3.14]])).detach().clone()
+            other = torch.zeros(1, 56)
+            for p in (transl, rot6d, other):
+                p.requires_grad = True
+        opt = torch.optim.Adam([transl, rot6d, other], lr=0.1 if t == 0 else 0.01)          # :312-317
+        for step in range(steps):
+            if step > 60:
+                for g in opt.param_groups:
+                    g['lr'] = 0.01
+            if step > 80:
+                for g in opt.param_groups:
+                    g['lr'] = 0.003
+            opt.zero_grad()
+            p75 = torch.cat([transl, rot6d, shape_t, other], dim=-1)
+            p72 = O.convert_to_3D_rot(p75)
+            body_pose = O.vposer_decode(vposer_w, p72[:, 16:48], 'aa').view(1, -1)
+            verts, _, _ = so.forward(betas=p72[:, 6:16], global_orient=p72[:, 3:6], body_pose=body_pose,
+                                     left_hand_pose=p72[:, 48:60], right_hand_pose=p72[:, 60:], transl=p72[:, 0:3])
+            loss = (w['rec_markers'] * F.l1_loss(verts[:, ids, :], tgt) + w['vposer'] * torch.mean(p72[:, 16:48] ** 2) +
+                    w['shape'] * torch.mean(p72[:, 6:16] ** 2) + w['hand'] * torch.mean(p72[:, 48:] ** 2))
+            loss.backward()
+            opt.step()
+        out.append(p72[0].detach().numpy().copy())
+        last.append(float(loss))
+    return np.asarray(out), np.asarray(last)

@@ -329,6 +329,23 @@ def pin_amass_loop_and_clip(report):
                         rec_mixed=rnd.numpy(), contact_lbl_mixed=lbl_r2.numpy(), markers_mixed=mk_r2.numpy())
 
 
+def pin_perframe(report):
+    """BASELINE configs[0]: exec the reference's per-frame loop text (opt_amass_perframe.py:291-364) -- 3 frames, the
+    full 100 steps each (so both lr switches fire) -- against oracle/pipeline_oracle.perframe_fit."""
+    import __graft_entry__ as ge
+    import ref_harness as RH
+    from oracle import pipeline_oracle as PO
+    prob = ge.small_problem()
+    so = O.SmplxOracle(prob['model'], extra_joint_ids=list(range(21)))
+    vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
+    _, markers = ge.oracle_for(prob)
+    betas = prob['seq']['init_params'][0, 6:16]
+    r = RH.run_perframe_text(so, vw, prob['ids']['markers67'], markers[:3], betas, steps=100)
+    o, last = PO.perframe_fit(so, vw, prob['ids']['markers67'], markers[:3], betas, steps=100)
+    report['perframe.body_params_opt_cur_clip'] = _rel(torch.from_numpy(o), torch.from_numpy(np.asarray(r)))
+    np.savez(os.path.join(HERE, 'perframe_fit.npz'), markers_rec=markers[:3], betas=betas, p72=np.asarray(r), final_loss=last)
+
+
 def pin_prox_and_emit(report):
     """(7) Drive the reference's OWN SMPLifyLoss / FittingMonitor closure / PerspectiveCamera / L2Prior /
     SMPLifyAnglePrior / JointMapper / optim_factory (imported under module stubs, tests/golden/ref_harness.py) on the
@@ -410,6 +427,7 @@ if __name__ == '__main__':
     emit_amass_iteration()
     pins = {}
     pin_amass_loop_and_clip(pins)
+    pin_perframe(pins)
     pin_prox_and_emit(pins)
     print('loop bodies and pipelines vs the text and classes of the reference itself (max rel err):')
     with open(os.path.join(HERE, 'oracle_vs_reference.txt'), 'a') as f:

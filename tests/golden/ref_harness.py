@@ -394,3 +394,30 @@ def run_amass_decode_text(clip_img_rec, clip_img, rot_0_pivot):
                   reconstruct_global_body=U.reconstruct_global_body)
         exec_reference_lines(f'{REF}/opt_amass_temp.py', 256, 329, ns)
     return ns['contact_lbl_rec'], ns['markers_rec_t']
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# per-frame fit (BASELINE configs[0]): opt_amass_perframe.py:291-363 run as text
+# ------------------------------------------------------------------------------------------------------------------
+def run_perframe_text(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec, betas, steps=100):
+    """exec the reference's per-frame loop.  ``total_steps = 100`` is a literal inside the text; ``steps`` < 100 is
+    obtained by substituting that one literal (the lr switches at 60 / 80 are then simply never reached)."""
+    import tempfile
+    import torch.nn.functional as F
+    import torch.optim as optim
+    U = ref_utils()
+    T = markers_rec.shape[0]
+    path = f'{REF}/opt_amass_perframe.py'
+    with open(path) as f:
+        text = textwrap.dedent(''.join(f.readlines()[290:364]))
+    assert text.count('total_steps = 100') == 1
+    text = text.replace('total_steps = 100', f'total_steps = {int(steps)}')
+    with tempfile.TemporaryDirectory() as tmp:
+        ns = dict(torch=torch, np=np, F=F, optim=optim, tqdm=lambda x: x, device=torch.device('cpu'), T=T, i=0, save_folder=tmp,
+                  args=types.SimpleNamespace(weight_loss_rec_markers=1.0, weight_loss_vposer=0.02, weight_loss_shape=0.01,
+                                             weight_loss_hand=0.01),
+                  body_joints_rec=np.asarray(markers_rec, np.float64), beta_gt=torch.from_numpy(np.asarray(betas, np.float32)),
+                  convert_to_6D_all=U.convert_to_6D_all, convert_to_3D_rot=U.convert_to_3D_rot, gen_body_mesh_v1=U.gen_body_mesh_v1,
+                  smplx_model=RefSmplx(so, 1), vposer_model=ref_vposer(vposer_w), marker_ids=[int(v) for v in markers67_ids])
+        exec(compile(text, f'{path}:291-364', 'exec'), ns)
+    return ns['body_params_opt_cur_clip']

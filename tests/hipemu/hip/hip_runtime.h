@@ -75,6 +75,7 @@ static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode
 static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphUpload(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 

@@ -94,17 +94,15 @@ def test_smplx_module_full_size_vs_oracle(dev):
     assert rel_err(out.joints.cpu(), j_ref) < VERT_TOL
     # blend GEMM variants: bf16 matrix cores with exactly split fp32 operands (default) vs fp32 MFMA -- the error
     # against the (fp32, CPU) oracle must be of the same size
-    from lemo_amd import _hip
-    lib = _hip.get_lib()
     e_split = rel_err(out.vertices.cpu(), v_ref)
     try:
-        lib.check(lib.lbs_set_variant(0))
+        model._device_body(dev).skin.blend_fp32 = 1                       # per-model constant (lemo_skin_const), no process-wide switch
         out0 = model(betas=p[:, 6:16].to(dev), global_orient=p[:, 3:6].to(dev), body_pose=body.to(dev),
                      left_hand_pose=p[:, 48:60].to(dev), right_hand_pose=p[:, 60:].to(dev), transl=p[:, 0:3].to(dev))
         e_f32 = rel_err(out0.vertices.cpu(), v_ref)
         e_ab = rel_err(out.vertices.cpu(), out0.vertices.cpu())
     finally:
-        lib.check(lib.lbs_set_variant(1))
+        model._device_body(dev).skin.blend_fp32 = 0
     print(f'\nvertices vs oracle: split-bf16 blend GEMM {e_split:.3e}, fp32-MFMA blend GEMM {e_f32:.3e}, A vs B {e_ab:.3e}')
     assert e_split < 3 * e_f32 + 1e-6 and e_ab < 2e-6
 

@@ -27,7 +27,7 @@ def test_pinning_report_all_exact():
                                          'decode_mixed.contact_lbl_rec', 'decode_mixed.markers_rec')]
     need += [f'prox.{s}_{w}.{k}' for s in ('S2', 'S3') for w in ('first', 'later')
              for k in ('loss_dict', 'g_pose_embedding', 'g_transl', 'g_global_orient', 'params_after3')]
-    need += ['prox_setup.body_markers_rec', 'prox_setup.contact_lbl_rec']
+    need += ['prox_setup.body_markers_rec', 'prox_setup.contact_lbl_rec', 'perframe.body_params_opt_cur_clip']
     for n in need:
         assert n in names, n
     assert all(float(r[1]) <= 2e-6 for r in rows)

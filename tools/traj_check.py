@@ -13,14 +13,12 @@ prob = G.small_problem()
 ofit, markers = G.oracle_for(prob)
 res = {}
 for conv, lbs in ((2, 0), (3, 0), (3, 1), (2, 1)):
-    lib.check(lib.lbs_set_variant(lbs))
     fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
-                              prob['B'], dev, full_vertices=True, conv_variant=conv)
+                              prob['B'], dev, full_vertices=True, conv_variant=conv, lbs_blend_fp32=not lbs)
     fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     fit.step(5, use_graph=False)
     torch.cuda.synchronize()
     res[(conv, lbs)] = fit.params75().cpu()
-lib.check(lib.lbs_set_variant(1))
 o, _ = G.oracle_for(prob)
 for _ in range(5):
     o.step()
