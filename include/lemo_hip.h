@@ -183,6 +183,15 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
  * utils/utils.py:184-203 reconstruct_global_body: in [T][J+2][3] = (ignored reference slot, J local joints, trajectory
  * (dx, dz, dr)); rot_0_pivot from the encode below; out [T][J][3] global positions. */
 int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_pivot, float* out, void* stream);
+/* opt_amass_temp.py:273-325 (twin fitting_temp_slide.py:895-940): decode of the infilling network's output in one launch.
+ * rec [d][T] = channel 0 of the un-padded output (d = 3 J + 4: J = pelvis + markers rows, then 4 contact logits);
+ * traj [3][T] = row 0 of channels 1..3 of the input image (normalised dx, dz, dr); stats [2 d + 4] doubles =
+ * Xmean_local[d], Xstd_local[d], Xmean_global_xy, Xstd_global_xy, Xmean_global_r, Xstd_global_r
+ * (preprocess_stats_infill_local_markers_4chan.npz); rot_0_pivot [1] double on the device; post [13] floats or NULL =
+ * (z shift, M[9] row-major, t[3]): out = (p + (0,0,shift)) . M + t  (PROX: back to the scene frame, :934-939).
+ * -> contact_lbl [T][4] in {0,1} (sigmoid > 0.5), markers [T][J-1][3] global (pelvis row dropped). */
+int lemo_decode_clip(const float* rec, const float* traj, const double* stats, const double* rot_0_pivot, const float* post, int T,
+                     int J, float* contact_lbl, float* markers, void* stream);
 /* utils/utils.py:209-265 get_local_markers_4chan: body [T][1+67][3] global pelvis + markers, contact [T][4] ->
  * image [4][T-1][3*68+4] (local markers + contacts | dx | dz | dr repeated) and rot_0_pivot[1] (float64, device). */
 int lemo_local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot_0_pivot,

@@ -193,6 +193,11 @@ int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_piv
   if (!in || !out) return LEMO_ERR_ARG;
   return reconstruct_global_body(in, T, J, rot_0_pivot, out, S(stream));
 }
+int lemo_decode_clip(const float* rec, const float* traj, const double* stats, const double* rot_0_pivot, const float* post, int T,
+                     int J, float* contact_lbl, float* markers, void* stream) {
+  if (!rec || !traj || !stats || !rot_0_pivot || !contact_lbl || !markers) return LEMO_ERR_ARG;
+  return decode_clip(rec, traj, stats, rot_0_pivot, post, T, J, contact_lbl, markers, S(stream));
+}
 int lemo_local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot_0_pivot,
                              void* stream) {
   if (!body || !contact || !image || !rot_0_pivot) return LEMO_ERR_ARG;
@@ -214,6 +219,7 @@ struct FitEngine {
   lemo_fit_desc d;
   hipGraphExec_t exec[FIT_LEVELS] = {nullptr, nullptr, nullptr};   // FIT_UNROLL[l] iterations each, captured on first use
   hipStream_t graph_stream = nullptr;
+  int head = 5;     // replays of the 1-iteration graph that open a call (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
 };
 
 static int fit_iteration(const lemo_fit_desc& d, hipStream_t s);
@@ -232,18 +238,30 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
   return ic;
 }
 
-// n iterations as replays of the 20 / 5 / 1-iteration graphs (largest first); launch = false only captures what is missing
+// n iterations as replays of the 20 / 5 / 1-iteration graphs; launch = false only captures what is missing.
+// hipGraphLaunch hands a graph to the queue only after the host has written all of its nodes (measured: a 20-step call
+// that opens with the 660-node graph starts ~0.7 ms late, 9 % of the call; later replays are enqueued while the device is
+// busy and cost nothing).  A call therefore opens with a few replays of the 33-node graph, continues with the 165-node
+// one, and only then switches to the large graph -- the device starts within ~40 us and the host stays ahead.
 static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
   if (e->graph_stream != s) {
     for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) { (void)hipGraphExecDestroy(e->exec[l]); e->exec[l] = nullptr; }
     e->graph_stream = s;
   }
   int left = n;
-  for (int l = 0; l < FIT_LEVELS; ++l) {
-    if (left < FIT_UNROLL[l]) continue;
-    if (!e->exec[l]) CHK(capture_iterations(e, s, FIT_UNROLL[l], &e->exec[l]));
-    for (; left >= FIT_UNROLL[l]; left -= FIT_UNROLL[l]) if (launch) CHK((int)hipGraphLaunch(e->exec[l], s));
+  int plan[FIT_LEVELS] = {0, 0, 0};                 // replays per level, in launch order: level 2 (1 it), 1 (5 it), 0 (20 it), then tails
+  int tail[FIT_LEVELS] = {0, 0, 0};
+  if (e->head > 0) {
+    plan[2] = left < e->head ? left : e->head; left -= plan[2];
+    const int mid = left >= 15 + FIT_UNROLL[0] ? 3 : left / FIT_UNROLL[1];      // 3 x 5 before the first 20, or all fives
+    plan[1] = mid; left -= mid * FIT_UNROLL[1];
   }
+  for (int l = 0; l < FIT_LEVELS; ++l) { tail[l] = left / FIT_UNROLL[l]; left -= tail[l] * FIT_UNROLL[l]; }
+  for (int l = 0; l < FIT_LEVELS; ++l)
+    if ((plan[l] || tail[l]) && !e->exec[l]) CHK(capture_iterations(e, s, FIT_UNROLL[l], &e->exec[l]));
+  if (!launch) return 0;
+  for (int l = FIT_LEVELS - 1; l >= 0; --l) for (int i = 0; i < plan[l]; ++i) CHK((int)hipGraphLaunch(e->exec[l], s));
+  for (int l = 0; l < FIT_LEVELS; ++l) for (int i = 0; i < tail[l]; ++i) CHK((int)hipGraphLaunch(e->exec[l], s));
   return 0;
 }
 
@@ -365,7 +383,10 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
   if (!d || d->B < (d->per_frame ? 1 : 10) || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
   if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
   FitEngine* e = new (std::nothrow) FitEngine();
-  if (e) e->d = *d;
+  if (e) {
+    e->d = *d;
+    if (const char* h = getenv("LEMO_FIT_HEAD")) e->head = atoi(h);       // diagnostics: A/B of the replay schedule
+  }
   return e;
 }
 

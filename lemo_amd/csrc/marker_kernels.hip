@@ -141,6 +141,78 @@ local_markers_4chan_kernel(const float* __restrict__ body, const float* __restri
   if (t == 0) rot0_out[0] = atan2(2.0 * qw[0] * qy[0], qw[0] * qw[0] - qy[0] * qy[0]);
 }
 
+// ---- decode of the infilling network's output (opt_amass_temp.py:273-325; twin fitting_temp_slide.py:895-940) ----------
+// One launch per clip replaces: sigmoid -> {0,1} contact labels (:273-275), the reshuffle of the image rows into
+// [T, traj + pelvis + 67 markers, 3] (:280-297), de-normalisation by the preprocess statistics (f64 arithmetic, f32
+// store, like numpy's in-place assignment into the f32 array, :303-311), the reorder into reconstruct_global_body's
+// input format (:317-319), the trajectory integration itself and the removal of the pelvis row (:320-321) -- and, for
+// the PROX twin, the shift back from the floor and the rigid transform back to PROX world coordinates (:934-939).
+//   rec   [d][T]     channel 0 of the network output, un-padded (d = 3 + 3 J67 + 4: pelvis, markers, 4 contact logits)
+//   traj  [3][T]     row 0 of channels 1..3 of the (un-masked) input image: normalised dx, dz, dr
+//   stats [2 d + 4]  doubles: Xmean_local[d], Xstd_local[d], Xmean_global_xy, Xstd_global_xy, Xmean_global_r, Xstd_global_r
+//   rot0  [1]        double, device: rot_0_pivot of the clip
+//   post  [13]       floats or NULL: z shift, then row-major M[9] and t[3] of  out = (p + (0,0,shift)) . M + t
+__global__ void __launch_bounds__(MK_T)
+decode_clip_kernel(const float* __restrict__ rec, const float* __restrict__ traj, const double* __restrict__ stats,
+                   const double* __restrict__ rot0p, const float* __restrict__ post, int T, int J, float* __restrict__ lbl,
+                   float* __restrict__ markers) {
+  __shared__ double ang[MK_T], tx[MK_T], tz[MK_T];
+  const int t = threadIdx.x, d = 3 * J + 4;                  // J = 1 pelvis + markers
+  const double* mean = stats, *sd = stats + d;
+  const double mxy = stats[2 * d], sxy = stats[2 * d + 1], mr = stats[2 * d + 2], sr = stats[2 * d + 3];
+  const double rot0 = rot0p[0];
+  for (int w = t; w < T * 4; w += MK_T) {                    // F.sigmoid(...) > 0.5 -> 1 else 0
+    const int i = w >> 2, k = w & 3;
+    const float s = 1.f / (1.f + expf(-rec[(size_t)(d - 4 + k) * T + i]));
+    lbl[w] = s > 0.5f ? 1.f : 0.f;
+  }
+  float vx = 0.f, vz = 0.f;
+  if (t < T) {
+    vx = (float)((double)traj[t] * sxy + mxy);
+    vz = (float)((double)traj[T + t] * sxy + mxy);
+    ang[t] = -(double)(float)((double)traj[2 * T + t] * sr + mr);
+  }
+  __syncthreads();
+  scan_inclusive(ang, T);
+  if (t < T) {
+    double dx, dz;
+    rot_y(ang[t] - rot0, (double)vx, (double)vz, dx, dz);
+    tx[t] = dx; tz[t] = dz;
+  }
+  __syncthreads();
+  scan_inclusive(tx, T);
+  scan_inclusive(tz, T);
+  const int Jm = J - 1;
+  for (int w = t; w < T * Jm; w += MK_T) {
+    const int i = w / Jm, m = w - i * Jm + 1;                // skip the pelvis (row 0 of the local body)
+    const double th = (i == 0 ? 0.0 : ang[i - 1]) - rot0;
+    const double ox = i == 0 ? 0.0 : tx[i - 1], oz = i == 0 ? 0.0 : tz[i - 1];
+    float p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = (float)((double)rec[(size_t)(3 * m + c) * T + i] * sd[3 * m + c] + mean[3 * m + c]);
+    double rx, rz;
+    rot_y(th, (double)p[0], (double)p[1], rx, rz);
+    float gx = (float)(rx + ox), gy = (float)(rz + oz), gz = p[2];
+    if (post) {
+      gz += post[0];
+      const float* M = post + 1, *tt = post + 10;
+      const float ax = gx * M[0] + gy * M[3] + gz * M[6] + tt[0];
+      const float ay = gx * M[1] + gy * M[4] + gz * M[7] + tt[1];
+      const float az = gx * M[2] + gy * M[5] + gz * M[8] + tt[2];
+      gx = ax; gy = ay; gz = az;
+    }
+    float* o = markers + ((size_t)i * Jm + (m - 1)) * 3;
+    o[0] = gx; o[1] = gy; o[2] = gz;
+  }
+}
+
+int decode_clip(const float* rec, const float* traj, const double* stats, const double* rot0, const float* post, int T, int J,
+                float* lbl, float* markers, hipStream_t s) {
+  if (T < 1 || T > MK_T || J < 2) return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(decode_clip_kernel, dim3(1), dim3(MK_T), 0, s, rec, traj, stats, rot0, post, T, J, lbl, markers);
+  return (int)hipGetLastError();
+}
+
 int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s) {
   if (T < 1 || T > MK_T || J < 1) return LEMO_ERR_SHAPE;
   hipLaunchKernelGGL(reconstruct_global_body_kernel, dim3(1), dim3(MK_T), 0, s, in, T, J, rot0, out);

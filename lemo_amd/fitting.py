@@ -171,15 +171,18 @@ class AmassTemporalFitter:
     # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------
     @torch.no_grad()
     def load_sequence(self, init_params: np.ndarray, markers_rec: np.ndarray, contact_lbl: np.ndarray):
-        """init_params [B,72] (per-frame fit result), markers_rec [B,67,3], contact_lbl [B,4] in {0,1}."""
-        p = torch.as_tensor(np.asarray(init_params, np.float32), device=self.device)
+        """init_params [B,72] (per-frame fit result), markers_rec [B,67,3], contact_lbl [B,4] in {0,1}: numpy arrays or
+        tensors (device tensors are taken as they are: no host round trip)."""
+        td = lambda a: (a.detach().to(self.device, torch.float32) if isinstance(a, torch.Tensor)
+                        else torch.as_tensor(np.asarray(a, np.float32), device=self.device))
+        p = td(init_params)
         assert p.shape == (self.B, 72)
         self.P['transl'].copy_(p[:, 0:3])
         self.P['rot6d'].copy_(convert_to_6D_all(p[:, 3:6]))
         self.P['shape'].copy_(p[:, 6:16])
         self.P['other'].copy_(p[:, 16:])
-        self.target.copy_(torch.as_tensor(np.asarray(markers_rec, np.float32), device=self.device))
-        self.contact.copy_(torch.as_tensor(np.asarray(contact_lbl, np.float32), device=self.device))
+        self.target.copy_(td(markers_rec))
+        self.contact.copy_(td(contact_lbl))
         self.reset_optimizer()
 
     @torch.no_grad()

@@ -1,0 +1,49 @@
+"""float64 instances of the oracle  --  TEST INFRASTRUCTURE.
+
+Used to put a number on "fp32 rounding": the GPU path and the fp32 CPU oracle are both compared with the same
+restatement evaluated in float64 (gradients, Adam trajectories), so that a parity tolerance can be stated as a
+multiple of what fp32 arithmetic costs the REFERENCE's own CPU path instead of a guessed constant."""
+from __future__ import annotations
+
+import contextlib
+
+import numpy as np
+import torch
+
+from . import lemo_oracle as O
+
+
+@contextlib.contextmanager
+def default_f64():
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(old)
+
+
+def _to_double(obj):
+    for k, v in list(vars(obj).items()):
+        if isinstance(v, torch.Tensor) and v.is_floating_point():
+            setattr(obj, k, v.double())
+
+
+def amass_fit_oracle_f64(model, vposer_w, enc_w, ids, Xmean, Xstd, init_params, markers_rec, contact_lbl, weights=None,
+                         extra_joint_ids=None) -> O.AmassFitOracle:
+    """AmassFitOracle whose every tensor is float64 (call its methods inside ``default_f64()``)."""
+    with default_f64():
+        so = O.SmplxOracle(model, extra_joint_ids=extra_joint_ids)
+        _to_double(so)
+        vw = {k: torch.as_tensor(np.asarray(v)).double() for k, v in vposer_w.items()}
+        ew = {k: torch.as_tensor(np.asarray(v)).double() for k, v in enc_w.items()}
+        fit = O.AmassFitOracle(so, vw, ew, ids, np.asarray(Xmean).reshape(1, 1, -1), Xstd, init_params, markers_rec, contact_lbl,
+                               faithful=False, weights=weights)
+        for k in ('Xmean', 'Xstd', 'markers_rec', 'contact', 'shape'):
+            setattr(fit, k, getattr(fit, k).double())
+        p = torch.from_numpy(np.asarray(init_params, np.float32))
+        fit.transl = p[:, 0:3].double().clone().requires_grad_(True)
+        fit.rot6d = O.convert_to_6D_all(p[:, 3:6].clone()).double().clone().requires_grad_(True)     # same f32 start as the fit
+        fit.other = p[:, 16:].double().clone().requires_grad_(True)
+        fit.opt = torch.optim.Adam([fit.transl, fit.rot6d, fit.other], lr=0.01)
+    return fit

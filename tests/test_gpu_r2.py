@@ -1,0 +1,322 @@
+"""GPU parity, round 2 (-m gpu): per-frame fit (BASELINE configs[0]), the per-clip pipeline against fixtures produced by the
+REFERENCE's own text, PROX against the reference-generated golden and at BASELINE size (B = 100, V = 10475, 256^3 SDF,
+S2 and S3), the module-API (autograd) composition of the AMASS iteration, the non-finite latch inside a replayed graph."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from lemo_amd import synthetic
+from lemo_amd.assets import load_assets
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL = 1e-5
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    from lemo_amd import _hip
+    assert not _hip.get_lib().is_emu
+    return torch.device('cuda:0')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-frame fit (configs[0])
+# ---------------------------------------------------------------------------------------------------------------------
+def test_perframe_fit_full_size_vs_oracle(dev):
+    """opt_amass_perframe.py:291-363 at V = 10475 with the real marker ids: 3 frames x 100 steps (both lr switches) on the
+    engine's per_frame mode (graph replay) vs the oracle, whose loop is pinned to the reference text at 0.0."""
+    from lemo_amd.fitting import PerFrameFitter
+    from lemo_amd.vposer import make_vposer_weights
+    from oracle import lemo_oracle as O, pipeline_oracle as PO
+    A = load_assets()
+    model = synthetic.make_synthetic_smplx(seed=0)
+    g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    mr, betas = g['markers_rec'][:3], seq['init_params'][0, 6:16]
+    vw = make_vposer_weights(2)
+    ref, last = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr, betas, steps=100)
+    pf = PerFrameFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], dev)
+    got = pf.fit_clip(mr, betas, steps=100).cpu().numpy()
+    torch.cuda.synchronize()
+    L = pf.rest.losses()
+    d = np.abs(got - ref)
+    print(f'\nper-frame fit, 3 frames x 100 steps: params vs oracle max {d.max():.2e} mean {d.mean():.2e}; final loss gpu {L["total"]:.6f} oracle {last[-1]:.6f}')
+    assert L['contact'] == 0.0 and L['smooth'] == 0.0
+    assert abs(L['total'] - last[-1]) < 2e-2 * last[-1]
+    assert d.mean() < 2e-3 and d.max() < 0.1               # 300 Adam steps with two optimiser restarts: trajectories, not iterates
+    assert pf.rest.nonfinite_step() == 0
+    # one update per frame is tight
+    ref2, _ = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr[:2], betas, steps=2)
+    got2 = pf.fit_clip(mr[:2], betas, steps=2).cpu().numpy()
+    assert np.abs(got2 - ref2).max() < 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-clip pipeline: fixtures written by the reference's own text (tests/golden/make_golden.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_decode_clip_vs_reference_fixture(dev):
+    from lemo_amd import pipeline as P
+    g = np.load(os.path.join(GOLDEN, 'amass_clip.npz'))
+    clip = torch.from_numpy(g['clip_img'])[0].to(dev)
+    for rk, lk, mk in (('clip_img_rec', 'contact_lbl_rec', 'markers_rec'), ('rec_mixed', 'contact_lbl_mixed', 'markers_mixed')):
+        lbl, m = P.decode_markers(torch.from_numpy(g[rk])[0, 0].to(dev), clip, torch.from_numpy(g['rot_0_pivot']).to(dev))
+        assert np.array_equal(lbl.cpu().numpy(), g[lk])
+        assert rel_err(m.cpu(), g[mk]) < 1e-6
+
+
+def test_finetune_60_steps_vs_reference_fixture(dev):
+    """opt_amass_temp.py:159-214 end to end on the device: masking, reflect pad, 60 x [AE forward, L1 on the reference's
+    row selection, backward, Adam 3e-6], eval forward -- against what the reference's text produced on the CPU."""
+    from lemo_amd import pipeline as P
+    from lemo_amd.infill import AE, finetune_and_infill
+    g = np.load(os.path.join(GOLDEN, 'amass_clip.npz'))
+    ae_w = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_ae_weights(7).items()}
+    ae = AE().to(dev)
+    x_in, m = P.amass_mask_input(torch.from_numpy(g['clip_img']).to(dev))
+    assert torch.equal(x_in.cpu(), torch.from_numpy(g['clip_img_input'])) and np.array_equal(m.cpu().numpy(), g['train_mask'])
+    rec, _ = finetune_and_infill(ae, ae_w, x_in, m, steps=60)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g['clip_img_rec'])
+    e = rel_err(rec.cpu(), ref)
+    rec0, _ = finetune_and_infill(ae, ae_w, x_in, m, steps=0)
+    moved = float((rec0.cpu() - ref).abs().max() / ref.abs().max())
+    print(f'\nfinetuned reconstruction vs the reference run: max rel {e:.2e} (the 60 steps moved it by {moved:.2e})')
+    assert e < 2e-3 and e < 0.2 * moved                      # 60 Adam steps at lr 3e-6 through max-pool argmax ties
+    lbl, mk = P.decode_markers(rec[0, 0], torch.from_numpy(g['clip_img'])[0].to(dev), torch.from_numpy(g['rot_0_pivot']).to(dev))
+    assert float((lbl.cpu() - torch.from_numpy(g['contact_lbl_rec'])).abs().mean()) < 0.01
+    assert float((mk.cpu() - torch.from_numpy(g['markers_rec'])).abs().max()) < 5e-3          # metres
+
+
+def test_amass_clip_pipeline_end_to_end_vs_oracle(dev):
+    """finetune -> decode -> load_sequence -> 100 Adam steps -> [B,72], chained on the device (AmassClipPipeline) against
+    the chained oracle (pipeline_oracle.amass_fit_clip): the saved block is body_params_opt_t_72 of the LAST forward."""
+    from lemo_amd import pipeline as P
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.infill import AE
+    from lemo_amd.vposer import make_vposer_weights
+    from oracle import lemo_oracle as O, pipeline_oracle as PO
+    torch.set_num_threads(32)
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'amass_clip.npz'))
+    model = synthetic.make_synthetic_smplx(seed=0)
+    vw = make_vposer_weights(2)
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    init = seq['init_params'].copy()
+    init[:, 0:3] = g['markers_rec'].mean(1) - np.array([0, 0, 0.2], np.float32)       # start the body near the decoded markers
+    ae_np = synthetic.make_ae_weights(7)
+    steps = 30
+    so = O.SmplxOracle(model)
+    ref = PO.amass_fit_clip(so, {k: torch.from_numpy(v) for k, v in vw.items()}, A['enc_w_torch'],
+                            {k: torch.from_numpy(v) for k, v in ae_np.items()}, A['ids'], A['Xmean'], A['Xstd'], P.load_infill_stats(),
+                            torch.from_numpy(g['clip_img']), g['rot_0_pivot'], init, steps=steps)
+    fit = AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 119, dev)
+    pipe = P.AmassClipPipeline(fit, AE().to(dev), {k: torch.from_numpy(v).to(dev) for k, v in ae_np.items()})
+    out = pipe.fit_clip(torch.from_numpy(g['clip_img']).to(dev), torch.from_numpy(g['rot_0_pivot']).to(dev), init, gender=1, steps=steps)
+    torch.cuda.synchronize()
+    assert out['p72'].shape == (119, 72) and fit.nonfinite_step() == 0
+    assert float((out['markers_rec'].cpu() - torch.from_numpy(ref['markers_rec']).float()).abs().max()) < 5e-3
+    with torch.no_grad():
+        p_ref = torch.from_numpy(ref['p72'])
+        bp = O.vposer_decode({k: torch.from_numpy(v) for k, v in vw.items()}, p_ref[:, 16:48], 'aa').view(119, -1)
+        _, j_ref, _ = so.forward(p_ref[:, 6:16], p_ref[:, 3:6], bp, p_ref[:, 48:60], p_ref[:, 60:], p_ref[:, 0:3])
+        p_gpu = out['p72'].cpu()
+        bp = O.vposer_decode({k: torch.from_numpy(v) for k, v in vw.items()}, p_gpu[:, 16:48], 'aa').view(119, -1)
+        _, j_gpu, _ = so.forward(p_gpu[:, 6:16], p_gpu[:, 3:6], bp, p_gpu[:, 48:60], p_gpu[:, 60:], p_gpu[:, 0:3])
+    mpjpe = O.mpjpe_mm(j_gpu, j_ref)
+    lg, lo = fit.losses()['total'], ref['hist'][-1]['total']
+    print(f'\nclip pipeline ({steps} steps): MPJPE gpu-vs-oracle {mpjpe:.3f} mm; final total gpu {lg:.4f} oracle {lo:.4f}')
+    assert mpjpe < 2.0 and abs(lg - lo) < 2e-2 * abs(lo)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PROX
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('stage', ['S3', 'S2'])
+@pytest.mark.parametrize('first', [False, True])
+def test_prox_iteration_vs_reference_generated_golden(dev, stage, first):
+    """golden (7) written from a run of the reference's own SMPLifyLoss / closure / camera / priors / JointMapper
+    (81 / 67-marker window): 14 loss_dict entries, three gradients, parameters after 3 Adam steps."""
+    import __graft_entry__ as ge
+    from lemo_amd.prox import LOSS_KEYS
+    g = np.load(os.path.join(GOLDEN, 'prox_iter.npz'))
+    tag = f'{stage}_{"first" if first else "later"}'
+    fit, bm = ge.prox_fitter_for(ge.prox_small_problem(stage=stage, real_markers=True), dev, first_batch_flag=first)
+    ld = fit.closure()
+    got = np.asarray([float(ld[k]) for k in LOSS_KEYS])
+    ref = g[tag + '_loss']
+    for k, a, b in zip(LOSS_KEYS, got, ref):
+        assert abs(a - b) <= LOSS_TOL * abs(b) + 1e-12, (k, a, b)
+    assert rel_err(fit.pose_embedding.grad.cpu(), g[tag + '_g_pose_embedding']) < 2e-4
+    assert rel_err(bm.transl.grad.cpu(), g[tag + '_g_transl']) < 2e-4
+    assert rel_err(bm.global_orient.grad.cpu(), g[tag + '_g_global_orient']) < 2e-4
+    fit.optimizer.step()
+    fit.step(2, use_graph=False)
+    assert float((fit.pose_embedding.detach().cpu() - torch.from_numpy(g[tag + '_pose_embedding_after3'])).abs().max()) < 2e-4
+    assert float((bm.transl.detach().cpu() - torch.from_numpy(g[tag + '_transl_after3'])).abs().max()) < 2e-4
+
+
+def _prox_full_problem(stage, B=100):
+    import __graft_entry__ as ge
+    from lemo_amd.prox import S2_WEIGHTS, S3_WEIGHTS, load_prox_tables
+    A = load_assets()
+    small = ge.prox_small_problem(B=B, stage=stage)
+    rng = np.random.default_rng(3)
+    D = 256
+    zz = np.linspace(-3, 6, D, dtype=np.float32)
+    sdf = (np.broadcast_to(zz[None, None, :], (D, D, D)) - 1.40).astype(np.float32).copy()
+    sdf += (rng.standard_normal((D // 8, D // 8, D // 8)).astype(np.float32) * 0.02).repeat(8, 0).repeat(8, 1).repeat(8, 2)
+    prob = dict(small, model=synthetic.make_synthetic_smplx(seed=0), V=10475, ids=A['ids'], Xmean=A['Xmean'], Xstd=A['Xstd'],
+                fric_ids=load_prox_tables()['contact_fric_verts_ids'], sdf=sdf, weights=S3_WEIGHTS if stage == 'S3' else S2_WEIGHTS)
+    if stage == 'S3':
+        mask = np.ones((B, 67), np.float32); mask[40:60, :22] = 0
+        prob['infill'] = dict(marker_mask=mask, body_markers_rec=(rng.standard_normal((B - 1, 67, 3)) * 0.3).astype(np.float32),
+                              contact_lbl_rec=(rng.random((B - 1, 4)) < 0.7).astype(np.float32))
+    return prob
+
+
+@pytest.mark.parametrize('stage', ['S2', 'S3'])
+def test_prox_baseline_size_vs_pinned_oracle(dev, stage):
+    """BASELINE configs[3] / [4] shape -- B = 100 frames, V = 10475, 256^3 SDF, 245 x 115 encoder image -- against the
+    oracle (pinned to the reference's SMPLifyLoss at 0.0): 14 loss_dict entries <= 1e-5, gradients, erase."""
+    import __graft_entry__ as ge
+    from lemo_amd.prox import LOSS_KEYS
+    torch.set_num_threads(32)
+    prob = _prox_full_problem(stage)
+    of = ge.prox_oracle_for(prob, first_batch_flag=False)
+    old = of.closure()
+    fit, bm = ge.prox_fitter_for(prob, dev, first_batch_flag=False)
+    ld = fit.closure()
+    torch.cuda.synchronize()
+    for k in LOSS_KEYS:
+        a, b = float(ld[k]), float(old[k])
+        assert abs(a - b) <= LOSS_TOL * abs(b) + 1e-12, (stage, k, a, b)
+    assert float(old['sdf_penetration_loss']) > 0 and float(old['loss_fric_tangent']) > 0 and float(old['motion_prior_smooth_loss']) > 0
+    if stage == 'S3':
+        assert float(old['motion_infill_loss']) > 0 and float(old['motion_infill_contact_loss']) > 0
+    worst = 0.0
+    for a, b in [(fit.pose_embedding.grad, of.pose_embedding.grad)] + \
+                [(getattr(bm, n).grad, of.p[n].grad) for n in ('transl', 'global_orient', 'left_hand_pose', 'right_hand_pose', 'expression', 'jaw_pose')]:
+        worst = max(worst, rel_err(a.cpu(), b))
+    print(f'\nPROX {stage} at B=100 / V=10475 / 256^3: 14 losses <= 1e-5; worst gradient max-rel error {worst:.2e}')
+    assert worst < 5e-4
+    assert float(fit.pose_embedding.grad[:15].abs().max()) == 0.0 and float(fit.pose_embedding.grad[15:].abs().max()) > 0
+
+
+def test_split_conv_245x115_vs_torch(dev):
+    """the PROX window's encoder image is 245 x 115 (B = 100): the split-bf16 64 -> 64 layer at that shape against
+    F.conv2d in float64, forward and backward-data"""
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import EncWeights, cg8p_alloc, from_cg8p, to_cg8p, _conv_layer
+    lib = _hip.get_lib()
+    A = load_assets()
+    enc = EncWeights(A['enc_w'], dev)
+    H, W, l = 245, 115, 5
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(64, H, W, generator=g) * 0.3
+    xin, out = to_cg8p(x.to(dev)), cg8p_alloc(64, H, W, dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    _conv_layer(lib, enc, l, False, xin, out, None, H, W, 3, s)
+    w = torch.from_numpy(A['enc_w'][f'enc_blc{l // 2 + 1}.main.{(l % 2) * 2}.weight']).double()
+    b = torch.from_numpy(A['enc_w'][f'enc_blc{l // 2 + 1}.main.{(l % 2) * 2}.bias']).double()
+    ref = F.leaky_relu(F.conv2d(x.double()[None], w, b, padding=1), 0.2)[0]
+    e = float((from_cg8p(out, H, W).cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f'\nsplit conv 64->64 at 245x115 vs float64: max err / max|out| = {e:.2e}')
+    assert e < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# AMASS iteration composed from the MODULE API (autograd route, not lemo_fit_*), full size
+# ---------------------------------------------------------------------------------------------------------------------
+def test_amass_iteration_from_modules_full_size(dev):
+    """The loop body of opt_amass_temp.py:355-453 written against the drop-in modules -- smplx-compatible SMPLX,
+    VPoser.decode, Enc, convert_to_3D_rot -- with torch autograd doing the backward through the HIP autograd
+    Functions: six losses, total and the three gradients vs golden (6) at B = 119 / V = 10475."""
+    from lemo_amd.body_model import create
+    from lemo_amd.priors import Enc
+    from lemo_amd.rotation import convert_to_3D_rot, convert_to_6D_all
+    from lemo_amd.vposer import VPoser, make_vposer_weights
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    B = 119
+    smplx_model = create(synthetic.make_synthetic_smplx(seed=0), batch_size=B).to(dev)
+    vposer_model = VPoser().eval()
+    vposer_model.load_state_dict({**vposer_model.state_dict(), **{k: torch.from_numpy(v) for k, v in make_vposer_weights(2).items()}})
+    vposer_model = vposer_model.to(dev)
+    smooth_encoder = Enc()
+    smooth_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in A['enc_w'].items()})
+    smooth_encoder = smooth_encoder.to(dev)
+    ip = torch.from_numpy(seq['init_params']).to(dev)
+    transl = ip[:, 0:3].clone().requires_grad_(True)
+    rot6d = convert_to_6D_all(ip[:, 3:6]).detach().clone().requires_grad_(True)
+    shape_t, other = ip[:, 6:16], ip[:, 16:].clone().requires_grad_(True)
+    ids = {k: torch.as_tensor(np.asarray(v, np.int64), device=dev) for k, v in A['ids'].items()}
+    Xmean, Xstd = torch.from_numpy(A['Xmean']).float().to(dev), torch.from_numpy(A['Xstd']).float().to(dev)
+    markers_rec, contact = torch.from_numpy(g['markers_rec']).to(dev), torch.from_numpy(seq['contact_lbl']).to(dev)
+    p72 = convert_to_3D_rot(torch.cat([transl, rot6d, shape_t, other], dim=-1))
+    body_pose = vposer_model.decode(p72[:, 16:48], output_type='aa').view(B, -1)
+    out = smplx_model(return_verts=True, transl=p72[:, 0:3], global_orient=p72[:, 3:6], betas=p72[:, 6:16], body_pose=body_pose,
+                      left_hand_pose=p72[:, 48:60], right_hand_pose=p72[:, 60:])
+    verts, joints = out.vertices, out.joints
+    markers_opt, markers_smooth = verts[:, ids['markers67']], verts[:, ids['markers81']]
+    j0 = joints[0].detach()
+    x_axis = j0[2] - j0[1]
+    x_axis = torch.cat([x_axis[:2], x_axis.new_zeros(1)])
+    x_axis = x_axis / torch.norm(x_axis)
+    z_axis = x_axis.new_tensor([0., 0., 1.])
+    y_axis = torch.linalg.cross(z_axis, x_axis)
+    y_axis = y_axis / torch.norm(y_axis)
+    R0 = torch.stack([x_axis, y_axis, z_axis], dim=1)
+    gm = torch.matmul(markers_smooth - markers_smooth[0].detach()[0], R0)
+    img = ((gm.reshape(B, -1).unsqueeze(0) - Xmean) / Xstd).permute(0, 2, 1).unsqueeze(1)
+    img_v = F.pad(img[..., 1:] - img[..., :-1], (8, 8, 1, 1), 'reflect')
+    motion_z = smooth_encoder(img_v)[0]
+    loss_smooth = torch.mean((motion_z[..., 1:] - motion_z[..., :-1]) ** 2)
+    loss_marker = F.l1_loss(markers_opt, markers_rec)
+    loss_vposer, loss_shape, loss_hand = torch.mean(p72[:, 16:48] ** 2), torch.mean(p72[:, 6:16] ** 2), torch.mean(p72[:, 48:] ** 2)
+    vel = (verts[1:] - verts[:-1]) * 30
+    loss_contact = verts.new_zeros(())
+    for k, name in enumerate(('left_heel', 'right_heel', 'left_toe', 'right_toe')):
+        sp = torch.norm(vel[:, ids[name]][contact[:-1, k] == 1], dim=-1)
+        if (sp - 0.1).gt(0).sum().item() >= 1:
+            loss_contact = loss_contact + sp[sp > 0.1].abs().mean()
+    loss = 1.0 * loss_marker + 0.02 * loss_vposer + 0.01 * loss_shape + 0.01 * loss_hand + 0.03 * loss_contact + 1e6 * loss_smooth
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, v in (('marker', loss_marker), ('vposer', loss_vposer), ('shape', loss_shape), ('hand', loss_hand),
+                 ('contact', loss_contact), ('smooth', loss_smooth)):
+        assert abs(float(v) - float(g['loss_' + k])) <= LOSS_TOL * abs(float(g['loss_' + k])), (k, float(v), float(g['loss_' + k]))
+    assert abs(float(loss) - float(g['total'])) <= LOSS_TOL * float(g['total'])
+    errs = [rel_err(transl.grad.cpu(), g['g_transl']), rel_err(rot6d.grad.cpu(), g['g_rot6d']), rel_err(other.grad.cpu(), g['g_other'])]
+    print(f'\nmodule-API AMASS iteration at B=119/V=10475: losses <= 1e-5, gradient max-rel errors {errs}')
+    assert max(errs) < 1e-3
+
+
+def test_nonfinite_latch_inside_replayed_graph(dev):
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], prob['B'], dev)
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        fit.step(4, use_graph=True)
+    torch.cuda.synchronize()
+    assert fit.nonfinite_step() == 0
+    fit.target[0, 0, 0] = float('nan')
+    with torch.cuda.stream(s):
+        fit.step(20, use_graph=True)               # 20 replays; the loss is NaN from the first of them
+    torch.cuda.synchronize()
+    assert fit.nonfinite_step() == 5 and int(fit.step_ctr.item()) == 24
+    p = fit.params75().clone()
+    with torch.cuda.stream(s):
+        fit.step(5, use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(fit.params75(), nan=3.0), torch.nan_to_num(p, nan=3.0))
