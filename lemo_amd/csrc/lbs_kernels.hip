@@ -202,24 +202,6 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
   }
   if (DBG) t_gemm = __builtin_amdgcn_s_memtime();
-  // ---- the first THREE 12-frame chunks of the per-joint transforms are requested here, before the hand-over: a chunk
-  // comes from L2/MALL (~2.5k cycles away) and one chunk of skinning is only ~1.2k cycles of work, so with one chunk in
-  // flight (round 1) every one of the 10 chunks waited for its successor: 28.7k cycles for the phase (tools/lbs_census.py)
-  const int fpf = nj * 12;                                        // floats per frame of A
-  const int nfr = (B - f0 < LBS_FR) ? B - f0 : LBS_FR;
-  const int nchunk = (nfr + 11) / 12;
-  const int n4 = 3 * fpf;                                          // float4 per chunk (12 * fpf / 4)
-  const int a_last4 = B * fpf / 4 - 1;                             // clamp: last float4 of A
-  float4 sA[3][5];
-#define LBS_ALOAD(RS, CH)                                                                         \
-  _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                 \
-    int i4 = (f0 + (CH) * 12) * (fpf / 4) + tid + k * 512;                                        \
-    if (i4 > a_last4) i4 = a_last4;                                                               \
-    sA[RS][k] = ld4(A + (size_t)i4 * 4);                                                          \
-  }
-  LBS_ALOAD(0, 0)
-  LBS_ALOAD(1, 1)
-  LBS_ALOAD(2, 2)
   // ---- hand the blend tile over through LDS (aliases the staging buffers: everyone is past the last read)
   float* vp = smem;
 #pragma unroll
@@ -234,15 +216,29 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   const int lv = tid % LBS_VPB, fg = tid / LBS_VPB;
   const int slot = s0 + lv;
   const bool skin = tid < 12 * LBS_VPB && slot < n;
+  // (Three chunks in flight instead of one were tried in round 2 and measured SLOWER -- 33.9k vs 28.7k cycles for the
+  // phase, tools/lbs_census.py: the phase is bound by LDS issue + the strided global stores, not by the A loads.)
   // The per-joint transforms A[f][nj][12] are gathered (KW joints per vertex) for every (vertex, frame)
   // pair: straight from L2 that is a chain of exposed round trips (measured 51k cycles per block), so
   // they are staged through LDS in chunks of 12 frames (one frame per thread group), double-buffered
   // behind the blend tile, the next chunk loading while the current one is consumed.
+  const int fpf = nj * 12;                                        // floats per frame of A
   float* Ab = smem + LBS_FR * LBS_PITCH;                           // [2][12 * fpf]
-#define LBS_ASTORE(RS, BUF)                                                                       \
+  const int nfr = (B - f0 < LBS_FR) ? B - f0 : LBS_FR;
+  const int nchunk = (nfr + 11) / 12;
+  const int n4 = 3 * fpf;                                          // float4 per chunk (12 * fpf / 4)
+  const int a_last4 = B * fpf / 4 - 1;                             // clamp: last float4 of A
+  float4 sA[5];
+#define LBS_ALOAD(CH)                                                                             \
+  _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                 \
+    int i4 = (f0 + (CH) * 12) * (fpf / 4) + tid + k * 512;                                        \
+    if (i4 > a_last4) i4 = a_last4;                                                               \
+    sA[k] = ld4(A + (size_t)i4 * 4);                                                              \
+  }
+#define LBS_ASTORE(BUF)                                                                           \
   _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                 \
     const int l4 = tid + k * 512;                                                                 \
-    if (l4 < n4) st4(Ab + (BUF) * 12 * fpf + l4 * 4, sA[RS][k]);                                  \
+    if (l4 < n4) st4(Ab + (BUF) * 12 * fpf + l4 * 4, sA[k]);                                      \
   }
   int vid = 0;
   float tx = 0.f, ty = 0.f, tz = 0.f;
@@ -264,11 +260,12 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     wk[k] = k < c.KW ? wv[kk] : 0.f;
   }
   const int kwr = c.KW < KWR ? c.KW : KWR;
-  LBS_ASTORE(0, 0)
-  if (3 < nchunk) { LBS_ALOAD(0, 3) }
+  LBS_ALOAD(0)
+  LBS_ASTORE(0)
   __syncthreads();
   for (int ch = 0; ch < nchunk; ++ch) {
     const int buf = ch & 1;
+    if (ch + 1 < nchunk) { LBS_ALOAD(ch + 1) }
     const int fl = ch * 12 + fg, f = f0 + fl;
     if (skin && fl < nfr) {
       const float px = vp[fl * LBS_PITCH + 3 * lv] + tx, py = vp[fl * LBS_PITCH + 3 * lv + 1] + ty,
@@ -300,11 +297,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
         q[0] = px; q[1] = py; q[2] = pz;
       }
     }
-    // chunk ch + 1 sits in register set (ch + 1) % 3, requested three iterations ago: publish it to the other LDS
-    // buffer and reuse the set for chunk ch + 4 (the branch is uniform across the block)
-#define LBS_ASTEP(RS) { if (ch + 1 < nchunk) { LBS_ASTORE(RS, buf ^ 1) } if (ch + 4 < nchunk) { LBS_ALOAD(RS, ch + 4) } }
-    switch ((ch + 1) % 3) { case 0: LBS_ASTEP(0) break; case 1: LBS_ASTEP(1) break; default: LBS_ASTEP(2) break; }
-#undef LBS_ASTEP
+    if (ch + 1 < nchunk) { LBS_ASTORE(buf ^ 1) }
     __syncthreads();
   }
 #undef LBS_ALOAD

@@ -302,10 +302,27 @@ class PerFrameFitter:
         init[0, 0:3], init[0, 3:6], init[0, 6:16] = self.INIT_TRANSL, self.INIT_ORIENT, np.asarray(betas, np.float32)
         zero_lbl = np.zeros((1, 4), np.float32)
         prev = None
+        graph = bool(use_graph) and not self.first.lib.is_emu
+        side = None
+        if graph:                                   # graph capture needs a non-default stream (kept: graphs are per stream)
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(self.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream(self.device))
+        import contextlib
+        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+        with ctx:
+            self._fit_frames(mr, T, init, zero_lbl, steps, graph, out)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        return out
+
+    def _fit_frames(self, mr, T, init, zero_lbl, steps, use_graph, out):
+        prev = None
         for t in range(T):
             fit = self.first if t == 0 else self.rest
             if t == 0:
-                fit.load_sequence(init, mr[0:1].cpu().numpy(), zero_lbl)
+                fit.load_sequence(init, mr[0:1], zero_lbl)
             else:
                 if t == 1:                                      # hand the running parameters to the lr-0.01 engine
                     for k in ('transl', 'rot6d', 'other', 'shape'):
@@ -316,4 +333,3 @@ class PerFrameFitter:
             fit.step(steps, use_graph=use_graph)
             out[t] = fit.params72()[0]
             prev = fit
-        return out
