@@ -129,7 +129,10 @@ typedef struct lemo_pose_ws {
   float *full_pose, *R, *J, *T, *A, *Jtr, *Xg;
   int Bp;
 } lemo_pose_ws;
-typedef struct lemo_pose_grad_in { const float *dA, *dJtr, *dX; } lemo_pose_grad_in;
+typedef struct lemo_pose_grad_in {
+  const float *dA, *dJtr, *dX;
+  const float* d_full_pose;  /* optional [B][3 nj]: extra d(loss)/d(full_pose) added before the pose chain (PROX angle prior) */
+} lemo_pose_grad_in;
 typedef struct lemo_pose_grad_out {
   float *d_global_orient, *d_body_pose, *d_jaw, *d_leye, *d_reye, *d_lh, *d_rh;
   int hand_stride;
@@ -162,6 +165,12 @@ typedef struct lemo_vertex_set_bwd {
   const float* DkT;         /* [NCs][512]: the same directions feature-contiguous (forward over the set), or NULL */
   const int *jcsr_start, *jcsr_u;
   const float* jcsr_w;
+  /* optional (large sets): deterministic dense backward.  The joint-major lists are sorted by set position, so the
+   * entries of the 512-vertex chunk c of joint j are jcsr_chunk[c * (nj + 1) + j] .. jcsr_chunk[(c + 1) * (nj + 1) + j];
+   * part: [part_frames][n_chunk][nj * 12 + 4] floats of per-chunk partial sums, reduced in chunk order. */
+  const int* jcsr_chunk;          /* [(n_chunk + 1) * (nj + 1)] or NULL */
+  float* part;
+  int part_frames;
 } lemo_vertex_set_bwd;
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
@@ -235,6 +244,9 @@ typedef struct lemo_fit_const {
   int n, n67, n81;
   const int *row67, *row81, *foot_start, *foot_row, *u_row, *u_m67, *u_m81, *u_foot_mask;
   const float *Xstd, *Xmean;
+  const float* cam2world;         /* optional [12] = R row-major, t (PROX, fitting_temp_slide.py:676-680): the canonical frame
+                                   * is built from WORLD joints R (J + transl) + t and applied to world markers R v + t; the
+                                   * published canon matrix is R^T R0 so that it acts on camera-frame vertices directly */
 } lemo_fit_const;
 
 typedef struct lemo_fit_desc {
@@ -310,6 +322,95 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream);
 /* record (without running anything) the graphs an n-iteration lemo_fit_step(use_graph = 1) on `stream` will replay,
  * so that the first such call does not pay for capture + instantiation */
 int lemo_fit_prepare(void* h, int n, void* stream);
+
+/* ---- PROX sliding-window fitting iteration (the twin of the loop body above) ------------------------------------------
+ * temp_prox/fitting_temp_slide.py: closure fitting_func :239-311 (VPoser decode, SMPL-X, loss, backward, erase of the
+ * first int(0.15 B) frames' gradients unless first_batch_flag), SMPLifyLoss.forward as configured by
+ * cfg_files/PROXD_temp_S2.yaml / S3.yaml -- 2-D keypoints :573-580 through PerspectiveCamera (camera.py:88-116, fixed
+ * identity pose) and JointMapper (misc_utils.py:44-57); L2 / angle priors :586-615 (prior.py:50-90); cam -> world
+ * :676-680; SDF penetration :685-694; friction :699-739; infill L1 + contact velocity :944-992 (S3); smoothness prior
+ * :997-1031; sum + loss_dict :1036-1061 -- and Adam (optimizers/optim_factory.py:43-46, lr 0.005).  Every .item() branch
+ * of the reference is a device-side count; nothing returns to the host. */
+typedef struct lemo_prox_const {
+  int n_op, n_sj;                 /* OpenPose keypoints (118); smplx joints nj + n_extra + n_lmk (127) */
+  const int* joint_map;           /* [n_op] smplx joint each keypoint reads */
+  const int *jm_start, *jm_list;  /* inverse of joint_map: CSR [n_sj + 1], [n_op] */
+  int n_extra, n_lmk;
+  const int* extra_rows;          /* [n_extra] vertex-pick joints */
+  const int* lmk_rows;            /* [n_lmk][3] face vertices of the barycentric landmarks */
+  const float* lmk_bary;          /* [n_lmk][3] */
+  /* S: sorted unique ids of every vertex that carries a term besides the SDF penetration (friction set, 67 + 81 markers,
+   * heel / toe sets, vertex-pick joints, landmark face vertices) */
+  int n_s;
+  const int *s_vid, *s_m67, *s_m81, *s_foot_mask, *s_fric;   /* [n_s]: position in the respective list or -1; 4-bit mask */
+  const int *s_jstart, *s_jidx;   /* CSR [n_s + 1] over (vertex-joint index in [0, n_extra + n_lmk), weight) */
+  const float* s_jw;
+  int n_fric;
+  const int* fric_vid;            /* [n_fric] contact_fric_verts_ids (fit_temp_loadprox_slide.py:343-349) */
+  int n67;
+  const int* m67_vid;             /* [n67] infill markers */
+  const int *foot_start, *foot_vid;   /* [5], [...]: left heel, right heel, left toe, right toe */
+} lemo_prox_const;
+
+/* weights[13] (device + host copy): data, body_pose, shape, bending_prior, hand_prior, expr_prior, jaw_prior,
+ * sdf_penetration, motion_prior_smooth, friction_normal, friction_tangent, motion_infill_rec, motion_infill_contact */
+#define LEMO_PROX_NW 13
+/* losses[16]: the 14 loss_dict entries in the reference's order (:1047-1061) -- total_loss, joint_loss, s2m_dist, m2s_dist,
+ * self_penetration_loss, sdf_penetration_loss, contact_loss, smooth_acc_loss, smooth_vel_loss, motion_prior_smooth_loss,
+ * loss_fric_tangent, loss_fric_normal, motion_infill_loss, motion_infill_contact_loss -- then 2 spare */
+typedef struct lemo_prox_desc {
+  int B, Bp, V;
+  int conv_variant;
+  int first_batch_flag;           /* 0: gradients of frames [0, int(0.15 B)) are erased every iteration (:282-289) */
+  int use_infill;                 /* S3 terms live (marker_mask has an occluded entry, :944) */
+  int T;                          /* rows of body_markers_rec / contact_lbl_rec (B - 1) */
+  lemo_vposer_w vposer;
+  lemo_body_const body;
+  lemo_skin_const skin;
+  lemo_vertex_set_bwd uset;       /* ALL vertices, with jcsr_chunk + part (deterministic dense backward) */
+  lemo_fit_const fit;             /* smoothness-marker tables: n81, row81, Xstd, Xmean, cam2world */
+  lemo_prox_const pc;
+  int enc_ch[11];
+  const float* enc_w[10]; const float* enc_b[10]; const float* enc_wbwd[10];
+  const float* enc_w2[10]; const float* enc_wbwd2[10];
+  const void* enc_w3[10]; const void* enc_wbwd3[10];
+  /* scene */
+  const float* sdf; int sdf_dim[3];           /* [D][H][W] */
+  float grid_min[3], grid_max[3];
+  float cam2world[12];            /* R row-major, t (host copy; fit.cam2world is the device copy) */
+  float cam[4];                   /* fx, fy, cx, cy (PROXD_temp_S2.yaml:111-114) */
+  /* window data */
+  const float* gt_joints;         /* [B][n_op][2] */
+  const float* w2;                /* [B][n_op] (joint_weights * joints_conf)^2 */
+  const float* marker_mask;       /* [B][n67] or NULL */
+  const float* body_markers_rec;  /* [T][n67][3] or NULL */
+  const float* contact_lbl_rec;   /* [T][4] or NULL */
+  const float* weights;           /* device [LEMO_PROX_NW] */
+  float weights_host[LEMO_PROX_NW];
+  /* parameters (the smplx module's nn.Parameters + pose_embedding), fixed betas */
+  float *global_orient, *transl, *left_hand_pose, *right_hand_pose, *jaw_pose, *leye_pose, *reye_pose, *expression, *pose_embedding;
+  const float* betas;             /* [B][10] */
+  float *adam_m, *adam_v;         /* [B][81] each, parameter order as listed above */
+  int* step_ctr; int* step_cur; int* nonfinite;   /* [1], [1], [2] */
+  float lr;
+  /* workspace */
+  float *h1, *h2, *vo, *vp_scratch;
+  lemo_pose_ws pose;
+  float *verts, *v_posed, *dverts;            /* [B][V][3] */
+  float *x0, *canon, *dx0;
+  float* act[11]; float* dact[2];
+  float *dJtr, *dJv, *dtr_j, *gp, *dfp_add;   /* [B][nj][3], [B][n_extra+n_lmk][3], [B][3], [B][81], [B][3 nj] (zeroed once) */
+  float *dvp, *dA, *dtr_v, *dX;
+  float *g_go, *g_lh, *g_rh, *g_jaw, *g_leye, *g_reye, *g_expr, *g_pe;
+  double* loss_acc;               /* [32][32] */
+  float* losses;                  /* [16] */
+} lemo_prox_desc;
+void* lemo_prox_create(const lemo_prox_desc* d);
+void lemo_prox_destroy(void* h);
+/* forward + backward without the update: losses[] and the g_* / dtr_* buffers (erase applied by the update only) */
+int lemo_prox_closure(void* h, void* stream);
+/* n iterations (closure + Adam); use_graph as lemo_fit_step */
+int lemo_prox_step(void* h, int n, int use_graph, void* stream);
 
 #ifdef __cplusplus
 }

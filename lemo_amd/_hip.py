@@ -45,7 +45,7 @@ class PoseWs(C.Structure):
 
 
 class PoseGradIn(C.Structure):
-    _fields_ = [(n, vp) for n in ('dA', 'dJtr', 'dX')]
+    _fields_ = [(n, vp) for n in ('dA', 'dJtr', 'dX', 'd_full_pose')]
 
 
 class PoseGradOut(C.Structure):
@@ -61,13 +61,14 @@ class SkinConst(C.Structure):
 
 class VertexSetBwd(C.Structure):
     _fields_ = [('n', C.c_int), ('NCs', C.c_int)] + \
-        [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'DkT', 'jcsr_start', 'jcsr_u', 'jcsr_w')]
+        [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'DkT', 'jcsr_start', 'jcsr_u', 'jcsr_w', 'jcsr_chunk', 'part')] + \
+        [('part_frames', C.c_int)]
 
 
 class FitConst(C.Structure):
     _fields_ = [('n', C.c_int), ('n67', C.c_int), ('n81', C.c_int)] + \
         [(n, vp) for n in ('row67', 'row81', 'foot_start', 'foot_row', 'u_row', 'u_m67', 'u_m81',
-                           'u_foot_mask', 'Xstd', 'Xmean')]
+                           'u_foot_mask', 'Xstd', 'Xmean', 'cam2world')]
 
 
 CHAIN_MAX = 8
@@ -99,6 +100,43 @@ class FitDesc(C.Structure):
         ('dA', vp), ('dX', vp), ('loss_acc', vp), ('step_cur', vp),
         ('g_transl', vp), ('g_rot6d', vp), ('g_other', vp), ('g_go', vp), ('g_body', vp),
         ('snap', vp), ('nonfinite', vp), ('per_frame', C.c_int), ('lr2', C.c_float), ('lr_switch2', C.c_int),
+    ]
+
+
+class ProxConst(C.Structure):
+    """lemo_prox_const"""
+    _fields_ = [('n_op', C.c_int), ('n_sj', C.c_int), ('joint_map', vp), ('jm_start', vp), ('jm_list', vp),
+                ('n_extra', C.c_int), ('n_lmk', C.c_int), ('extra_rows', vp), ('lmk_rows', vp), ('lmk_bary', vp),
+                ('n_s', C.c_int), ('s_vid', vp), ('s_m67', vp), ('s_m81', vp), ('s_foot_mask', vp), ('s_fric', vp),
+                ('s_jstart', vp), ('s_jidx', vp), ('s_jw', vp), ('n_fric', C.c_int), ('fric_vid', vp), ('n67', C.c_int),
+                ('m67_vid', vp), ('foot_start', vp), ('foot_vid', vp)]
+
+
+PROX_NW = 13
+
+
+class ProxDesc(C.Structure):
+    """lemo_prox_desc"""
+    _fields_ = [
+        ('B', C.c_int), ('Bp', C.c_int), ('V', C.c_int), ('conv_variant', C.c_int), ('first_batch_flag', C.c_int),
+        ('use_infill', C.c_int), ('T', C.c_int),
+        ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst), ('pc', ProxConst),
+        ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10), ('enc_w2', vp * 10),
+        ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10),
+        ('sdf', vp), ('sdf_dim', C.c_int * 3), ('grid_min', C.c_float * 3), ('grid_max', C.c_float * 3),
+        ('cam2world', C.c_float * 12), ('cam', C.c_float * 4),
+        ('gt_joints', vp), ('w2', vp), ('marker_mask', vp), ('body_markers_rec', vp), ('contact_lbl_rec', vp),
+        ('weights', vp), ('weights_host', C.c_float * PROX_NW),
+        ('global_orient', vp), ('transl', vp), ('left_hand_pose', vp), ('right_hand_pose', vp), ('jaw_pose', vp),
+        ('leye_pose', vp), ('reye_pose', vp), ('expression', vp), ('pose_embedding', vp), ('betas', vp),
+        ('adam_m', vp), ('adam_v', vp), ('step_ctr', vp), ('step_cur', vp), ('nonfinite', vp), ('lr', C.c_float),
+        ('h1', vp), ('h2', vp), ('vo', vp), ('vp_scratch', vp), ('pose', PoseWs),
+        ('verts', vp), ('v_posed', vp), ('dverts', vp), ('x0', vp), ('canon', vp), ('dx0', vp),
+        ('act', vp * 11), ('dact', vp * 2),
+        ('dJtr', vp), ('dJv', vp), ('dtr_j', vp), ('gp', vp), ('dfp_add', vp),
+        ('dvp', vp), ('dA', vp), ('dtr_v', vp), ('dX', vp),
+        ('g_go', vp), ('g_lh', vp), ('g_rh', vp), ('g_jaw', vp), ('g_leye', vp), ('g_reye', vp), ('g_expr', vp), ('g_pe', vp),
+        ('loss_acc', vp), ('losses', vp),
     ]
 
 
@@ -167,6 +205,10 @@ _SIGS = {
     'lemo_fit_backward': (C.c_int, [vp, vp]),
     'lemo_fit_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'lemo_fit_prepare': (C.c_int, [vp, C.c_int, vp]),
+    'lemo_prox_create': (vp, [C.POINTER(ProxDesc)]),
+    'lemo_prox_destroy': (None, [vp]),
+    'lemo_prox_closure': (C.c_int, [vp, vp]),
+    'lemo_prox_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

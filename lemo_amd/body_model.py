@@ -29,6 +29,7 @@ from ._hip import ptr
 EXTRA_JOINT_VERTEX_IDS = [9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8463, 8474, 8635,
                           5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022]
 K_PAD = 512          # blend-shape GEMM depth: 20 shape/expression + 486 pose features, padded
+DENSE_CHUNK = 512    # LBS_DENSE_CHUNK of lbs_kernels.hip
 
 
 def _roundup(x, m):
@@ -143,6 +144,14 @@ class BodyModelData:
         extra = {}
         if n <= 4096:          # small sets also get the feature-contiguous copy used by the small-set FORWARD
             extra['DkT'] = np.ascontiguousarray(Dk.T)
+        if n > 1024:           # sets beyond the staged per-frame kernel (LBS_BWD_STAGE): per-chunk offsets into the
+            # (position-sorted) joint lists -> deterministic dense backward
+            nchunk = (n + DENSE_CHUNK - 1) // DENSE_CHUNK
+            tab = np.zeros((nchunk + 1, self.nj + 1), np.int32)
+            for j in range(self.nj):
+                tab[:, j] = js[j] + np.searchsorted(ju[j], np.arange(nchunk + 1) * DENSE_CHUNK)
+            tab[:, self.nj] = js[self.nj]
+            extra['jcsr_chunk'] = tab
         return dict(n=n, NCs=NCs, ids=ids.astype(np.int32), **extra,
                     vp_row=(ids if vp_row is None else np.asarray(vp_row)).astype(np.int32), Dk=Dk,
                     jcsr_start=np.asarray(js, np.int32),
@@ -166,15 +175,22 @@ class DeviceBody:
         self.skin = _hip.SkinConst(d.V, d.NC, d.KW, 0, ptr(T['Dg']), ptr(T['v_template']), ptr(T['w_idx']), ptr(T['w_val']))
         self._sets = {}
 
-    def vertex_set(self, key, ids: np.ndarray, vp_row=None):
-        """cached device copy of ``BodyModelData.vertex_set`` -> (ctypes struct, tensors)."""
+    def vertex_set(self, key, ids: np.ndarray, vp_row=None, frames: int = 0):
+        """cached device copy of ``BodyModelData.vertex_set`` -> (ctypes struct, tensors).  ``frames``: batch size the
+        deterministic dense backward of a large set must hold partial sums for (scratch grows on demand)."""
         if key not in self._sets:
             s = self.data.vertex_set(ids, vp_row)
             tt = {k: torch.from_numpy(v).to(self.device) for k, v in s.items() if isinstance(v, np.ndarray)}
             st = _hip.VertexSetBwd(s['n'], s['NCs'], ptr(tt['ids']), ptr(tt['vp_row']), ptr(tt['Dk']),
                                    ptr(tt['DkT']) if 'DkT' in tt else None,
-                                   ptr(tt['jcsr_start']), ptr(tt['jcsr_u']), ptr(tt['jcsr_w']))
+                                   ptr(tt['jcsr_start']), ptr(tt['jcsr_u']), ptr(tt['jcsr_w']),
+                                   ptr(tt['jcsr_chunk']) if 'jcsr_chunk' in tt else None, None, 0)
             self._sets[key] = (st, tt)
+        st, tt = self._sets[key]
+        if 'jcsr_chunk' in tt and frames > st.part_frames:
+            nchunk = tt['jcsr_chunk'].shape[0] - 1
+            tt['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
+            st.part, st.part_frames = ptr(tt['part']), frames
         return self._sets[key]
 
 
@@ -237,7 +253,7 @@ class _SmplxFn(torch.autograd.Function):
             dl = djoints[:, d.nj + ne:]                                             # [B,51,3]
             contrib = dl.unsqueeze(2) * dev.t['lmk_bary'].view(1, -1, 3, 1)          # [B,51,3(f),3]
             dverts.index_add_(1, dev.t['lmk_rows'].long().view(-1), contrib.reshape(B, -1, 3))
-        uset, _ = dev.vertex_set('all', np.arange(d.V))
+        uset, _ = dev.vertex_set('all', np.arange(d.V), frames=B)
         dvp, dA, dtransl, dX = z(B, uset.NCs), z(B, d.nj, 12), z(B, 3), z(B, K_PAD)
         lib.check(lib.lbs_verts_bwd(C.byref(dev.skin), C.byref(uset), ptr(tt['A']), d.nj, ptr(ctx.v_posed), d.V,
                                     ptr(dverts), B, Bp, ptr(dvp), ptr(dA), ptr(dtransl), ptr(dX), s), 'lbs_verts_bwd')

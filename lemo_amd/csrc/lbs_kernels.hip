@@ -724,6 +724,101 @@ lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   }
 }
 
+// ---- dense variant, deterministic (round 2): the same (frame, 512-vertex chunk) decomposition, but dA is gathered
+// joint-major inside the chunk (the joint lists are sorted by set position: chunk c of joint j is a contiguous run,
+// u.jcsr_chunk) by one wave per joint with a fixed reduction tree, written as a per-chunk partial, and the partials are
+// added in chunk order by lbs_bwd_reduce_kernel.  No atomics anywhere: two runs give identical bits.
+#define LBS_PART_STRIDE(nj) ((nj) * 12 + 4)
+__global__ void __launch_bounds__(256)
+lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj, const float* __restrict__ v_posed,
+                     int vp_rows, const float* __restrict__ dverts, float* __restrict__ dvp) {
+  __shared__ float As[64 * 12];
+  __shared__ float gs[LBS_DENSE_CHUNK * 3], vs[LBS_DENSE_CHUNK * 3];
+  __shared__ float red[3 * 4];
+  const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
+  const int nchunk = gridDim.x;
+  const int s0 = ch * LBS_DENSE_CHUNK, s_end = min(s0 + LBS_DENSE_CHUNK, u.n), cn = s_end - s0;
+  const float* Af = A + (size_t)b * nj * 12;
+  for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
+  for (int i = t; i < cn * 3; i += 256) {
+    const int s = s0 + i / 3, e = i % 3;
+    gs[i] = dverts[((size_t)b * u.n + s) * 3 + e];
+    vs[i] = v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + e];
+  }
+  __syncthreads();
+  // ---- vertex-major: d(v_posed) = T^T g
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int l = t; l < cn; l += 256) {
+    const int vid = u.ids[s0 + l];
+    const float gx = gs[3 * l], gy = gs[3 * l + 1], gz = gs[3 * l + 2];
+    sx += gx; sy += gy; sz += gz;
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+    const int* wi = c.w_idx + (size_t)vid * c.KW;
+    const float* wv = c.w_val + (size_t)vid * c.KW;
+    for (int k = 0; k < c.KW; ++k) {
+      const float w = wv[k];
+      const float* Aj = As + wi[k] * 12;                        // ELL padding rows carry weight 0
+      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
+      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
+      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+    }
+    float* d = dvp + (size_t)b * u.NCs + 3 * (s0 + l);
+    d[0] = T[0] * gx + T[3] * gy + T[6] * gz;
+    d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
+    d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
+  }
+  float* part = u.part + ((size_t)b * nchunk + ch) * LBS_PART_STRIDE(nj);
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  if ((t & 63) == 0) { red[3 * (t >> 6)] = sx; red[3 * (t >> 6) + 1] = sy; red[3 * (t >> 6) + 2] = sz; }
+  __syncthreads();
+  if (t < 3) part[nj * 12 + t] = ((red[t] + red[3 + t]) + red[6 + t]) + red[9 + t];
+  // ---- joint-major: dA[j][r][:] = sum over the chunk's entries of joint j of  w g_r (x) [v, 1]
+  const int wave = t >> 6, lane = t & 63;
+  const int* tab0 = u.jcsr_chunk + (size_t)ch * (nj + 1);
+  const int* tab1 = tab0 + (nj + 1);
+  for (int j = wave; j < nj; j += 4) {
+    const int q0 = tab0[j], q1 = tab1[j];
+    float acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+    for (int q = q0 + lane; q < q1; q += 64) {
+      const int l = u.jcsr_u[q] - s0;
+      const float w = u.jcsr_w[q];
+      const float vx = vs[3 * l], vy = vs[3 * l + 1], vz = vs[3 * l + 2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float gv = gs[3 * l + r] * w;
+        acc[4 * r] = fmaf(gv, vx, acc[4 * r]); acc[4 * r + 1] = fmaf(gv, vy, acc[4 * r + 1]);
+        acc[4 * r + 2] = fmaf(gv, vz, acc[4 * r + 2]); acc[4 * r + 3] += gv;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = wave_sum(acc[e]);
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) part[j * 12 + e] = acc[e];
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+lbs_bwd_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
+  const int b = blockIdx.x, t = threadIdx.x, st = LBS_PART_STRIDE(nj);
+  const float* p = u.part + (size_t)b * nchunk * st;
+  for (int i = t; i < nj * 12; i += 256) {
+    float a = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) a += p[(size_t)ch * st + i];
+    dA[(size_t)b * nj * 12 + i] = a;
+  }
+  if (dtransl && t < 3) {
+    float a = 0.f;
+    for (int ch = 0; ch < nchunk; ++ch) a += p[(size_t)ch * st + nj * 12 + t];
+    dtransl[(size_t)b * 3 + t] = a;
+  }
+  for (int i = 3 * u.n + t; i < u.NCs; i += 256) dvp[(size_t)b * u.NCs + i] = 0.f;     // padding columns of the GEMM operand
+}
+
 // the staged (frame in LDS) kernel takes the set; only that one has the fused d(verts) form
 bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj) {
   return u.n <= LBS_BWD_STAGE && nj <= 64 && (long)u.n * c.KW <= LBS_BWD_NNZ;
@@ -740,6 +835,11 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
     {
     if (fuse) hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, true>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, *fuse);
     else hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, false>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, FitFuse{});
+  }
+  else if (nj <= 64 && u.jcsr_chunk && u.part && B <= u.part_frames) {
+    const int nchunk = (u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK;
+    hipLaunchKernelGGL(lbs_bwd_chunk_kernel, dim3(nchunk, B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp);
+    hipLaunchKernelGGL(lbs_bwd_reduce_kernel, dim3(B), dim3(256), 0, s, u, nj, nchunk, dvp, dA, dtransl);
   }
   else if (nj <= 64) {
     hipLaunchKernelGGL(lbs_bwd_zero_kernel, dim3(B), dim3(256), 0, s, dvp, u.NCs, 3 * u.n, dA, nj * 12, dtransl);

@@ -1,0 +1,154 @@
+// PROX sliding-window fitting engine (C ABI lemo_prox_*): one iteration of temp_prox/fitting_temp_slide.py's
+// `optimizer.step(closure)` as a fixed sequence of kernel launches, captured once into hipGraphs and replayed.
+// The twin of the AMASS engine in lemo_hip.hip; kernels: prox_kernels.hip + the shared pose / LBS / encoder kernels.
+#include "kernels.hpp"
+#include <new>
+
+namespace lemo {
+int prox_frame(const lemo_prox_desc& d, hipStream_t s);
+int prox_dense(const lemo_prox_desc& d, hipStream_t s);
+int prox_sparse(const lemo_prox_desc& d, double smooth_count, hipStream_t s);
+int prox_adam(const lemo_prox_desc& d, hipStream_t s);
+}
+using namespace lemo;
+
+#define CHK(x) do { int e_ = (x); if (e_) return e_; } while (0)
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+static const int PROX_LEVELS = 2;
+static const int PROX_UNROLL[PROX_LEVELS] = {10, 1};
+
+struct ProxEngine {
+  lemo_prox_desc d;
+  hipGraphExec_t exec[PROX_LEVELS] = {nullptr, nullptr};
+  hipStream_t graph_stream = nullptr;
+};
+
+static int conv_layer(const lemo_prox_desc& d, int l, bool bwd, const float* x, const float* aux, float* out, int H, int W, hipStream_t s) {
+  const int cin = bwd ? d.enc_ch[l + 1] : d.enc_ch[l], cout = bwd ? d.enc_ch[l] : d.enc_ch[l + 1];
+  const float* wt = bwd ? d.enc_wbwd[l] : d.enc_w[l];
+  const float* wt2 = bwd ? d.enc_wbwd2[l] : d.enc_w2[l];
+  const void* w3 = bwd ? d.enc_wbwd3[l] : d.enc_w3[l];
+  const float* bias = bwd ? nullptr : d.enc_b[l];
+  const int epi = bwd ? 1 : 0;
+  if (d.conv_variant == 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
+    return conv3x3_mfma_split(x, w3, wt, bias, aux, out, H, W, cin, cout, epi, s);
+  if (d.conv_variant >= 2 && 127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 <= 416)
+    return conv3x3_mfma_lds(x, wt, wt2, bias, aux, out, H, W, cin, cout, epi, s);
+  return conv3x3_mfma(x, wt, bias, aux, out, H, W, cin, cout, epi, 1, s);
+}
+
+// forward + backward of one iteration (fitting_func :239-311 without the erase, which the update applies)
+static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
+  const int B = d.B, nj = d.body.nj;
+  const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
+  // ---- body: VPoser decode (:243), ONE SMPL-X forward for both joint sets (:248, :253-258)
+  CHK(gemm_nt16(d.vposer.w1, 32, d.pose_embedding, 32, 512, B, 32, d.h1, 512, d.vposer.b1, nullptr, 0, 1, s));
+  CHK(gemm_nt16(d.vposer.w2, 512, d.h1, 512, 512, B, 512, d.h2, 512, d.vposer.b2, nullptr, 0, 1, s));
+  CHK(gemm_nt16(d.vposer.w3, 512, d.h2, 512, 128, B, 512, d.vo, 128, d.vposer.b3, nullptr, 0, 2, s));
+  lemo_pose_in in{};
+  in.global_orient = d.global_orient; in.vposer_o = d.vo;
+  in.jaw = d.jaw_pose; in.leye = d.leye_pose; in.reye = d.reye_pose;
+  in.lh = d.left_hand_pose; in.rh = d.right_hand_pose; in.hand_stride = 12;
+  in.betas = d.betas; in.betas_stride = 10; in.expr = d.expression;
+  in.zero_f64 = d.loss_acc; in.n_zero = 32 * 32 + 32 * 16; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
+  in.nonfinite = d.nonfinite;
+  CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
+  CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
+  // ---- loss: per-frame terms, dense SDF term, smoothness prior through the encoder
+  CHK(prox_frame(d, s));
+  CHK(prox_dense(d, s));
+  CHK(marker_c1(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
+  for (int l = 1; l < 10; ++l) CHK(conv_layer(d, l, false, d.act[l], nullptr, d.act[l + 1], H, W, s));
+  const double cnt = (double)d.enc_ch[10] * H * (W - 1);
+  const float coef2 = (float)((double)d.weights_host[8] * 2.0 / cnt);
+  CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 32 * 32));
+  // ---- backward
+  int cur = 0;
+  for (int l = 9; l >= 1; --l) { CHK(conv_layer(d, l, true, d.dact[cur], d.act[l], d.dact[1 - cur], H, W, s)); cur = 1 - cur; }
+  CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(prox_sparse(d, cnt, s));
+  CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.V, d.dverts, B, d.Bp, d.dvp, d.dA, d.dtr_v, d.dX, s));
+  lemo_pose_grad_in gi{d.dA, d.dJtr, d.dX, d.dfp_add};
+  lemo_pose_grad_out go{};
+  go.d_global_orient = d.g_go; go.d_jaw = d.g_jaw; go.d_leye = d.g_leye; go.d_reye = d.g_reye;
+  go.d_lh = d.g_lh; go.d_rh = d.g_rh; go.hand_stride = 12; go.d_expr = d.g_expr;
+  go.vposer_o = d.vo; go.d_vposer_o = d.vp_scratch;
+  CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
+  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, d.g_pe, 32, d.vp_scratch, s));
+  return 0;
+}
+
+static int prox_iteration(const lemo_prox_desc& d, hipStream_t s) {
+  CHK(prox_closure(d, s));
+  return prox_adam(d, s);
+}
+
+static int prox_capture(ProxEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; ++i) rc = prox_iteration(e->d, s);
+  const int ec = (int)hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  CHK(ec);
+  const int ic = (int)hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (!ic) (void)hipGraphUpload(*out, s);
+  return ic;
+}
+
+extern "C" {
+
+void* lemo_prox_create(const lemo_prox_desc* d) {
+  if (!d || d->B < 10 || d->B > d->Bp || !d->verts || !d->dverts || !d->sdf || d->uset.n != d->V || !d->fit.cam2world) return nullptr;
+  // the all-vertex backward must be one of the deterministic forms: the staged per-frame kernel (small models) or the
+  // chunked gather with its partial-sum scratch
+  if (!lbs_verts_bwd_fusable(d->skin, d->uset, d->body.nj) && (!d->uset.jcsr_chunk || !d->uset.part || d->uset.part_frames < d->B))
+    return nullptr;
+  if (d->use_infill && (!d->marker_mask || !d->body_markers_rec || !d->contact_lbl_rec || d->T > d->B - 1 || d->T < 1)) return nullptr;
+  if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
+  ProxEngine* e = new (std::nothrow) ProxEngine();
+  if (e) e->d = *d;
+  return e;
+}
+
+void lemo_prox_destroy(void* h) {
+  ProxEngine* e = (ProxEngine*)h;
+  if (!e) return;
+  for (int l = 0; l < PROX_LEVELS; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
+  delete e;
+}
+
+int lemo_prox_closure(void* h, void* stream) {
+  ProxEngine* e = (ProxEngine*)h;
+  if (!e) return LEMO_ERR_ARG;
+  return prox_closure(e->d, S(stream));
+}
+
+int lemo_prox_step(void* h, int n, int use_graph, void* stream) {
+  ProxEngine* e = (ProxEngine*)h;
+  if (!e || n < 0) return LEMO_ERR_ARG;
+  hipStream_t s = S(stream);
+  if (!use_graph) {
+    for (int i = 0; i < n; ++i) CHK(prox_iteration(e->d, s));
+    return 0;
+  }
+  if (e->graph_stream != s) {
+    for (int l = 0; l < PROX_LEVELS; ++l) if (e->exec[l]) { (void)hipGraphExecDestroy(e->exec[l]); e->exec[l] = nullptr; }
+    e->graph_stream = s;
+  }
+  // open with single-iteration replays (the device starts while the host still enqueues), then the 10-iteration graph
+  int left = n;
+  const int head = left < 3 ? left : 3;
+  if (head && !e->exec[1]) CHK(prox_capture(e, s, 1, &e->exec[1]));
+  if (left - head >= PROX_UNROLL[0] && !e->exec[0]) CHK(prox_capture(e, s, PROX_UNROLL[0], &e->exec[0]));
+  for (int i = 0; i < head; ++i) CHK((int)hipGraphLaunch(e->exec[1], s));
+  left -= head;
+  for (; left >= PROX_UNROLL[0]; left -= PROX_UNROLL[0]) CHK((int)hipGraphLaunch(e->exec[0], s));
+  if (left && !e->exec[1]) CHK(prox_capture(e, s, 1, &e->exec[1]));
+  for (; left > 0; --left) CHK((int)hipGraphLaunch(e->exec[1], s));
+  return 0;
+}
+
+}  // extern "C"

@@ -461,7 +461,7 @@ smplx_pose_bwd_kernel(BodyConst c, PoseWs ws, PoseGradIn gi, PoseGradOut go) {
     float fp3[3], d3[3];
     for (int k = 0; k < 3; ++k) fp3[k] = fps[3 * t + k];
     rodrigues_bwd(fp3, &dRl[9 * t], d3);
-    for (int k = 0; k < 3; ++k) dfp[3 * t + k] = d3[k];
+    for (int k = 0; k < 3; ++k) dfp[3 * t + k] = d3[k] + (gi.d_full_pose ? gi.d_full_pose[(size_t)b * np + 3 * t + k] : 0.f);
   }
   __syncthreads(); CENSUS()
   // fused consumers: d(global_orient) -> d(rot6d) ; d(body_pose) -> d(VPoser out layer)

@@ -266,3 +266,225 @@ class ProxTemporalFitter:
                 lib.check(lib.graph_destroy(exe), 'graph_destroy')
         torch.cuda.current_stream(dev).wait_stream(side)
         return ld
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Native engine: the same iteration as ``ProxTemporalFitter`` as ONE C call (lemo_prox_step) replaying hipGraphs
+# ----------------------------------------------------------------------------------------------------------------------
+WEIGHT_ORDER = ('data_weight', 'body_pose_weight', 'shape_weight', 'bending_prior_weight', 'hand_prior_weight',
+                'expr_prior_weight', 'jaw_prior_weight', 'sdf_penetration_weight', 'motion_prior_smooth_weight',
+                'friction_normal_weight', 'friction_tangent_weight', 'motion_infill_rec_weight', 'motion_infill_contact_weight')
+"""order of ``lemo_prox_desc.weights`` (include/lemo_hip.h)."""
+ENGINE_PARAMS = (('global_orient', 3), ('transl', 3), ('left_hand_pose', 12), ('right_hand_pose', 12), ('jaw_pose', 3),
+                 ('leye_pose', 3), ('reye_pose', 3), ('expression', 10), ('pose_embedding', 32))
+"""the optimised tensors in the engine's Adam order: ``body_model.parameters()`` with requires_grad + pose_embedding
+(fit_temp_loadprox_slide.py:511-519)."""
+
+
+class ProxWindowEngine:
+    """One sliding window (B frames) of the PROX temporal fit on the native engine (``lemo_prox_*``): closure
+    ``fitting_func`` (fitting_temp_slide.py:239-311), the S2 / S3-active ``SMPLifyLoss`` terms, backward, first-15 % erase
+    and Adam (lr 0.005) are a fixed sequence of ~40 HIP kernels captured once and replayed -- no torch op, no host sync,
+    no atomics-ordered accumulation (graph replay == eager launches bit for bit).  Same constructor as
+    :class:`ProxTemporalFitter` (which stays as the module-level / autograd composition of the same kernels)."""
+
+    def __init__(self, body_model: SMPLX, vposer: VPoser, smooth_encoder: Enc, ids: Dict[str, np.ndarray], Xmean, Xstd,
+                 weights: dict, R, t, sdf: torch.Tensor, grid_min, grid_max, params: Dict[str, np.ndarray], gt_joints,
+                 joints_conf, joint_map=None, fric_ids=None, cam: Optional[dict] = None, marker_mask=None,
+                 body_markers_rec=None, contact_lbl_rec=None, first_batch_flag: bool = False, lr: float = 0.005,
+                 conv_variant: Optional[int] = None):
+        import ctypes as C
+        from ._hip import ptr
+        from .body_model import K_PAD, alloc_pose_ws
+        from .priors import DEFAULT_CONV_VARIANT, ENC_CHANNELS, EncWeights, cg8p_alloc
+        from .vposer import vposer_weight_struct
+        self.lib = lib = body_model._lib_override or _hip.get_lib()
+        dev = sdf.device
+        self.device = dev
+        _hip.check_device(lib, sdf)
+        data = body_model.data
+        assert data.ncomp == 12 and data.use_pca, 'the PROX configs fit 12 PCA coefficients per hand'
+        self.data, self.dbody = data, body_model._device_body(dev)
+        B = int(np.asarray(params['pose_embedding']).shape[0])
+        self.B, V, nj = B, data.V, data.nj
+        tables = load_prox_tables()
+        ti = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
+        tf = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        jm = np.asarray(tables['joint_map'] if joint_map is None else joint_map, np.int64)
+        fric = np.asarray(tables['contact_fric_verts_ids'] if fric_ids is None else fric_ids, np.int64)
+        assert len(set(fric.tolist())) == len(fric), 'duplicate friction vertex ids'
+        m67, m81 = np.asarray(ids['markers67'], np.int64), np.asarray(ids['markers81'], np.int64)
+        foot = [np.asarray(ids[k], np.int64) for k in ('left_heel', 'right_heel', 'left_toe', 'right_toe')]
+        for f in foot:
+            assert len(set(f.tolist())) == len(f), 'duplicate vertex id in a foot set'
+        n_sj = data.n_joints_out
+        nvj = n_sj - nj
+        # inverse of the joint map (index_select backward as a gather)
+        jl = [np.nonzero(jm == j)[0] for j in range(n_sj)]
+        jm_start = np.cumsum([0] + [len(x) for x in jl])
+        # special vertex set S
+        extra, lmk_rows, lmk_bary = data.extra_ids.astype(np.int64), data.lmk_rows.astype(np.int64), data.lmk_bary
+        S = np.unique(np.concatenate([fric, m67, m81] + foot + [extra, lmk_rows.reshape(-1)]))
+        pos = {int(v): i for i, v in enumerate(S)}
+        n_s = len(S)
+        s_m67, s_m81, s_fric = (-np.ones(n_s, np.int32) for _ in range(3))
+        s_mask = np.zeros(n_s, np.int32)
+        for i, v in enumerate(m67): s_m67[pos[int(v)]] = i
+        for i, v in enumerate(m81): s_m81[pos[int(v)]] = i
+        for i, v in enumerate(fric): s_fric[pos[int(v)]] = i
+        for k, f in enumerate(foot):
+            for v in f: s_mask[pos[int(v)]] |= (1 << k)
+        jlists = [[] for _ in range(n_s)]
+        for i, v in enumerate(extra): jlists[pos[int(v)]].append((i, 1.0))
+        for l in range(lmk_rows.shape[0]):
+            for f in range(3): jlists[pos[int(lmk_rows[l, f])]].append((len(extra) + l, float(lmk_bary[l, f])))
+        s_jstart = np.cumsum([0] + [len(x) for x in jlists])
+        s_jidx = np.asarray([q[0] for x in jlists for q in x] + [0], np.int32)
+        s_jw = np.asarray([q[1] for x in jlists for q in x] + [0.0], np.float32)
+        T_ = self._t = dict(joint_map=ti(jm), jm_start=ti(jm_start), jm_list=ti(np.concatenate(jl + [np.zeros(1, np.int64)])),
+                            s_vid=ti(S), s_m67=ti(s_m67), s_m81=ti(s_m81), s_mask=ti(s_mask), s_fric=ti(s_fric),
+                            s_jstart=ti(s_jstart), s_jidx=ti(s_jidx), s_jw=tf(s_jw), fric=ti(fric), m67=ti(m67),
+                            foot_start=ti(np.cumsum([0] + [len(f) for f in foot])), foot_vid=ti(np.concatenate(foot)),
+                            row81=ti(m81), Xstd=tf(np.asarray(Xstd).reshape(-1)), Xmean=tf(np.asarray(Xmean).reshape(-1)))
+        dt = self.dbody.t
+        pc = _hip.ProxConst(len(jm), n_sj, ptr(T_['joint_map']), ptr(T_['jm_start']), ptr(T_['jm_list']), len(extra), lmk_rows.shape[0],
+                            ptr(dt['extra_ids']), ptr(dt['lmk_rows']), ptr(dt['lmk_bary']), n_s, ptr(T_['s_vid']), ptr(T_['s_m67']),
+                            ptr(T_['s_m81']), ptr(T_['s_mask']), ptr(T_['s_fric']), ptr(T_['s_jstart']), ptr(T_['s_jidx']), ptr(T_['s_jw']),
+                            len(fric), ptr(T_['fric']), len(m67), ptr(T_['m67']), ptr(T_['foot_start']), ptr(T_['foot_vid']))
+        Rn, tn = np.asarray(R, np.float32).reshape(3, 3), np.asarray(t, np.float32).reshape(3)
+        c2w = np.concatenate([Rn.reshape(-1), tn]).astype(np.float32)
+        T_['c2w'] = tf(c2w)
+        n81 = len(m81)
+        assert T_['Xstd'].numel() == 3 * n81
+        fitc = _hip.FitConst(0, len(m67), n81, None, ptr(T_['row81']), None, None, None, None, None, None, ptr(T_['Xstd']),
+                             ptr(T_['Xmean']), ptr(T_['c2w']))
+        # weights
+        w = dict(weights)
+        w['bending_prior_weight'] = 3.17 * w['body_pose_weight']                    # fit_temp_loadprox_slide.py:524
+        self.w = w
+        wl = [float(w[k]) for k in WEIGHT_ORDER]
+        T_['weights'] = tf(wl)
+        # model weights
+        vp_sd = {k: v.detach().cpu().numpy() for k, v in vposer.state_dict().items() if k.startswith('bodyprior_dec_')}
+        self.vposer_struct, self._vp_t = vposer_weight_struct(vp_sd, dev)
+        self.enc = EncWeights({k: v.detach().cpu().numpy() for k, v in smooth_encoder.state_dict().items()}, dev)
+        # window data
+        cam = dict(PROX_CAMERA if cam is None else cam)
+        jw = joint_weights_for(B, w, dev)
+        T_['w2'] = ((jw * tf(joints_conf)) ** 2).contiguous()
+        T_['gt'] = tf(gt_joints)
+        self.use_infill = body_markers_rec is not None and bool(np.asarray(marker_mask).size > np.asarray(marker_mask).sum())
+        if body_markers_rec is not None:
+            T_['mask'], T_['rec'], T_['clbl'] = tf(marker_mask), tf(body_markers_rec), tf(contact_lbl_rec)
+            assert T_['rec'].shape[0] == B - 1 and T_['clbl'].shape == (B - 1, 4), 'body_markers_rec / contact_lbl_rec carry B - 1 frames'
+        # parameters + Adam state
+        self.P = {k: tf(np.asarray(params[k], np.float32).reshape(B, d)) for k, d in ENGINE_PARAMS}
+        self.betas = tf(np.asarray(params['betas'], np.float32).reshape(B, 10))
+        self.adam_m, self.adam_v = z(B, 81), z(B, 81)
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_cur = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)
+        # workspace
+        self.H, self.W = 3 * n81 + 2, B - 1 + 16
+        H, W = self.H, self.W
+        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
+        uset, self._uset_t = self.dbody.vertex_set('all', np.arange(V), frames=B)
+        self.ws = dict(h1=z(B, 512), h2=z(B, 512), vo=z(B, 128), vp_scratch=z(B, 1152), verts=z(B, V, 3), v_posed=z(B, V, 3),
+                       dverts=z(B, V, 3), x0=z((H + 2) * (W + 2)), canon=z(12), dx0=z(H * W), dJtr=z(B, nj, 3), dJv=z(B, nvj, 3),
+                       dtr_j=z(B, 3), gp=z(B, 81), dfp_add=z(B, nj * 3), dvp=z(B, uset.NCs), dA=z(B, nj, 12), dtr_v=z(B, 3),
+                       dX=z(B, K_PAD), g_go=z(B, 3), g_lh=z(B, 12), g_rh=z(B, 12), g_jaw=z(B, 3), g_leye=z(B, 3), g_reye=z(B, 3),
+                       g_expr=z(B, 10), g_pe=z(B, 32), losses=z(16))
+        self.loss_acc = torch.zeros(32 * 32 + 32 * 16, dtype=torch.float64, device=dev)
+        self.act = [None] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
+        self.dact = [cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)]
+        self.sdf = sdf.contiguous().float()
+        d = _hip.ProxDesc()
+        d.B, d.Bp, d.V = B, Bp, V
+        cv = DEFAULT_CONV_VARIANT if conv_variant is None else int(conv_variant)
+        if cv >= 2 and 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 > 416:
+            cv = 1
+        self.conv_variant = d.conv_variant = cv
+        d.first_batch_flag, d.use_infill, d.T = int(bool(first_batch_flag)), int(self.use_infill), B - 1
+        d.vposer, d.body, d.skin, d.uset, d.fit, d.pc = self.vposer_struct, self.dbody.body, self.dbody.skin, uset, fitc, pc
+        for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
+        for l in range(10):
+            d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
+            d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
+            d.enc_w3[l] = ptr(self.enc.w3[l]) if self.enc.w3[l] is not None else None
+            d.enc_wbwd3[l] = ptr(self.enc.wbwd3[l]) if self.enc.wbwd3[l] is not None else None
+        d.sdf = ptr(self.sdf)
+        for i in range(3):
+            d.sdf_dim[i], d.grid_min[i], d.grid_max[i] = int(self.sdf.shape[i]), float(grid_min[i]), float(grid_max[i])
+        for i in range(12): d.cam2world[i] = float(c2w[i])
+        for i, k in enumerate(('fx', 'fy', 'cx', 'cy')): d.cam[i] = float(cam[k])
+        d.gt_joints, d.w2 = ptr(T_['gt']), ptr(T_['w2'])
+        if body_markers_rec is not None:
+            d.marker_mask, d.body_markers_rec, d.contact_lbl_rec = ptr(T_['mask']), ptr(T_['rec']), ptr(T_['clbl'])
+        d.weights = ptr(T_['weights'])
+        for i, v in enumerate(wl): d.weights_host[i] = v
+        for k, _ in ENGINE_PARAMS: setattr(d, k, ptr(self.P[k]))
+        d.betas, d.adam_m, d.adam_v = ptr(self.betas), ptr(self.adam_m), ptr(self.adam_v)
+        d.step_ctr, d.step_cur, d.nonfinite, d.lr = ptr(self.step_ctr), ptr(self.step_cur), ptr(self.nonfinite), float(lr)
+        for k in ('h1', 'h2', 'vo', 'vp_scratch', 'verts', 'v_posed', 'dverts', 'x0', 'canon', 'dx0', 'dJtr', 'dJv', 'dtr_j', 'gp',
+                  'dfp_add', 'dvp', 'dA', 'dtr_v', 'dX', 'g_go', 'g_lh', 'g_rh', 'g_jaw', 'g_leye', 'g_reye', 'g_expr', 'g_pe', 'losses'):
+            setattr(d, k, ptr(self.ws[k]))
+        d.pose = pose_ws
+        for l in range(1, 11): d.act[l] = ptr(self.act[l])
+        d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
+        d.loss_acc = ptr(self.loss_acc)
+        self.desc = d
+        self.handle = lib.prox_create(C.byref(d))
+        if not self.handle:
+            raise _hip.LemoHipError('lemo_prox_create rejected the descriptor')
+        self.first_batch_flag = bool(first_batch_flag)
+
+    def __del__(self):
+        h, self.handle = getattr(self, 'handle', None), None
+        if h:
+            self.lib.prox_destroy(h)
+
+    def _s(self):
+        return None if self.lib.is_emu else torch.cuda.current_stream(self.device).cuda_stream
+
+    def closure(self) -> Dict[str, float]:
+        """forward + backward (no update, no erase): fills the loss record and the gradient buffers"""
+        self.lib.check(self.lib.prox_closure(self.handle, self._s()), 'prox_closure')
+        return self.loss_dict()
+
+    def step(self, n: int = 1, use_graph: bool = True) -> None:
+        """n x ``optimizer.step(closure)``; asynchronous.  Graph capture needs a non-default current stream."""
+        self.lib.check(self.lib.prox_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()), 'prox_step')
+
+    def loss_dict(self) -> Dict[str, float]:
+        v = self.ws['losses'].detach().cpu().numpy()
+        return {k: float(v[i]) for i, k in enumerate(LOSS_KEYS)}
+
+    def grads(self, erase: bool = True) -> Dict[str, torch.Tensor]:
+        """d(total_loss)/d(parameter) of the last closure including the priors' own terms, with the first-15 % erase
+        applied like the reference's closure does (:282-289)"""
+        g = {'global_orient': self.ws['g_go'], 'transl': self.ws['dtr_v'] + self.ws['dtr_j'], 'left_hand_pose': self.ws['g_lh'],
+             'right_hand_pose': self.ws['g_rh'], 'jaw_pose': self.ws['g_jaw'], 'leye_pose': self.ws['g_leye'],
+             'reye_pose': self.ws['g_reye'], 'expression': self.ws['g_expr'], 'pose_embedding': self.ws['g_pe']}
+        out, o = {}, 0
+        for k, dim in ENGINE_PARAMS:
+            v = g[k] + self.ws['gp'][:, o:o + dim]
+            if erase and not self.first_batch_flag:
+                v = v.clone()
+                v[:int(self.B * 0.15)] = 0
+            out[k] = v
+            o += dim
+        return out
+
+    def nonfinite_step(self) -> int:
+        """1-based index of the first iteration with a NaN / Inf total loss (0 = none): FittingMonitor.run_fitting's stop
+        (fitting_temp_slide.py:198-204) inside the replayed graph -- later iterations skip their update"""
+        return int(self.nonfinite[0].item())
+
+    def write_back(self, body_model: SMPLX) -> torch.Tensor:
+        """copy the fitted parameters into the smplx-compatible module (what fit_temp_loadprox_slide.py:577-594 pickles);
+        returns pose_embedding"""
+        with torch.no_grad():
+            for k, _ in ENGINE_PARAMS[:-1]:
+                getattr(body_model, k).copy_(self.P[k])
+        return self.P['pose_embedding']

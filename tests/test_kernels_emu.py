@@ -324,7 +324,8 @@ def test_conv_chain_single_layer_coherent_path(emu_lib):
 
 def test_dense_vertex_backward_large_set(emu_lib):
     """vertex sets above 1024 vertices (the PROX window differentiates through all of them) take the chunked dense
-    backward kernel (LDS atomics + one global add per chunk): every input gradient against the oracle's autograd"""
+    backward (joint-major gather per 512-vertex chunk, per-chunk partials reduced in order: no atomics): every input
+    gradient against the oracle's autograd"""
     from lemo_amd.body_model import create
     from oracle import lemo_oracle as O
     m = synthetic.make_synthetic_smplx(seed=5, V=1300, F=600)
@@ -346,6 +347,8 @@ def test_dense_vertex_backward_large_set(emu_lib):
     assert rel_err(out.vertices.detach(), v_ref.detach()) < 1e-4
     for k in p:
         assert rel_err(p[k].grad, q[k].grad) < 1e-4, k
+    st, tt = model._device_body(torch.device('cpu')).vertex_set('all', np.arange(1300), frames=B)
+    assert 'jcsr_chunk' in tt and st.part_frames >= B                   # the deterministic path was the one that ran
 
 
 @pytest.mark.parametrize('ci,co,ks', [(64, 64, 4), (40, 32, 7), (128, 64, 8)])

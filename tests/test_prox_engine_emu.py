@@ -1,0 +1,68 @@
+"""The native PROX engine (C ABI lemo_prox_*, lemo_amd.prox.ProxWindowEngine) on the emulator library against the
+oracle -- which make_golden.py pins to the reference's own SMPLifyLoss / closure / camera / priors / optimiser at 0.0."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('stage,first', [('S3', False), ('S2', True)])
+def test_prox_engine_iteration_vs_oracle(emu_lib, stage, first):
+    import __graft_entry__ as ge
+    from lemo_amd.prox import ENGINE_PARAMS, LOSS_KEYS
+    prob = ge.prox_small_problem(stage=stage)
+    of = ge.prox_oracle_for(prob, first_batch_flag=first)
+    old = of.closure()
+    eng, bm = ge.prox_engine_for(prob, torch.device('cpu'), first_batch_flag=first, lib=emu_lib)
+    ld = eng.closure()
+    for k in LOSS_KEYS:
+        a, b = ld[k], float(old[k])
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-12, (k, a, b)
+    assert ld['sdf_penetration_loss'] > 0 and ld['loss_fric_tangent'] > 0 and ld['loss_fric_normal'] > 0
+    assert (ld['motion_infill_loss'] > 0 and ld['motion_infill_contact_loss'] > 0) == (stage == 'S3')
+    g = eng.grads()
+    n_erase = int(prob['B'] * 0.15)
+    for n, _ in ENGINE_PARAMS:
+        ref = of.pose_embedding.grad if n == 'pose_embedding' else of.p[n].grad
+        assert rel_err(g[n], ref) < 2e-4, n
+        assert (float(g[n][:n_erase].abs().max()) > 0) == (first and float(ref[:n_erase].abs().max()) > 0), n
+    # three optimiser steps: parameters and the loss trajectory
+    of.opt.step()
+    eng.step(1, use_graph=False)
+    for n, _ in ENGINE_PARAMS:
+        ref = of.pose_embedding if n == 'pose_embedding' else of.p[n]
+        assert float((eng.P[n] - ref.detach()).abs().max()) < 2e-6, n
+    for _ in range(2):
+        o = of.step()
+    eng.step(2, use_graph=False)
+    ld = eng.loss_dict()
+    assert abs(ld['total_loss'] - o['total_loss']) <= 1e-4 * abs(o['total_loss'])
+    for n, _ in ENGINE_PARAMS:
+        ref = of.pose_embedding if n == 'pose_embedding' else of.p[n]
+        assert float((eng.P[n] - ref.detach()).abs().max()) < 1e-4, n
+    assert int(eng.step_ctr.item()) == 3 and eng.nonfinite_step() == 0
+    # the frozen frames of a later window never move
+    if not first:
+        p0 = torch.from_numpy(np.asarray(prob['params']['pose_embedding'], np.float32))
+        assert torch.equal(eng.P['pose_embedding'][:n_erase], p0[:n_erase])
+    eng.write_back(bm)
+    assert torch.equal(bm.transl.detach(), eng.P['transl'])
+
+
+@pytest.mark.timeout(1200)
+def test_prox_engine_nonfinite_latch_and_validation(emu_lib):
+    import __graft_entry__ as ge
+    from lemo_amd import _hip
+    prob = ge.prox_small_problem(stage='S2')
+    eng, _ = ge.prox_engine_for(prob, torch.device('cpu'), first_batch_flag=True, lib=emu_lib)
+    eng._t['gt'][0, 0, 0] = float('nan')
+    eng.step(1, use_graph=False)
+    assert eng.nonfinite_step() == 1
+    p = eng.P['transl'].clone()
+    eng.step(2, use_graph=False)
+    assert torch.equal(torch.nan_to_num(eng.P['transl'], nan=5.0), torch.nan_to_num(p, nan=5.0)) and int(eng.step_ctr.item()) == 3
+    bad = dict(prob, fric_ids=np.concatenate([prob['fric_ids'], prob['fric_ids'][:1]]))
+    with pytest.raises(AssertionError):
+        ge.prox_engine_for(bad, torch.device('cpu'), lib=emu_lib)
