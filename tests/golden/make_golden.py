@@ -329,6 +329,33 @@ def pin_amass_loop_and_clip(report):
                         rec_mixed=rnd.numpy(), contact_lbl_mixed=lbl_r2.numpy(), markers_mixed=mk_r2.numpy())
 
 
+def pin_dropin(report):
+    """The drop-in claim: the reference's loop-body TEXT (opt_amass_temp.py:355-453 + backward + Adam step) is
+    exec'd against the PRODUCT modules -- lemo_amd.compat smplx.create, lemo_amd.vposer.VPoser, lemo_amd.priors.Enc,
+    lemo_amd.rotation.convert_to_3D_rot, running the unmodified kernel sources on the host emulator -- and against the
+    oracle-backed objects; both runs start from the same seeded small problem.  Rows ``dropin.*`` = max rel error of the
+    product run vs the reference run; the reference run's outputs are committed as dropin_amass_small.npz."""
+    import __graft_entry__ as ge
+    import ref_harness as RH
+    from lemo_amd import _hip
+    import subprocess
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'lemo_amd', 'csrc'), '-j8', 'emu'], check=True, capture_output=True)
+    emu = _hip.HipLib(_hip.EMU_LIB_PATH, is_emu=True)
+    prob = ge.small_problem()
+    ofit, markers = ge.oracle_for(prob, faithful=True)
+    ref = RH.run_amass_loop_body(ofit.smplx, ofit.vposer_w, prob['ids'], prob['Xmean'].reshape(1, 1, -1), prob['Xstd'],
+                                 prob['seq']['init_params'], markers, prob['seq']['contact_lbl'], steps=2)
+    got = RH.run_amass_loop_body_on_product(prob, markers, emu, steps=2)
+    for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total'):
+        report['dropin.' + k] = abs(got[k] - ref[k]) / max(abs(ref[k]), 1e-30)
+    for k in ('g_transl', 'g_rot6d', 'g_other'):
+        report['dropin.' + k] = float(np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max())
+    report['dropin.p75_after3'] = float(np.abs(got['p75_hist'][2] - ref['p75_hist'][2]).max())
+    np.savez(os.path.join(HERE, 'dropin_amass_small.npz'), markers_rec=markers,
+             **{k: np.asarray(ref[k]) for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total', 'g_transl', 'g_rot6d', 'g_other')},
+             p75_after1=ref['p75_hist'][0], p75_after3=ref['p75_hist'][2])
+
+
 def pin_perframe(report):
     """BASELINE configs[0]: exec the reference's per-frame loop text (opt_amass_perframe.py:291-364) -- 3 frames, the
     full 100 steps each (so both lr switches fire) -- against oracle/pipeline_oracle.perframe_fit."""
@@ -436,5 +463,14 @@ if __name__ == '__main__':
             f.write(f'{k}\t{v}\n')
             bad = bad or not (v <= 2e-6)
     assert not bad, 'oracle disagrees with the reference'
+    drop = {}
+    pin_dropin(drop)
+    print('reference loop text on the PRODUCT modules (emulator library) vs on the oracle-backed objects:')
+    with open(os.path.join(HERE, 'dropin_vs_reference.txt'), 'w') as f:
+        for k, v in drop.items():
+            print(f'  {k:44s} {v}')
+            f.write(f'{k}\t{v}\n')
+    assert max(v for k, v in drop.items() if not k.startswith('dropin.g_') and k != 'dropin.p75_after3') <= 1e-5, 'loss scalars'
+    assert max(v for k, v in drop.items() if k.startswith('dropin.g_')) <= 2e-4 and drop['dropin.p75_after3'] <= 1e-5
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -200,7 +200,7 @@ def run_amass_loop_body(so: O.SmplxOracle, vposer_w, ids, Xmean, Xstd, init_para
                                  weight_loss_smooth=w['smooth'], weight_loss_vposer=w['vposer'],
                                  weight_loss_shape=w['shape'], weight_loss_hand=w['hand'])
     device = torch.device('cpu')
-    ip = np.asarray(init_params, np.float32)
+    ip = np.array(init_params, np.float32)              # a copy: torch.from_numpy shares memory and Adam updates in place
     ns = dict(torch=torch, F=F, np=np, args=args, device=device,
               convert_to_3D_rot=U.convert_to_3D_rot, gen_body_mesh_v1=U.gen_body_mesh_v1,
               gen_body_joints_v1=U.gen_body_joints_v1,
@@ -421,3 +421,72 @@ def run_perframe_text(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec, b
                   smplx_model=RefSmplx(so, 1), vposer_model=ref_vposer(vposer_w), marker_ids=[int(v) for v in markers67_ids])
         exec(compile(text, f'{path}:291-364', 'exec'), ns)
     return ns['body_params_opt_cur_clip']
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Drop-in proof: the reference's loop-body TEXT against the PRODUCT modules (host-emulated kernel library)
+# ------------------------------------------------------------------------------------------------------------------
+def run_amass_loop_body_on_product(prob, markers_rec, emu_lib, steps=0):
+    """exec opt_amass_temp.py:355-453 in a namespace whose smplx model, VPoser, smoothness encoder and
+    ``convert_to_3D_rot`` are the lemo_amd drop-ins (``lemo_amd.compat`` smplx.create, ``lemo_amd.vposer.VPoser``,
+    ``lemo_amd.priors.Enc``, ``lemo_amd.rotation``) running the UNMODIFIED kernel sources compiled for the host
+    (liblemo_emu.so); ``gen_body_mesh_v1`` / ``gen_body_joints_v1`` stay the reference's own functions.  Backward is
+    torch autograd through the HIP autograd Functions, the update ``optimizer.step()`` as at :454-455."""
+    import functools
+    import torch.nn.functional as F
+    from lemo_amd import rotation
+    from lemo_amd.compat import smplx as compat_smplx
+    from lemo_amd.priors import Enc
+    from lemo_amd.vposer import VPoser
+    U = ref_utils()
+    B = prob['B']
+    w = dict(O.LOSS_WEIGHTS)
+    args = types.SimpleNamespace(weight_loss_rec_markers=w['rec_markers'], weight_loss_contact_vel=w['contact_vel'],
+                                 weight_loss_smooth=w['smooth'], weight_loss_vposer=w['vposer'],
+                                 weight_loss_shape=w['shape'], weight_loss_hand=w['hand'])
+    smplx_model = compat_smplx.create(prob['model'], model_type='smplx', gender='male', ext='npz', num_pca_comps=12,
+                                      create_global_orient=True, create_body_pose=True, create_betas=True, create_left_hand_pose=True,
+                                      create_right_hand_pose=True, create_expression=True, create_jaw_pose=True, create_leye_pose=True,
+                                      create_reye_pose=True, create_transl=True, batch_size=B,
+                                      extra_joint_ids=list(range(21)) if prob['V'] < 9930 else None, _lib=emu_lib)
+    vposer_model = VPoser(_lib=emu_lib).eval()
+    vposer_model.load_state_dict({**vposer_model.state_dict(), **{k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}})
+    smooth_encoder = Enc(_lib=emu_lib)
+    smooth_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in prob['enc_w'].items()})
+    smooth_encoder.eval()
+    for p in smooth_encoder.parameters():
+        p.requires_grad = False
+    ids, ip = prob['ids'], np.array(prob['seq']['init_params'], np.float32)     # a copy (Adam updates in place)
+    ns = dict(torch=torch, F=F, np=np, args=args, device=torch.device('cpu'),
+              convert_to_3D_rot=functools.partial(rotation.convert_to_3D_rot, _lib=emu_lib),
+              gen_body_mesh_v1=U.gen_body_mesh_v1, gen_body_joints_v1=U.gen_body_joints_v1,
+              smplx_model=smplx_model, vposer_model=vposer_model, smooth_encoder=smooth_encoder,
+              infill_marker_ids=[int(i) for i in ids['markers67']], smooth_marker_ids=[int(i) for i in ids['markers81']],
+              left_heel_verts_id=np.asarray(ids['left_heel']), right_heel_verts_id=np.asarray(ids['right_heel']),
+              left_toe_verts_id=np.asarray(ids['left_toe']), right_toe_verts_id=np.asarray(ids['right_toe']),
+              Xmean_global_markers=torch.from_numpy(np.asarray(prob['Xmean']).reshape(1, 1, -1)).float(),
+              Xstd_global_markers=torch.from_numpy(np.asarray(prob['Xstd'])).float(),
+              markers_rec_t=torch.from_numpy(np.asarray(markers_rec, np.float32)),
+              contact_lbl_rec=torch.from_numpy(np.asarray(prob['seq']['contact_lbl'], np.float32)))
+    ns['transl_opt_t'] = torch.from_numpy(ip[:, 0:3]).float()
+    ns['rot_6d_opt_t'] = rotation.convert_to_6D_all(torch.from_numpy(ip[:, 3:6]).float()).detach().clone()
+    ns['shape_t'] = torch.from_numpy(ip[:, 6:16]).float()
+    ns['other_params_opt_t'] = torch.from_numpy(ip[:, 16:]).float()
+    for k in ('transl_opt_t', 'rot_6d_opt_t', 'other_params_opt_t'):
+        ns[k].requires_grad = True
+    final = [ns['transl_opt_t'], ns['rot_6d_opt_t'], ns['other_params_opt_t']]
+    opt = torch.optim.Adam(final, lr=0.01)
+    out = {}
+    for step in range(steps + 1):
+        opt.zero_grad()
+        exec_reference_lines(f'{REF}/opt_amass_temp.py', 355, 453, ns)
+        ns['loss'].backward(retain_graph=True)
+        if step == 0:
+            out.update(total=float(ns['loss']), marker=float(ns['loss_marker']), vposer=float(ns['loss_vposer']),
+                       shape=float(ns['loss_shape']), hand=float(ns['loss_hand']), contact=float(ns['loss_contact_vel']),
+                       smooth=float(ns['loss_smooth']), g_transl=final[0].grad.numpy().copy(),
+                       g_rot6d=final[1].grad.numpy().copy(), g_other=final[2].grad.numpy().copy())
+        if steps:
+            opt.step()
+            out.setdefault('p75_hist', []).append(torch.cat([final[0], final[1], ns['shape_t'], final[2]], -1).detach().numpy().copy())
+    return out

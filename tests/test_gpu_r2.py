@@ -47,10 +47,15 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     d = np.abs(got - ref)
     print(f'\nper-frame fit, 3 frames x 100 steps: params vs oracle max {d.max():.2e} mean {d.mean():.2e}; final loss gpu {L["total"]:.6f} oracle {last[-1]:.6f}')
     assert L['contact'] == 0.0 and L['smooth'] == 0.0
-    # 300 Adam steps with two optimiser restarts (lr 0.1, sign() gradients of the L1 term): trajectories, not iterates --
-    # the tight checks are the two-step run below and the B = 1 gradient check of the emulator suite
+    # 300 Adam steps with two optimiser restarts (lr 0.1, sign() gradients of the L1 term) are chaotic in the parameters
+    # (measured: mean |diff| 0.12 while the final losses agree to 3 %): the full run is compared through its loss, the
+    # iterates through the 10-step and 2-step runs below and the B = 1 gradient check of the emulator suite
     assert abs(L['total'] - last[-1]) < 0.1 * last[-1]
-    assert d.mean() < 1e-2
+    ref10, last10 = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr, betas, steps=10)
+    got10 = pf.fit_clip(mr, betas, steps=10).cpu().numpy()
+    d10 = np.abs(got10 - ref10)
+    print(f'3 frames x 10 steps: params vs oracle max {d10.max():.2e} mean {d10.mean():.2e}')
+    assert d10.mean() < 2e-3 and abs(pf.rest.losses()['total'] - last10[-1]) < 2e-2 * last10[-1]
     assert pf.rest.nonfinite_step() == 0
     # one update per frame is tight
     ref2, _ = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr[:2], betas, steps=2)
