@@ -192,6 +192,8 @@ int lemo_joints_assemble(const float* Jtr, int nj, const float* verts, int vrows
  * utils/utils.py:184-203 reconstruct_global_body: in [T][J+2][3] = (ignored reference slot, J local joints, trajectory
  * (dx, dz, dr)); rot_0_pivot from the encode below; out [T][J][3] global positions. */
 int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_pivot, float* out, void* stream);
+/* same, rot_0_pivot read from device memory ([1] double, as lemo_local_markers_4chan leaves it): no host round trip */
+int lemo_reconstruct_global_body_dev(const float* in, int T, int J, const double* rot_0_pivot, float* out, void* stream);
 /* opt_amass_temp.py:273-325 (twin fitting_temp_slide.py:895-940): decode of the infilling network's output in one launch.
  * rec [d][T] = channel 0 of the un-padded output (d = 3 J + 4: J = pelvis + markers rows, then 4 contact logits);
  * traj [3][T] = row 0 of channels 1..3 of the input image (normalised dx, dz, dr); stats [2 d + 4] doubles =

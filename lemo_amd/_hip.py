@@ -163,6 +163,7 @@ _SIGS = {
     'lemo_graph_launch': (C.c_int, [vp, vp]),
     'lemo_graph_destroy': (C.c_int, [vp]),
     'lemo_reconstruct_global_body': (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp]),
+    'lemo_reconstruct_global_body_dev': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_local_markers_4chan': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_decode_clip': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_conv3x3_split_chain_supported': (C.c_int, [C.c_int, C.c_int]),

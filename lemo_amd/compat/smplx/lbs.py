@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ...body_model import SMPLX
 
-_CACHE: Dict[Tuple, SMPLX] = {}
+_CACHE: Dict[Tuple, Tuple] = {}
 _NJ = 55
 
 
@@ -29,9 +29,11 @@ def transform_mat(R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
 def _model_for(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights, lib) -> SMPLX:
     tensors = (v_template, shapedirs, posedirs, J_regressor, parents, lbs_weights)
     key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors) + (id(lib),)
-    m = _CACHE.get(key)
-    if m is not None:
-        return m
+    hit = _CACHE.get(key)
+    # the entry keeps the caller's tensors alive (so their addresses cannot be recycled for another model) and a hit
+    # must be the very same tensor objects
+    if hit is not None and all(a is b for a, b in zip(hit[1], tensors)):
+        return hit[0]
     v_template = v_template.reshape(-1, 3) if v_template.dim() == 3 else v_template       # smplx passes [1,V,3] too
     V = int(v_template.shape[0])
     nb = int(shapedirs.shape[-1])
@@ -62,7 +64,7 @@ def _model_for(v_template, shapedirs, posedirs, J_regressor, parents, lbs_weight
         p.requires_grad_(False)
     if len(_CACHE) > 8:
         _CACHE.clear()
-    _CACHE[key] = m
+    _CACHE[key] = (m, tensors)
     return m
 
 

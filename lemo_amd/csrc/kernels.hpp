@@ -121,7 +121,7 @@ int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float*
               int lr_switch2 = 0, float* snap = nullptr, int* nonfinite = nullptr, const float* losses = nullptr);
 
 // ---------------- marker_kernels.hip ----------------
-int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s);
+int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s, const double* rot0_dev = nullptr);
 int local_markers_4chan(const float* body, const float* contact, int T, int M1, float* image, double* rot0, hipStream_t s);
 int decode_clip(const float* rec, const float* traj, const double* stats, const double* rot0, const float* post, int T, int J,
                 float* lbl, float* markers, hipStream_t s);

@@ -193,6 +193,10 @@ int lemo_reconstruct_global_body(const float* in, int T, int J, double rot_0_piv
   if (!in || !out) return LEMO_ERR_ARG;
   return reconstruct_global_body(in, T, J, rot_0_pivot, out, S(stream));
 }
+int lemo_reconstruct_global_body_dev(const float* in, int T, int J, const double* rot_0_pivot, float* out, void* stream) {
+  if (!in || !out || !rot_0_pivot) return LEMO_ERR_ARG;
+  return reconstruct_global_body(in, T, J, 0.0, out, S(stream), rot_0_pivot);
+}
 int lemo_decode_clip(const float* rec, const float* traj, const double* stats, const double* rot_0_pivot, const float* post, int T,
                      int J, float* contact_lbl, float* markers, void* stream) {
   if (!rec || !traj || !stats || !rot_0_pivot || !contact_lbl || !markers) return LEMO_ERR_ARG;

@@ -31,9 +31,11 @@ __device__ __forceinline__ void rot_y(double a, double x, double z, double& xo, 
 }
 
 __global__ void __launch_bounds__(MK_T)
-reconstruct_global_body_kernel(const float* __restrict__ in, int T, int J, double rot0, float* __restrict__ out) {
+reconstruct_global_body_kernel(const float* __restrict__ in, int T, int J, double rot0_host, const double* __restrict__ rot0_dev,
+                               float* __restrict__ out) {
   __shared__ double ang[MK_T], tx[MK_T], tz[MK_T];
   const int t = threadIdx.x, E = J + 2;
+  const double rot0 = rot0_dev ? rot0_dev[0] : rot0_host;     // the pivot may live on the device (no host round trip)
   // frame i is rotated by R_y(theta_i), theta_i = -rot0 - sum_{k<i} r_k ; after frame i the heading becomes
   // theta_{i+1} and the translation advances by R_y(theta_{i+1}) (x_i, 0, z_i)          (utils.py:193-200)
   if (t < T) ang[t] = -(double)in[((size_t)t * E + J + 1) * 3 + 2];
@@ -213,9 +215,9 @@ int decode_clip(const float* rec, const float* traj, const double* stats, const 
   return (int)hipGetLastError();
 }
 
-int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s) {
+int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s, const double* rot0_dev) {
   if (T < 1 || T > MK_T || J < 1) return LEMO_ERR_SHAPE;
-  hipLaunchKernelGGL(reconstruct_global_body_kernel, dim3(1), dim3(MK_T), 0, s, in, T, J, rot0, out);
+  hipLaunchKernelGGL(reconstruct_global_body_kernel, dim3(1), dim3(MK_T), 0, s, in, T, J, rot0, rot0_dev, out);
   return (int)hipGetLastError();
 }
 

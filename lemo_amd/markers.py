@@ -40,10 +40,13 @@ def reconstruct_global_body(body_joints_input, rot_0_pivot, device=None, _lib=No
     _hip.check_device(lib, x)
     assert x.dim() == 3 and x.shape[2] == 3 and x.shape[1] >= 3, 'expects [T, 1+J+1, 3]'
     T, J = x.shape[0], x.shape[1] - 2
-    rot0 = float(np.asarray(rot_0_pivot.detach().cpu() if isinstance(rot_0_pivot, torch.Tensor) else rot_0_pivot,
-                            np.float64).reshape(-1)[0])
     out = torch.empty(T, J, 3, dtype=torch.float32, device=dev)
-    lib.check(lib.reconstruct_global_body(ptr(x), T, J, rot0, ptr(out), lib.stream(dev)), 'reconstruct_global_body')
+    if isinstance(rot_0_pivot, torch.Tensor):          # a device tensor (e.g. from get_local_markers_4chan) is read in place
+        piv = rot_0_pivot.detach().to(dev, torch.float64).reshape(-1)[:1].contiguous()
+        lib.check(lib.reconstruct_global_body_dev(ptr(x), T, J, ptr(piv), ptr(out), lib.stream(dev)), 'reconstruct_global_body')
+    else:
+        rot0 = float(np.asarray(rot_0_pivot, np.float64).reshape(-1)[0])
+        lib.check(lib.reconstruct_global_body(ptr(x), T, J, rot0, ptr(out), lib.stream(dev)), 'reconstruct_global_body')
     return out.cpu().numpy().astype(np.float64) if as_numpy else out
 
 

@@ -231,6 +231,7 @@ class ProxTemporalFitter:
         lib = _hip.get_lib() if self.pose_embedding.is_cuda else None
         if use_graph is None:
             use_graph = lib is not None and n > 4
+        use_graph = bool(use_graph) and n > 3              # the captured path runs 3 eager iterations first
 
         def one():
             ld = self.closure()

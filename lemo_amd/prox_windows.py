@@ -27,9 +27,11 @@ def slide_stride(batch_size: int) -> int:
 
 
 def sliding_windows(n_frames: int, batch_size: int) -> List[Tuple[int, int]]:
-    """[start, end) frame ranges of the windows of one recording, in processing order.  The last window may be
-    shorter than ``batch_size`` (the reference then feeds a short batch); recordings shorter than one window plus
-    one stride yield the first window only... exactly as ``range(int(seq_n) + 1)`` does for negative ``seq_n``."""
+    """[start, end) frame ranges of the windows of one recording, in processing order: the slices the reference's loop
+    appends to ``img_paths_slide`` (data_parser_slide.py:199-212; checked against a literal restatement).  The last
+    window(s) may be shorter than ``batch_size``.  NOTE the reference does not fit these windows one by one: it cuts
+    their concatenation into DataLoader batches -- see :func:`reference_batches` for the batches it really forms
+    (identical to these windows as long as every window is full)."""
     if n_frames < 1 or batch_size < 2:
         raise ValueError('need n_frames >= 1 and batch_size >= 2')
     stride = slide_stride(batch_size)
@@ -46,6 +48,21 @@ def sliding_windows(n_frames: int, batch_size: int) -> List[Tuple[int, int]]:
 def slide_frame_index(n_frames: int, batch_size: int) -> np.ndarray:
     """the concatenated frame list (``img_paths_slide``) as frame numbers"""
     return np.concatenate([np.arange(s, e) for s, e in sliding_windows(n_frames, batch_size)])
+
+
+def reference_batches(n_frames: int, batch_size: int, drop_last: bool = True) -> List[np.ndarray]:
+    """The batches ``main_slide.py`` actually fits: the reference does NOT iterate over the windows -- it concatenates
+    their frame lists (data_parser_slide.py:199-212) and lets a ``DataLoader(batch_size, shuffle=False,
+    drop_last=True)`` (main_slide.py:146-149) cut that list into consecutive chunks.  Full windows are exactly one
+    chunk each; the short tail windows are glued together, so a tail chunk can straddle two windows (e.g. n = 300,
+    batch 100: windows (210,300) + (280,300) give the chunk 210..299 + 280..289), and an incomplete last chunk is
+    dropped.  ``sliding_windows`` is the schedule as designed; this function is the schedule as executed."""
+    idx = slide_frame_index(n_frames, batch_size)
+    n_full = len(idx) // batch_size
+    out = [idx[i * batch_size:(i + 1) * batch_size] for i in range(n_full)]
+    if not drop_last and len(idx) % batch_size:
+        out.append(idx[n_full * batch_size:])
+    return out
 
 
 def frozen_prefix(batch_size: int, first_window: bool) -> int:
@@ -88,15 +105,22 @@ def init_params_for_window(frame_names: Sequence[str], current_dir: str, prox_di
     return {k: np.stack([r[k] for r in rows]) for k in BODY_PARAM_KEYS}
 
 
-def run_recording(frame_names: Sequence[str], batch_size: int, current_dir: str, prox_dir: str, fit_window) -> int:
+def run_recording(frame_names: Sequence[str], batch_size: int, current_dir: str, prox_dir: str, fit_window,
+                  reference_chunking: bool = False) -> int:
     """drive ``fit_window(frame_names, init_params, first_window, n_frozen) -> (camera_params, body_params,
-    pose_embedding, body_pose)`` over the windows of one recording and write every frame's result (later windows
-    overwrite the overlap, like the reference).  Returns the number of windows."""
-    wins = sliding_windows(len(frame_names), batch_size)
-    for w, (s, e) in enumerate(wins):
-        names = list(frame_names[s:e])
+    pose_embedding, body_pose)`` over one recording and write every frame's result (later windows overwrite the
+    overlap, like the reference).  Default: one call per window of :func:`sliding_windows`, short tail windows included
+    (every frame gets a result).  ``reference_chunking=True`` reproduces the batches the reference's DataLoader forms
+    (:func:`reference_batches`: tail windows glued, incomplete last batch dropped) -- identical whenever every window is
+    full.  Returns the number of calls."""
+    if reference_chunking:
+        batches = [list(b) for b in reference_batches(len(frame_names), batch_size)]
+    else:
+        batches = [list(range(s, e)) for s, e in sliding_windows(len(frame_names), batch_size)]
+    for w, ids in enumerate(batches):
+        names = [frame_names[i] for i in ids]
         init = init_params_for_window(names, current_dir, prox_dir)
         cam, body, emb, bp = fit_window(names, init, w == 0, frozen_prefix(batch_size, w == 0))
         for i, fn in enumerate(names):
             write_result_pkl(result_path(current_dir, fn), cam, body, emb, bp, i)
-    return len(wins)
+    return len(batches)

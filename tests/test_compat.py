@@ -84,3 +84,44 @@ def test_install_registers_reference_import_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_load_vposer_reads_snapshot_and_ini(tmp_path):
+    """human_body_prior/tools/model_loader.py:25-72: newest snapshots/*.pt + the experiment's *.ini settings"""
+    import os
+    import time
+    from lemo_amd.vposer import VPoser, load_vposer, make_vposer_weights
+    d = tmp_path / 'vposer_v1_0'
+    (d / 'snapshots').mkdir(parents=True)
+    src = VPoser()
+    src.load_state_dict({**src.state_dict(), **{k: torch.from_numpy(v) for k, v in make_vposer_weights(4).items()}})
+    torch.save({k: torch.zeros_like(v) for k, v in src.state_dict().items()}, d / 'snapshots' / 'TR00_E001.pt')
+    time.sleep(0.02)
+    torch.save(src.state_dict(), d / 'snapshots' / 'TR00_E096.pt')
+    os.utime(d / 'snapshots' / 'TR00_E001.pt', (1, 1))
+    (d / 'TR00_vposer_defaults.ini').write_text('[All]\nnum_neurons = 512\nlatentD = 32\ndata_shape = [1, 21, 3]\nkl_coef = 5e-3\n')
+    vp, ps = load_vposer(str(d), vp_model='snapshot')
+    assert isinstance(vp, VPoser) and not vp.training
+    assert ps.num_neurons == 512 and ps.latentD == 32 and list(ps.data_shape) == [1, 21, 3] and ps.best_model_fname.endswith('TR00_E096.pt')
+    assert torch.equal(vp.state_dict()['bodyprior_dec_fc2.weight'], src.state_dict()['bodyprior_dec_fc2.weight'])
+    (d / 'TR00_vposer_defaults.ini').write_text('[All]\nnum_neurons = 256\nlatentD = 32\ndata_shape = [1, 21, 3]\n')
+    with pytest.raises(NotImplementedError):
+        load_vposer(str(d))
+    with pytest.raises(ValueError):
+        load_vposer(str(tmp_path / 'missing'))
+
+
+def test_lbs_cache_is_keyed_on_tensor_identity(emu_lib):
+    """a cached model must not be served for different tensors that happen to share address / version / shape"""
+    from lemo_amd.compat.smplx import lbs as L
+    L._CACHE.clear()
+    m = synthetic.make_synthetic_smplx(seed=3, V=640, F=1200)
+    so = O.SmplxOracle(m)
+    sd = torch.cat([so.shapedirs, so.expr_dirs], -1)
+    args = (so.v_template, sd, so.posedirs, so.J_regressor, so.parents, so.lbs_weights)
+    a = L._model_for(*args, emu_lib)
+    assert L._model_for(*args, emu_lib) is a
+    key = next(iter(L._CACHE))
+    other = tuple(t.clone() for t in args)
+    L._CACHE[key] = (a, other)                         # same key, different tensor objects: must rebuild
+    assert L._model_for(*args, emu_lib) is not a

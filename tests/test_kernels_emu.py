@@ -370,3 +370,39 @@ def test_conv3x3_splitk_matches_reference(emu_lib, ci, co, ks):
     ref1 = F.conv2d(x[None], w, None, padding=1)[0] * torch.where(aux > 0, 1.0, 0.2)
     assert rel_err(from_cg8p(out, H, W), ref1) < 2e-6
     assert emu_lib.conv3x3_mfma_splitk(ptr(xin), ptr(wt), ptr(b), None, ptr(out), ptr(part), 9 * (ci // 8) + 1, H, W, ci, co, 0, None) != 0
+
+
+@pytest.mark.timeout(600)
+def test_real_file_shaped_model_400_shapedirs_and_kw_above_8(emu_lib):
+    """a model shaped like the licensed SMPLX_*.npz -- shapedirs [V,3,400] (300 shape + 100 expression directions: the
+    expression block is read at [300:310]) and skinning rows with more than 8 non-zeros (the ELL tail loop of the vertex
+    kernel, KW > 8) -- forward and every input gradient against the oracle"""
+    from lemo_amd.body_model import create
+    from oracle import lemo_oracle as O
+    m = synthetic.make_synthetic_smplx(seed=9, V=640, F=1200, n_shape=400, nnz_w=11)
+    assert m['shapedirs'].shape == (640, 3, 400) and int((m['weights'] != 0).sum(1).max()) > 8
+    B = 3
+    g = torch.Generator().manual_seed(6)
+    mk = lambda *s, sc=0.3: (torch.randn(*s, generator=g) * sc)
+    vals = dict(betas=mk(B, 10, sc=0.5), expression=mk(B, 10, sc=0.5), global_orient=mk(B, 3), body_pose=mk(B, 63),
+                lh=mk(B, 12, sc=0.1), rh=mk(B, 12, sc=0.1), transl=mk(B, 3), jaw=mk(B, 3, sc=0.1))
+    wv, wj = torch.randn(B, 640, 3, generator=g), torch.randn(B, 127, 3, generator=g)
+    model = create(m, batch_size=B, num_pca_comps=12, extra_joint_ids=list(range(21)), _lib=emu_lib)
+    assert model._device_body(torch.device('cpu')).data.KW > 8
+    p = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    out = model(betas=p['betas'], expression=p['expression'], global_orient=p['global_orient'], body_pose=p['body_pose'],
+                left_hand_pose=p['lh'], right_hand_pose=p['rh'], transl=p['transl'], jaw_pose=p['jaw'])
+    ((out.vertices * wv).sum() + (out.joints * wj).sum()).backward()
+    so = O.SmplxOracle(m, extra_joint_ids=list(range(21)))
+    q = {k: v.clone().requires_grad_(True) for k, v in vals.items()}
+    v_ref, j_ref, _ = so.forward(q['betas'], q['global_orient'], q['body_pose'], q['lh'], q['rh'], q['transl'],
+                                 expression=q['expression'], jaw_pose=q['jaw'])
+    ((v_ref * wv).sum() + (j_ref * wj).sum()).backward()
+    assert rel_err(out.vertices.detach(), v_ref.detach()) < 1e-4 and rel_err(out.joints.detach(), j_ref.detach()) < 1e-4
+    # the expression directions really are columns 300..309: zeroing them changes the vertices
+    m0 = dict(m, shapedirs=m['shapedirs'].copy()); m0['shapedirs'][:, :, 300:310] = 0
+    v0, _, _ = O.SmplxOracle(m0, extra_joint_ids=list(range(21))).forward(vals['betas'], vals['global_orient'], vals['body_pose'],
+                                                                         vals['lh'], vals['rh'], vals['transl'], expression=vals['expression'])
+    assert float((v0 - v_ref.detach()).abs().max()) > 1e-3
+    for k in p:
+        assert rel_err(p[k].grad, q[k].grad) < 2e-4, k

@@ -18,6 +18,20 @@ def test_window_schedule_matches_reference_loop(n, b):
     assert all(wins[i + 1][0] - wins[i][0] == int(0.7 * b) for i in range(len(wins) - 1))
 
 
+def test_reference_batches_are_the_dataloader_chunks():
+    """data_parser_slide.py:199-212 + DataLoader(batch_size, drop_last=True) (main_slide.py:146-149): full windows are
+    one batch each, tail windows are glued, the incomplete rest is dropped"""
+    for n, b in [(100, 100), (240, 100), (300, 100), (1000, 100), (37, 10)]:
+        flat = slide_index_oracle(n, b)
+        ref = [flat[i:i + b] for i in range(0, len(flat) - b + 1, b)]
+        got = PW.reference_batches(n, b)
+        assert [g.tolist() for g in got] == ref
+    b300 = PW.reference_batches(300, 100)
+    assert b300[-1].tolist() == list(range(210, 300)) + list(range(280, 290))          # a batch that straddles two tail windows
+    full = [w for w in PW.sliding_windows(1000, 100) if w[1] - w[0] == 100]
+    assert [g.tolist() for g in PW.reference_batches(1000, 100)][:len(full)] == [list(range(s, e)) for s, e in full]
+
+
 def test_frozen_prefix():
     assert PW.frozen_prefix(100, True) == 0 and PW.frozen_prefix(100, False) == 15 and PW.frozen_prefix(10, False) == 1
 
