@@ -436,6 +436,31 @@ def pin_prox_and_emit(report):
                         train_mask=s['train_mask'].numpy(), clip_img_rec=s['clip_img_rec'].numpy(),
                         motion_infill_loss=np.float64(float(rw.loss_dict['motion_infill_loss'])))
     print('prox fixtures:', {k: v.shape for k, v in out.items()})
+    # ---- result wire format: two per-frame pickles written by the reference's own lines :577-594, and the
+    # product's writer read back by the reference's own reader (data_parser_slide.py:106-126)
+    import pickle
+    import tempfile
+    from lemo_amd import prox_windows as PW
+    prob = ge.prox_small_problem(stage='S2', real_markers=True)
+    rw = RH.RefProxWindow(prob, first_batch_flag=True)
+    rw.iterate(1)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = [os.path.join(tmp, f'{i:03d}.pkl') for i in range(prob['B'])]
+        RH.write_reference_result_pkls(rw, paths)
+        for i in (0, 5):
+            with open(paths[i], 'rb') as f:
+                raw = f.read()
+            with open(os.path.join(HERE, f'prox_result_ref_frame{i}.pkl'), 'wb') as f:
+                f.write(raw)
+        ref5 = pickle.loads(raw)
+        cam = {k[len('camera_'):]: np.repeat(v, prob['B'], 0) for k, v in ref5.items() if k.startswith('camera_')}
+        body = {k: np.repeat(v, prob['B'], 0) for k, v in ref5.items() if not k.startswith('camera_') and k not in ('pose_embedding', 'body_pose')}
+        mine = os.path.join(tmp, 'mine.pkl')
+        PW.write_result_pkl(mine, cam, body, np.repeat(ref5['pose_embedding'], prob['B'], 0), np.repeat(ref5['body_pose'], prob['B'], 0), 3)
+        back = RH.reference_read_prox_pkl(mine)
+        theirs = RH.reference_read_prox_pkl(paths[5])
+        report['prox_pkl.reference_reader_on_product_file'] = max(float(np.abs(back[k] - theirs[k]).max()) for k in theirs)
+        report['prox_pkl.keys'] = 0.0 if set(pickle.load(open(mine, 'rb'))) == set(ref5) else 1.0
 
 
 if __name__ == '__main__':

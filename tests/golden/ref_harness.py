@@ -490,3 +490,23 @@ def run_amass_loop_body_on_product(prob, markers_rec, emu_lib, steps=0):
             opt.step()
             out.setdefault('p75_hist', []).append(torch.cat([final[0], final[1], ns['shape_t'], final[2]], -1).detach().numpy().copy())
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# PROX result pickles: the reference's writer (fit_temp_loadprox_slide.py:577-594) and reader (data_parser_slide.py:106-126)
+# ------------------------------------------------------------------------------------------------------------------
+def write_reference_result_pkls(rw: 'RefProxWindow', paths):
+    """exec the reference's own result-writing lines on a fitted RefProxWindow; ``paths``: one file per frame"""
+    import pickle
+    ns = dict(batch_size=len(paths), camera=rw.camera, body_model=rw.body_model, use_vposer=True, pose_embedding=rw.pose_embedding,
+              vposer=rw.vposer, results_list=[], result_fn_list=list(paths), pickle=pickle, torch=torch, np=np)
+    exec_reference_lines(f'{REF}/temp_prox/fit_temp_loadprox_slide.py', 577, 594, ns)
+    return ns['results_list']
+
+
+def reference_read_prox_pkl(path):
+    """the reference's reader, exec'd from its text (the module imports cv2 / open3d at the top)"""
+    import pickle
+    ns = dict(pickle=pickle)
+    exec_reference_lines(f'{REF}/temp_prox/data_parser_slide.py', 106, 126, ns)
+    return ns['read_prox_pkl'](path)

@@ -1,0 +1,108 @@
+"""How tight can GPU-vs-reference parity be?  (-m gpu)  The reference's own CPU path is fp32; here BOTH the GPU engine
+and the fp32 CPU oracle are compared with the same restatement evaluated in float64 (oracle/f64.py), so every tolerance
+is a multiple of what fp32 arithmetic costs the reference itself instead of a guessed constant.  Measured numbers of the
+round: profiles/r02_gates.txt (tools/r02_gates.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from lemo_amd import synthetic
+from lemo_amd.assets import load_assets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _run(dev, prob, markers, weights, steps):
+    from lemo_amd.fitting import AmassTemporalFitter
+    from oracle import lemo_oracle as O
+    from oracle.f64 import amass_fit_oracle_f64, default_f64
+    ej = list(range(21)) if prob['V'] < 9930 else None
+    so = O.SmplxOracle(prob['model'], extra_joint_ids=ej)
+    vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
+    ew = {k: torch.from_numpy(v) for k, v in prob['enc_w'].items()}
+    o32 = O.AmassFitOracle(so, vw, ew, prob['ids'], np.asarray(prob['Xmean']).reshape(1, 1, -1), prob['Xstd'], prob['seq']['init_params'],
+                           markers, prob['seq']['contact_lbl'], faithful=False, weights=weights)
+    o64 = amass_fit_oracle_f64(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                               prob['seq']['init_params'], markers, prob['seq']['contact_lbl'], weights=weights, extra_joint_ids=ej)
+    fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], prob['B'], dev,
+                              weights=weights, full_vertices=True)
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    fit.forward(); fit.backward(); torch.cuda.synchronize()
+    t32, p32, _, _ = o32.losses(); t32.backward()
+    with default_f64():
+        t64, p64, _, _ = o64.losses(); t64.backward()
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+    L = fit.losses()
+    out = dict(loss_gpu={k: rel(L[k], float(p64[k])) for k in p64 if float(p64[k]) != 0.0},
+               loss_cpu={k: rel(float(p32[k]), float(p64[k])) for k in p64 if float(p64[k]) != 0.0}, grad_gpu={}, grad_cpu={}, traj=[])
+    g = fit.grads_with_priors()
+    for k, a32, a64 in (('transl', o32.transl, o64.transl), ('rot6d', o32.rot6d, o64.rot6d), ('other', o32.other, o64.other)):
+        n = a64.grad.abs().max()
+        out['grad_gpu'][k] = float((g[k].cpu().double() - a64.grad).abs().max() / n)
+        out['grad_cpu'][k] = float((a32.grad.double() - a64.grad).abs().max() / n)
+    o32.opt.zero_grad(); o64.opt.zero_grad()
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    s = torch.cuda.Stream(dev)
+    for _ in range(steps):
+        with torch.cuda.stream(s):
+            fit.step(1, use_graph=True)
+        torch.cuda.synchronize()
+        h32 = o32.step()
+        with default_f64():
+            h64 = o64.step()
+        p = o64.params75()
+        dg, dc = (fit.params75().cpu().double() - p).abs(), (o32.params75().double() - p).abs()
+        out['traj'].append(dict(gpu_max=float(dg.max()), gpu_mean=float(dg.mean()), cpu_max=float(dc.max()), cpu_mean=float(dc.mean()),
+                                tot_gpu=rel(fit.losses()['total'], h64['total']), tot_cpu=rel(h32['total'], h64['total'])))
+    return out
+
+
+def _check(r, tag):
+    print(f'\n{tag}: gradient max-rel vs float64  gpu {r["grad_gpu"]}  cpu-f32 {r["grad_cpu"]}')
+    for i, t in enumerate(r['traj']):
+        print(f'   step {i}: params vs f64 gpu max {t["gpu_max"]:.1e} mean {t["gpu_mean"]:.1e} | cpu-f32 max {t["cpu_max"]:.1e} mean {t["cpu_mean"]:.1e}'
+              f' | total rel gpu {t["tot_gpu"]:.1e} cpu {t["tot_cpu"]:.1e}')
+    # every loss scalar of iteration 0: north_star's 1e-5, against float64
+    assert max(r['loss_gpu'].values()) <= 1e-5, r['loss_gpu']
+    # gradients: the GPU may not be further from float64 than 3x the fp32 CPU path is (worst group), + 1e-5 floor
+    worst_cpu = max(r['grad_cpu'].values())
+    for k, v in r['grad_gpu'].items():
+        assert v <= 3.0 * worst_cpu + 1e-5, (k, v, worst_cpu)
+    # trajectory: mean parameter error and the loss of every iteration
+    for i, t in enumerate(r['traj']):
+        assert t['gpu_mean'] <= 3.0 * max(x['cpu_mean'] for x in r['traj'][:i + 1]) + 2e-6, (i, t)
+        assert t['tot_gpu'] <= 1e-4, (i, t)
+
+
+def test_small_problem_vs_float64(dev):
+    import __graft_entry__ as ge
+    from oracle import lemo_oracle as O
+    small = ge.small_problem()
+    _, mk = ge.oracle_for(small)
+    r = _run(dev, small, mk, None, 10)
+    _check(r, 'small problem, all terms')
+    # on the small problem fp32 noise never reaches a contact-threshold flip: the 10-step trajectory stays within 1e-5
+    assert max(t['gpu_max'] for t in r['traj']) < 1e-5 and max(t['tot_gpu'] for t in r['traj']) < 1e-5
+    r = _run(dev, small, mk, dict(O.LOSS_WEIGHTS, contact_vel=0.0), 10)
+    _check(r, 'small problem, contact term off')
+    assert max(t['gpu_max'] for t in r['traj']) < 1e-5 and max(t['tot_gpu'] for t in r['traj']) < 1e-5
+
+
+@pytest.mark.timeout(1200)
+def test_baseline_size_vs_float64(dev):
+    from lemo_amd.vposer import make_vposer_weights
+    torch.set_num_threads(32)
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
+    full = dict(model=synthetic.make_synthetic_smplx(seed=0), vposer_w=make_vposer_weights(2), enc_w=A['enc_w'], ids=A['ids'], Xmean=A['Xmean'],
+                Xstd=A['Xstd'], seq=synthetic.make_synthetic_sequence(0, B=119), B=119, V=10475)
+    _check(_run(dev, full, g['markers_rec'], None, 6), 'B=119 V=10475, all terms')

@@ -55,8 +55,19 @@ def test_rot6d_vposer_golden(dev):
     aa = vp.decode(Z, 'aa')
     assert rel_err(aa.detach().cpu(), g['aa']) < VERT_TOL
     assert rel_err(vp.decode(Z, 'matrot').detach().cpu(), g['matrot']) < VERT_TOL
-    aa.sum().backward()
-    assert torch.isfinite(Z.grad).all()
+    # backward: d(sum w aa)/dZ through the HIP rotation head + MLP vs autograd on the oracle's decode
+    from oracle import lemo_oracle as O
+    wgt = torch.randn(aa.shape, generator=torch.Generator().manual_seed(1))
+    (aa * wgt.to(dev)).sum().backward()
+    Zo = torch.from_numpy(g['Z']).clone().requires_grad_(True)
+    (O.vposer_decode(O.make_vposer_weights(2), Zo, 'aa') * wgt).sum().backward()
+    assert rel_err(Z.grad.cpu(), Zo.grad) < 1e-4
+    Z2 = torch.from_numpy(g['Z']).to(dev).requires_grad_(True)
+    wm = torch.randn(g['matrot'].shape, generator=torch.Generator().manual_seed(2))
+    (vp.decode(Z2, 'matrot') * wm.to(dev)).sum().backward()
+    Zo2 = torch.from_numpy(g['Z']).clone().requires_grad_(True)
+    (O.vposer_decode(O.make_vposer_weights(2), Zo2, 'matrot') * wm).sum().backward()
+    assert rel_err(Z2.grad.cpu(), Zo2.grad) < 1e-4
 
 
 def test_smplx_module_golden(dev):
@@ -272,9 +283,10 @@ def test_fit_full_size_golden(full_problem, dev, conv_variant):
     assert abs(float(v.double().sum()) - float(g['verts_sum'])) < 1e-6 * float(v.double().abs().sum())
     assert rel_err(fit.params72().cpu(), g['p72_0']) < 1e-5
     gr = fit.grads_with_priors()
-    assert rel_err(gr['transl'].cpu(), g['g_transl']) < 1e-3
-    assert rel_err(gr['rot6d'].cpu(), g['g_rot6d']) < 1e-3
-    assert rel_err(gr['other'].cpu(), g['g_other']) < 1e-3
+    # vs the fp32 CPU oracle; both sit ~1e-4 from float64 at this size (tests/test_gpu_gates.py measures that directly)
+    assert rel_err(gr['transl'].cpu(), g['g_transl']) < 5e-4
+    assert rel_err(gr['rot6d'].cpu(), g['g_rot6d']) < 5e-4
+    assert rel_err(gr['other'].cpu(), g['g_other']) < 5e-4
     s = torch.cuda.Stream(dev)
     with torch.cuda.stream(s):
         fit.step(1, use_graph=True)
@@ -398,7 +410,7 @@ def test_mpjpe_after_full_fit(full_problem, dev):
     Lg = fit.losses()['total']
     print(f'MPJPE gpu-vs-oracle after {steps} steps: {mpjpe:.4f} mm ; total loss {first["total"]:.4f} -> oracle {last["total"]:.4f} / gpu {Lg:.4f}')
     assert Lg < 0.7 * first['total']                    # the fit actually descends
-    assert mpjpe < 5.0, mpjpe
+    assert mpjpe < 2.0, mpjpe
 
 
 @pytest.mark.parametrize('stage,first', [('S3', False), ('S2', True)])
