@@ -171,6 +171,10 @@ typedef struct lemo_vertex_set_bwd {
   const int* jcsr_chunk;          /* [(n_chunk + 1) * (nj + 1)] or NULL */
   float* part;
   int part_frames;
+  /* optional: K-slab partial tiles of the feature-gradient GEMM dX = Dk . d(v_posed) (K = NCs): gemm_slabs x 128 x 512
+   * floats; when NULL the one-workgroup-per-output-tile GEMM is used (fine for the compact sets, 107 us for all vertices) */
+  int gemm_slabs;
+  float* gemm_part;
 } lemo_vertex_set_bwd;
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);

@@ -30,6 +30,7 @@ EXTRA_JOINT_VERTEX_IDS = [9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8463, 8474
                           5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022]
 K_PAD = 512          # blend-shape GEMM depth: 20 shape/expression + 486 pose features, padded
 DENSE_CHUNK = 512    # LBS_DENSE_CHUNK of lbs_kernels.hip
+GEMM_SLABS = 32      # K slabs of the all-vertex feature-gradient GEMM (gemm_nt16_splitk)
 
 
 def _roundup(x, m):
@@ -191,6 +192,9 @@ class DeviceBody:
             nchunk = tt['jcsr_chunk'].shape[0] - 1
             tt['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
             st.part, st.part_frames = ptr(tt['part']), frames
+            if st.gemm_slabs == 0:                 # K-slab partials of the feature-gradient GEMM (long K): 32 x 128 x 512 floats
+                tt['gemm_part'] = torch.zeros(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)
+                st.gemm_part, st.gemm_slabs = ptr(tt['gemm_part']), GEMM_SLABS
         return self._sets[key]
 
 

@@ -87,6 +87,92 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
   return (int)hipGetLastError();
 }
 
+// ---- long-K form: C[n][m] = sum_k A[m][k] B[n][k] with K in the tens of thousands and only M x N <= 512 x 128 outputs (the
+// feature gradient of the all-vertex LBS backward: A = Dk [512][3V], B = d(v_posed) [frames][3V]).  gemm_nt16 gives every
+// 16 x 16 output tile its own workgroup: 224 workgroups that each walk the whole K and re-read A once per frame tile
+// (7 x 64 MB) -- 107 us.  Here a workgroup owns 64 rows of A x ALL frames x one K slab (A is streamed exactly once, the
+// B slab is shared by the 8 row blocks through L2), writes its partial tile, and a second launch adds the slabs in slab
+// order (deterministic).
+#define GEMM_SK_NT 8            // frame tiles of 16 (N <= 128)
+#define GEMM_SK_CH 2
+__global__ void __launch_bounds__(256)
+gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
+                        float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int mblocks = M >> 6;
+  const int mb = blockIdx.x % mblocks, slab = blockIdx.x / mblocks;
+  const int mt = mb * 4 + wave;
+  const int k16 = K >> 4, per = (k16 + S - 1) / S;
+  const int c0 = slab * per, c1 = (c0 + per < k16) ? c0 + per : k16;
+  const float* ap = Am + (size_t)(mt * 16 + i) * lda + 4 * q;
+  const float* bp[GEMM_SK_NT];
+#pragma unroll
+  for (int t = 0; t < GEMM_SK_NT; ++t) {
+    const int n = t * 16 + i;
+    bp[t] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * q;
+  }
+  f32x4 acc[GEMM_SK_NT];
+#pragma unroll
+  for (int t = 0; t < GEMM_SK_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int cb = c0; cb < c1; cb += GEMM_SK_CH) {
+    float4 a[GEMM_SK_CH], b[GEMM_SK_CH][GEMM_SK_NT];
+#pragma unroll
+    for (int u = 0; u < GEMM_SK_CH; ++u) {
+      const int c = (cb + u < c1) ? cb + u : c1 - 1;
+      a[u] = ld4(ap + (size_t)c * 16);
+#pragma unroll
+      for (int t = 0; t < GEMM_SK_NT; ++t) b[u][t] = ld4(bp[t] + (size_t)c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < GEMM_SK_CH; ++u) {
+      if (cb + u < c1) {
+#pragma unroll
+        for (int t = 0; t < GEMM_SK_NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][t].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][t].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][t].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][t].w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D: col = n (lane & 15), rows 4 q + r -> m ;  part[slab][n][m]
+  float* pp = part + (size_t)slab * (GEMM_SK_NT * 16) * M;
+#pragma unroll
+  for (int t = 0; t < GEMM_SK_NT; ++t)
+    st4(pp + (size_t)(t * 16 + i) * M + mt * 16 + 4 * q, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
+}
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_kernel(const float* __restrict__ part, int M, int N, int S, float* __restrict__ C, int ldc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;           // float4 index over [N][M / 4]
+  const int m4 = M >> 2;
+  if (i >= N * m4) return;
+  const int n = i / m4, mq = i - n * m4;
+  const size_t stride = (size_t)(GEMM_SK_NT * 16) * M;
+  const float* p = part + (size_t)n * M + mq * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < S; s0 += 8) {                      // 8 loads in flight, added in slab order
+    float4 r[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = ld4(p + (size_t)(s0 + u < S ? s0 + u : S - 1) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (s0 + u < S) { v.x += r[u].x; v.y += r[u].y; v.z += r[u].z; v.w += r[u].w; }
+  }
+  st4(C + (size_t)n * ldc + mq * 4, v);
+}
+
+int gemm_nt16_splitk_part_floats(int M, int S) { return S * GEMM_SK_NT * 16 * M; }
+
+int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
+                     hipStream_t s) {
+  if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || (ldc & 3) || S < 1 || !part)
+    return LEMO_ERR_SHAPE;
+  hipLaunchKernelGGL(gemm_nt16_splitk_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((N * (M >> 2) + 255) / 256), dim3(256), 0, s, part, M, N, S, C, ldc);
+  return (int)hipGetLastError();
+}
+
 // C[n][m] = sum_k A[m][k] * X(n, k) with X in the KG8 layout [K/8][rows][8]
 int gemm_nt16_kg8(const float* A, int lda, const float* Xg, int rows, int M, int N, int K, float* C, int ldc, hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0 || (M & 15) || (K & 15) || (lda & 3) || (ldc & 3) || N > rows) return LEMO_ERR_SHAPE;

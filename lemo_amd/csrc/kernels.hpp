@@ -35,6 +35,10 @@ int smooth_loss(const float* z, float* dpre, float* partial, int H, int W, int C
 int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
               const float* bias, const float* aux, int ldaux, int epi, hipStream_t s);
 
+// long-K, few-outputs form (N <= 128, M % 64 == 0): S K-slabs, partial tiles in `part` (gemm_nt16_splitk_part_floats), fixed-order sum
+int gemm_nt16_splitk_part_floats(int M, int S);
+int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
+                     hipStream_t s);
 int gemm_nt16_kg8(const float* A, int lda, const float* Xg, int rows, int M, int N, int K, float* C, int ldc, hipStream_t s);
 
 // ---------------- pose_kernels.hip ----------------

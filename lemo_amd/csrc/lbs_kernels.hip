@@ -780,6 +780,10 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   const int* tab1 = tab0 + (nj + 1);
   for (int j = wave; j < nj; j += 4) {
     const int q0 = tab0[j], q1 = tab1[j];
+    if (q1 <= q0) {                                              // wave-uniform: most joints own no vertex of a 512-vertex chunk
+      if (lane < 12) part[j * 12 + lane] = 0.f;
+      continue;
+    }
     float acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0.f;
@@ -806,15 +810,21 @@ __global__ void __launch_bounds__(256)
 lbs_bwd_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
   const int b = blockIdx.x, t = threadIdx.x, st = LBS_PART_STRIDE(nj);
   const float* p = u.part + (size_t)b * nchunk * st;
-  for (int i = t; i < nj * 12; i += 256) {
+  // one thread per output, its chunk partials loaded 8 at a time (a dependent load per addend was 21 L2 round trips:
+  // 18 us for a kernel that moves 5 MB) and added in chunk order
+  const int nout = nj * 12 + (dtransl ? 3 : 0);
+  for (int i = t; i < nout; i += 256) {
+    const int col = i < nj * 12 ? i : nj * 12 + (i - nj * 12);
     float a = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) a += p[(size_t)ch * st + i];
-    dA[(size_t)b * nj * 12 + i] = a;
-  }
-  if (dtransl && t < 3) {
-    float a = 0.f;
-    for (int ch = 0; ch < nchunk; ++ch) a += p[(size_t)ch * st + nj * 12 + t];
-    dtransl[(size_t)b * 3 + t] = a;
+    for (int c0 = 0; c0 < nchunk; c0 += 8) {
+      float r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = p[(size_t)(c0 + u < nchunk ? c0 + u : nchunk - 1) * st + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (c0 + u < nchunk) a += r[u];
+    }
+    if (i < nj * 12) dA[(size_t)b * nj * 12 + i] = a;
+    else dtransl[(size_t)b * 3 + (i - nj * 12)] = a;
   }
   for (int i = 3 * u.n + t; i < u.NCs; i += 256) dvp[(size_t)b * u.NCs + i] = 0.f;     // padding columns of the GEMM operand
 }
@@ -850,6 +860,8 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
   int e = (int)hipGetLastError();
   if (e) return e;
   // dX[b][k] = sum_col Dk[k][col] dvp[b][col]  : A = Dk (M = 512 features), B = dvp (N = B frames)
+  if (u.gemm_part && u.gemm_slabs > 0 && B <= 128)
+    return gemm_nt16_splitk(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, u.gemm_part, u.gemm_slabs, s);
   return gemm_nt16(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, nullptr, nullptr, 0, 0, s);
 }
 

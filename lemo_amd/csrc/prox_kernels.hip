@@ -57,6 +57,10 @@ prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, 
   float acc[PA_COUNT];
 #pragma unroll
   for (int i = 0; i < PA_COUNT; ++i) acc[i] = 0.f;
+  // blockIdx.y splits the frame's work over two workgroups: 0 = joints, priors, infill and contact sums; 1 = the
+  // friction sums (~1000 vertices x 2 world transforms + an SDF lookup: half of the kernel's time when one block did both)
+  const bool do_main = blockIdx.y == 0, do_fric = blockIdx.y == gridDim.y - 1;
+  if (do_main) {
   // ---- the 127 smplx joints of this frame: posed skeleton + transl | vertex picks | barycentric landmarks
   for (int w = t; w < nsj * 3; w += 256) {
     const int i = w / 3, c = w % 3;
@@ -137,10 +141,11 @@ prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, 
     else v = h45[side * 45 + k];
     gp[6 + t] = 2.f * wh * wh * v;
   }
+  }   // do_main
   // ---- pairwise terms between frame b and b + 1
   if (b < B - 1) {
     // friction (:699-739): foot / gluteus vertices with sdf < 0.01 at frame b; floor normal n = (0,0,1)
-    for (int q = t; q < pc.n_fric; q += 256) {
+    for (int q = do_fric ? t : pc.n_fric; q < pc.n_fric; q += 256) {
       const int vid = pc.fric_vid[q];
       float w0[3], w1[3];
       to_world(cw, in.verts + ((size_t)b * V + vid) * 3, w0);
@@ -152,7 +157,7 @@ prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, 
         if (vz < 0.f) { acc[PA_FN] += fabsf(vz); acc[PA_FN_N] += 1.f; }
       }
     }
-    if (in.use_infill && b < in.T) {                       // contact velocity of the heel / toe sets (:953-992)
+    if (do_main && in.use_infill && b < in.T) {            // contact velocity of the heel / toe sets (:953-992)
       for (int k = 0; k < 4; ++k) {
         if (in.clbl[(size_t)b * 4 + k] != 1.f) continue;
         for (int q = pc.foot_start[k] + t; q < pc.foot_start[k + 1]; q += 256) {
@@ -167,7 +172,7 @@ prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, 
       }
     }
   }
-  if (in.use_infill && b < in.T) {                         // infill L1 on the occluded markers (:944-951)
+  if (do_main && in.use_infill && b < in.T) {              // infill L1 on the occluded markers (:944-951)
     for (int w = t; w < pc.n67 * 3; w += 256) {
       const int m = w / 3, c = w % 3;
       float mw[3];
@@ -278,7 +283,7 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
   if (t == 1) inv[1] = tots[PA_FN_N] >= 1.0 ? in.weights[PW_FRIC_N] / (float)tots[PA_FN_N] : 0.f;
   if (t == 2) inv[2] = (in.use_infill && tots[PA_INF_N] >= 1.0) ? in.weights[PW_INFILL] / (float)tots[PA_INF_N] : 0.f;
   if (t >= 3 && t < 7) inv[t] = (in.use_infill && tots[PA_CT_N + (t - 3)] >= 1.0) ? in.weights[PW_INFILL_CONTACT] / (float)tots[PA_CT_N + (t - 3)] : 0.f;
-  if (b == 0 && t == 64) {
+  if (b == 0 && blockIdx.y == 0 && t == 64) {
     float rec[16];
     prox_finalize(tots, in.weights, B, pc.n_op, in.smooth_count, in.use_infill, rec);
     for (int i = 0; i < 16; ++i) losses_out[i] = rec[i];
@@ -286,7 +291,7 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
   __syncthreads();
   // target / contact are only dereferenced (clamped reads), never used: m67 = -1, fm = 0 -> any buffer of >= B * max(n67 * 3, 4) floats
   const DvertsIn din = {in.verts, V, in.verts, in.verts, in.dx0, in.canon, in.weights, B};
-  for (int u = t; u < pc.n_s; u += 256) {
+  for (int u = blockIdx.y * 256 + t; u < pc.n_s; u += 256 * gridDim.y) {     // (frame, quarter of S) per workgroup
     const int vid = pc.s_vid[u];
     const float* p = in.verts + ((size_t)b * V + vid) * 3;
     float g[3] = {0.f, 0.f, 0.f}, gw[3] = {0.f, 0.f, 0.f};
@@ -416,7 +421,7 @@ int prox_frame(const lemo_prox_desc& d, hipStream_t s) {
   in.nj = d.body.nj; in.ncomp = d.body.ncomp; in.V = d.V; in.B = d.B; in.T = d.T; in.use_infill = d.use_infill;
   in.fx = d.cam[0]; in.fy = d.cam[1]; in.cx = d.cam[2]; in.cy = d.cam[3];
   ProxFrameOut out{d.loss_acc, d.dJtr, d.dJv, d.dtr_j, d.gp, d.dfp_add};
-  hipLaunchKernelGGL(prox_frame_kernel, dim3(d.B), dim3(256), 0, s, d.pc, in, out, make_cw(d.cam2world),
+  hipLaunchKernelGGL(prox_frame_kernel, dim3(d.B, 2), dim3(256), 0, s, d.pc, in, out, make_cw(d.cam2world),
                      make_sdf_vol(d.sdf, d.sdf_dim[0], d.sdf_dim[1], d.sdf_dim[2], d.grid_min, d.grid_max));
   return (int)hipGetLastError();
 }
@@ -433,7 +438,7 @@ int prox_sparse(const lemo_prox_desc& d, double smooth_count, hipStream_t s) {
   in.verts = d.verts; in.dJv = d.dJv; in.weights = d.weights; in.marker_mask = d.marker_mask; in.rec = d.body_markers_rec;
   in.clbl = d.contact_lbl_rec; in.dx0 = d.dx0; in.canon = d.canon; in.acc = d.loss_acc; in.V = d.V; in.B = d.B; in.T = d.T;
   in.use_infill = d.use_infill; in.nvj = d.pc.n_sj - d.body.nj; in.smooth_count = smooth_count;
-  hipLaunchKernelGGL(prox_sparse_kernel, dim3(d.B), dim3(256), 0, s, d.pc, d.fit, in, make_cw(d.cam2world),
+  hipLaunchKernelGGL(prox_sparse_kernel, dim3(d.B, (d.pc.n_s + 255) / 256), dim3(256), 0, s, d.pc, d.fit, in, make_cw(d.cam2world),
                      make_sdf_vol(d.sdf, d.sdf_dim[0], d.sdf_dim[1], d.sdf_dim[2], d.grid_min, d.grid_max), d.dverts, d.losses);
   return (int)hipGetLastError();
 }
