@@ -94,7 +94,9 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
 // B slab is shared by the 8 row blocks through L2), writes its partial tile, and a second launch adds the slabs in slab
 // order (deterministic).
 #define GEMM_SK_NT 8            // frame tiles of 16 (N <= 128)
-#define GEMM_SK_CH 2
+// Measured (rocprofv3, B = 100, K = 31440): with 32 slabs = one wave per SIMD and the loads of a step waited for before
+// its MFMAs, the kernel was a chain of exposed HBM round trips (101.8 us, no better than the 107 us it replaced).  Now:
+// 96 slabs (768 workgroups, 3 waves per SIMD) and the operands of step c + 1 are requested before the 32 MFMAs of step c.
 __global__ void __launch_bounds__(256)
 gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
                         float* __restrict__ part) {
@@ -115,28 +117,31 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
   f32x4 acc[GEMM_SK_NT];
 #pragma unroll
   for (int t = 0; t < GEMM_SK_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int cb = c0; cb < c1; cb += GEMM_SK_CH) {
-    float4 a[GEMM_SK_CH], b[GEMM_SK_CH][GEMM_SK_NT];
-#pragma unroll
-    for (int u = 0; u < GEMM_SK_CH; ++u) {
-      const int c = (cb + u < c1) ? cb + u : c1 - 1;
-      a[u] = ld4(ap + (size_t)c * 16);
-#pragma unroll
-      for (int t = 0; t < GEMM_SK_NT; ++t) b[u][t] = ld4(bp[t] + (size_t)c * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < GEMM_SK_CH; ++u) {
-      if (cb + u < c1) {
-#pragma unroll
-        for (int t = 0; t < GEMM_SK_NT; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u][t].x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u][t].y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u][t].z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u][t].w, acc[t], 0, 0, 0);
-        }
+  float4 a0, b0[GEMM_SK_NT], a1, b1[GEMM_SK_NT];
+#define SK_LOAD(A_, B_, C_) { const int cc_ = (C_) < c1 ? (C_) : (c1 > c0 ? c1 - 1 : c0); A_ = ld4(ap + (size_t)cc_ * 16);                \
+    _Pragma("unroll") for (int t = 0; t < GEMM_SK_NT; ++t) B_[t] = ld4(bp[t] + (size_t)cc_ * 16); }
+#define SK_MFMA(A_, B_) _Pragma("unroll") for (int t = 0; t < GEMM_SK_NT; ++t) {                                                          \
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B_[t].x, acc[t], 0, 0, 0);                                                       \
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B_[t].y, acc[t], 0, 0, 0);                                                       \
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B_[t].z, acc[t], 0, 0, 0);                                                       \
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B_[t].w, acc[t], 0, 0, 0); }
+  if (c0 < c1) {
+    SK_LOAD(a0, b0, c0)
+    for (int c = c0; c < c1; c += 2) {
+      SK_LOAD(a1, b1, c + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      SK_MFMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < c1) {
+        SK_LOAD(a0, b0, c + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        SK_MFMA(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+#undef SK_LOAD
+#undef SK_MFMA
   // D: col = n (lane & 15), rows 4 q + r -> m ;  part[slab][n][m]
   float* pp = part + (size_t)slab * (GEMM_SK_NT * 16) * M;
 #pragma unroll

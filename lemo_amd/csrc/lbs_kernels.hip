@@ -290,12 +290,9 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
       float oy = T[4] * px + T[5] * py + T[6] * pz + T[7];
       float oz = T[8] * px + T[9] * py + T[10] * pz + T[11];
       if (transl) { ox += transl[(size_t)f * 3]; oy += transl[(size_t)f * 3 + 1]; oz += transl[(size_t)f * 3 + 2]; }
-      float* o = verts + ((size_t)f * n + slot) * 3;
-      o[0] = ox; o[1] = oy; o[2] = oz;
-      if (v_posed) {
-        float* q = v_posed + ((size_t)f * n + slot) * 3;
-        q[0] = px; q[1] = py; q[2] = pz;
-      }
+      // one 12-byte store per output row (global_store_dwordx3) instead of three dword stores with a 12-byte lane stride
+      *reinterpret_cast<float3*>(verts + ((size_t)f * n + slot) * 3) = make_float3(ox, oy, oz);
+      if (v_posed) *reinterpret_cast<float3*>(v_posed + ((size_t)f * n + slot) * 3) = make_float3(px, py, pz);
     }
     if (ch + 1 < nchunk) { LBS_ASTORE(buf ^ 1) }
     __syncthreads();
@@ -739,17 +736,44 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   const int nchunk = gridDim.x;
   const int s0 = ch * LBS_DENSE_CHUNK, s_end = min(s0 + LBS_DENSE_CHUNK, u.n), cn = s_end - s0;
   const float* Af = A + (size_t)b * nj * 12;
+  // the all-vertex set is the identity (ids[s] == vp_row[s] == s): its staging reads are then plain contiguous runs
+  // instead of index -> row chains; every read of the kernel is issued here, before the barrier (the first version
+  // chased ids -> weights -> LDS per vertex after it: 51 us for a kernel that moves 38 MB)
+  const bool ident = u.n == c.V && vp_rows == c.V;
+  __shared__ int tabs[2][64];                                // this chunk's [q0, q1) per joint (read in the wave loops below)
+  if (t < 2 * 64) {
+    const int which = t >> 6, j = min(t & 63, nj);
+    tabs[which][t & 63] = u.jcsr_chunk[(size_t)(ch + which) * (nj + 1) + j];
+  }
   for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
   for (int i = t; i < cn * 3; i += 256) {
     const int s = s0 + i / 3, e = i % 3;
     gs[i] = dverts[((size_t)b * u.n + s) * 3 + e];
-    vs[i] = v_posed[((size_t)b * vp_rows + u.vp_row[s]) * 3 + e];
+    vs[i] = v_posed[((size_t)b * vp_rows + (ident ? s : u.vp_row[s])) * 3 + e];
   }
+  constexpr int KWF = 4;                                     // skinning weights of a vertex read together (real SMPL-X: <= 4)
+  int wj[2][KWF]; float wk[2][KWF]; int vids[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int l = min(t + 256 * r, cn - 1);
+    vids[r] = ident ? s0 + l : u.ids[s0 + l];
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < KWF; ++k) {
+      const int kk = k < c.KW ? k : c.KW - 1;
+      wj[r][k] = c.w_idx[(size_t)vids[r] * c.KW + kk] * 12;
+      wk[r][k] = k < c.KW ? c.w_val[(size_t)vids[r] * c.KW + kk] : 0.f;
+    }
   __syncthreads();
   // ---- vertex-major: d(v_posed) = T^T g
   float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int l = t; l < cn; l += 256) {
-    const int vid = u.ids[s0 + l];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int l = t + 256 * r;
+    if (l >= cn) continue;
+    const int vid = vids[r];
     const float gx = gs[3 * l], gy = gs[3 * l + 1], gz = gs[3 * l + 2];
     sx += gx; sy += gy; sz += gz;
     float T[9];
@@ -757,7 +781,15 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     for (int e = 0; e < 9; ++e) T[e] = 0.f;
     const int* wi = c.w_idx + (size_t)vid * c.KW;
     const float* wv = c.w_val + (size_t)vid * c.KW;
-    for (int k = 0; k < c.KW; ++k) {
+#pragma unroll
+    for (int k = 0; k < KWF; ++k) {
+      const float w = wk[r][k];
+      const float* Aj = As + wj[r][k];
+      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
+      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
+      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+    }
+    for (int k = KWF; k < c.KW; ++k) {                         // models with more than 4 weights per vertex
       const float w = wv[k];
       const float* Aj = As + wi[k] * 12;                        // ELL padding rows carry weight 0
       T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
@@ -776,10 +808,8 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   if (t < 3) part[nj * 12 + t] = ((red[t] + red[3 + t]) + red[6 + t]) + red[9 + t];
   // ---- joint-major: dA[j][r][:] = sum over the chunk's entries of joint j of  w g_r (x) [v, 1]
   const int wave = t >> 6, lane = t & 63;
-  const int* tab0 = u.jcsr_chunk + (size_t)ch * (nj + 1);
-  const int* tab1 = tab0 + (nj + 1);
   for (int j = wave; j < nj; j += 4) {
-    const int q0 = tab0[j], q1 = tab1[j];
+    const int q0 = tabs[0][j], q1 = tabs[1][j];
     if (q1 <= q0) {                                              // wave-uniform: most joints own no vertex of a 512-vertex chunk
       if (lane < 12) part[j * 12 + lane] = 0.f;
       continue;
