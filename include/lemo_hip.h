@@ -165,10 +165,12 @@ typedef struct lemo_vertex_set_bwd {
   const float* DkT;         /* [NCs][512]: the same directions feature-contiguous (forward over the set), or NULL */
   const int *jcsr_start, *jcsr_u;
   const float* jcsr_w;
-  /* optional (large sets): deterministic dense backward.  The joint-major lists are sorted by set position, so the
-   * entries of the 512-vertex chunk c of joint j are jcsr_chunk[c * (nj + 1) + j] .. jcsr_chunk[(c + 1) * (nj + 1) + j];
+  /* optional (large sets): deterministic dense backward.  Chunk c (512 consecutive set positions) owns the entries
+   * jcsr_chunk[c * (nj + 1) + j] .. jcsr_chunk[c * (nj + 1) + j + 1] of jc_u / jc_w for joint j;
    * part: [part_frames][n_chunk][nj * 12 + 4] floats of per-chunk partial sums, reduced in chunk order. */
-  const int* jcsr_chunk;          /* [(n_chunk + 1) * (nj + 1)] or NULL */
+  const int* jcsr_chunk;          /* [n_chunk * (nj + 1)] offsets into jc_u / jc_w, or NULL */
+  const int* jc_u;                /* the same (set position, weight) pairs as jcsr_u / jcsr_w, reordered CHUNK-major (chunk, */
+  const float* jc_w;              /* then joint, then position): the entries of one 512-vertex chunk are one contiguous run */
   float* part;
   int part_frames;
   /* optional: K-slab partial tiles of the feature-gradient GEMM dX = Dk . d(v_posed) (K = NCs): gemm_slabs x 128 x 512

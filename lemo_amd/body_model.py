@@ -148,11 +148,18 @@ class BodyModelData:
         if n > 1024:           # sets beyond the staged per-frame kernel (LBS_BWD_STAGE): per-chunk offsets into the
             # (position-sorted) joint lists -> deterministic dense backward
             nchunk = (n + DENSE_CHUNK - 1) // DENSE_CHUNK
-            tab = np.zeros((nchunk + 1, self.nj + 1), np.int32)
-            for j in range(self.nj):
-                tab[:, j] = js[j] + np.searchsorted(ju[j], np.arange(nchunk + 1) * DENSE_CHUNK)
-            tab[:, self.nj] = js[self.nj]
+            tab = np.zeros((nchunk, self.nj + 1), np.int32)
+            cu, cw, off = [], [], 0
+            for c in range(nchunk):                  # chunk-major copy of the joint lists: one contiguous run per chunk
+                for j in range(self.nj):
+                    lo, hi = np.searchsorted(ju[j], [c * DENSE_CHUNK, (c + 1) * DENSE_CHUNK])
+                    tab[c, j] = off
+                    cu.append(ju[j][lo:hi]); cw.append(jw[j][lo:hi])
+                    off += hi - lo
+                tab[c, self.nj] = off
             extra['jcsr_chunk'] = tab
+            extra['jc_u'] = np.concatenate(cu + [np.zeros(1, np.int32)]).astype(np.int32)
+            extra['jc_w'] = np.concatenate(cw + [np.zeros(1, np.float32)]).astype(np.float32)
         return dict(n=n, NCs=NCs, ids=ids.astype(np.int32), **extra,
                     vp_row=(ids if vp_row is None else np.asarray(vp_row)).astype(np.int32), Dk=Dk,
                     jcsr_start=np.asarray(js, np.int32),
@@ -185,11 +192,12 @@ class DeviceBody:
             st = _hip.VertexSetBwd(s['n'], s['NCs'], ptr(tt['ids']), ptr(tt['vp_row']), ptr(tt['Dk']),
                                    ptr(tt['DkT']) if 'DkT' in tt else None,
                                    ptr(tt['jcsr_start']), ptr(tt['jcsr_u']), ptr(tt['jcsr_w']),
-                                   ptr(tt['jcsr_chunk']) if 'jcsr_chunk' in tt else None, None, 0)
+                                   ptr(tt['jcsr_chunk']) if 'jcsr_chunk' in tt else None,
+                                   ptr(tt['jc_u']) if 'jc_u' in tt else None, ptr(tt['jc_w']) if 'jc_w' in tt else None, None, 0)
             self._sets[key] = (st, tt)
         st, tt = self._sets[key]
         if 'jcsr_chunk' in tt and frames > st.part_frames:
-            nchunk = tt['jcsr_chunk'].shape[0] - 1
+            nchunk = tt['jcsr_chunk'].shape[0]
             tt['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
             st.part, st.part_frames = ptr(tt['part']), frames
             if st.gemm_slabs == 0:                 # K-slab partials of the feature-gradient GEMM (long K): 32 x 128 x 512 floats

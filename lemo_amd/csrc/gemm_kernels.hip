@@ -94,54 +94,80 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
 // B slab is shared by the 8 row blocks through L2), writes its partial tile, and a second launch adds the slabs in slab
 // order (deterministic).
 #define GEMM_SK_NT 8            // frame tiles of 16 (N <= 128)
-// Measured (rocprofv3, B = 100, K = 31440): with 32 slabs = one wave per SIMD and the loads of a step waited for before
-// its MFMAs, the kernel was a chain of exposed HBM round trips (101.8 us, no better than the 107 us it replaced).  Now:
-// 96 slabs (768 workgroups, 3 waves per SIMD) and the operands of step c + 1 are requested before the 32 MFMAs of step c.
+// Measured (rocprofv3, B = 100, K = 31440).  v1: 32 slabs, every wave loading its own A and all 8 B fragments of a step and
+// waiting for them: 101.8 us (no better than the 107 us it replaced).  v2: 96 slabs + operands of the next step requested
+// before the MFMAs of the current one: 76 us -- still 9 KB of global loads per wave and step for 32 MFMAs, one step
+// (0.43 us of MFMA work) of look-ahead against ~2 us of memory latency.  v3 (this): the 4 waves of a workgroup need the SAME
+// B fragments, so the B tile of a step (128 frames x 16 k = 8 KB) is staged once per workgroup through LDS (double
+// buffered, global -> register -> LDS two steps ahead) and only the wave's own A fragment (1 KB) comes straight from
+// global memory, three steps ahead: 3 KB of global loads per wave and step instead of 9.
 __global__ void __launch_bounds__(256)
 gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
                         float* __restrict__ part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ __attribute__((aligned(16))) float Bs[2][4][GEMM_SK_NT * 16][4];      // [buffer][k quarter][frame][4 k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int mblocks = M >> 6;
   const int mb = blockIdx.x % mblocks, slab = blockIdx.x / mblocks;
   const int mt = mb * 4 + wave;
   const int k16 = K >> 4, per = (k16 + S - 1) / S;
   const int c0 = slab * per, c1 = (c0 + per < k16) ? c0 + per : k16;
+  const int nst = c1 - c0;
   const float* ap = Am + (size_t)(mt * 16 + i) * lda + 4 * q;
-  const float* bp[GEMM_SK_NT];
+  // staging role of this thread: float4 idx = tid + 256 r -> frame idx >> 2, k quarter idx & 3
+  const float* bsrc[2];
+  int bdst[2];
 #pragma unroll
-  for (int t = 0; t < GEMM_SK_NT; ++t) {
-    const int n = t * 16 + i;
-    bp[t] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * q;
+  for (int r = 0; r < 2; ++r) {
+    const int idx = tid + 256 * r, n = idx >> 2, kq = idx & 3;
+    bsrc[r] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * kq;
+    bdst[r] = (kq * (GEMM_SK_NT * 16) + n) * 4;
   }
   f32x4 acc[GEMM_SK_NT];
 #pragma unroll
   for (int t = 0; t < GEMM_SK_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float4 a0, b0[GEMM_SK_NT], a1, b1[GEMM_SK_NT];
-#define SK_LOAD(A_, B_, C_) { const int cc_ = (C_) < c1 ? (C_) : (c1 > c0 ? c1 - 1 : c0); A_ = ld4(ap + (size_t)cc_ * 16);                \
-    _Pragma("unroll") for (int t = 0; t < GEMM_SK_NT; ++t) B_[t] = ld4(bp[t] + (size_t)cc_ * 16); }
-#define SK_MFMA(A_, B_) _Pragma("unroll") for (int t = 0; t < GEMM_SK_NT; ++t) {                                                          \
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.x, B_[t].x, acc[t], 0, 0, 0);                                                       \
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.y, B_[t].y, acc[t], 0, 0, 0);                                                       \
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.z, B_[t].z, acc[t], 0, 0, 0);                                                       \
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_.w, B_[t].w, acc[t], 0, 0, 0); }
-  if (c0 < c1) {
-    SK_LOAD(a0, b0, c0)
-    for (int c = c0; c < c1; c += 2) {
-      SK_LOAD(a1, b1, c + 1)
-      __builtin_amdgcn_sched_barrier(0);
-      SK_MFMA(a0, b0)
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < c1) {
-        SK_LOAD(a0, b0, c + 2)
-        __builtin_amdgcn_sched_barrier(0);
-        SK_MFMA(a1, b1)
-        __builtin_amdgcn_sched_barrier(0);
+  if (nst > 0) {
+    auto clampc = [&](int c) { return c < c1 ? c : c1 - 1; };
+    float4 a[3], bg[2][2];                                     // A of steps s, s+1, s+2 ; B (global) of steps s+1, s+2
+#pragma unroll
+    for (int u = 0; u < 3; ++u) a[u] = ld4(ap + (size_t)clampc(c0 + u) * 16);
+    {                                                          // step 0 straight into LDS buffer 0, steps 1 and 2 into registers
+      float4 b0[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) st4(&Bs[0][0][0][0] + bdst[r], b0[r]);
+    }
+    __syncthreads();
+    for (int s_ = 0; s_ < nst; ++s_) {
+      const int buf = s_ & 1;
+      const float4 av = a[0];
+      // B fragments of this step from LDS, then the MFMAs
+      float4 bf[GEMM_SK_NT];
+#pragma unroll
+      for (int t = 0; t < GEMM_SK_NT; ++t) bf[t] = ld4(&Bs[buf][q][t * 16 + i][0]);
+      // publish step s+1 (held in registers since two steps ago) to the other buffer, refill the registers with step s+3
+      if (s_ + 1 < nst) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) st4(&Bs[buf ^ 1][0][0][0] + bdst[r], bg[0][r]);
       }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { bg[0][r] = bg[1][r]; bg[1][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + 3) * 16); }
+      a[0] = a[1]; a[1] = a[2]; a[2] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * 16);
+#pragma unroll
+      for (int t = 0; t < GEMM_SK_NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bf[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bf[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bf[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bf[t].w, acc[t], 0, 0, 0);
+      }
+      __syncthreads();
     }
   }
-#undef SK_LOAD
-#undef SK_MFMA
   // D: col = n (lane & 15), rows 4 q + r -> m ;  part[slab][n][m]
   float* pp = part + (size_t)slab * (GEMM_SK_NT * 16) * M;
 #pragma unroll

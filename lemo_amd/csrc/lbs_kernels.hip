@@ -726,6 +726,7 @@ lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
 // u.jcsr_chunk) by one wave per joint with a fixed reduction tree, written as a per-chunk partial, and the partials are
 // added in chunk order by lbs_bwd_reduce_kernel.  No atomics anywhere: two runs give identical bits.
 #define LBS_PART_STRIDE(nj) ((nj) * 12 + 4)
+#define LBS_CHUNK_NNZ 2560       // staged (position, weight) pairs per chunk: 512 vertices x <= 5 weights (20 KB); above: global reads
 __global__ void __launch_bounds__(256)
 lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj, const float* __restrict__ v_posed,
                      int vp_rows, const float* __restrict__ dverts, float* __restrict__ dvp) {
@@ -740,11 +741,18 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   // instead of index -> row chains; every read of the kernel is issued here, before the barrier (the first version
   // chased ids -> weights -> LDS per vertex after it: 51 us for a kernel that moves 38 MB)
   const bool ident = u.n == c.V && vp_rows == c.V;
-  __shared__ int tabs[2][64];                                // this chunk's [q0, q1) per joint (read in the wave loops below)
-  if (t < 2 * 64) {
-    const int which = t >> 6, j = min(t & 63, nj);
-    tabs[which][t & 63] = u.jcsr_chunk[(size_t)(ch + which) * (nj + 1) + j];
-  }
+  // this chunk's joint lists: offsets per joint + the (position, weight) pairs themselves, one contiguous run of the
+  // chunk-major arrays, staged before the barrier (read per joint from global memory in the wave loops below they were a
+  // dependent L2 round trip per joint: with weights spread over many joints, ~14 per wave)
+  __shared__ int tabs[65];
+  __shared__ int cus[LBS_CHUNK_NNZ];
+  __shared__ float cws[LBS_CHUNK_NNZ];
+  const int* tabg = u.jcsr_chunk + (size_t)ch * (nj + 1);
+  if (t <= nj) tabs[t] = tabg[t];
+  const int e0 = tabg[0], e1 = tabg[nj];
+  const bool staged = e1 - e0 <= LBS_CHUNK_NNZ;
+  if (staged)
+    for (int i = t; i < e1 - e0; i += 256) { cus[i] = u.jc_u[e0 + i]; cws[i] = u.jc_w[e0 + i]; }
   for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
   for (int i = t; i < cn * 3; i += 256) {
     const int s = s0 + i / 3, e = i % 3;
@@ -809,7 +817,7 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   // ---- joint-major: dA[j][r][:] = sum over the chunk's entries of joint j of  w g_r (x) [v, 1]
   const int wave = t >> 6, lane = t & 63;
   for (int j = wave; j < nj; j += 4) {
-    const int q0 = tabs[0][j], q1 = tabs[1][j];
+    const int q0 = tabs[j], q1 = tabs[j + 1];
     if (q1 <= q0) {                                              // wave-uniform: most joints own no vertex of a 512-vertex chunk
       if (lane < 12) part[j * 12 + lane] = 0.f;
       continue;
@@ -818,8 +826,8 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0.f;
     for (int q = q0 + lane; q < q1; q += 64) {
-      const int l = u.jcsr_u[q] - s0;
-      const float w = u.jcsr_w[q];
+      const int l = (staged ? cus[q - e0] : u.jc_u[q]) - s0;
+      const float w = staged ? cws[q - e0] : u.jc_w[q];
       const float vx = vs[3 * l], vy = vs[3 * l + 1], vz = vs[3 * l + 2];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
@@ -876,7 +884,7 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
     if (fuse) hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, true>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, *fuse);
     else hipLaunchKernelGGL((lbs_bwd_frame_kernel<true, false>), dim3(B), dim3(1024), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp, dA, dtransl, FitFuse{});
   }
-  else if (nj <= 64 && u.jcsr_chunk && u.part && B <= u.part_frames) {
+  else if (nj <= 64 && u.jcsr_chunk && u.jc_u && u.jc_w && u.part && B <= u.part_frames) {
     const int nchunk = (u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK;
     hipLaunchKernelGGL(lbs_bwd_chunk_kernel, dim3(nchunk, B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp);
     hipLaunchKernelGGL(lbs_bwd_reduce_kernel, dim3(B), dim3(256), 0, s, u, nj, nchunk, dvp, dA, dtransl);
