@@ -751,13 +751,28 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   if (t <= nj) tabs[t] = tabg[t];
   const int e0 = tabg[0], e1 = tabg[nj];
   const bool staged = e1 - e0 <= LBS_CHUNK_NNZ;
-  if (staged)
-    for (int i = t; i < e1 - e0; i += 256) { cus[i] = u.jc_u[e0 + i]; cws[i] = u.jc_w[e0 + i]; }
-  for (int i = t; i < nj * 12; i += 256) As[i] = Af[i];
-  for (int i = t; i < cn * 3; i += 256) {
+  if (staged) {                                               // same rule: every read in flight before the first store
+    int ru[LBS_CHUNK_NNZ / 256]; float rw[LBS_CHUNK_NNZ / 256];
+    const int ne = e1 - e0;
+#pragma unroll
+    for (int k = 0; k < LBS_CHUNK_NNZ / 256; ++k) {
+      const int i = e0 + min(t + 256 * k, max(ne - 1, 0));
+      ru[k] = u.jc_u[i]; rw[k] = u.jc_w[i];
+    }
+#pragma unroll
+    for (int k = 0; k < LBS_CHUNK_NNZ / 256; ++k) if (t + 256 * k < ne) { cus[t + 256 * k] = ru[k]; cws[t + 256 * k] = rw[k]; }
+  }
+  // all 12 + 3 staging reads of a thread are issued before the first LDS store (a load inside a rolled loop is waited
+  // for in the same trip: six dependent round trips)
+  float rg[6], rv[6], ra[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ra[k] = Af[min(t + 256 * k, nj * 12 - 1)];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int i = min(t + 256 * k, cn * 3 - 1);
     const int s = s0 + i / 3, e = i % 3;
-    gs[i] = dverts[((size_t)b * u.n + s) * 3 + e];
-    vs[i] = v_posed[((size_t)b * vp_rows + (ident ? s : u.vp_row[s])) * 3 + e];
+    rg[k] = dverts[((size_t)b * u.n + s) * 3 + e];
+    rv[k] = v_posed[((size_t)b * vp_rows + (ident ? s : u.vp_row[s])) * 3 + e];
   }
   constexpr int KWF = 4;                                     // skinning weights of a vertex read together (real SMPL-X: <= 4)
   int wj[2][KWF]; float wk[2][KWF]; int vids[2];
@@ -774,6 +789,10 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       wj[r][k] = c.w_idx[(size_t)vids[r] * c.KW + kk] * 12;
       wk[r][k] = k < c.KW ? c.w_val[(size_t)vids[r] * c.KW + kk] : 0.f;
     }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) if (t + 256 * k < nj * 12) As[t + 256 * k] = ra[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) if (t + 256 * k < cn * 3) { gs[t + 256 * k] = rg[k]; vs[t + 256 * k] = rv[k]; }
   __syncthreads();
   // ---- vertex-major: d(v_posed) = T^T g
   float sx = 0.f, sy = 0.f, sz = 0.f;
