@@ -396,12 +396,16 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
                 # their reuse.  Raw capture (lemo_capture_*): the step is ~60 HIP kernels + ~150 small torch ops.
                 opt.zero_grad()
                 sh = torch.cuda.current_stream(clip_img_input.device).cuda_stream
-                lib.check(lib.capture_begin(sh), 'capture_begin')
-                try:
-                    train_step()
-                finally:
-                    exe = C.c_void_p()
-                    rc = lib.capture_end(sh, C.byref(exe))
+                # the captured step allocates from a PRIVATE pool that lives as long as the graph (the replays write into
+                # those addresses; the shared caching allocator could hand them out again between two replays)
+                pool = torch.cuda.MemPool()
+                with torch.cuda.use_mem_pool(pool):
+                    lib.check(lib.capture_begin(sh), 'capture_begin')
+                    try:
+                        train_step()
+                    finally:
+                        exe = C.c_void_p()
+                        rc = lib.capture_end(sh, C.byref(exe))
                 lib.check(rc, 'capture_end')
                 try:
                     for _ in range(steps - 3):               # capture records the step without running it

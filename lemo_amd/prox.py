@@ -252,12 +252,17 @@ class ProxTemporalFitter:
                 ld = one()
             del ld
             self.optimizer.zero_grad()
-            lib.check(lib.capture_begin(side.cuda_stream), 'capture_begin')
-            try:
-                ld = one()
-            finally:
-                exe = C.c_void_p()
-                rc = lib.capture_end(side.cuda_stream, C.byref(exe))
+            # everything the captured iteration allocates comes from a PRIVATE pool that lives as long as the graph:
+            # the replays write into those addresses, which the shared caching allocator could otherwise hand to
+            # another allocation (another thread, an empty_cache()) between two replays
+            pool = torch.cuda.MemPool()
+            with torch.cuda.use_mem_pool(pool):
+                lib.check(lib.capture_begin(side.cuda_stream), 'capture_begin')
+                try:
+                    ld = one()
+                finally:
+                    exe = C.c_void_p()
+                    rc = lib.capture_end(side.cuda_stream, C.byref(exe))
             lib.check(rc, 'capture_end')
             try:
                 for _ in range(n - 3):                           # capture records the iteration without running it
@@ -265,6 +270,8 @@ class ProxTemporalFitter:
                 side.synchronize()
             finally:
                 lib.check(lib.graph_destroy(exe), 'graph_destroy')
+            ld = {k: v.clone() for k, v in ld.items()}
+            self._capture_pool = pool        # the parameters' .grad tensors of the captured iteration live in it
         torch.cuda.current_stream(dev).wait_stream(side)
         return ld
 
