@@ -71,33 +71,46 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     const int dstb = scol * 16 + shalf * 8;                       // + (group * 3 + piece) * PL
     // D streams from HBM (~2 us away under load) and one stage is only ~0.75 us of MFMA work: the global
     // loads run TWO stages ahead (two register sets), the LDS image one stage ahead
-    float4 sa[2][2], sb[2][2];
-#define LBS_SPLIT_LOAD(SET, ST)                                                                    \
-    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                \
-      sa[SET][k] = ld4(c.Dg + (size_t)((ST) * SG + sg0 + 2 * k) * dg_stride + a_off);              \
-      sb[SET][k] = ld4(Xg + (size_t)((ST) * SG + sg0 + 2 * k) * xg_stride + b_off);                \
-    }
-#define LBS_SPLIT_STORE(SET, BUF)                                                                  \
+    // (LBS_PFA = stages the D loads run ahead: 2 in the product; 3 / 4 are A/B builds, tools/ab_build.sh)
+#ifndef LBS_PFA
+#define LBS_PFA 2
+#endif
+    constexpr int PA = LBS_PFA;
+    float4 sa[PA][2], sb[2][2];
+#define LBS_SPLIT_LOAD_A(SET, ST)                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                  \
+      sa[SET][k] = ld4(c.Dg + (size_t)((ST) * SG + sg0 + 2 * k) * dg_stride + a_off);
+#define LBS_SPLIT_LOAD_B(SET, ST)                                                                  \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                  \
+      sb[SET][k] = ld4(Xg + (size_t)((ST) * SG + sg0 + 2 * k) * xg_stride + b_off);
+#define LBS_SPLIT_STORE(SETA, SETB, BUF)                                                           \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                \
       uint2 p0, p1, p2;                                                                            \
       unsigned char* d = sm + (BUF) * BUFB + (sg0 + 2 * k) * 3 * PL + dstb;                        \
-      split3x4(sa[SET][k], p0, p1, p2);                                                            \
+      split3x4(sa[SETA][k], p0, p1, p2);                                                           \
       *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PL) = p1; *reinterpret_cast<uint2*>(d + 2 * PL) = p2; \
-      split3x4(sb[SET][k], p0, p1, p2);                                                            \
+      split3x4(sb[SETB][k], p0, p1, p2);                                                           \
       *reinterpret_cast<uint2*>(d + OPB) = p0; *reinterpret_cast<uint2*>(d + OPB + PL) = p1;       \
       *reinterpret_cast<uint2*>(d + OPB + 2 * PL) = p2;                                            \
     }
-    LBS_SPLIT_LOAD(0, 0)
-    LBS_SPLIT_LOAD(1, 1)
-    LBS_SPLIT_STORE(0, 0)
+#pragma unroll
+    for (int i = 0; i < PA; ++i) { LBS_SPLIT_LOAD_A(i, i) }
+    LBS_SPLIT_LOAD_B(0, 0)
+    LBS_SPLIT_LOAD_B(1, 1)
+    LBS_SPLIT_STORE(0, 0, 0)
     __syncthreads();
     if (DBG) t_pro = __builtin_amdgcn_s_memtime();
     const int a_rdb = (mp * 64 + j) * 16, b_rdb = OPB + (nt * 32 + j) * 16;
+#if LBS_PFA == 2
 #pragma unroll 2
+#else
+#pragma unroll
+#endif
     for (int st = 0; st < NSTS; ++st) {
       const int buf = st & 1;
-      // register set (st & 1) held stage st (already in LDS): refill it with stage st + 2
-      if (st + 2 < NSTS) { if (st & 1) { LBS_SPLIT_LOAD(1, st + 2) } else { LBS_SPLIT_LOAD(0, st + 2) } }
+      // register set (st % PA) held stage st (already in LDS): refill it with stage st + PA; same for B with 2 sets
+      if (st + PA < NSTS) { LBS_SPLIT_LOAD_A(st % PA, st + PA) }
+      if (st + 2 < NSTS) { LBS_SPLIT_LOAD_B(st & 1, st + 2) }
       const unsigned char* base = sm + buf * BUFB + h * 3 * PL;   // lane half h takes group 2c + h of chunk c
       uint4 ra[2][2][3], rb[2][3];                                // [set][m-tile][piece]
 #define LBS_SREAD(SET, C)                                                                          \
@@ -124,11 +137,12 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
 #undef LBS_SMFMA
       // (running the two waves of a SIMD out of phase -- one converting while the other owns the MFMA pipe --
       // measured slower: 49.9k vs 43.1k cycles)
-      if (st + 1 < NSTS) { if (st & 1) { LBS_SPLIT_STORE(0, 0) } else { LBS_SPLIT_STORE(1, 1) } }
+      if (st + 1 < NSTS) { LBS_SPLIT_STORE((st + 1) % PA, (st + 1) & 1, (st + 1) & 1) }
       __syncthreads();
     }
 #undef LBS_SPLIT_STORE
-#undef LBS_SPLIT_LOAD
+#undef LBS_SPLIT_LOAD_A
+#undef LBS_SPLIT_LOAD_B
   } else {
   float* As0 = smem;                                   // [2 buffers] of LBS_STAGE_FLOATS
   float* Bs0 = smem + 2 * LBS_STAGE_FLOATS;

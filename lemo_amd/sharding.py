@@ -50,3 +50,54 @@ def fit_sharded(n_seq: int, fit_one: Callable[[int], torch.Tensor], rank: int, w
     mine = [fit_one(s) for s in my_sequences(n_seq, rank, world)]
     allp = gather_fitted_params(torch.stack(mine, 0), group)
     return allp[torch.tensor(unshard_order(n_seq, world), device=allp.device)]
+
+
+class ConcurrentClips:
+    """Several independent clips fitted SIDE BY SIDE on one GPU: one :class:`~lemo_amd.fitting.AmassTemporalFitter` and
+    one stream per clip, all replaying their graphs at the same time.
+
+    One clip's iteration is a chain of 33 dependent kernels; a quarter of it is kernel-boundary latency and its per-frame
+    kernels (119 workgroups) leave half of the 256 CUs idle.  Clips carry no state between each other
+    (``opt_amass_temp.py:251``), so a second and third clip fill those holes: measured 2616 -> 3139 (2 clips) -> 3340
+    (3 clips) fitting-iterations/s in aggregate on one MI355X, every clip bit-identical to a run on its own
+    (``tools/concurrent_clips.py``, ``tests/test_gpu_r2.py``).  This is the per-GPU leg of the sequence sharding above:
+    rank r takes its sequences ``clips_per_gpu`` at a time."""
+
+    def __init__(self, fitters: Sequence):
+        assert len(fitters) >= 1
+        self.fitters = list(fitters)
+        dev = self.fitters[0].device
+        self.device = dev
+        self._gpu = dev.type == 'cuda' and not self.fitters[0].lib.is_emu
+        self.streams = [torch.cuda.Stream(dev) for _ in self.fitters] if self._gpu else [None] * len(self.fitters)
+
+    def _on(self, i, fn):
+        if self._gpu:
+            with torch.cuda.stream(self.streams[i]):
+                fn()
+        else:
+            fn()
+
+    def prepare(self, n: int) -> None:
+        for i, f in enumerate(self.fitters):
+            self._on(i, lambda f=f: f.prepare(n))
+
+    def step(self, n: int, use_graph: bool = True) -> None:
+        """``n`` iterations of every clip; asynchronous (call :meth:`synchronize` before reading results)."""
+        if self._gpu:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.streams:
+                s.wait_stream(cur)
+        for i, f in enumerate(self.fitters):
+            self._on(i, lambda f=f: f.step(n, use_graph=use_graph))
+
+    def synchronize(self) -> None:
+        if self._gpu:
+            cur = torch.cuda.current_stream(self.device)
+            for s in self.streams:
+                cur.wait_stream(s)
+                s.synchronize()
+
+    def params72(self) -> torch.Tensor:
+        """[clips,B,72] (after :meth:`synchronize`)"""
+        return torch.stack([f.params72() for f in self.fitters], 0)

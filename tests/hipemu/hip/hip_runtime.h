@@ -7,13 +7,17 @@
 // time is spent.  It is NOT a product path: lemo_amd never loads the emulated library, the
 // product loader only opens liblemo_hip.so built by hipcc for gfx950.
 //
-// Model: one block at a time; every thread of the block is a ucontext fiber on ONE OS thread,
-// scheduled round-robin; __syncthreads / cross-lane ops / MFMA are generation barriers that yield.
+// Model: every thread of a block is a fiber on ONE OS thread, scheduled round-robin; __syncthreads / cross-lane
+// ops / MFMA are generation barriers that yield.  The blocks of a launch are spread over up to HIPEMU_THREADS OS
+// threads (default min(8, cores)); `__shared__`, threadIdx & co and the scheduler state are thread_local.  Results do
+// not depend on the thread count: atomicAdd (the kernels never use its return value) is LOGGED per block and applied
+// after the launch in block order = exactly the order of the one-thread emulator.
 // Wavefront = 64 lanes.  MFMA f32 lane maps follow /opt/skills/guides/cdna_hip_programming.md §3:
 //   32x32x2 : A[i=l&31][k=l>>5]  B[k=l>>5][j=l&31]  D: col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
 //   16x16x4 : A[i=l&15][k=l>>4]  B[k=l>>4][j=l&15]  D: col=l&15, row=4*(l>>4)+r
 // and numerics are a k-ordered fmaf chain (bit-exact per the guide).
 #pragma once
+#include <link.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -22,7 +26,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #define HIPEMU 1
@@ -31,7 +39,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __noinline__ __attribute__((noinline))
-#define __shared__ static
+#define __shared__ static thread_local
 #define LEMO_PIN(x) ((void)0)
 #define __launch_bounds__(...)
 #define __constant__ static
@@ -120,6 +128,8 @@ hipemu_switch:
 )");
 struct Fiber { Ctx ctx; bool done = false; dim3 tid; int wave = 0, lane = 0; };
 
+// one deferred atomicAdd: applied after the launch, in (block, program) order
+struct AtomicRec { long long key; void* p; void (*apply)(void*, const void*); alignas(8) char val[8]; };
 struct State {
   std::vector<Fiber> fibers;
   std::vector<WaveBuf> waves;
@@ -127,17 +137,19 @@ struct State {
   Group block;
   Ctx sched;
   int cur = -1;
-  std::function<void()> body;
+  long long block_key = 0;
+  const std::function<void()>* body = nullptr;
+  std::vector<AtomicRec> atomics;
 };
-inline State& st() { static State s; return s; }
+inline State& st() { static thread_local State s; return s; }
 
 }  // namespace hipemu
 
 // threadIdx / blockIdx are plain globals rewritten by the scheduler before every resume
-inline dim3& hipemu_threadIdx() { static dim3 v; return v; }
-inline dim3& hipemu_blockIdx() { static dim3 v; return v; }
-inline dim3& hipemu_blockDim() { static dim3 v; return v; }
-inline dim3& hipemu_gridDim() { static dim3 v; return v; }
+inline dim3& hipemu_threadIdx() { static thread_local dim3 v; return v; }
+inline dim3& hipemu_blockIdx() { static thread_local dim3 v; return v; }
+inline dim3& hipemu_blockDim() { static thread_local dim3 v; return v; }
+inline dim3& hipemu_gridDim() { static thread_local dim3 v; return v; }
 #define threadIdx (hipemu_threadIdx())
 #define blockIdx (hipemu_blockIdx())
 #define blockDim (hipemu_blockDim())
@@ -160,16 +172,17 @@ inline WaveBuf& mywave() { State& s = st(); return s.waves[s.fibers[s.cur].wave]
 
 inline void fiber_entry() {
   State& s = st();
-  s.body();
+  (*s.body)();
   s.fibers[s.cur].done = true;
   hipemu_switch(&s.fibers[s.cur].ctx, &s.sched);
   abort();                                                   // a finished fiber is never resumed
 }
 
-inline std::vector<char>& dyn_smem_buf() { static std::vector<char> b; return b; }
+inline std::vector<char>& dyn_smem_buf() { static thread_local std::vector<char> b; return b; }
 inline void* dyn_smem() { return (void*)(((uintptr_t)dyn_smem_buf().data() + 63) & ~(uintptr_t)63); }
 
-inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+// all blocks [next, nblk) of one launch that this OS thread manages to claim
+inline void run_blocks(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body, std::atomic<long long>& next, long long nblk) {
   State& s = st();
   if (dyn_smem_buf().size() < shmem + 64) dyn_smem_buf().resize(shmem + 64);
   const int nthr = (int)(block.x * block.y * block.z);
@@ -179,43 +192,152 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
     if (p == MAP_FAILED) { perror("hipemu mmap"); abort(); }
     s.stacks.push_back((char*)p);
   }
-  s.body = std::move(body);
+  s.body = &body;
   hipemu_blockDim() = block;
   hipemu_gridDim() = grid;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        s.fibers.assign(nthr, Fiber());
-        s.waves.assign(nw, WaveBuf());
-        s.block = Group();
-        s.block.count = nthr;
-        for (int t = 0; t < nthr; ++t) {
-          Fiber& f = s.fibers[t];
-          f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-          f.wave = t / WAVE;
-          f.lane = t % WAVE;
-          s.waves[f.wave].g.count++;
-          // initial frame: 6 callee-saved slots + return address = fiber_entry; after the `ret` the stack
-          // pointer is == 8 (mod 16), as at any function entry
-          uintptr_t top = ((uintptr_t)s.stacks[t] + STACK) & ~(uintptr_t)15;
-          void** sp = (void**)(top - 8) - 7;
-          for (int q = 0; q < 6; ++q) sp[q] = nullptr;
-          sp[6] = (void*)&fiber_entry;
-          f.ctx.sp = sp;
-        }
-        int alive = nthr;
-        while (alive > 0) {
-          for (int t = 0; t < nthr; ++t) {
-            Fiber& f = s.fibers[t];
-            if (f.done) continue;
-            s.cur = t;
-            hipemu_threadIdx() = f.tid;
-            hipemu_blockIdx() = dim3(bx, by, bz);
-            hipemu_switch(&s.sched, &f.ctx);
-            if (f.done) --alive;
-          }
-        }
+  for (;;) {
+    const long long lin = next.fetch_add(1);
+    if (lin >= nblk) break;
+    const unsigned bx = (unsigned)(lin % grid.x), by = (unsigned)((lin / grid.x) % grid.y), bz = (unsigned)(lin / ((long long)grid.x * grid.y));
+    s.block_key = lin;
+    s.fibers.assign(nthr, Fiber());
+    s.waves.assign(nw, WaveBuf());
+    s.block = Group();
+    s.block.count = nthr;
+    for (int t = 0; t < nthr; ++t) {
+      Fiber& f = s.fibers[t];
+      f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      f.wave = t / WAVE;
+      f.lane = t % WAVE;
+      s.waves[f.wave].g.count++;
+      // initial frame: 6 callee-saved slots + return address = fiber_entry; after the `ret` the stack
+      // pointer is == 8 (mod 16), as at any function entry
+      uintptr_t top = ((uintptr_t)s.stacks[t] + STACK) & ~(uintptr_t)15;
+      void** sp = (void**)(top - 8) - 7;
+      for (int q = 0; q < 6; ++q) sp[q] = nullptr;
+      sp[6] = (void*)&fiber_entry;
+      f.ctx.sp = sp;
+    }
+    int alive = nthr;
+    while (alive > 0) {
+      for (int t = 0; t < nthr; ++t) {
+        Fiber& f = s.fibers[t];
+        if (f.done) continue;
+        s.cur = t;
+        hipemu_threadIdx() = f.tid;
+        hipemu_blockIdx() = dim3(bx, by, bz);
+        hipemu_switch(&s.sched, &f.ctx);
+        if (f.done) --alive;
       }
+    }
+  }
+}
+
+inline int max_threads() {
+  static const int n = [] {
+    const char* e = getenv("HIPEMU_THREADS");
+    int v = e ? atoi(e) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    return v < 1 ? 1 : v;
+  }();
+  return n;
+}
+
+// [lo, hi) of the calling thread's TLS block of THIS library (where `__shared__` = static thread_local lives): atomics
+// on LDS are block-local and applied at once, atomics on global memory are deferred (see launch)
+inline void tls_range(uintptr_t& lo, uintptr_t& hi) {
+  static thread_local uintptr_t r[2] = {0, 0};
+  static thread_local bool have = false;
+  if (!have) {
+    static thread_local char probe;                               // lives in the TLS block we are looking for
+    struct Q { uintptr_t probe, lo, hi; } q{(uintptr_t)&probe, 0, 0};
+    dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) -> int {
+      Q* q = (Q*)data;
+      if (!info->dlpi_tls_data) return 0;
+      for (int i = 0; i < info->dlpi_phnum; ++i)
+        if (info->dlpi_phdr[i].p_type == PT_TLS) {
+          const uintptr_t lo = (uintptr_t)info->dlpi_tls_data, hi = lo + info->dlpi_phdr[i].p_memsz;
+          if (q->probe >= lo && q->probe < hi) { q->lo = lo; q->hi = hi; return 1; }
+        }
+      return 0;
+    }, &q);
+    r[0] = q.lo; r[1] = q.hi; have = true;
+  }
+  lo = r[0]; hi = r[1];
+}
+inline bool is_lds(const void* p) {
+  uintptr_t lo, hi;
+  tls_range(lo, hi);
+  const uintptr_t a = (uintptr_t)p;
+  if (a >= lo && a < hi) return true;
+  const std::vector<char>& d = dyn_smem_buf();
+  return !d.empty() && a >= (uintptr_t)d.data() && a < (uintptr_t)d.data() + d.size();
+}
+
+// persistent workers (their thread_local fiber stacks and LDS live across launches)
+struct Job { dim3 grid, block; size_t shmem = 0; const std::function<void()>* body = nullptr; std::atomic<long long> next{0}; long long nblk = 0; };
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv_go, cv_done;
+  std::vector<std::thread> th;
+  std::vector<std::vector<AtomicRec>> logs;
+  Job* job = nullptr;
+  unsigned long long gen = 0;
+  int want = 0, done = 0;
+  void worker(int i) {
+    unsigned long long seen = 0;
+    for (;;) {
+      Job* j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_go.wait(lk, [&] { return gen != seen && i < want; });
+        seen = gen;
+        j = job;
+      }
+      st().atomics.clear();
+      run_blocks(j->grid, j->block, j->shmem, *j->body, j->next, j->nblk);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        logs[i].swap(st().atomics);
+        if (++done == want) cv_done.notify_one();
+      }
+    }
+  }
+  // run `j` with `n` helper threads next to the caller
+  void run(Job& j, int n) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      while ((int)th.size() < n) { const int i = (int)th.size(); logs.emplace_back(); th.emplace_back([this, i] { worker(i); }); th.back().detach(); }
+      for (auto& l : logs) l.clear();
+      job = &j; want = n; done = 0; ++gen;
+    }
+    cv_go.notify_all();
+    run_blocks(j.grid, j.block, j.shmem, *j.body, j.next, j.nblk);
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return done == want; });
+    want = 0;
+  }
+};
+inline Pool& pool() { static Pool* p = new Pool(); return *p; }      // leaked on purpose: workers are detached
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+  Job j;
+  j.grid = grid; j.block = block; j.shmem = shmem; j.body = &body;
+  j.nblk = (long long)grid.x * grid.y * grid.z;
+  const int nt = (int)std::min<long long>(max_threads(), j.nblk);
+  std::vector<AtomicRec>& mine = st().atomics;
+  mine.clear();
+  if (nt > 1) {
+    Pool& p = pool();
+    p.run(j, nt - 1);
+    for (int i = 0; i < nt - 1; ++i) mine.insert(mine.end(), p.logs[i].begin(), p.logs[i].end());
+    // deferred global atomics: block order, program order inside a block (a block runs on one OS thread, so its
+    // records are contiguous and ordered in that thread's log)
+    std::stable_sort(mine.begin(), mine.end(), [](const AtomicRec& a, const AtomicRec& b) { return a.key < b.key; });
+  } else {
+    run_blocks(grid, block, shmem, body, j.next, j.nblk);
+  }
+  for (const AtomicRec& r : mine) r.apply(r.p, r.val);
+  mine.clear();
 }
 
 }  // namespace hipemu
@@ -346,11 +468,20 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x
   return d;
 }
 
-// ---- atomics (single OS thread => plain RMW is atomic w.r.t. other fibers) --------------------
-template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
-static inline float atomicAdd(float* p, double v) { float o = *p; *p = o + (float)v; return o; }
-template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; *p = std::max(o, v); return o; }
-template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
+// ---- atomics: atomicAdd on GLOBAL memory is deferred to the end of the launch (see hipemu::launch); its return value is
+// NOT the old value (no kernel uses it).  Integer fetch-adds whose result IS used (last-block detection) are real atomics.
+template <typename T> static void hipemu_apply_add(void* p, const void* v) { T a; memcpy(&a, v, sizeof(T)); *(T*)p = *(T*)p + a; }
+template <typename T> static inline T atomicAdd(T* p, T v) {
+  static_assert(sizeof(T) <= 8, "atomicAdd operand <= 8 bytes");
+  if (hipemu::is_lds(p)) { T o = *p; *p = o + v; return o; }     // LDS: block-local, one OS thread
+  hipemu::State& s = hipemu::st();
+  hipemu::AtomicRec r;
+  r.key = s.block_key; r.p = (void*)p; r.apply = &hipemu_apply_add<T>;
+  memcpy(r.val, &v, sizeof(T));
+  s.atomics.push_back(r);
+  return T();
+}
+static inline float atomicAdd(float* p, double v) { return atomicAdd(p, (float)v); }
 
 // ---- buffer resources / cache-policy loads & stores / scoped atomics (plain memory on the host) ------------
 struct hipDeviceProp_t { int multiProcessorCount; };
@@ -372,9 +503,9 @@ static inline void __builtin_amdgcn_raw_buffer_store_b128(hipemu_u32x4 v, __amdg
 static inline void __builtin_amdgcn_raw_buffer_store_b64(hipemu_u32x2 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) { memcpy(r.p + voff + soff, &v, 8); }
 static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int) { memcpy(r.p + voff + soff, &v, 4); }
 #define __HIP_MEMORY_SCOPE_AGENT 4
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
-template <typename T> static inline T hipemu_fetch_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_SEQ_CST)
+template <typename T> static inline T hipemu_fetch_add(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_fetch_add(p, v, order, scope) hipemu_fetch_add((p), (v))
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}

@@ -114,3 +114,31 @@ def test_duplicate_foot_ids_rejected(emu_lib):
     with pytest.raises(AssertionError):
         AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], ids, prob['Xmean'], prob['Xstd'], prob['B'], 'cpu',
                             lib=emu_lib)
+
+
+@pytest.mark.timeout(900)
+def test_concurrent_clips_helper_equals_separate_runs(emu_lib):
+    """lemo_amd.sharding.ConcurrentClips on the emulator (no streams there: the clips run one after the other): every clip
+    ends exactly where a run on its own ends"""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.sharding import ConcurrentClips
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    mk = lambda: AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                                     prob['B'], 'cpu', full_vertices=True, lib=emu_lib)
+    fits = [mk(), mk()]
+    inits = [prob['seq']['init_params'], prob['seq']['init_params'] * np.float32(0.9)]
+    for f, ip in zip(fits, inits):
+        f.load_sequence(ip, markers, prob['seq']['contact_lbl'])
+    cc = ConcurrentClips(fits)
+    cc.prepare(2)
+    cc.step(2, use_graph=False)
+    cc.synchronize()
+    got = cc.params72()
+    assert got.shape == (2, prob['B'], 72) and not torch.equal(got[0], got[1])
+    solo = mk()
+    for i, ip in enumerate(inits):
+        solo.load_sequence(ip, markers, prob['seq']['contact_lbl'])
+        solo.step(2, use_graph=False)
+        assert torch.equal(solo.params72(), got[i])

@@ -407,3 +407,80 @@ def test_prox_engine_baseline_size(dev, stage):
     dt = time.time() - t0
     print(f'PROX engine {stage} window B=100 V=10475: {n / dt:.1f} iterations/s ({dt / n * 1e3:.3f} ms/iteration), total {l0:.2f} -> {e1.loss_dict()["total_loss"]:.2f}')
     assert n / dt > 800
+
+
+def test_concurrent_clips_bit_identical_to_solo_runs(dev):
+    """three BASELINE-size clips fitted side by side (lemo_amd.sharding.ConcurrentClips: one engine + stream each, graphs
+    replayed concurrently) end bit-identically to each clip fitted on its own -- the kernels are deterministic and share
+    nothing but read-only model constants"""
+    import bench
+    from lemo_amd.sharding import ConcurrentClips
+    fits, probs = [], []
+    for i in range(3):
+        f, p = bench.build_problem(i, 119, dev, full_vertices=True, conv_variant=3)
+        fits.append(f); probs.append(p)
+    solo = []
+    s = torch.cuda.Stream(dev)
+    for f, p in zip(fits, probs):
+        f.load_sequence(p['seq']['init_params'], p['markers'], p['seq']['contact_lbl'])
+        with torch.cuda.stream(s):
+            f.step(25)
+        s.synchronize()
+        solo.append((f.params72().clone(), f.params75().clone(), f.losses()['total']))
+    for f, p in zip(fits, probs):
+        f.load_sequence(p['seq']['init_params'], p['markers'], p['seq']['contact_lbl'])
+    cc = ConcurrentClips(fits)
+    cc.prepare(25)
+    cc.step(25)
+    cc.synchronize()
+    got = cc.params72()
+    for i, f in enumerate(fits):
+        assert torch.equal(got[i], solo[i][0]) and torch.equal(f.params75(), solo[i][1]), i
+        assert f.losses()['total'] == solo[i][2] and f.nonfinite_step() == 0
+    assert not torch.equal(got[0], got[1])
+
+
+def test_two_prox_windows_chained_on_the_device(dev, tmp_path):
+    """N3 on the GPU: a 17-frame recording, batch 10 -> windows (0,10) and (7,17) (fit_temp_loadprox_slide.py's schedule);
+    each window is fitted by the native PROX engine with graph replay (30 iterations), initialised from the newest
+    pickles; window 2 starts from window 1's results on the 3-frame overlap, its frozen first frame (int(0.15 * 10) = 1)
+    does not move, and the overlap's pickles end up holding window 2's values"""
+    import __graft_entry__ as ge
+    from lemo_amd import prox_windows as PW
+    from lemo_amd.prox import ENGINE_PARAMS
+    n, B = 17, 10
+    base = ge.prox_small_problem(B=n, stage='S2')
+    names = [f's001_frame_{i:05d}' for i in range(n)]
+    cur, prox = str(tmp_path / 'cur'), str(tmp_path / 'prox')
+    P0 = base['params']
+    body0 = {k: np.asarray(P0[k], np.float32) for k in ('transl', 'global_orient', 'betas', 'left_hand_pose', 'right_hand_pose', 'jaw_pose',
+                                                       'leye_pose', 'reye_pose', 'expression')}
+    for i, fn in enumerate(names):
+        PW.write_result_pkl(PW.result_path(prox, fn), {}, body0, np.asarray(P0['pose_embedding'], np.float32), np.zeros((n, 63), np.float32), i)
+    seen = []
+    stream = torch.cuda.Stream(dev)
+
+    def fit_window(fns, init, first, n_frozen):
+        s = names.index(fns[0])
+        prob = dict(base, B=len(fns), params=init, gt_joints=base['gt_joints'][s:s + len(fns)], joints_conf=base['joints_conf'][s:s + len(fns)])
+        eng, bm = ge.prox_engine_for(prob, dev, first_batch_flag=first)
+        before = {k: eng.P[k].clone() for k, _ in ENGINE_PARAMS}
+        l0 = eng.closure()['total_loss']
+        with torch.cuda.stream(stream):
+            eng.step(30, use_graph=True)
+        stream.synchronize()
+        assert eng.nonfinite_step() == 0 and eng.loss_dict()['total_loss'] < l0
+        seen.append((s, first, n_frozen, before, {k: eng.P[k].clone() for k, _ in ENGINE_PARAMS}))
+        body = {k: eng.P[k].cpu().numpy() for k, _ in ENGINE_PARAMS[:-1]}
+        body['betas'] = np.asarray(init['betas'], np.float32)
+        return {}, body, eng.P['pose_embedding'].cpu().numpy(), np.zeros((len(fns), 63), np.float32)
+
+    assert PW.run_recording(names, B, cur, prox, fit_window) == 2
+    (s0, f0, z0, b0, a0), (s1, f1, z1, b1, a1) = seen
+    assert (s0, f0, z0) == (0, True, 0) and (s1, f1, z1) == (7, False, 1)
+    for k, _ in ENGINE_PARAMS:
+        assert torch.equal(b1[k][:3], a0[k][7:10]), k
+        assert torch.equal(a1[k][:1], b1[k][:1]), k
+    assert not torch.equal(a1['transl'][1:], b1['transl'][1:]) and not torch.equal(a0['transl'], b0['transl'])
+    assert np.array_equal(PW.read_prox_pkl(PW.result_path(cur, names[8]))['transl'], a1['transl'][1].cpu().numpy())
+    assert np.array_equal(PW.read_prox_pkl(PW.result_path(cur, names[3]))['transl'], a0['transl'][3].cpu().numpy())

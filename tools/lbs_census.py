@@ -21,3 +21,16 @@ d = dbg.cpu().numpy().reshape(nblk, 8, 4)
 t0, tp, tg, t1 = d[..., 0], d[..., 1], d[..., 2], d[..., 3]
 print('blocks', nblk, 'median cycles: prologue %d  gemm %d  handover+skinning %d  total %d (max %d)' % (
     np.median(tp - t0), np.median(tg - tp), np.median(t1 - tg), np.median(t1 - t0), (t1 - t0).max()))
+# wall time of the product kernel (no census stamps), HIP events around 20 launches
+def run():
+    lib.check(lib.lbs_verts_fwd(C.byref(db.skin), ptr(tt['Xg']), Bp, ptr(tt['A']), data.nj, None, None, data.V, B, ptr(verts), ptr(vp), s))
+for _ in range(5): run()
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) * 1e3 / 20)
+print('lbs_verts_fwd (product kernel): %.2f us per launch (best of 5 x 20 back-to-back launches)' % best)
