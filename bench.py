@@ -348,7 +348,7 @@ def main():
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',
                      'peak_note': peak_note,
-                     'kernel': kname + ' 64->64ch 245x134, 14 of the 33 launches/iteration',
+                     'kernel': kname + ' 64->64ch 245x134, 14 of the 31 launches/iteration',
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops},
     }
     if vs is not None:
@@ -362,7 +362,7 @@ def main():
     if per_rank is not None:
         out['per_rank_iterations_per_s'] = per_rank
     if rank == 0 and world == 1 and args.concurrent_clips > 1 and use_graph and not args.active_vertices_only:
-        out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, args.steps, args.conv_variant)
+        out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, max(args.steps, 100), args.conv_variant)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(prob, B)
         out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

@@ -119,6 +119,29 @@ int loss_finalize(const double* acc, int B, int n67, double smooth_count, const 
 int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
                     const float* dx0, const float* canon, const float* weights, const double* acc, double smooth_count,
                     float* losses, int B, float* dverts, hipStream_t s);
+// arguments of fit_tail_kernel (loss_kernels.hip): last VPoser-backward layer + Adam + first VPoser-forward layer of the
+// next iteration, one workgroup per frame
+struct FitTail {
+  const float *w1, *w1t, *b1;      // bodyprior_dec_fc1 [512][32], its transpose [32][512], bias
+  const float* dh1;                // [B][512]
+  float* g_other;                  // [B][56]: dz goes to columns 0..31
+  float* h1;                       // [B][512] out (nullptr: no forward layer)
+  float *transl, *rot6d, *other;
+  const float *g_transl, *g_rot6d;
+  float *m0, *v0, *m1, *v1, *m2, *v2;
+  const float* weights;
+  int* step_ctr;
+  const int* step_cur;
+  float lr0, lr1;
+  int lr_switch;
+  float lr2;
+  int lr_switch2;
+  float* snap;
+  int* nonfinite;
+  const float* losses;
+  int B, do_dz, do_adam;
+};
+int fit_tail(const FitTail& a, hipStream_t s);
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
               int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s, float lr2 = 0.f,

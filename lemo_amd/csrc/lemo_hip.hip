@@ -226,13 +226,13 @@ struct FitEngine {
   int head = 5;     // replays of the 1-iteration graph that open a call (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
 };
 
-static int fit_iteration(const lemo_fit_desc& d, hipStream_t s);
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last);
 
 static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s);
+  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s, i == 0, i == iters - 1);
   const int ec = (int)hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   CHK(ec);
@@ -269,13 +269,30 @@ static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
   return 0;
 }
 
-static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
+// arguments of the fused tail launch (kernels.hpp FitTail) from the descriptor
+static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1) {
+  FitTail a{};
+  a.w1 = d.vposer.w1; a.w1t = d.vposer.w1t; a.b1 = d.vposer.b1;
+  a.dh1 = d.vp_scratch + (size_t)d.B * 128 + (size_t)d.B * 512;       // vposer_mlp_bwd's layout: dout | dh2 | dh1
+  a.g_other = d.g_other; a.h1 = h1 ? d.h1 : nullptr;
+  a.transl = d.transl; a.rot6d = d.rot6d; a.other = d.other; a.g_transl = d.g_transl; a.g_rot6d = d.g_rot6d;
+  a.m0 = d.adam_m[0]; a.v0 = d.adam_v[0]; a.m1 = d.adam_m[1]; a.v1 = d.adam_v[1]; a.m2 = d.adam_m[2]; a.v2 = d.adam_v[2];
+  a.weights = d.weights; a.step_ctr = d.step_ctr; a.step_cur = d.step_cur;
+  a.lr0 = d.lr0; a.lr1 = d.lr1; a.lr_switch = d.lr_switch; a.lr2 = d.lr2; a.lr_switch2 = d.lr_switch2;
+  a.snap = d.snap; a.nonfinite = d.nonfinite; a.losses = d.losses;
+  a.B = d.B; a.do_dz = dz; a.do_adam = adam;
+  return a;
+}
+
+// compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
+// a run of iterations the previous iteration's tail launch has already produced it from the updated latent
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   // VPoser MLP (3 MFMA GEMMs); its rotation head and the 6-D -> axis-angle conversion of the global
   // orientation are fused into the pose-stage kernel, which also zeroes the loss accumulators and
   // latches the step counter for this iteration.
-  CHK(gemm_nt16(d.vposer.w1, 32, d.other, 56, 512, B, 32, d.h1, 512, d.vposer.b1, nullptr, 0, 1, s));
+  if (compute_h1) CHK(fit_tail(fit_tail_args(d, false, false, true), s));
   CHK(gemm_nt16(d.vposer.w2, 512, d.h1, 512, 512, B, 512, d.h2, 512, d.vposer.b2, nullptr, 0, 1, s));
   CHK(gemm_nt16(d.vposer.w3, 512, d.h2, 512, 128, B, 512, d.vo, 128, d.vposer.b3, nullptr, 0, 2, s));
   lemo_pose_in in{};
@@ -325,7 +342,9 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize) {
   return 0;
 }
 
-static int fit_backward(const lemo_fit_desc& d, hipStream_t s) {
+// update = false: gradients only (lemo_fit_backward).  update = true: the tail launch also runs Adam and, with next_h1,
+// the first VPoser layer of the next iteration.
+static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
@@ -370,16 +389,15 @@ vertex_stage:
   go.rot6d = d.rot6d; go.d_rot6d = d.g_rot6d;            // d(global_orient) -> d(rot6d), fused
   go.vposer_o = d.vo; go.d_vposer_o = d.vp_scratch;      // d(body_pose) -> d(VPoser out layer), fused
   CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
-  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, d.g_other, 56, d.vp_scratch, s));
+  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, nullptr, 56, d.vp_scratch, s));      // dh2, dh1; the last layer is in the tail
+  CHK(fit_tail(fit_tail_args(d, true, update, update && next_h1), s));
   return 0;
 }
 
-static int fit_iteration(const lemo_fit_desc& d, hipStream_t s) {
-  CHK(fit_forward(d, s, false));
-  CHK(fit_backward(d, s));
-  CHK(adam_step(d.transl, d.g_transl, d.adam_m[0], d.adam_v[0], d.rot6d, d.g_rot6d, d.adam_m[1], d.adam_v[1], d.other,
-                d.g_other, d.adam_m[2], d.adam_v[2], d.B, d.weights, d.step_ctr, d.step_cur, d.lr0, d.lr1, d.lr_switch, s,
-                d.lr2, d.lr_switch2, d.snap, d.nonfinite, d.losses));
+// first / last: position inside the run of iterations issued together (one graph, or one eager call)
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last) {
+  CHK(fit_forward(d, s, false, first));
+  CHK(fit_backward(d, s, true, !last));
   return 0;
 }
 
@@ -418,7 +436,7 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
   if (!e || n < 0) return LEMO_ERR_ARG;
   hipStream_t s = S(stream);
   if (!use_graph) {
-    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s));
+    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s, i == 0, i == n - 1));
     return 0;
   }
   CHK(fit_graphs(e, s, n, false));

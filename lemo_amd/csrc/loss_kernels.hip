@@ -267,6 +267,29 @@ int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const flo
 // state[0] = step counter (as float bits of an int), incremented here.
 // lr = step > lr_switch ? lr1 : lr0   with step counted from 0 (opt_amass_temp.py:349-352).
 struct AdamGroup { float* p; const float* g; float* m; float* v; int n; };
+// gradient of the L2 priors on "other" = [z 32 | hands 24] (opt_amass_temp.py:397-404)
+__device__ __forceinline__ float adam_prior_grad(int col, float pv, const float* __restrict__ weights, int B) {
+  return col < 32 ? weights[1] * 2.f * pv / ((float)B * 32.f) : weights[3] * 2.f * pv / ((float)B * 24.f);
+}
+// one element of torch.optim.Adam (shared by adam_kernel and fit_tail_kernel: the same arithmetic, bit for bit)
+// step-dependent scalars of one Adam update: step size lr / (1 - beta1^t) and sqrt(1 - beta2^t)
+struct AdamCoef { float lr_bc1, bc2s; };
+__device__ __forceinline__ AdamCoef adam_coef(int step, float lr0, float lr1, int lr_switch, float lr2, int lr_switch2) {
+  const float lr = (lr_switch2 > 0 && step > lr_switch2) ? lr2 : (step > lr_switch ? lr1 : lr0);
+  const double t1 = (double)(step + 1);
+  const float bc1 = (float)(1.0 - pow(0.9, t1));
+  AdamCoef c;
+  c.bc2s = (float)sqrt(1.0 - pow(0.999, t1));
+  c.lr_bc1 = lr / bc1;
+  return c;
+}
+__device__ __forceinline__ void adam_update_one(float* p, float* mp, float* vp, float grad, AdamCoef c) {
+  const float m = *mp + (grad - *mp) * (1.f - 0.9f);               // lerp_
+  const float v = *vp * 0.999f + (1.f - 0.999f) * grad * grad;
+  *mp = m; *vp = v;
+  const float denom = sqrtf(v) / c.bc2s + 1e-8f;
+  *p = *p - c.lr_bc1 * (m / denom);
+}
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __restrict__ weights, int* __restrict__ step_ctr,
             const int* __restrict__ step_cur, float lr0, float lr1, int lr_switch, float lr2, int lr_switch2,
@@ -298,18 +321,9 @@ adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __rest
     float grad = G.g[k];
     if (G.p == g2.p) {                       // "other" = [z 32 | hands 24]: L2 priors (opt_amass_temp.py:397-404)
       const int col = k % 56;
-      const float pv = G.p[k];
-      grad += col < 32 ? weights[1] * 2.f * pv / ((float)B * 32.f) : weights[3] * 2.f * pv / ((float)B * 24.f);
+      grad += adam_prior_grad(col, G.p[k], weights, B);
     }
-    const float lr = (lr_switch2 > 0 && step > lr_switch2) ? lr2 : (step > lr_switch ? lr1 : lr0);
-    const double t1 = (double)(step + 1);
-    const float bc1 = (float)(1.0 - pow(0.9, t1));
-    const float bc2s = (float)sqrt(1.0 - pow(0.999, t1));
-    const float m = G.m[k] + (grad - G.m[k]) * (1.f - 0.9f);           // lerp_
-    const float v = G.v[k] * 0.999f + (1.f - 0.999f) * grad * grad;
-    G.m[k] = m; G.v[k] = v;
-    const float denom = sqrtf(v) / bc2s + 1e-8f;
-    G.p[k] = G.p[k] - (lr / bc1) * (m / denom);
+    adam_update_one(G.p + k, G.m + k, G.v + k, grad, adam_coef(step, lr0, lr1, lr_switch, lr2, lr_switch2));
   }
 }
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,
@@ -321,6 +335,128 @@ int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float*
   if (nonfinite && !losses) return LEMO_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr0, lr1, lr_switch,
                      lr2, lr_switch2, snap, nonfinite, losses);
+  return (int)hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Tail of one fitting iteration, one workgroup per frame (three launches -> one):
+//   dz   = dh1 . W1                 the last layer of the VPoser decoder backward (vposer_smpl.py:107-115 transposed)
+//   Adam on this frame's 65 parameters (adam_kernel above: same arithmetic, same snapshot / latch / counter protocol)
+//   h1'  = lrelu(W1 z' + b1)        the FIRST layer of the NEXT iteration's decoder forward, on the updated latent
+// Plain fp32 FMAs in a fixed order (K = 512 and K = 32 dot products of one frame: nothing for the matrix cores to do);
+// the stand-alone first-layer launch that opens a graph runs this same kernel with do_dz = do_adam = 0, so h1 has the
+// same bits whichever launch produced it (graph replay == eager launches).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fit_tail_kernel(FitTail a) {
+  __shared__ __attribute__((aligned(16))) float dh[512];
+  __shared__ float zs[32], dzs[32];
+  const int b = blockIdx.x, t = threadIdx.x, B = a.B;
+  // ---- every global read of the kernel is issued here, before the first barrier, with clamped (never predicated)
+  // addresses: the phases below depend on each other and would otherwise each begin with an exposed L2 round trip
+  // (pose_kernels.hip has the measurements behind this rule).  Launch-uniform switches only select whether a value is used.
+  const int m_dz = t >> 3, part = t & 7;
+  float dh_a = 0.f, dh_b = 0.f;
+  float4 wv[16];
+  if (a.do_dz) {
+    dh_a = a.dh1[(size_t)b * 512 + t];
+    dh_b = a.dh1[(size_t)b * 512 + t + 256];
+    const float* wr = a.w1t + (size_t)m_dz * 512 + 4 * part;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wv[i] = ld4(wr + 32 * i);
+  }
+  float4 w8[2][8];
+  float bias[2] = {0.f, 0.f};
+  if (a.h1) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float* wr = a.w1 + (size_t)(t + 256 * r) * 32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w8[r][i] = ld4(wr + 4 * i);
+      bias[r] = a.b1[t + 256 * r];
+    }
+  }
+  // this thread's parameter (threads >= 65 shadow element 64: same addresses, nothing stored)
+  const int te = t < 65 ? t : 64;
+  float *p, *mp, *vp;
+  const float* gp;
+  int flat, col = -1;
+  if (te < 3) { const int k = b * 3 + te; p = a.transl + k; mp = a.m0 + k; vp = a.v0 + k; gp = a.g_transl + k; flat = k; }
+  else if (te < 9) { const int k = b * 6 + (te - 3); p = a.rot6d + k; mp = a.m1 + k; vp = a.v1 + k; gp = a.g_rot6d + k; flat = 3 * B + k; }
+  else { col = te - 9; const int k = b * 56 + col; p = a.other + k; mp = a.m2 + k; vp = a.v2 + k; gp = a.g_other + k; flat = 9 * B + k; }
+  float p_old = *p, m_old = 0.f, v_old = 0.f, g_in = 0.f, w_v = 0.f, w_h = 0.f, tot = 0.f;
+  int step = 0, nf0 = 0, nf1 = 0;
+  if (a.do_adam) {
+    m_old = *mp; v_old = *vp; g_in = *gp;                         // (columns 0..31 of g_other are replaced by dz below)
+    w_v = a.weights[1]; w_h = a.weights[3];
+    step = *a.step_cur;
+    if (a.nonfinite) { nf0 = a.nonfinite[0]; nf1 = a.nonfinite[1]; tot = a.losses[6]; }
+  }
+  // the two double-precision pow() of the bias corrections depend on the (scalar-loaded) step only: they run here, in the
+  // shadow of the vector loads above
+  AdamCoef coef{0.f, 1.f};
+  if (a.do_adam) coef = adam_coef(step, a.lr0, a.lr1, a.lr_switch, a.lr2, a.lr_switch2);
+  LEMO_PIN(p_old); LEMO_PIN(m_old); LEMO_PIN(v_old); LEMO_PIN(g_in); LEMO_PIN(w_v); LEMO_PIN(w_h); LEMO_PIN(tot);
+  LEMO_PIN(bias[0]); LEMO_PIN(bias[1]);
+  if (a.do_dz) {
+    // ---- dz[m] = sum_k w1t[m][k] dh1[b][k] : thread = (m = t >> 3, part = t & 7) takes k = 4 part + 32 i .. + 3
+    dh[t] = dh_a;
+    dh[t + 256] = dh_b;
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 d4 = ld4(&dh[4 * part + 32 * i]);
+      acc = fmaf(wv[i].x, d4.x, acc); acc = fmaf(wv[i].y, d4.y, acc); acc = fmaf(wv[i].z, d4.z, acc); acc = fmaf(wv[i].w, d4.w, acc);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (part == 0) { a.g_other[(size_t)b * 56 + m_dz] = acc; dzs[m_dz] = acc; }
+  }
+  __syncthreads();                              // dz of this frame is in dzs
+  float p_new = p_old;
+  if (a.do_adam) {
+    if (b == 0 && t == 0) {
+      *a.step_ctr = step + 1;
+      // non-finite total loss: record the first offending iteration; updates stop from the NEXT iteration on (the
+      // pose-stage kernel latches nonfinite[0] into nonfinite[1] at the start of every iteration)
+      if (a.nonfinite && nf0 == 0 && !(fabsf(tot) <= 3.402823466e38f)) a.nonfinite[0] = step + 1;
+    }
+    if (t < 65) {
+      float grad = g_in;
+      if (col >= 0) {
+        if (a.do_dz && col < 32) grad = dzs[col];
+        grad += col < 32 ? w_v * 2.f * p_old / ((float)B * 32.f) : w_h * 2.f * p_old / ((float)B * 24.f);
+      }
+      if (a.snap) a.snap[flat] = p_old;
+      if (nf1 == 0) {
+        float mm = m_old, vv = v_old;
+        adam_update_one(&p_new, &mm, &vv, grad, coef);
+        *p = p_new; *mp = mm; *vp = vv;
+      }
+    }
+  }
+  if (!a.h1) return;
+  if (t >= 9 && t < 41) zs[t - 9] = p_new;      // the latent of this frame, as updated above
+  __syncthreads();
+  // ---- h1[m] = lrelu(b1[m] + sum_k w1[m][k] z[k]) : thread t takes rows t and t + 256
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float acc = bias[r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc = fmaf(w8[r][i].x, zs[4 * i], acc); acc = fmaf(w8[r][i].y, zs[4 * i + 1], acc);
+      acc = fmaf(w8[r][i].z, zs[4 * i + 2], acc); acc = fmaf(w8[r][i].w, zs[4 * i + 3], acc);
+    }
+    a.h1[(size_t)b * 512 + t + 256 * r] = lrelu(acc);
+  }
+}
+int fit_tail(const FitTail& a, hipStream_t s) {
+  if (a.B <= 0 || (a.do_dz && (!a.dh1 || !a.g_other || !a.w1t)) || (a.h1 && (!a.w1 || !a.b1 || !a.other))) return LEMO_ERR_ARG;
+  if (a.do_adam && (!a.step_ctr || !a.step_cur || (a.nonfinite && !a.losses))) return LEMO_ERR_ARG;
+  hipLaunchKernelGGL(fit_tail_kernel, dim3(a.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -96,6 +96,7 @@ int vposer_mlp_bwd(const VPoserW& w, const float* h1, const float* h2, int B, fl
   int e;
   if ((e = gemm_nt16(w.w3t, 128, dout, 128, VP_H, B, 128, dh2, VP_H, nullptr, h2, VP_H, 3, s))) return e;
   if ((e = gemm_nt16(w.w2t, VP_H, dh2, VP_H, VP_H, B, VP_H, dh1, VP_H, nullptr, h1, VP_H, 3, s))) return e;
+  if (!dz) return 0;                     // the fitting engine computes the last layer in its fused tail launch (fit_tail)
   return gemm_nt16(w.w1t, VP_H, dh1, VP_H, VP_Z, B, VP_H, dz, dz_stride, nullptr, nullptr, 0, 0, s);
 }
 

@@ -56,7 +56,7 @@ class ConcurrentClips:
     """Several independent clips fitted SIDE BY SIDE on one GPU: one :class:`~lemo_amd.fitting.AmassTemporalFitter` and
     one stream per clip, all replaying their graphs at the same time.
 
-    One clip's iteration is a chain of 33 dependent kernels; a quarter of it is kernel-boundary latency and its per-frame
+    One clip's iteration is a chain of 31 dependent kernels; a quarter of it is kernel-boundary latency and its per-frame
     kernels (119 workgroups) leave half of the 256 CUs idle.  Clips carry no state between each other
     (``opt_amass_temp.py:251``), so a second and third clip fill those holes: measured 2616 -> 3139 (2 clips) -> 3340
     (3 clips) fitting-iterations/s in aggregate on one MI355X, every clip bit-identical to a run on its own

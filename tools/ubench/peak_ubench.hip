@@ -4,6 +4,7 @@
 //   (2) HBM stream: read-only sum, write-only fill and copy of 1 GiB (sheet: ~8 TB/s)
 // hipcc --offload-arch=gfx950 -O3 peak_ubench.hip -o peak_ubench
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,21 +59,25 @@ int main() {
   hipDeviceProp_t pr; (void)hipGetDeviceProperties(&pr, 0);
   const int cus = pr.multiProcessorCount;
   printf("%s: %d CUs, clock %d MHz (sheet)\n", pr.name, cus, pr.clockRate / 1000);
-  {
-    const int threads = 512, blocks = cus, n = 4096;             // 4096 * 8 * 4 = 131072 MFMAs per wave: ~2 ms
-    float* out; unsigned long long* cyc;
-    (void)hipMalloc(&out, sizeof(float) * threads * blocks); (void)hipMalloc(&cyc, 8 * (threads / 64) * blocks);
-    for (int rep = 0; rep < 3; ++rep) {
-      const float ms = time_ms([&] { mfma_k<4><<<blocks, threads>>>(out, cyc, n); }, 5);
-      std::vector<unsigned long long> h((threads / 64) * blocks);
-      (void)hipMemcpy(h.data(), cyc, 8 * h.size(), hipMemcpyDeviceToHost);
-      double mean = 0; for (auto v : h) mean += v; mean /= h.size();
-      const double nm = (double)n * 8 * 4, flop = nm * 32768.0 * h.size();
-      printf("bf16 MFMA 32x32x16, %d CUs x 2 waves/SIMD x 4 accumulators: %.1f cycles per MFMA per SIMD, %.2f ms, %.0f TFLOP/s sustained, clock ~%.2f GHz\n",
-             cus, mean / nm / 2.0, ms, flop / (ms * 1e-3) / 1e12, mean / (ms * 1e-3) / 1e9);
-    }
-    (void)hipFree(out); (void)hipFree(cyc);
+  // NACC independent accumulator chains per wave x waves per SIMD: how many chains the pipe needs to stay full
+  // (the split convolution runs 2 waves x 2 accumulators per SIMD)
+#define RUN(NACC, THREADS)                                                                                          \
+  {                                                                                                                 \
+    const int threads = THREADS, blocks = cus, n = 16384 / NACC;                                                    \
+    float* out; unsigned long long* cyc;                                                                            \
+    (void)hipMalloc(&out, sizeof(float) * threads * blocks); (void)hipMalloc(&cyc, 8 * (threads / 64) * blocks);    \
+    float ms = 1e9f;                                                                                                \
+    for (int rep = 0; rep < 3; ++rep) ms = fminf(ms, time_ms([&] { mfma_k<NACC><<<blocks, threads>>>(out, cyc, n); }, 5)); \
+    std::vector<unsigned long long> h((threads / 64) * blocks);                                                     \
+    (void)hipMemcpy(h.data(), cyc, 8 * h.size(), hipMemcpyDeviceToHost);                                            \
+    double mean = 0; for (auto v : h) mean += v; mean /= h.size();                                                  \
+    const double nm = (double)n * 8 * NACC, flop = nm * 32768.0 * h.size();                                         \
+    printf("bf16 MFMA 32x32x16: %d wave(s)/SIMD x %d accumulator chain(s): %5.1f s_memtime ticks per MFMA per SIMD, %.2f ms, %4.0f TFLOP/s sustained\n", \
+           threads / 256, NACC, mean / nm / (threads / 256), ms, flop / (ms * 1e-3) / 1e12);                        \
+    (void)hipFree(out); (void)hipFree(cyc);                                                                         \
   }
+  RUN(4, 512) RUN(2, 512) RUN(1, 512) RUN(4, 256) RUN(2, 256) RUN(1, 256)
+  printf("(sheet: 32 shader cycles per MFMA per SIMD = 2516 TFLOP/s at 2.4 GHz; ticks/MFMA x TFLOP/s tells the s_memtime rate)\n");
   {
     const size_t bytes = (size_t)1 << 30, n4 = bytes / 16;
     float4 *a, *b; float* o;
