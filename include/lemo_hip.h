@@ -227,6 +227,19 @@ int lemo_stuff2_bwd(const float* dout, int H, int W, const float* act, float* di
 int lemo_conv3x3_wgrad_nslab(int H, int W);
 int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
                        float* partial, float* dw, float* db, void* stream);
+/* the same in two stages for a whole network: slab partials per layer (any stream), then ONE launch that reduces the partials
+   of up to LEMO_WGRAD_MAX_JOBS layers (same summation order as lemo_conv3x3_wgrad: identical bits).  models/AE.py:36-108 has
+   20 convolutions; the per-layer reduce launches were 0.25 ms of its 2 ms training step. */
+#define LEMO_WGRAD_MAX_JOBS 24
+typedef struct lemo_wgrad_job {
+  const float* partial;     /* [nslab][9][cout][cin] written by lemo_conv3x3_wgrad_partial */
+  const float* dy;          /* CG8P, cout channels (bias gradient) */
+  float* dw;                /* [cout_real][cin_real][3][3] */
+  float* db;                /* [cout_real] or NULL */
+  int nslab, cin, cout, cin_real, cout_real, H, W;
+} lemo_wgrad_job;
+int lemo_conv3x3_wgrad_partial(const float* dy, const float* x, int H, int W, int cin, int cout, float* partial, void* stream);
+int lemo_conv3x3_wgrad_reduce_multi(const lemo_wgrad_job* jobs, int n, void* stream);
 /* torch.optim.Adam (defaults) over a flat buffer; step is 1-based */
 int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream);
 /* same with the step count on the device (step_ctr[0] = completed steps; advanced by one after the update), so that a

@@ -54,6 +54,14 @@ class PoseGradOut(C.Structure):
          ('rot6d', vp), ('d_rot6d', vp), ('vposer_o', vp), ('d_vposer_o', vp)]
 
 
+WGRAD_MAX_JOBS = 24
+
+
+class WgradJob(C.Structure):
+    _fields_ = [('partial', vp), ('dy', vp), ('dw', vp), ('db', vp), ('nslab', C.c_int), ('cin', C.c_int), ('cout', C.c_int),
+                ('cin_real', C.c_int), ('cout_real', C.c_int), ('H', C.c_int), ('W', C.c_int)]
+
+
 class SkinConst(C.Structure):
     _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int), ('blend_fp32', C.c_int)] + \
         [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val')]
@@ -197,6 +205,8 @@ _SIGS = {
     'lemo_stuff2_bwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_wgrad_nslab': (C.c_int, [C.c_int, C.c_int]),
     'lemo_conv3x3_wgrad': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    'lemo_conv3x3_wgrad_partial': (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'lemo_conv3x3_wgrad_reduce_multi': (C.c_int, [C.POINTER(WgradJob), C.c_int, vp]),
     'lemo_adam_flat': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
     'lemo_adam_flat_ctr': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, vp, vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),

@@ -146,10 +146,12 @@ int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, in
 
 // ---- weight gradient of a 3x3 / stride-1 / pad-1 convolution on the matrix cores --------------------------
 //   dW[co][ci][tap] = sum_p dY[co][p] * X[ci][p + tap]      (X zero-padded: CG8P border)
-// GEMM per tap: M = co (A = dY), N = ci (B = X shifted), K = pixels.  One wave = one 32(co) x 32(ci) tile
-// of one tap over a slab of pixels; v_mfma_f32_32x32x2_f32 consumes 2 pixels per step (lane half = pixel
-// parity), 8 steps in flight.  Slabs write partial tiles; a second kernel reduces them in a fixed order
-// (deterministic) and also produces the bias gradient sum_p dY[co][p].
+// GEMM per tap: M = co (A = dY), N = ci (B = X shifted), K = pixels.  One workgroup = one 32(co) x 32(ci) tile
+// of one tap over a slab of 512 pixels, its four waves a quarter of the slab each (summed through LDS in wave order);
+// v_mfma_f32_32x32x2_f32 consumes 2 pixels per step (lane half = pixel parity), 8 steps in flight.  Slabs write partial
+// tiles; a second kernel reduces them in a fixed order (deterministic) and also produces the bias gradient sum_p dY[co][p].
+// (One wave per tile over the whole slab -- round 1 -- left the 20 launches of an AE step at 126-144 workgroups of a
+// 256-MFMA dependent chain each: 29 us per launch, 0.59 of the step's 1.7 ms, on two waves per CU.)
 #define WG_SLAB 512               // pixels per slab
 __global__ void __launch_bounds__(256)
 conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int H, int W, unsigned wmagic, int cin, int cout,
@@ -158,9 +160,8 @@ conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
   const int i = lane & 31, kk = lane >> 5;
   const int Wp = W + 2, HWp = (H + 2) * Wp, P = H * W;
   const int cot = cout >> 5, cit = (cin + 31) >> 5;
-  int tile = blockIdx.x * 4 + wave;                                // (slab, tap, co tile, ci tile)
-  const int ntile = nslab * 9 * cot * cit;
-  if (tile >= ntile) return;
+  __shared__ float red[3][16][64];
+  int tile = blockIdx.x;                                           // (slab, tap, co tile, ci tile); grid = their count
   const int ct = tile % cit; tile /= cit;
   const int mt = tile % cot; tile /= cot;
   const int tap = tile % 9, slab = tile / 9;
@@ -174,7 +175,8 @@ conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int p0 = slab * WG_SLAB, p1 = (p0 + WG_SLAB < P) ? p0 + WG_SLAB : P;
+  const int q0 = slab * WG_SLAB + wave * (WG_SLAB / 4);            // this wave's quarter (empty past the image end)
+  const int p0 = q0 < P ? q0 : P, p1 = (q0 + WG_SLAB / 4 < P) ? q0 + WG_SLAB / 4 : P;
   // operands of step pb + 16 are requested before the 8 MFMAs of step pb (two register sets): without the prefetch
   // every step exposed a full memory round trip of 16 strided dword loads (72 us per launch, 40 % of the AE step)
   float a[2][8], b[2][8];
@@ -207,6 +209,16 @@ conv3x3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, 
   }
 #undef WG_LOAD
 #undef WG_MFMA
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
   // D: col = lane&31 -> ci (B index), rows -> co (A index)
   float* out = partial + (((size_t)slab * 9 + tap) * cout) * cin;
   if (ci_ok) {
@@ -247,6 +259,66 @@ conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, int nslab, int ci
 
 int conv3x3_wgrad_nslab(int H, int W) { return (H * W + WG_SLAB - 1) / WG_SLAB; }
 
+// All weight-gradient reductions of a training step in ONE launch (the AE has 20 layers: 20 reduce launches of ~12 us, most of
+// it launch latency, become one).  Same per-element arithmetic as conv3x3_wgrad_reduce_kernel (slab order), so the
+// gradients have the same bits.  jobs: by value in the kernel argument (<= LEMO_WGRAD_MAX_JOBS).
+struct WgradJobs { lemo_wgrad_job j[LEMO_WGRAD_MAX_JOBS]; int first_block[LEMO_WGRAD_MAX_JOBS + 1]; int n; };
+__global__ void __launch_bounds__(256)
+conv3x3_wgrad_reduce_multi_kernel(WgradJobs J) {
+  __shared__ float red[4];
+  int k = 0;
+  while (k + 1 < J.n && (int)blockIdx.x >= J.first_block[k + 1]) ++k;         // block -> job (uniform)
+  const lemo_wgrad_job& q = J.j[k];
+  const int blk = (int)blockIdx.x - J.first_block[k];
+  const int n = q.cout_real * q.cin_real * 9, nb = (n + 255) / 256;
+  if (blk < nb) {
+    const int t = blk * 256 + (int)threadIdx.x;
+    if (t < n) {
+      const int tap = t % 9, ci = (t / 9) % q.cin_real, co = t / (9 * q.cin_real);
+      float a = 0.f;
+      for (int s = 0; s < q.nslab; ++s) a += q.partial[(((size_t)s * 9 + tap) * q.cout + co) * q.cin + ci];
+      q.dw[t] = a;
+    }
+  } else if (q.db) {
+    const int co = blk - nb;
+    const int Wp = q.W + 2, HWp = (q.H + 2) * Wp, P = q.H * q.W;
+    float a = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const int y = p / q.W, xx = p - y * q.W;
+      a += q.dy[((size_t)(co >> 3) * HWp + (y + 1) * Wp + (xx + 1)) * 8 + (co & 7)];
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) q.db[co] = a;
+  }
+}
+
+int conv3x3_wgrad_partial(const float* dy, const float* x, int H, int W, int cin, int cout, float* partial, hipStream_t s) {
+  if (cin % 8 || cout % 32 || H < 1 || W < 1 || (long)H * W > (1l << 24)) return LEMO_ERR_SHAPE;
+  const int nslab = conv3x3_wgrad_nslab(H, W);
+  const unsigned wmagic = (unsigned)((1ull << 32) / (unsigned)W + 1);
+  const int ntile = nslab * 9 * (cout / 32) * ((cin + 31) / 32);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(ntile), dim3(256), 0, s, dy, x, H, W, wmagic, cin, cout, partial, nslab);
+  return (int)hipGetLastError();
+}
+
+int conv3x3_wgrad_reduce_multi(const lemo_wgrad_job* jobs, int n, hipStream_t s) {
+  if (!jobs || n < 1 || n > LEMO_WGRAD_MAX_JOBS) return LEMO_ERR_ARG;
+  WgradJobs J;
+  J.n = n;
+  int nb = 0;
+  for (int k = 0; k < n; ++k) {
+    const lemo_wgrad_job& q = jobs[k];
+    if (!q.partial || !q.dw || !q.dy || q.cin % 8 || q.cout % 32 || q.cin_real > q.cin || q.cout_real > q.cout || q.H < 1 || q.W < 1 ||
+        q.nslab != conv3x3_wgrad_nslab(q.H, q.W)) return LEMO_ERR_SHAPE;
+    J.j[k] = q;
+    J.first_block[k] = nb;
+    nb += (q.cout_real * q.cin_real * 9 + 255) / 256 + (q.db ? q.cout_real : 0);
+  }
+  J.first_block[n] = nb;
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_multi_kernel, dim3(nb), dim3(256), 0, s, J);
+  return (int)hipGetLastError();
+}
+
 // dy: CG8P with `cout` (multiple of 32) channels, x: CG8P with `cin` (multiple of 8) channels; dw [cout_real][cin_real][3][3]
 int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
                   float* partial, float* dw, float* db, hipStream_t s) {
@@ -254,7 +326,7 @@ int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int co
   const int nslab = conv3x3_wgrad_nslab(H, W);
   const unsigned wmagic = (unsigned)((1ull << 32) / (unsigned)W + 1);          // exact for p < 2^32 / W
   const int ntile = nslab * 9 * (cout / 32) * ((cin + 31) / 32);
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((ntile + 3) / 4), dim3(256), 0, s, dy, x, H, W, wmagic, cin, cout, partial, nslab);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(ntile), dim3(256), 0, s, dy, x, H, W, wmagic, cin, cout, partial, nslab);
   int e = (int)hipGetLastError();
   if (e) return e;
   const int n = cout_real * cin_real * 9;

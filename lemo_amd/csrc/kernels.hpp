@@ -98,6 +98,8 @@ int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act
 int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s);
 int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, hipStream_t s);
 int conv3x3_wgrad_nslab(int H, int W);
+int conv3x3_wgrad_partial(const float* dy, const float* x, int H, int W, int cin, int cout, float* partial, hipStream_t s);
+int conv3x3_wgrad_reduce_multi(const lemo_wgrad_job* jobs, int n, hipStream_t s);
 int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int cout, int cin_real, int cout_real,
                   float* partial, float* dw, float* db, hipStream_t s);
 int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, int* step_dev, hipStream_t s);

@@ -146,6 +146,13 @@ int lemo_conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, i
   if (!dy || !x || !partial || !dw) return LEMO_ERR_ARG;
   return conv3x3_wgrad(dy, x, H, W, cin, cout, cin_real, cout_real, partial, dw, db, S(stream));
 }
+int lemo_conv3x3_wgrad_partial(const float* dy, const float* x, int H, int W, int cin, int cout, float* partial, void* stream) {
+  if (!dy || !x || !partial) return LEMO_ERR_ARG;
+  return conv3x3_wgrad_partial(dy, x, H, W, cin, cout, partial, S(stream));
+}
+int lemo_conv3x3_wgrad_reduce_multi(const lemo_wgrad_job* jobs, int n, void* stream) {
+  return conv3x3_wgrad_reduce_multi(jobs, n, S(stream));
+}
 int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, void* stream) {
   if (!p || !g || !m || !v) return LEMO_ERR_ARG;
   return adam_flat(p, g, m, v, n, lr, step, nullptr, S(stream));

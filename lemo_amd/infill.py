@@ -265,7 +265,11 @@ class _AEFn(torch.autograd.Function):
         keep = []          # operands of side-stream launches stay referenced until the join: a tensor released earlier goes
                            # back to the caching allocator, which may hand it to the next main-stream op while it is still read
 
+        jobs = (_hip.WgradJob * len(L))()
+        njobs = [0]
+
         def wgrad(i, dpre, xin, h, w):
+            """slab partials of layer i now (second stream when there is one); all 20 reductions in ONE launch at the end"""
             l = L[i]
             npart = nsl(h, w) * 9 * l.cout_pad * l.cin_pad
             part = ctx.ws.flat(npart) if ctx.ws is not None else torch.empty(npart, dtype=torch.float32, device=dev)
@@ -274,9 +278,12 @@ class _AEFn(torch.autograd.Function):
             if side is not None:
                 side.wait_stream(main)                     # dpre was just produced on the main stream
                 sw = side.cuda_stream
-                keep.extend((dpre, xin))
-            lib.check(lib.conv3x3_wgrad(ptr(dpre), ptr(xin), h, w, l.cin_pad, l.cout_pad, l.cin, l.cout, ptr(part), ptr(dw),
-                                        ptr(db), sw), 'conv3x3_wgrad')
+            keep.extend((dpre, xin, part))
+            lib.check(lib.conv3x3_wgrad_partial(ptr(dpre), ptr(xin), h, w, l.cin_pad, l.cout_pad, ptr(part), sw), 'conv3x3_wgrad_partial')
+            j = jobs[njobs[0]]
+            j.partial, j.dy, j.dw, j.db = ptr(part), ptr(dpre), ptr(dw), ptr(db)
+            j.nslab, j.cin, j.cout, j.cin_real, j.cout_real, j.H, j.W = nsl(h, w), l.cin_pad, l.cout_pad, l.cin, l.cout, h, w
+            njobs[0] += 1
 
         # ---- decoder, last block first.  dpre = d(pre-activation of the block's deconv2 output)
         d = torch.zeros(32, H, Wd, dtype=torch.float32, device=dev)
@@ -316,6 +323,7 @@ class _AEFn(torch.autograd.Function):
                 dpre = dprev
         if side is not None:
             main.wait_stream(side)
+        lib.check(lib.conv3x3_wgrad_reduce_multi(jobs, njobs[0], s), 'conv3x3_wgrad_reduce_multi')
         return None, None, dwdb[T.idx_grad], None
 
 
