@@ -193,7 +193,7 @@ class _AEFn(torch.autograd.Function):
     """(x [4,H,W], flat parameter vector, see `flatten_params`) -> (out [H,W], z [256,h,w])"""
 
     @staticmethod
-    def forward(ctx, lib, x, flat, ws=None):
+    def forward(ctx, lib, x, flat, ws=None, need_z=True):
         x = x.contiguous().float()
         if ws is not None:
             ws.reset()
@@ -239,8 +239,11 @@ class _AEFn(torch.autograd.Function):
             dec_rec.append((cur, curH, curW, S, b1, b2, tH, tW))
             cur, curH, curW = b2, tH, tW
         out = from_cg8p(cur, H, Wd)[0]
-        z = from_cg8p(z_buf, zH, zW)[:256]
+        z = from_cg8p(z_buf, zH, zW)[:256] if need_z else out.new_empty(0)        # (the finetune loop never reads the latent)
         ctx.lib, ctx.T, ctx.flatz, ctx.enc_rec, ctx.dec_rec, ctx.shape, ctx.ws = lib, T, flatz, enc_rec, dec_rec, (H, Wd, zH, zW), ws
+        ctx.need_z = need_z
+        if not need_z:
+            ctx.mark_non_differentiable(z)
         return out, z
 
     @staticmethod
@@ -303,7 +306,7 @@ class _AEFn(torch.autograd.Function):
             # the block's input is the previous decoder block's LeakyReLU output (mask) or the latent z (no activation)
             lib.check(lib.stuff2_bwd(ptr(dS), tH, tW, ptr(zin) if b > 0 else None, ptr(dzin), zh, zw, L[i1].cin_pad, s), 'stuff2_bwd')
             dpre = dzin
-        if dz is not None:
+        if dz is not None and ctx.need_z:
             dzp = torch.zeros(256, zH, zW, dtype=torch.float32, device=dev)
             dzp[:] = dz.float()
             dpre = dpre + to_cg8p(dzp)
@@ -324,7 +327,7 @@ class _AEFn(torch.autograd.Function):
         if side is not None:
             main.wait_stream(side)
         lib.check(lib.conv3x3_wgrad_reduce_multi(jobs, njobs[0], s), 'conv3x3_wgrad_reduce_multi')
-        return None, None, dwdb[T.idx_grad], None
+        return None, None, dwdb[T.idx_grad], None, None
 
 
 class _Conv(nn.Module):
@@ -409,88 +412,126 @@ class FlatAdam:
             o += p.numel()
 
 
+class _FinetuneSession:
+    """Everything one finetune loop needs, at FIXED device addresses, kept across clips of the same shape: the flat parameter
+    leaf and its Adam state, static copies of the clip image and of mask / count, the step's workspace, the stream all of it
+    runs on and -- after the first clip -- the captured graph of one training step.  A clip then costs a few small copies
+    into the static buffers plus ``steps`` replays; capture + instantiation (~10 ms) is paid once per process and shape,
+    not once per clip."""
+
+    def __init__(self, lib, n_param, x_shape, lr, device):
+        self.lib, self.lr, self.device = lib, lr, torch.device(device)
+        self.gpu = self.device.type == 'cuda' and not lib.is_emu
+        self.stream = torch.cuda.Stream(self.device) if self.gpu else None
+        with self._on():
+            # The step trains ONE flat leaf created on the stream the step runs on.  Autograd keeps one AccumulateGrad node
+            # per leaf and pins it to the stream it was first used on: with the module's own parameters, a caller that still
+            # holds an output of an earlier forward (made on another stream) forces a cross-stream event wait into every
+            # backward -- fatal inside a stream capture (segfault in hipStreamEndCapture, tools/graph_repro.py).
+            self.flat = torch.zeros(n_param, dtype=torch.float32, device=self.device).requires_grad_(True)
+            self.opt = FlatAdam([self.flat], lr, lib)
+            self.ws = AEWorkspace(self.device)           # the step's ~45 activation buffers: zeroed once, not per step
+            self.x = torch.zeros(x_shape, dtype=torch.float32, device=self.device)
+            self.moc = torch.zeros(x_shape[-2:], dtype=torch.float32, device=self.device)     # mask / count
+        self.exe, self.pool = None, None
+
+    def _on(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.gpu else contextlib.nullcontext()
+
+    def __del__(self):
+        exe, self.exe = getattr(self, 'exe', None), None
+        if exe is not None:
+            try:
+                self.lib.graph_destroy(exe)
+            except Exception:
+                pass
+
+    def train_step(self):
+        # loss = (|rec - x| * m).sum() / cnt (opt_amass_temp.py:199-203); its gradient is closed-form, so the eleven small
+        # launches of the loss and its autograd tape are three (same bits: +-1 / 0 times m / cnt)
+        self.opt.zero_grad()
+        rec, _ = _AEFn.apply(self.lib, self.x[0], self.flat, self.ws, False)
+        rec.backward(torch.sign(rec.detach() - self.x[0, 0]) * self.moc)
+        self.opt.step()
+
+    def run(self, flat0, x, m_over_cnt, steps, use_graph):
+        import ctypes as C
+        lib = self.lib
+        if self.gpu:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with self._on(), torch.no_grad():
+            self.flat.copy_(flat0)                            # a fresh optimiser on the pretrained weights (:160-164)
+            self.opt.m.zero_(); self.opt.v.zero_(); self.opt.step_ctr.zero_(); self.opt.t = 0
+            self.x.copy_(x); self.moc.copy_(m_over_cnt)
+        with self._on():
+            left = steps
+            if use_graph and self.exe is None and steps > 3:
+                for _ in range(3):                           # eager: warms the allocator cache and every lazy init
+                    self.train_step()
+                left -= 3
+                # After three identical steps every allocation of the step is served from the caching allocator and
+                # everything runs on this stream (+ the workspace's second one, forked and joined inside the step), so the
+                # recorded addresses stay valid.  Raw capture (lemo_capture_*).  The captured step allocates from a PRIVATE
+                # pool that lives as long as the graph (the replays write into those addresses; the shared caching
+                # allocator could hand them out again between two replays).
+                self.opt.zero_grad()
+                sh = self.stream.cuda_stream
+                self.pool = torch.cuda.MemPool()
+                with torch.cuda.use_mem_pool(self.pool):
+                    lib.check(lib.capture_begin(sh), 'capture_begin')
+                    try:
+                        self.train_step()
+                    finally:
+                        exe = C.c_void_p()
+                        rc = lib.capture_end(sh, C.byref(exe))
+                lib.check(rc, 'capture_end')
+                self.exe = exe
+            if use_graph and self.exe is not None:
+                for _ in range(left):                        # capture records the step without running it
+                    lib.check(lib.graph_launch(self.exe, self.stream.cuda_stream), 'graph_launch')
+            else:
+                for _ in range(left):
+                    self.train_step()
+        if self.gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return self.flat.detach()
+
+
+_SESSIONS: Dict[tuple, _FinetuneSession] = {}
+
+
 def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, train_mask: torch.Tensor, steps: int = 60,
                         lr: float = 3e-6, use_graph: Optional[bool] = None):
     """The per-clip block of opt_amass_temp.py:160-215: reload the pretrained weights, ``steps`` x [forward, L1 on
     ``train_mask`` (bool [d+2, T+16] over channel 0), backward, Adam], then one eval forward.  Returns
     ``(clip_img_rec [1,1,d,T] un-padded, z)``.
 
-    ``use_graph`` (default: on a HIP device): the training step -- ~70 HIP kernels plus ~300 small packing ops -- is
-    captured ONCE per clip into a graph (after 3 eager steps that also warm the allocator) and replayed, which takes
-    the host out of the loop; Adam's bias-correction step lives on the device (``lemo_adam_flat_ctr``) so the replays
-    advance it.  Same kernels, same order: results are bit-identical to eager launches (tested).  The step itself is
-    2.0 ms of GPU time and 227 launches (tools/ae_prof.py: 19 weight-gradient kernels + reductions 0.75 ms, the split-K
-    convolutions of the 128/256-channel layers 0.45 ms, ~65 zero-fills 0.3 ms)."""
+    ``use_graph`` (default: on a HIP device): the training step -- ~110 HIP kernels plus ~40 small packing ops -- is captured
+    ONCE per process and clip shape into a graph (after 3 eager steps that also warm the allocator) and replayed for every
+    later step and clip (:class:`_FinetuneSession`), which takes the host out of the loop; Adam's bias-correction step lives
+    on the device (``lemo_adam_flat_ctr``) so the replays advance it.  Same kernels, same order: results are bit-identical
+    to eager launches (tested).  Round 2 (tools/ae_prof.py, profiles/r02_ae_kernel_stats.csv): 2.0 -> 1.26 ms of kernel
+    time per step -- weight gradients one tile per workgroup (29 -> 12 us per layer) on a second stream, their 20
+    reductions in one launch, no per-step zero fills, closed-form loss gradient."""
     model.load_state_dict(weights)
     lib = model._lib_override or _hip.get_lib()
     m = train_mask.to(clip_img_input.dtype)
     cnt = m.sum()
     if use_graph is None:
         use_graph = clip_img_input.is_cuda
-    use_graph = bool(use_graph) and steps > 3
-
-    def run(stream_ctx):
-        # The step trains ONE fresh flat leaf copy of the parameters created on the stream the step runs on.  Autograd
-        # keeps one AccumulateGrad node per leaf for as long as ANY graph references it and pins it to the stream it
-        # was first used on: with the module's own parameters, a caller that still holds an output of an earlier
-        # forward (made on another stream) forces a cross-stream event wait into every backward -- fatal inside a
-        # stream capture (segfault in hipStreamEndCapture, tools/graph_repro.py).
-        with stream_ctx:
-            flat = flatten_params([p.detach() for p in model.ordered_parameters()]).clone().requires_grad_(True)
-            opt = FlatAdam([flat], lr, lib)
-            ws = AEWorkspace(clip_img_input.device)          # the step's ~45 activation buffers: zeroed once, not per step
-
-            def train_step():
-                opt.zero_grad()
-                rec, _ = _AEFn.apply(lib, clip_img_input[0], flat, ws)
-                loss = ((rec - clip_img_input[0, 0]).abs() * m).sum() / cnt
-                loss.backward()
-                opt.step()
-
-            if not use_graph:
-                for _ in range(steps):
-                    train_step()
-            else:
-                import ctypes as C
-                for _ in range(3):                           # eager: warms the allocator cache and every lazy init
-                    train_step()
-                # After three identical steps every allocation of the step is served from the caching allocator and
-                # everything runs on this one stream, so the recorded addresses stay valid and stream order protects
-                # their reuse.  Raw capture (lemo_capture_*): the step is ~60 HIP kernels + ~150 small torch ops.
-                opt.zero_grad()
-                sh = torch.cuda.current_stream(clip_img_input.device).cuda_stream
-                # the captured step allocates from a PRIVATE pool that lives as long as the graph (the replays write into
-                # those addresses; the shared caching allocator could hand them out again between two replays)
-                pool = torch.cuda.MemPool()
-                with torch.cuda.use_mem_pool(pool):
-                    lib.check(lib.capture_begin(sh), 'capture_begin')
-                    try:
-                        train_step()
-                    finally:
-                        exe = C.c_void_p()
-                        rc = lib.capture_end(sh, C.byref(exe))
-                lib.check(rc, 'capture_end')
-                try:
-                    for _ in range(steps - 3):               # capture records the step without running it
-                        lib.check(lib.graph_launch(exe, sh), 'graph_launch')
-                    torch.cuda.current_stream(clip_img_input.device).synchronize()
-                finally:
-                    lib.check(lib.graph_destroy(exe), 'graph_destroy')
-            with torch.no_grad():
-                o = 0
-                for p in model.ordered_parameters():
-                    p.copy_(flat[o:o + p.numel()].view_as(p))
-                    o += p.numel()
-
-    if clip_img_input.is_cuda:
-        dev = clip_img_input.device
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        run(torch.cuda.stream(side))
-        torch.cuda.current_stream(dev).wait_stream(side)
-    else:
-        import contextlib
-        run(contextlib.nullcontext())
+    use_graph = bool(use_graph) and clip_img_input.is_cuda and not lib.is_emu
+    flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
+    key = (str(clip_img_input.device), tuple(clip_img_input.shape), float(lr), id(lib))
+    ses = _SESSIONS.get(key)
+    if ses is None:
+        ses = _SESSIONS[key] = _FinetuneSession(lib, flat0.numel(), tuple(clip_img_input.shape), lr, clip_img_input.device)
+    flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
+    with torch.no_grad():
+        o = 0
+        for p in model.ordered_parameters():
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
     with torch.no_grad():
         rec, z = model(clip_img_input)
     return rec[:, :, 1:-1, 8:-8], z
