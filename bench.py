@@ -220,7 +220,7 @@ def concurrent_probe(fit0, prob0, B, device, k, steps, conv_variant):
     cc = ConcurrentClips(fits)
     cc.prepare(steps); cc.prepare(10)
     best = 0.0
-    for rep in range(2):
+    for rep in range(3):                                  # (the first repetition doubles as the clock ramp after the CPU-side setup)
         for f, p in zip(fits, probs):
             f.load_sequence(p['seq']['init_params'], p['markers'], p['seq']['contact_lbl'])
         cc.step(10); cc.synchronize()

@@ -283,10 +283,13 @@ def test_fit_full_size_golden(full_problem, dev, conv_variant):
     assert abs(float(v.double().sum()) - float(g['verts_sum'])) < 1e-6 * float(v.double().abs().sum())
     assert rel_err(fit.params72().cpu(), g['p72_0']) < 1e-5
     gr = fit.grads_with_priors()
-    # vs the fp32 CPU oracle; both sit ~1e-4 from float64 at this size (tests/test_gpu_gates.py measures that directly)
-    assert rel_err(gr['transl'].cpu(), g['g_transl']) < 5e-4
-    assert rel_err(gr['rot6d'].cpu(), g['g_rot6d']) < 5e-4
-    assert rel_err(gr['other'].cpu(), g['g_other']) < 5e-4
+    # vs the fp32 CPU oracle.  Max norm: both paths sit a few 1e-4 from float64 at this size, in the handful of frames where
+    # one of them crossed a LeakyReLU / L1 kink the other did not (tests/test_gpu_gates.py, tools/grad_vs_golden.py);
+    # everywhere else -- the median over frames of the per-frame maximum -- they agree to ~5e-6
+    for k in ('transl', 'rot6d', 'other'):
+        a, b = gr[k].cpu().double(), torch.from_numpy(g['g_' + k]).double()
+        e = (a - b).abs() / b.abs().max()
+        assert float(e.max()) < 2e-3 and float(e.max(1).values.median()) < 2e-5, (k, float(e.max()), float(e.max(1).values.median()))
     s = torch.cuda.Stream(dev)
     with torch.cuda.stream(s):
         fit.step(1, use_graph=True)
