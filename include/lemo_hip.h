@@ -128,6 +128,8 @@ typedef struct lemo_pose_in {
 typedef struct lemo_pose_ws {
   float *full_pose, *R, *J, *T, *A, *Jtr, *Xg;
   int Bp;
+  unsigned short* XgS;   /* optional [512/16][3][Bp][2][8] bf16: Xg split into its three exact bf16 pieces, in the fragment order of
+                            lemo_lbs_verts_fwd_xs's blend GEMM (written by lemo_smplx_pose_fwd when non-NULL; pad entries stay 0) */
 } lemo_pose_ws;
 typedef struct lemo_pose_grad_in {
   const float *dA, *dJtr, *dX;
@@ -181,8 +183,12 @@ typedef struct lemo_vertex_set_bwd {
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 /* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */
+/* same, with the per-frame features also given pre-split (lemo_pose_ws.XgS): the blend GEMM reads its B operand from there */
+int lemo_lbs_verts_fwd_xs(const lemo_skin_const* c, const float* Xg, const unsigned short* XgS, int Bp, const float* A, int nj,
+                          const float* transl, const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream);
+                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream,
+                              const unsigned short* XgS /* optional, see lemo_lbs_verts_fwd_xs */);
 /* forward over a small vertex set U only: verts / v_posed [B][u->n][3] in U's order, identical arithmetic
  * per vertex up to the summation order of the blend GEMM; blend: [B][u->NCs] floats of scratch; needs u->DkT */
 int lemo_lbs_verts_fwd_active(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* Xg, int Bp, const float* A,

@@ -41,7 +41,7 @@ class PoseIn(C.Structure):
 
 
 class PoseWs(C.Structure):
-    _fields_ = [(n, vp) for n in ('full_pose', 'R', 'J', 'T', 'A', 'Jtr', 'Xg')] + [('Bp', C.c_int)]
+    _fields_ = [(n, vp) for n in ('full_pose', 'R', 'J', 'T', 'A', 'Jtr', 'Xg')] + [('Bp', C.c_int), ('XgS', vp)]
 
 
 class PoseGradIn(C.Structure):
@@ -195,7 +195,8 @@ _SIGS = {
     'lemo_smplx_pose_bwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseWs), C.POINTER(PoseGradIn),
                                       C.POINTER(PoseGradOut), C.c_int, vp]),
     'lemo_lbs_verts_fwd': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
-    'lemo_lbs_verts_fwd_census': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    'lemo_lbs_verts_fwd_xs': (C.c_int, [C.POINTER(SkinConst), vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    'lemo_lbs_verts_fwd_census': (C.c_int, [C.POINTER(SkinConst), vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     'lemo_lbs_verts_bwd': (C.c_int, [C.POINTER(SkinConst), C.POINTER(VertexSetBwd), vp, C.c_int, vp, C.c_int, vp,
                                      C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     'lemo_joints_assemble': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),

@@ -211,9 +211,11 @@ def alloc_pose_ws(B: int, nj: int, device):
     Bp = _roundup(B, 32)
     z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
     tt = dict(full_pose=z(B, nj * 3), R=z(B, nj, 9), J=z(B, nj, 3), T=z(B, nj, 12), A=z(B, nj, 12),
-              Jtr=z(B, nj, 3), Xg=z(K_PAD // 8, Bp, 8))
+              Jtr=z(B, nj, 3), Xg=z(K_PAD // 8, Bp, 8),
+              # Xg again as three exact bf16 pieces in MFMA-fragment order (lemo_pose_ws.XgS): the blend GEMM's B operand
+              XgS=torch.zeros(K_PAD // 16, 3, Bp, 2, 8, dtype=torch.int16, device=device))
     ws = _hip.PoseWs(ptr(tt['full_pose']), ptr(tt['R']), ptr(tt['J']), ptr(tt['T']), ptr(tt['A']), ptr(tt['Jtr']),
-                     ptr(tt['Xg']), Bp)
+                     ptr(tt['Xg']), Bp, ptr(tt['XgS']))
     return ws, tt, Bp
 
 
@@ -236,8 +238,8 @@ class _SmplxFn(torch.autograd.Function):
         lib.check(lib.smplx_pose_fwd(C.byref(dev.body), C.byref(pin), C.byref(ws), B, s), 'smplx_pose_fwd')
         verts = torch.empty(B, d.V, 3, dtype=torch.float32, device=device)
         v_posed = torch.empty(B, d.V, 3, dtype=torch.float32, device=device)
-        lib.check(lib.lbs_verts_fwd(C.byref(dev.skin), ptr(tt['Xg']), Bp, ptr(tt['A']), d.nj, ptr(tr), None, d.V, B,
-                                    ptr(verts), ptr(v_posed), s), 'lbs_verts_fwd')
+        lib.check(lib.lbs_verts_fwd_xs(C.byref(dev.skin), ptr(tt['Xg']), ptr(tt['XgS']), Bp, ptr(tt['A']), d.nj, ptr(tr), None, d.V, B,
+                                       ptr(verts), ptr(v_posed), s), 'lbs_verts_fwd')
         joints = torch.empty(B, d.n_joints_out, 3, dtype=torch.float32, device=device)
         lib.check(lib.joints_assemble(ptr(tt['Jtr']), d.nj, ptr(verts), d.V, ptr(dev.t['extra_ids']), len(d.extra_ids),
                                       ptr(dev.t['lmk_rows']), ptr(dev.t['lmk_bary']), d.lmk_rows.shape[0], ptr(tr), B,

@@ -79,7 +79,8 @@ int lbs_init();
 int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
                          const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s);
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr);
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr,
+                  const unsigned short* XgS = nullptr);
 bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj);
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts /*[B][n][3]*/, int B, int Bp, float* dvp /*[B][NCs] scratch*/,

@@ -29,11 +29,17 @@ static inline int lbs_smem_bytes(int nj) { const int b = (LBS_FR * LBS_PITCH + 2
 // 8 waves: wave w = (frame tile w&3, column-tile pair w>>2) -> 2 waves per SIMD.  Both GEMM operands go
 // through LDS (register-staged, double-buffered, all loads of a stage issued up front); operand
 // reads run one 2-group chunk ahead of the MFMAs that consume them.
-template <bool DBG, bool SPLIT>
+// PRE (with SPLIT): the B operand (per-frame features, identical for every workgroup) was split into its three bf16
+// pieces ONCE by the pose-stage kernel, in MFMA-fragment order (XgS[k-chunk][piece][frame][lane half][8 bf16]); the waves read
+// their B fragments straight from L2 (1 KiB coalesced per fragment, one stage ahead) and only the streamed D operand goes
+// through registers -> split -> LDS.  Without it every one of the 250 workgroups converted the same 128 x 512 features and
+// both operands shared the LDS port: 196 KB of LDS traffic per 32-feature stage = as many cycles as its 48 MFMAs.
+template <bool DBG, bool SPLIT, bool PRE = false>
 __global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
-                     float* __restrict__ verts, float* __restrict__ v_posed, unsigned long long* __restrict__ dbg) {
+                     float* __restrict__ verts, float* __restrict__ v_posed, unsigned long long* __restrict__ dbg,
+                     const unsigned short* __restrict__ XgS) {
   LEMO_DYN_SMEM(smem);
   unsigned long long t_start = 0, t_pro = 0, t_gemm = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
@@ -69,6 +75,73 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     constexpr int SG = 4, PL = 128 * 16, OPB = SG * 3 * PL, BUFB = 2 * OPB, NSTS = 64 / SG;
     unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
     const int dstb = scol * 16 + shalf * 8;                       // + (group * 3 + piece) * PL
+    if (PRE) {
+      // ---- D through LDS (as below), B fragments from the pre-split copy in L2 ----
+      const int fr = (f0 + nt * 32 + j < Bp) ? f0 + nt * 32 + j : Bp - 1;
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(XgS) + ((size_t)fr * 2 + h) * 16;
+      const size_t piece_b = (size_t)Bp * 32, chunk_b = 3 * piece_b;          // bytes per piece / per 16-feature chunk
+      float4 sa[2][2];
+      uint4 rbg[2][2][3];                                                     // [stage parity][chunk of the stage][piece]
+#define LBS_PRE_LOAD_A(SET, ST)                                                                    \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
+        sa[SET][k] = ld4(c.Dg + (size_t)((ST) * SG + sg0 + 2 * k) * dg_stride + a_off);
+#define LBS_PRE_LOAD_B(SET, ST)                                                                    \
+      _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                             \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
+          rbg[SET][c_][s_] = *reinterpret_cast<const uint4*>(xb + (size_t)((ST) * 2 + c_) * chunk_b + s_ * piece_b);
+#define LBS_PRE_STORE_A(SET, BUF)                                                                  \
+      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
+        uint2 p0, p1, p2;                                                                          \
+        unsigned char* d = sm + (BUF) * BUFB + (sg0 + 2 * k) * 3 * PL + dstb;                      \
+        split3x4(sa[SET][k], p0, p1, p2);                                                          \
+        *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PL) = p1; *reinterpret_cast<uint2*>(d + 2 * PL) = p2; \
+      }
+      LBS_PRE_LOAD_A(0, 0)
+      LBS_PRE_LOAD_A(1, 1)
+      LBS_PRE_LOAD_B(0, 0)
+      LBS_PRE_STORE_A(0, 0)
+      __syncthreads();
+      if (DBG) t_pro = __builtin_amdgcn_s_memtime();
+      const int a_rdb = (mp * 64 + j) * 16;
+#define LBS_PRE_READ(C)                                                                            \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
+          ra[C][0][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb);   \
+          ra[C][1][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb + 32 * 16); \
+        }
+#define LBS_PRE_MFMA1(PAR, C, SA, SB)                                                              \
+        _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                           \
+          acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[C][m_][SA]), \
+                                                            __builtin_bit_cast(bf16x8, rbg[PAR][C][SB]), acc[m_], 0, 0, 0);
+#define LBS_PRE_MFMA(PAR, C) LBS_PRE_MFMA1(PAR, C, 0, 2) LBS_PRE_MFMA1(PAR, C, 2, 0) LBS_PRE_MFMA1(PAR, C, 1, 1) \
+                             LBS_PRE_MFMA1(PAR, C, 0, 1) LBS_PRE_MFMA1(PAR, C, 1, 0) LBS_PRE_MFMA1(PAR, C, 0, 0)
+      // one stage; PAR = stage parity (literal: register sets and LDS buffers are indexed at compile time)
+#define LBS_PRE_STAGE(PAR, ST) {                                                                   \
+        if ((ST) + 2 < NSTS) { LBS_PRE_LOAD_A(PAR, (ST) + 2) }                                     \
+        if ((ST) + 1 < NSTS) { LBS_PRE_LOAD_B(1 - PAR, (ST) + 1) }                                 \
+        const unsigned char* base = sm + PAR * BUFB + h * 3 * PL;                                  \
+        uint4 ra[2][2][3];                                                                         \
+        LBS_PRE_READ(0)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_PRE_READ(1)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_PRE_MFMA(PAR, 0)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_PRE_MFMA(PAR, 1)                                                                       \
+        if ((ST) + 1 < NSTS) { LBS_PRE_STORE_A(1 - PAR, 1 - PAR) }                                 \
+        __syncthreads();                                                                           \
+      }
+      for (int st = 0; st < NSTS; st += 2) {
+        LBS_PRE_STAGE(0, st)
+        LBS_PRE_STAGE(1, st + 1)
+      }
+#undef LBS_PRE_STAGE
+#undef LBS_PRE_READ
+#undef LBS_PRE_MFMA1
+#undef LBS_PRE_MFMA
+#undef LBS_PRE_LOAD_A
+#undef LBS_PRE_LOAD_B
+#undef LBS_PRE_STORE_A
+    } else {
     // D streams from HBM (~2 us away under load) and one stage is only ~0.75 us of MFMA work: the global
     // loads run TWO stages ahead (two register sets), the LDS image one stage ahead
     // (LBS_PFA = stages the D loads run ahead: 2 in the product; 3 / 4 are A/B builds, tools/ab_build.sh)
@@ -143,6 +216,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
 #undef LBS_SPLIT_STORE
 #undef LBS_SPLIT_LOAD_A
 #undef LBS_SPLIT_LOAD_B
+    }
   } else {
   float* As0 = smem;                                   // [2 buffers] of LBS_STAGE_FLOATS
   float* Bs0 = smem + 2 * LBS_STAGE_FLOATS;
@@ -323,22 +397,24 @@ int lbs_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
   rc = 0;
-#define OPTIN(DBG_, SPLIT_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, SPLIT_>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
-  OPTIN(false, false) OPTIN(true, false) OPTIN(false, true) OPTIN(true, true)
+#define OPTIN(DBG_, SPLIT_, PRE_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
+  OPTIN(false, false, false) OPTIN(true, false, false) OPTIN(false, true, false) OPTIN(true, true, false) OPTIN(false, true, true) OPTIN(true, true, true)
 #undef OPTIN
   return rc;
 }
 
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg) {
+                  const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg,
+                  const unsigned short* XgS) {
   if (n <= 0 || B <= 0 || B > Bp || (Bp % 32) || (!ids && n != c.V)) return LEMO_ERR_SHAPE;
   if (lbs_init()) return LEMO_ERR_STATE;
   if (nj > 64 || 3 * nj * 12 > 5 * 512) return LEMO_ERR_SHAPE;
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
-#define LAUNCH(DBG_, SPLIT_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg)
-  if (!c.blend_fp32) { if (dbg) LAUNCH(true, true); else LAUNCH(false, true); }
-  else { if (dbg) LAUNCH(true, false); else LAUNCH(false, false); }
+#define LAUNCH(DBG_, SPLIT_, PRE_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
+  if (!c.blend_fp32 && XgS) { if (dbg) LAUNCH(true, true, true); else LAUNCH(false, true, true); }
+  else if (!c.blend_fp32) { if (dbg) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
+  else { if (dbg) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
 #undef LAUNCH
   return (int)hipGetLastError();
 }

@@ -107,10 +107,16 @@ int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const 
   if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;
   return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, S(stream));
 }
+int lemo_lbs_verts_fwd_xs(const lemo_skin_const* c, const float* Xg, const unsigned short* XgS, int Bp, const float* A, int nj,
+                          const float* transl, const int* ids, int n, int B, float* verts, float* v_posed, void* stream) {
+  if (!c || !Xg || !A || !verts) return LEMO_ERR_ARG;
+  return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, S(stream), nullptr, XgS);
+}
 int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
-                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream) {
+                              int n, int B, float* verts, float* v_posed, unsigned long long* dbg, void* stream,
+                              const unsigned short* XgS) {
   if (!c || !Xg || !A || !verts || !dbg) return LEMO_ERR_ARG;
-  return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, nullptr, n, B, verts, v_posed, S(stream), dbg);
+  return lbs_verts_fwd(*c, Xg, Bp, A, nj, transl, nullptr, n, B, verts, v_posed, S(stream), dbg, XgS);
 }
 int lemo_lbs_verts_bwd(const lemo_skin_const* c, const lemo_vertex_set_bwd* u, const float* A, int nj, const float* v_posed,
                        int vp_rows, const float* dverts, int B, int Bp, float* dvp, float* dA, float* dtransl, float* dX,
@@ -309,10 +315,10 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   in.nonfinite = d.nonfinite;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
-  if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
+  if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
     CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
-  else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s));
+  else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   if (d.per_frame) {       // opt_amass_perframe.py:324-351: marker L1 + the three L2 priors, nothing temporal
     CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
     if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, 1.0, d.weights, d.losses, s));

@@ -263,6 +263,18 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
         v = Rs[9 + f] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
       }
       ws.Xg[((size_t)(k >> 3) * ws.Bp + b) * 8 + (k & 7)] = v;
+      if (ws.XgS) {
+        // the same value as its three exact bf16 pieces, in the B-fragment order of the blend GEMM of lbs_verts_fwd
+        // (chunk = 16 features, lane half = 8-feature group parity): XgS[k >> 4][piece][frame][(k >> 3) & 1][k & 7]
+        const __bf16 hi = (__bf16)v;
+        float r = v - (float)hi;
+        const __bf16 mid = (__bf16)r;
+        r -= (float)mid;
+        const __bf16 lo = (__bf16)r;
+        __bf16* q = reinterpret_cast<__bf16*>(ws.XgS) + ((((size_t)(k >> 4) * 3) * ws.Bp + b) * 2 + ((k >> 3) & 1)) * 8 + (k & 7);
+        const size_t ps = (size_t)ws.Bp * 16;
+        q[0] = hi; q[ps] = mid; q[2 * ps] = lo;
+      }
     }
   }
   // ---- kinematic chain: T[i] = L[root] * ... * L[parent(i)] * L[i],  L[j] = [R_j | J_j - J_parent(j)]
