@@ -125,9 +125,10 @@ def time_vertex_stage(fit, stream, reps=30):
         return None
     lib, d = fit.lib, fit.data
     t = fit._pose_t
-    args = (C.byref(fit.dev.skin), ptr(t['Xg']), fit.Bp, ptr(t['A']), d.nj, ptr(fit.P['transl']), None, d.V, fit.B,
+    # the launch the engine makes: per-frame features also given pre-split (lemo_pose_ws.XgS)
+    args = (C.byref(fit.dev.skin), ptr(t['Xg']), ptr(t['XgS']), fit.Bp, ptr(t['A']), d.nj, ptr(fit.P['transl']), None, d.V, fit.B,
             ptr(fit.ws['verts']), ptr(fit.ws['v_posed']))
-    ms = events_ms(stream, lambda: lib.check(lib.lbs_verts_fwd(*args, stream.cuda_stream)), reps)
+    ms = events_ms(stream, lambda: lib.check(lib.lbs_verts_fwd_xs(*args, stream.cuda_stream)), reps)
     nbytes = 3.0 * d.V * 506 * 4 + 2.0 * fit.B * d.V * 12
     flops = 2.0 * 128 * 3 * d.V * 512
     return ms, nbytes, flops

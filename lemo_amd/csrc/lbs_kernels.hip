@@ -80,61 +80,70 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
       const int fr = (f0 + nt * 32 + j < Bp) ? f0 + nt * 32 + j : Bp - 1;
       const unsigned char* xb = reinterpret_cast<const unsigned char*>(XgS) + ((size_t)fr * 2 + h) * 16;
       const size_t piece_b = (size_t)Bp * 32, chunk_b = 3 * piece_b;          // bytes per piece / per 16-feature chunk
-      float4 sa[2][2];
-      uint4 rbg[2][2][3];                                                     // [stage parity][chunk of the stage][piece]
-#define LBS_PRE_LOAD_A(SET, ST)                                                                    \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k)                                                \
-        sa[SET][k] = ld4(c.Dg + (size_t)((ST) * SG + sg0 + 2 * k) * dg_stride + a_off);
-#define LBS_PRE_LOAD_B(SET, ST)                                                                    \
+      // One LDS stage = 64 features (8 groups, 48 KB per buffer now that only D is staged) = two 32-feature halves: the block
+      // barrier, the split + LDS store burst and the exposed LDS read latency behind it are paid 8 times instead of 16
+      // (a 32-feature stage took 2.7 k cycles for 1.5 k cycles of MFMAs; three stages of D loads in flight instead of two
+      // changed nothing, so it was not HBM latency).  D loads run one stage (= 64 features, as many bytes as before) ahead,
+      // B fragments one half ahead.
+      constexpr int SGB = 8, BUFA = SGB * 3 * PL, NSTB = 64 / SGB;
+      float4 sa[4];
+      uint4 rbg[2][2][3];                                                     // [half parity][chunk of the half][piece]
+#define LBS_PRE_LOAD_A(ST)                                                                         \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                \
+        sa[k] = ld4(c.Dg + (size_t)((ST) * SGB + sg0 + 2 * k) * dg_stride + a_off);
+#define LBS_PRE_LOAD_B(SET, G)                                                                     \
       _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                             \
         _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_)                                           \
-          rbg[SET][c_][s_] = *reinterpret_cast<const uint4*>(xb + (size_t)((ST) * 2 + c_) * chunk_b + s_ * piece_b);
-#define LBS_PRE_STORE_A(SET, BUF)                                                                  \
-      _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                              \
+          rbg[SET][c_][s_] = *reinterpret_cast<const uint4*>(xb + (size_t)((G) * 2 + c_) * chunk_b + s_ * piece_b);
+#define LBS_PRE_STORE_A(BUF)                                                                       \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                              \
         uint2 p0, p1, p2;                                                                          \
-        unsigned char* d = sm + (BUF) * BUFB + (sg0 + 2 * k) * 3 * PL + dstb;                      \
-        split3x4(sa[SET][k], p0, p1, p2);                                                          \
+        unsigned char* d = sm + (BUF) * BUFA + (sg0 + 2 * k) * 3 * PL + dstb;                      \
+        split3x4(sa[k], p0, p1, p2);                                                               \
         *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PL) = p1; *reinterpret_cast<uint2*>(d + 2 * PL) = p2; \
       }
-      LBS_PRE_LOAD_A(0, 0)
-      LBS_PRE_LOAD_A(1, 1)
+      LBS_PRE_LOAD_A(0)
       LBS_PRE_LOAD_B(0, 0)
-      LBS_PRE_STORE_A(0, 0)
+      LBS_PRE_STORE_A(0)
+      LBS_PRE_LOAD_A(1)
       __syncthreads();
       if (DBG) t_pro = __builtin_amdgcn_s_memtime();
       const int a_rdb = (mp * 64 + j) * 16;
-#define LBS_PRE_READ(C)                                                                            \
+#define LBS_PRE_READ(P, C)                                                                         \
         _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                         \
-          ra[C][0][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb);   \
-          ra[C][1][s_] = *reinterpret_cast<const uint4*>(base + (C) * 6 * PL + s_ * PL + a_rdb + 32 * 16); \
+          ra[C][0][s_] = *reinterpret_cast<const uint4*>(base + ((P) * 2 + (C)) * 6 * PL + s_ * PL + a_rdb);   \
+          ra[C][1][s_] = *reinterpret_cast<const uint4*>(base + ((P) * 2 + (C)) * 6 * PL + s_ * PL + a_rdb + 32 * 16); \
         }
-#define LBS_PRE_MFMA1(PAR, C, SA, SB)                                                              \
+#define LBS_PRE_MFMA1(P, C, SA, SB)                                                                \
         _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                           \
           acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra[C][m_][SA]), \
-                                                            __builtin_bit_cast(bf16x8, rbg[PAR][C][SB]), acc[m_], 0, 0, 0);
-#define LBS_PRE_MFMA(PAR, C) LBS_PRE_MFMA1(PAR, C, 0, 2) LBS_PRE_MFMA1(PAR, C, 2, 0) LBS_PRE_MFMA1(PAR, C, 1, 1) \
-                             LBS_PRE_MFMA1(PAR, C, 0, 1) LBS_PRE_MFMA1(PAR, C, 1, 0) LBS_PRE_MFMA1(PAR, C, 0, 0)
-      // one stage; PAR = stage parity (literal: register sets and LDS buffers are indexed at compile time)
-#define LBS_PRE_STAGE(PAR, ST) {                                                                   \
-        if ((ST) + 2 < NSTS) { LBS_PRE_LOAD_A(PAR, (ST) + 2) }                                     \
-        if ((ST) + 1 < NSTS) { LBS_PRE_LOAD_B(1 - PAR, (ST) + 1) }                                 \
-        const unsigned char* base = sm + PAR * BUFB + h * 3 * PL;                                  \
+                                                            __builtin_bit_cast(bf16x8, rbg[P][C][SB]), acc[m_], 0, 0, 0);
+#define LBS_PRE_MFMA(P, C) LBS_PRE_MFMA1(P, C, 0, 2) LBS_PRE_MFMA1(P, C, 2, 0) LBS_PRE_MFMA1(P, C, 1, 1) \
+                           LBS_PRE_MFMA1(P, C, 0, 1) LBS_PRE_MFMA1(P, C, 1, 0) LBS_PRE_MFMA1(P, C, 0, 0)
+      // half P (literal 0 / 1) of stage ST: 32 features; the global half index 2 ST + P has parity P
+#define LBS_PRE_HALF(P, ST) {                                                                      \
+        if (2 * (ST) + (P) + 1 < 2 * NSTB) { LBS_PRE_LOAD_B(1 - (P), 2 * (ST) + (P) + 1) }         \
         uint4 ra[2][2][3];                                                                         \
-        LBS_PRE_READ(0)                                                                            \
+        LBS_PRE_READ(P, 0)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        LBS_PRE_READ(1)                                                                            \
+        LBS_PRE_READ(P, 1)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        LBS_PRE_MFMA(PAR, 0)                                                                       \
+        LBS_PRE_MFMA(P, 0)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        LBS_PRE_MFMA(PAR, 1)                                                                       \
-        if ((ST) + 1 < NSTS) { LBS_PRE_STORE_A(1 - PAR, 1 - PAR) }                                 \
-        __syncthreads();                                                                           \
+        LBS_PRE_MFMA(P, 1)                                                                         \
       }
-      for (int st = 0; st < NSTS; st += 2) {
-        LBS_PRE_STAGE(0, st)
-        LBS_PRE_STAGE(1, st + 1)
+      for (int st = 0; st < NSTB; ++st) {
+        const unsigned char* base = sm + (st & 1) * BUFA + h * 3 * PL;
+        LBS_PRE_HALF(0, st)
+        __builtin_amdgcn_sched_barrier(0);
+        LBS_PRE_HALF(1, st)
+        if (st + 1 < NSTB) {
+          LBS_PRE_STORE_A((st + 1) & 1)
+          if (st + 2 < NSTB) { LBS_PRE_LOAD_A(st + 2) }
+        }
+        __syncthreads();
       }
-#undef LBS_PRE_STAGE
+#undef LBS_PRE_HALF
 #undef LBS_PRE_READ
 #undef LBS_PRE_MFMA1
 #undef LBS_PRE_MFMA

@@ -406,3 +406,41 @@ def test_real_file_shaped_model_400_shapedirs_and_kw_above_8(emu_lib):
     assert float((v0 - v_ref.detach()).abs().max()) > 1e-3
     for k in p:
         assert rel_err(p[k].grad, q[k].grad) < 2e-4, k
+
+
+def test_presplit_blend_operand_is_bit_identical(emu_lib):
+    """lemo_lbs_verts_fwd_xs (per-frame features pre-split into bf16 pieces by the pose kernel, lemo_pose_ws.XgS) against
+    lemo_lbs_verts_fwd (every workgroup converts them itself): same pieces, same products in the same order -> same bits;
+    and XgS really is the exact 3-way split of Xg"""
+    import ctypes as C
+    from lemo_amd._hip import ptr
+    from lemo_amd.body_model import BodyModelData, DeviceBody, alloc_pose_ws
+    lib = emu_lib
+    data = BodyModelData(synthetic.make_synthetic_smplx(seed=3, V=200, F=300))
+    db = DeviceBody(data, 'cpu')
+    B = 5
+    ws, tt, Bp = alloc_pose_ws(B, data.nj, 'cpu')
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).contiguous()
+    go, body, lh, rh, betas = r(B, 3), r(B, 63), r(B, 12), r(B, 12), r(B, 10)
+    z3 = torch.zeros(B, 3)
+    expr = torch.zeros(B, 10)
+    from lemo_amd import _hip
+    pin = _hip.PoseIn(ptr(go), ptr(body), ptr(z3), ptr(z3), ptr(z3), ptr(lh), ptr(rh), 12, ptr(betas), 10, ptr(expr))
+    lib.check(lib.smplx_pose_fwd(C.byref(db.body), C.byref(pin), C.byref(ws), B, None))
+    # XgS[k >> 4][piece][frame][(k >> 3) & 1][k & 7] (bf16 bits) sums back to Xg[k >> 3][frame][k & 7] exactly
+    pieces = (tt['XgS'].to(torch.int32) & 0xFFFF) << 16
+    xs = pieces.view(torch.float32).double().sum(1)                                      # [K/16][Bp][2][8]
+    xg = tt['Xg'].view(-1, 2, Bp, 8).permute(0, 2, 1, 3).double()                        # [K/16][Bp][2][8]
+    assert torch.equal(xs, xg) and float(xg.abs().max()) > 0
+    out = []
+    for pre in (False, True):
+        v, vp = torch.empty(B, data.V, 3), torch.empty(B, data.V, 3)
+        if pre:
+            lib.check(lib.lbs_verts_fwd_xs(C.byref(db.skin), ptr(tt['Xg']), ptr(tt['XgS']), Bp, ptr(tt['A']), data.nj, None, None, data.V, B,
+                                           ptr(v), ptr(vp), None))
+        else:
+            lib.check(lib.lbs_verts_fwd(C.byref(db.skin), ptr(tt['Xg']), Bp, ptr(tt['A']), data.nj, None, None, data.V, B, ptr(v), ptr(vp), None))
+        out.append((v, vp))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert float(out[0][0].abs().max()) > 0
