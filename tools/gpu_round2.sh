@@ -6,18 +6,7 @@ R=$GRAFT_REPO_ROOT
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit" | head -4 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|^CPU\(s\)|Core|Socket" >> $OUT/gpu.txt
 git -C $R rev-parse HEAD >> $OUT/gpu.txt 2>/dev/null
-# 1. the driver's own command, three times + the 100-step run with the CPU baseline
-for i in 1 2 3; do timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --concurrent-clips 0 > $OUT/bench_driver_style_$i.json 2>> $OUT/bench.err; done
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2>> $OUT/bench.err
-timeout 400 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 > $OUT/bench_100.json 2>> $OUT/bench.err
-timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --active-vertices-only > $OUT/bench_active.json 2>> $OUT/bench.err
-# 2. kernel stats of the same command (rocprofv3 --kernel-trace --stats)
-cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o prof -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --ramp-ms 100 > $R/$OUT/bench_prof.json 2> $R/$OUT/prof.err
-cd $R
-find $OUT/prof -name "*kernel_stats*" | head -1 | while read f; do cp "$f" $OUT/kernel_stats.csv; done
-find $OUT/prof -name "*domain_stats*" | head -1 | while read f; do cp "$f" $OUT/domain_stats.csv; done
-rm -rf $OUT/prof
-# 3. PMC passes (separate runs, kernel-trace only) on the same code
+# 1. PMC passes (separate runs, kernel-trace only) on the same code
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
@@ -28,7 +17,20 @@ done
 cd $R
 python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1
 cp $OUT/pmc/pmc_summary.json $OUT/pmc_summary.json 2>/dev/null
+# bench.py reads roofline.traffic from profiles/r02_pmc_summary.json: give it THIS visit's counters (box-local copy)
+cp $OUT/pmc_summary.json profiles/r02_pmc_summary.json 2>/dev/null
 rm -f $OUT/pmc/*.csv
+# 2. the driver's own command, three times + the 100-step run with the CPU baseline
+for i in 1 2 3; do timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --concurrent-clips 0 > $OUT/bench_driver_style_$i.json 2>> $OUT/bench.err; done
+timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2>> $OUT/bench.err
+timeout 400 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 > $OUT/bench_100.json 2>> $OUT/bench.err
+timeout 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --active-vertices-only > $OUT/bench_active.json 2>> $OUT/bench.err
+# 3. kernel stats of the same command (rocprofv3 --kernel-trace --stats)
+cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o prof -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --ramp-ms 100 > $R/$OUT/bench_prof.json 2> $R/$OUT/prof.err
+cd $R
+find $OUT/prof -name "*kernel_stats*" | head -1 | while read f; do cp "$f" $OUT/kernel_stats.csv; done
+find $OUT/prof -name "*domain_stats*" | head -1 | while read f; do cp "$f" $OUT/domain_stats.csv; done
+rm -rf $OUT/prof
 # 4. PROX engine: throughput + kernel stats
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/pp -o p -- python $R/tools/prox_engine_prof.py S3 > $R/$OUT/prox_engine.txt 2>&1
 cd $R

@@ -34,7 +34,7 @@ def run(name, prob, markers, weights, steps=10):
     with default_f64():
         t64, p64, _, _ = o64.losses(); t64.backward()
     L = fit.losses()
-    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+    rel = lambda a, b: abs(a - b) / abs(b) if b != 0 else float('nan')      # nan: the term is switched off
     print(f'== {name}: loss scalars rel err vs f64   gpu / cpu-f32')
     for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
         print(f'   {k:8s} {rel(L[k], float(p64[k])):.2e} / {rel(float(p32[k]), float(p64[k])):.2e}')
