@@ -257,8 +257,8 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
 
 // n iterations as replays of the 20 / 5 / 1-iteration graphs; launch = false only captures what is missing.
 // hipGraphLaunch hands a graph to the queue only after the host has written all of its nodes (measured: a 20-step call
-// that opens with the 660-node graph starts ~0.7 ms late, 9 % of the call; later replays are enqueued while the device is
-// busy and cost nothing).  A call therefore opens with a few replays of the 33-node graph, continues with the 165-node
+// that opens with the 621-node graph starts ~0.7 ms late, 9 % of the call; later replays are enqueued while the device is
+// busy and cost nothing).  A call therefore opens with a few replays of the 32-node graph, continues with the 156-node
 // one, and only then switches to the large graph -- the device starts within ~40 us and the host stays ahead.
 static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
   if (e->graph_stream != s) {
