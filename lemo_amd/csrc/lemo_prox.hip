@@ -54,7 +54,7 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   in.zero_f64 = d.loss_acc; in.n_zero = 32 * 32 + 32 * 16; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   in.nonfinite = d.nonfinite;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
-  CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s));
+  CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   // ---- loss: per-frame terms, dense SDF term, smoothness prior through the encoder
   CHK(prox_frame(d, s));
   CHK(prox_dense(d, s));
