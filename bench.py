@@ -363,7 +363,10 @@ def main():
     if per_rank is not None:
         out['per_rank_iterations_per_s'] = per_rank
     if rank == 0 and world == 1 and args.concurrent_clips > 1 and use_graph and not args.active_vertices_only:
-        out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, max(args.steps, 100), args.conv_variant)
+        try:      # an extra, never the headline: a failure here must not cost the line
+            out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, max(args.steps, 100), args.conv_variant)
+        except Exception as e:       # noqa: BLE001
+            out['concurrent_clips'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(prob, B)
         out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']
