@@ -179,6 +179,8 @@ typedef struct lemo_vertex_set_bwd {
    * floats; when NULL the one-workgroup-per-output-tile GEMM is used (fine for the compact sets, 107 us for all vertices) */
   int gemm_slabs;
   float* gemm_part;
+  const float* DkG;         /* optional, with gemm_part: Dk again as [NCs/16][512][16] (k-chunk major: the 64-row x 16-k operand tile of a
+                               split-K step is one contiguous 4 KB run instead of 64 segments 4 NCs bytes apart) */
 } lemo_vertex_set_bwd;
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);

@@ -70,7 +70,7 @@ class SkinConst(C.Structure):
 class VertexSetBwd(C.Structure):
     _fields_ = [('n', C.c_int), ('NCs', C.c_int)] + \
         [(n, vp) for n in ('ids', 'vp_row', 'Dk', 'DkT', 'jcsr_start', 'jcsr_u', 'jcsr_w', 'jcsr_chunk', 'jc_u', 'jc_w', 'part')] + \
-        [('part_frames', C.c_int), ('gemm_slabs', C.c_int), ('gemm_part', vp)]
+        [('part_frames', C.c_int), ('gemm_slabs', C.c_int), ('gemm_part', vp), ('DkG', vp)]
 
 
 class FitConst(C.Structure):

@@ -203,6 +203,9 @@ class DeviceBody:
             if st.gemm_slabs == 0:                 # K-slab partials of the feature-gradient GEMM (long K): 32 x 128 x 512 floats
                 tt['gemm_part'] = torch.zeros(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)
                 st.gemm_part, st.gemm_slabs = ptr(tt['gemm_part']), GEMM_SLABS
+                # Dk k-chunk major for the split-K GEMM: [NCs/16][512][16]
+                tt['DkG'] = tt['Dk'].view(K_PAD, s['NCs'] // 16, 16).permute(1, 0, 2).contiguous()
+                st.DkG = ptr(tt['DkG'])
         return self._sets[key]
 
 

@@ -6,6 +6,7 @@
 // workgroup: its 4 waves split K, each issues ALL its operand loads (<= 16 dwordx4 per lane) before
 // its v_mfma_f32_16x16x4_f32 chain (one exposed memory round trip), and the partial tiles are
 // reduced through LDS in a fixed order (deterministic).
+#include <cstdlib>
 #include "kernels.hpp"
 
 namespace lemo {
@@ -174,6 +175,106 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
   for (int t = 0; t < GEMM_SK_NT; ++t)
     st4(pp + (size_t)(t * 16 + i) * M + mt * 16 + 4 * q, make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]));
 }
+// v4: the same decomposition on the bf16 matrix cores with exact fp32 operands (3 bf16 pieces per operand, 6 products per 16-deep
+// k-step, fp32 accumulate: conv_split_kernels.hip has the error analysis) -- the fp32 MFMA floor of this GEMM (4.1 GFLOP at
+// 157 TFLOP/s = 26 us) was above its HBM floor (64 MB of A: ~12 us).  Wave = one 32-row M-tile x two 32-frame N-tiles; A fragments
+// (8 consecutive k of one row per lane) straight from global memory three steps ahead and split in registers, the B tile of a
+// step split ONCE per workgroup on its way into LDS ([piece][k half][frame][8 bf16]: every fragment one conflict-free b128).
+__global__ void __launch_bounds__(256)
+gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
+                             float* __restrict__ part, int a_grouped) {
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][2][GEMM_SK_NT * 16][16];   // [buffer][piece][k half][frame][8 bf16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int mblocks = M >> 6;
+  const int mb = blockIdx.x % mblocks, slab = blockIdx.x / mblocks;
+  const int mtile = wave & 1, npair = wave >> 1;                 // rows mb*64 + mtile*32 .. +31 ; frames npair*64 .. +63
+  const int k16 = K >> 4, per = (k16 + S - 1) / S;
+  const int c0 = slab * per, c1 = (c0 + per < k16) ? c0 + per : k16;
+  const int nst = c1 - c0;
+  // A element (row, k): row-major [M][lda], or k-chunk major [K/16][M][16] (a_grouped: a step's 64 x 16 tile is contiguous)
+  const int arow = mb * 64 + mtile * 32 + j;
+  const float* ap = a_grouped ? Am + (size_t)arow * 16 + 8 * h : Am + (size_t)arow * lda + 8 * h;
+  const size_t astep = a_grouped ? (size_t)M * 16 : 16;
+  // staging role: float4 idx = tid + 256 r -> frame idx >> 2, k quarter idx & 3 (4 k each)
+  const float* bsrc[2];
+  int bdst[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int idx = tid + 256 * r, n = idx >> 2, kq = idx & 3;
+    bsrc[r] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * kq;
+    bdst[r] = (((kq >> 1) * (GEMM_SK_NT * 16) + n) * 16) + (kq & 1) * 8;       // + piece * (2 * 128 * 16)
+  }
+  constexpr int PIECE = 2 * GEMM_SK_NT * 16 * 16, BUF = 3 * PIECE;
+  unsigned char* bs = &Bs[0][0][0][0][0];
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  if (nst > 0) {
+    auto clampc = [&](int c) { return c < c1 ? c : c1 - 1; };
+    float4 a[3][2], bg[2][2];                                  // A of steps s, s+1, s+2 ; B (global) of steps s+1, s+2
+#pragma unroll
+    for (int u = 0; u < 3; ++u) { a[u][0] = ld4(ap + (size_t)clampc(c0 + u) * astep); a[u][1] = ld4(ap + (size_t)clampc(c0 + u) * astep + 4); }
+#define SK_STORE_B(BUFI, V)                                                                          \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                \
+      uint2 p0, p1, p2;                                                                            \
+      split3x4(V[r], p0, p1, p2);                                                                  \
+      unsigned char* d = bs + (BUFI) * BUF + bdst[r];                                              \
+      *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PIECE) = p1; *reinterpret_cast<uint2*>(d + 2 * PIECE) = p2; \
+    }
+    {
+      float4 b0[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
+      SK_STORE_B(0, b0)
+    }
+    __syncthreads();
+    for (int s_ = 0; s_ < nst; ++s_) {
+      const int buf = s_ & 1;
+      // this step's A fragment: 8 consecutive k of row j (lane half h: k 8h .. 8h+7) as three bf16 pieces
+      uint4 af[3];
+      {
+        uint2 l0, l1, l2, u0, u1, u2;
+        split3x4(a[0][0], l0, l1, l2);
+        split3x4(a[0][1], u0, u1, u2);
+        af[0] = make_uint4(l0.x, l0.y, u0.x, u0.y); af[1] = make_uint4(l1.x, l1.y, u1.x, u1.y); af[2] = make_uint4(l2.x, l2.y, u2.x, u2.y);
+      }
+      uint4 bf[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          bf[t][p] = *reinterpret_cast<const uint4*>(bs + buf * BUF + p * PIECE + ((h * (GEMM_SK_NT * 16)) + npair * 64 + t * 32 + j) * 16);
+      // publish step s+1 (held in registers since two steps ago) to the other buffer, refill the registers with step s+3
+      if (s_ + 1 < nst) { SK_STORE_B(buf ^ 1, bg[0]) }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { bg[0][r] = bg[1][r]; bg[1][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + 3) * 16); }
+      a[0][0] = a[1][0]; a[0][1] = a[1][1]; a[1][0] = a[2][0]; a[1][1] = a[2][1];
+      a[2][0] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep); a[2][1] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep + 4);
+#define SK_MFMA1(SA, SB)                                                                             \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[SA]), __builtin_bit_cast(bf16x8, bf[t][SB]), acc[t], 0, 0, 0);
+      SK_MFMA1(0, 2) SK_MFMA1(2, 0) SK_MFMA1(1, 1) SK_MFMA1(0, 1) SK_MFMA1(1, 0) SK_MFMA1(0, 0)      // smallest products first
+#undef SK_MFMA1
+      __syncthreads();
+    }
+#undef SK_STORE_B
+  }
+  // D: col = lane & 31 -> frame, rows (r & 3) + 8 (r >> 2) + 4 h -> m ;  part[slab][n][m]
+  float* pp = part + (size_t)slab * (GEMM_SK_NT * 16) * M;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      st4(pp + (size_t)(npair * 64 + t * 32 + j) * M + mb * 64 + mtile * 32 + 8 * rq + 4 * h,
+          make_float4(acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]));
+}
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ part, int M, int N, int S, float* __restrict__ C, int ldc) {
   const int i = blockIdx.x * 256 + threadIdx.x;           // float4 index over [N][M / 4]
@@ -196,10 +297,13 @@ gemm_splitk_reduce_kernel(const float* __restrict__ part, int M, int N, int S, f
 int gemm_nt16_splitk_part_floats(int M, int S) { return S * GEMM_SK_NT * 16 * M; }
 
 int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
-                     hipStream_t s) {
+                     hipStream_t s, const float* A_grouped) {
   if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || (ldc & 3) || S < 1 || !part)
     return LEMO_ERR_SHAPE;
-  hipLaunchKernelGGL(gemm_nt16_splitk_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part);
+  static const bool fp32_mfma = getenv("LEMO_SPLITK_FP32") != nullptr;       // A/B switch (diagnostics): v3, the fp32-MFMA kernel
+  if (fp32_mfma) hipLaunchKernelGGL(gemm_nt16_splitk_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part);
+  else if (A_grouped) hipLaunchKernelGGL(gemm_nt16_splitk_bf16_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A_grouped, lda, B, ldb, M, N, K, S, part, 1);
+  else hipLaunchKernelGGL(gemm_nt16_splitk_bf16_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part, 0);
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((N * (M >> 2) + 255) / 256), dim3(256), 0, s, part, M, N, S, C, ldc);
   return (int)hipGetLastError();
 }

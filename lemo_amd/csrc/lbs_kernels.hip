@@ -1017,7 +1017,7 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
   if (e) return e;
   // dX[b][k] = sum_col Dk[k][col] dvp[b][col]  : A = Dk (M = 512 features), B = dvp (N = B frames)
   if (u.gemm_part && u.gemm_slabs > 0 && B <= 128)
-    return gemm_nt16_splitk(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, u.gemm_part, u.gemm_slabs, s);
+    return gemm_nt16_splitk(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, u.gemm_part, u.gemm_slabs, s, u.DkG);
   return gemm_nt16(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, dX, 512, nullptr, nullptr, 0, 0, s);
 }
 

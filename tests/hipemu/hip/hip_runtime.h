@@ -60,6 +60,8 @@ static inline float3 make_float3(float x, float y, float z) { return {x, y, z}; 
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return {x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
 
 typedef void* hipStream_t;
 typedef void* hipGraph_t;
