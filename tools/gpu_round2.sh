@@ -48,4 +48,5 @@ rm -rf $OUT/ae
 timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|MPJPE|it/s|iterations/s|max rel|vs float64|module-API|per-frame|3 frames|PROX|finetuned|clip pipeline|step [0-9]|gradient|s per clip|ms per clip|eager launches|vertices vs" > $OUT/pytest_gpu_measurements.txt
 timeout 120 python tools/lbs_census.py 2>&1 | grep blocks > $OUT/lbs_census.txt
 timeout 600 python tools/r02_gates.py 2>&1 | grep -v "amdgpu\|Warn\|float(\|detach" > $OUT/gates.txt
-cat $OUT/bench_driver_style.json; tail -3 $OUT/pytest_gpu_measurements.txt; grep PROX $OUT/prox_engine.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2 > $OUT/smoke.txt
+cat $OUT/bench_driver_style.json; tail -3 $OUT/pytest_gpu_measurements.txt; grep PROX $OUT/prox_engine.txt; cat $OUT/smoke.txt
