@@ -251,6 +251,17 @@ class HipLib:
         return torch.cuda.current_stream(device).cuda_stream
 
 
+def quiesce(device, lib=None) -> None:
+    """wait for everything queued on `device` (destructors of objects whose buffers are in use on non-default streams call
+    this before they release them); never raises -- it also runs at interpreter shutdown"""
+    try:
+        dev = torch.device(device)
+        if dev.type == 'cuda' and not (lib is not None and lib.is_emu) and torch.cuda.is_available():
+            torch.cuda.synchronize(dev)
+    except Exception:
+        pass
+
+
 _LIB: Optional[HipLib] = None
 
 

@@ -166,6 +166,10 @@ class AmassTemporalFitter:
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None
         if h:
+            # The engine's buffers are torch tensors allocated on the default stream but written by graph replays on whatever
+            # stream step() ran on.  When the last reference goes, the caching allocator may hand those blocks to the next
+            # default-stream allocation at once -- while a replay is still in flight they would be written from two places.
+            _hip.quiesce(self.device, self.lib)
             self.lib.fit_destroy(h)
 
     # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------

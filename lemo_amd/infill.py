@@ -443,6 +443,7 @@ class _FinetuneSession:
         exe, self.exe = getattr(self, 'exe', None), None
         if exe is not None:
             try:
+                _hip.quiesce(self.device, self.lib)
                 self.lib.graph_destroy(exe)
             except Exception:
                 pass

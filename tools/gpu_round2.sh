@@ -45,7 +45,7 @@ cd $R
 find $OUT/ae -name "*kernel_stats*" | head -1 | while read f; do cp "$f" $OUT/ae_kernel_stats.csv; done
 rm -rf $OUT/ae
 # 5. the whole GPU suite with its printed measurements, the float64 gates, LBS census
-timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "passed|failed|MPJPE|it/s|iterations/s|max rel|vs float64|module-API|per-frame|3 frames|PROX|finetuned|clip pipeline|step [0-9]|gradient|s per clip|ms per clip|eager launches|vertices vs" > $OUT/pytest_gpu_measurements.txt
+timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest_full.log 2>&1; grep -E "^FAILED|^ERROR" $OUT/pytest_full.log > $OUT/pytest_failures.txt; grep -E "passed|failed|MPJPE|it/s|iterations/s|max rel|vs float64|module-API|per-frame|3 frames|PROX|finetuned|clip pipeline|step [0-9]|gradient|s per clip|ms per clip|eager launches|vertices vs" $OUT/pytest_full.log > $OUT/pytest_gpu_measurements.txt; tail -c 20000 $OUT/pytest_full.log > $OUT/pytest_tail.log; rm -f $OUT/pytest_full.log
 timeout 120 python tools/lbs_census.py 2>&1 | grep blocks > $OUT/lbs_census.txt
 timeout 600 python tools/r02_gates.py 2>&1 | grep -v "amdgpu\|Warn\|float(\|detach" > $OUT/gates.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2 > $OUT/smoke.txt
