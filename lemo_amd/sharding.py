@@ -58,8 +58,8 @@ class ConcurrentClips:
 
     One clip's iteration is a chain of 31 dependent kernels; a quarter of it is kernel-boundary latency and its per-frame
     kernels (119 workgroups) leave half of the 256 CUs idle.  Clips carry no state between each other
-    (``opt_amass_temp.py:251``), so a second and third clip fill those holes: measured 2616 -> 3139 (2 clips) -> 3340
-    (3 clips) fitting-iterations/s in aggregate on one MI355X, every clip bit-identical to a run on its own
+    (``opt_amass_temp.py:251``), so a second and third clip fill those holes: measured +18 % with 2 and +25 % with 3 clips in aggregate on one MI355X (2532 -> 2980 -> 3155 fitting-iterations/s on
+    the evidence box of round 2), every clip bit-identical to a run on its own
     (``tools/concurrent_clips.py``, ``tests/test_gpu_r2.py``).  This is the per-GPU leg of the sequence sharding above:
     rank r takes its sequences ``clips_per_gpu`` at a time."""
 
