@@ -98,6 +98,13 @@ int lemo_vposer_mlp_bwd(const lemo_vposer_w* w, const float* h1, const float* h2
 /* generic small NT GEMM on the matrix cores: C[n][m] = epi(sum_k A[m][k] B[n][k]); M, K multiples of 16 */
 int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc,
                    const float* bias, const float* aux, int ldaux, int epi, void* stream);
+/* long-K form of the same contraction (M x N <= 512 x 128 outputs, K in the tens of thousands: the feature gradient of the
+   all-vertex LBS backward, lbs.py:94-99 transposed): K slabs on the bf16 matrix cores with exactly split fp32 operands, partial
+   tiles reduced in slab order (deterministic).  part: lemo_gemm_nt16_splitk_part_floats(M, S) floats of scratch;
+   A_grouped: optional copy of A as [K/16][M][16] (contiguous operand tiles); N <= 128, M % 64 == 0, K % 16 == 0 */
+int lemo_gemm_nt16_splitk_part_floats(int M, int S);
+int lemo_gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
+                          const float* A_grouped, void* stream);
 /* convert_to_3D_rot's 6-D -> axis-angle, utils/utils.py:111-123 (+63-81) */
 int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream);
 int lemo_rot6d_to_aa_bwd(const float* x6, int stride, const float* d_aa, int N, float* dx6, void* stream);

@@ -189,6 +189,8 @@ _SIGS = {
     'lemo_vposer_decode_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_vposer_mlp_bwd': (C.c_int, [C.POINTER(VPoserW), vp, vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_gemm_nt16': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp]),
+    'lemo_gemm_nt16_splitk_part_floats': (C.c_int, [C.c_int, C.c_int]),
+    'lemo_gemm_nt16_splitk': (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_rot6d_to_aa_fwd': (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     'lemo_rot6d_to_aa_bwd': (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     'lemo_smplx_pose_fwd': (C.c_int, [C.POINTER(BodyConst), C.POINTER(PoseIn), C.POINTER(PoseWs), C.c_int, vp]),

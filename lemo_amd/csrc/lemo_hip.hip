@@ -82,6 +82,12 @@ int lemo_gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int 
   if (!A || !B || !C) return LEMO_ERR_ARG;
   return gemm_nt16(A, lda, B, ldb, M, N, K, C, ldc, bias, aux, ldaux, epi, S(stream));
 }
+int lemo_gemm_nt16_splitk_part_floats(int M, int S) { return gemm_nt16_splitk_part_floats(M, S); }
+int lemo_gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
+                          const float* A_grouped, void* stream) {
+  if (!A || !B || !C || !part) return LEMO_ERR_ARG;
+  return gemm_nt16_splitk(A, lda, B, ldb, M, N, K, C, ldc, part, S, S(stream), A_grouped);
+}
 int lemo_rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, void* stream) {
   return rot6d_to_aa_fwd(x6, stride, N, aa, S(stream));
 }

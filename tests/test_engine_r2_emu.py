@@ -142,3 +142,24 @@ def test_concurrent_clips_helper_equals_separate_runs(emu_lib):
         solo.load_sequence(ip, markers, prob['seq']['contact_lbl'])
         solo.step(2, use_graph=False)
         assert torch.equal(solo.params72(), got[i])
+
+
+@pytest.mark.timeout(900)
+def test_run_of_iterations_equals_single_iteration_calls(emu_lib):
+    """Inside a run of iterations (one graph, or one eager call) the first VPoser layer of iteration i + 1 comes out of
+    iteration i's fused tail launch; a call of its own recomputes it with the stand-alone launch of the SAME kernel.  The two must
+    agree bit for bit -- this is what makes replaying 20- / 5- / 1-iteration graphs equal to eager launches."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    mk = lambda: AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                                     prob['B'], 'cpu', full_vertices=False, lib=emu_lib)
+    a, b = mk(), mk()
+    for f in (a, b):
+        f.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    a.step(3, use_graph=False)
+    for _ in range(3):
+        b.step(1, use_graph=False)
+    assert torch.equal(a.params75(), b.params75()) and torch.equal(a.params72(), b.params72())
+    assert a.losses() == b.losses() and int(a.step_ctr.item()) == int(b.step_ctr.item()) == 3

@@ -444,3 +444,27 @@ def test_presplit_blend_operand_is_bit_identical(emu_lib):
         out.append((v, vp))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert float(out[0][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize('grouped', [False, True])
+def test_splitk_gemm_matches_float64(emu_lib, grouped):
+    """lemo_gemm_nt16_splitk (the feature-gradient GEMM of the all-vertex LBS backward): K slabs on the bf16 matrix cores with
+    exactly split fp32 operands against a float64 product -- fp32-sized error (the three dropped products are < 2^-24 each);
+    the k-chunk-major copy of A (`A_grouped`) gives the same bits as the row-major one; ragged N and a K that the slabs do not
+    divide evenly"""
+    from lemo_amd._hip import ptr
+    lib = emu_lib
+    g = torch.Generator().manual_seed(5)
+    M, N, K, S = 128, 37, 16 * 41, 6
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) * 0.5
+    ref = (B.double() @ A.double().t())                                            # C[n][m]
+    part = torch.zeros(lib.gemm_nt16_splitk_part_floats(M, S))
+    outs = []
+    for use_g in (False, grouped):
+        Cm = torch.zeros(N, M)
+        Ag = A.view(M, K // 16, 16).permute(1, 0, 2).contiguous() if use_g else None
+        lib.check(lib.gemm_nt16_splitk(ptr(A), K, ptr(B), K, M, N, K, ptr(Cm), M, ptr(part), S, ptr(Ag) if use_g else None, None))
+        outs.append(Cm)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 2e-6
