@@ -253,15 +253,37 @@ class HipLib:
         return torch.cuda.current_stream(device).cuda_stream
 
 
-def quiesce(device, lib=None) -> None:
+_DEFERRED: list = []
+
+
+def quiesce(device, lib=None) -> bool:
     """wait for everything queued on `device` (destructors of objects whose buffers are in use on non-default streams call
-    this before they release them); never raises -- it also runs at interpreter shutdown"""
+    this before they release them).  Returns False -- and does nothing -- while the current stream is being captured: a device
+    synchronisation would invalidate the capture (the garbage collector can run a destructor in the middle of somebody
+    else's capture).  Never raises: it also runs at interpreter shutdown."""
     try:
         dev = torch.device(device)
         if dev.type == 'cuda' and not (lib is not None and lib.is_emu) and torch.cuda.is_available():
+            if torch.cuda.is_current_stream_capturing():
+                return False
             torch.cuda.synchronize(dev)
     except Exception:
         pass
+    return True
+
+
+def release(device, lib, destroy) -> None:
+    """run `destroy()` (a native handle's destructor) once the device is quiet; during a stream capture it is parked and run
+    by the next release outside one"""
+    if quiesce(device, lib):
+        pending, _DEFERRED[:] = list(_DEFERRED), []
+        for fn in pending + [destroy]:
+            try:
+                fn()
+            except Exception:
+                pass
+    else:
+        _DEFERRED.append(destroy)
 
 
 _LIB: Optional[HipLib] = None

@@ -169,8 +169,8 @@ class AmassTemporalFitter:
             # The engine's buffers are torch tensors allocated on the default stream but written by graph replays on whatever
             # stream step() ran on.  When the last reference goes, the caching allocator may hand those blocks to the next
             # default-stream allocation at once -- while a replay is still in flight they would be written from two places.
-            _hip.quiesce(self.device, self.lib)
-            self.lib.fit_destroy(h)
+            lib = self.lib
+            _hip.release(self.device, lib, lambda: lib.fit_destroy(h))
 
     # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------
     @torch.no_grad()

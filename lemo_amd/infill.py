@@ -442,11 +442,8 @@ class _FinetuneSession:
     def __del__(self):
         exe, self.exe = getattr(self, 'exe', None), None
         if exe is not None:
-            try:
-                _hip.quiesce(self.device, self.lib)
-                self.lib.graph_destroy(exe)
-            except Exception:
-                pass
+            lib = self.lib
+            _hip.release(self.device, lib, lambda: lib.graph_destroy(exe))
 
     def train_step(self):
         # loss = (|rec - x| * m).sum() / cnt (opt_amass_temp.py:199-203); its gradient is closed-form, so the eleven small

@@ -453,8 +453,8 @@ class ProxWindowEngine:
             # The engine's buffers are torch tensors allocated on the default stream but written by graph replays on whatever
             # stream step() ran on.  When the last reference goes, the caching allocator may hand those blocks to the next
             # default-stream allocation at once -- while a replay is still in flight they would be written from two places.
-            _hip.quiesce(self.device, self.lib)
-            self.lib.prox_destroy(h)
+            lib = self.lib
+            _hip.release(self.device, lib, lambda: lib.prox_destroy(h))
 
     def _s(self):
         return None if self.lib.is_emu else torch.cuda.current_stream(self.device).cuda_stream
