@@ -8,7 +8,9 @@ for rep in 1 2; do
     LEMO_HIP_LIB=$([ -z "$so" ] || echo $PWD/$so) timeout 200 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --concurrent-clips 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-10s %.1f it/s  %.1f us' % ('$n', d['value'], d['ms_per_step']*1e3))"
   done
 done | tee $O/ab.log
-cd /tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-graph > /dev/null 2>&1
+# (as first written -- no timeout, default rocpd output instead of csv, eager launches incl. the 250 ms ramp -- this line ran into the
+# call's 1500 s limit and cost 25 GPU-minutes: ALWAYS `timeout`, `--output-format csv`, and a short `--ramp-ms` under the profiler)
+cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --ramp-ms 100 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT; f=$(find $O/prof -name "*kernel_stats.csv" | head -1); head -24 $f | cut -c1-60,150-260 > $O/kernel_stats_head.txt; python - "$f" <<'P'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
