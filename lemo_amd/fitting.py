@@ -169,8 +169,10 @@ class AmassTemporalFitter:
             # The engine's buffers are torch tensors allocated on the default stream but written by graph replays on whatever
             # stream step() ran on.  When the last reference goes, the caching allocator may hand those blocks to the next
             # default-stream allocation at once -- while a replay is still in flight they would be written from two places.
-            lib = self.lib
-            _hip.release(self.device, lib, lambda: lib.fit_destroy(h))
+            lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
+            if rel is None:                  # interpreter shutdown: module globals are gone, the process is about to exit
+                return
+            rel(self.device, lib, lambda: lib.fit_destroy(h))
 
     # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------
     @torch.no_grad()
@@ -289,51 +291,82 @@ class PerFrameFitter:
     INIT_ORIENT = (0.0, 1.6, 3.14)        # :303-304
 
     def __init__(self, body, vposer_weights, enc_state, ids, Xmean, Xstd, device, weights: Optional[dict] = None,
-                 lib: Optional[_hip.HipLib] = None):
+                 lib: Optional[_hip.HipLib] = None, full_vertices: bool = False):
+        # full_vertices = False: stage 1 reads 67 marker vertices of ONE frame and returns parameters only;
+        # regressing all 10475 vertices per iteration is a 250-workgroup launch (40 of the iteration's 99 us at B = 1, and
+        # the whole device) that nothing consumes.  Losses, gradients and results are identical (tested); True restores it.
         w = dict(LOSS_WEIGHTS if weights is None else weights, contact_vel=0.0, smooth=0.0)
         mk = lambda lr0: AmassTemporalFitter(body, vposer_weights, enc_state, ids, Xmean, Xstd, 1, device, weights=w,
+                                             full_vertices=full_vertices,
                                              lr0=lr0, lr1=0.01, lr_switch=60, lr2=0.003, lr_switch2=80, per_frame=True, lib=lib)
         self.first, self.rest = mk(0.1), mk(0.01)
         self.device = self.first.device
 
-    @torch.no_grad()
-    def fit_clip(self, markers_rec: np.ndarray, betas: np.ndarray, steps: int = 100, use_graph: bool = True) -> torch.Tensor:
-        """markers_rec [T,67,3], betas [10] (fixed, ``beta_gt``) -> ``body_params_opt_cur_clip`` [T,72]"""
+    def _stream(self, use_graph: bool):
+        """the persistent side stream the frames of this fitter run on (graph capture needs a non-default stream and graphs
+        are per stream); None on the emulator / for eager launches"""
+        if not (bool(use_graph) and not self.first.lib.is_emu):
+            return None
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
+    def begin_clip(self, markers_rec: np.ndarray, betas: np.ndarray) -> dict:
+        """state of one clip's frame loop (see :meth:`fit_frame`)"""
         mr = torch.as_tensor(np.asarray(markers_rec, np.float32), device=self.device)
-        T = mr.shape[0]
-        out = torch.empty(T, 72, device=self.device)
         init = np.zeros((1, 72), np.float32)
         init[0, 0:3], init[0, 3:6], init[0, 6:16] = self.INIT_TRANSL, self.INIT_ORIENT, np.asarray(betas, np.float32)
-        zero_lbl = np.zeros((1, 4), np.float32)
-        prev = None
-        graph = bool(use_graph) and not self.first.lib.is_emu
-        side = None
-        if graph:                                   # graph capture needs a non-default stream (kept: graphs are per stream)
-            if getattr(self, '_side', None) is None:
-                self._side = torch.cuda.Stream(self.device)
-            side = self._side
-            side.wait_stream(torch.cuda.current_stream(self.device))
-        import contextlib
-        ctx = torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
-        with ctx:
-            self._fit_frames(mr, T, init, zero_lbl, steps, graph, out)
-        if side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(side)
-        return out
+        return dict(mr=mr, T=mr.shape[0], out=torch.empty(mr.shape[0], 72, device=self.device), init=init,
+                    zero_lbl=np.zeros((1, 4), np.float32))
 
-    def _fit_frames(self, mr, T, init, zero_lbl, steps, use_graph, out):
-        prev = None
-        for t in range(T):
+    @torch.no_grad()
+    def fit_frame(self, st: dict, t: int, steps: int = 100, use_graph: bool = True) -> None:
+        """frame t of the clip (frames must be fitted in order: t starts from the result of t - 1); asynchronous on the
+        fitter's side stream when graphs are used"""
+        import contextlib
+        side = self._stream(use_graph)
+        graph = side is not None
+        if side is not None and t == 0:
+            side.wait_stream(torch.cuda.current_stream(self.device))
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             fit = self.first if t == 0 else self.rest
             if t == 0:
-                fit.load_sequence(init, mr[0:1], zero_lbl)
+                fit.load_sequence(st['init'], st['mr'][0:1], st['zero_lbl'])
             else:
                 if t == 1:                                      # hand the running parameters to the lr-0.01 engine
                     for k in ('transl', 'rot6d', 'other', 'shape'):
-                        fit.P[k].copy_(prev.P[k])
+                        fit.P[k].copy_(self.first.P[k])
                     fit.contact.zero_()
-                fit.target.copy_(mr[t:t + 1])
+                fit.target.copy_(st['mr'][t:t + 1])
                 fit.reset_optimizer()
-            fit.step(steps, use_graph=use_graph)
-            out[t] = fit.params72()[0]
-            prev = fit
+            fit.step(steps, use_graph=graph)
+            st['out'][t] = fit.params72()[0]
+
+    def end_clip(self, st: dict) -> torch.Tensor:
+        side = getattr(self, '_side', None)
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        return st['out']
+
+    @torch.no_grad()
+    def fit_clip(self, markers_rec: np.ndarray, betas: np.ndarray, steps: int = 100, use_graph: bool = True) -> torch.Tensor:
+        """markers_rec [T,67,3], betas [10] (fixed, ``beta_gt``) -> ``body_params_opt_cur_clip`` [T,72]"""
+        st = self.begin_clip(markers_rec, betas)
+        for t in range(st['T']):
+            self.fit_frame(st, t, steps, use_graph)
+        return self.end_clip(st)
+
+
+def fit_clips_per_frame(fitters, markers_list, betas_list, steps: int = 100, use_graph: bool = True):
+    """Stage 1 for several clips SIDE BY SIDE: ``fitters[i]`` (a :class:`PerFrameFitter` each, its own engines and stream) fits
+    clip i; the frame loops advance in lockstep so that the device always holds one frame fit of every clip.  A B = 1 fit uses a
+    sliver of the device (eleven launches of one workgroup or so per iteration, each dominated by its ~4.7 us launch boundary),
+    and frame t of a clip needs frame t - 1 of the SAME clip only -- clips are the parallelism stage 1 has.  Results are
+    bit-identical to ``fitters[i].fit_clip`` run one after the other (tested)."""
+    assert len(fitters) >= len(markers_list) == len(betas_list)
+    sts = [f.begin_clip(m, b) for f, m, b in zip(fitters, markers_list, betas_list)]
+    for t in range(max(st['T'] for st in sts)):
+        for f, st in zip(fitters, sts):
+            if t < st['T']:
+                f.fit_frame(st, t, steps, use_graph)
+    return [f.end_clip(st) for f, st in zip(fitters, sts)]

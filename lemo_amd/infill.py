@@ -442,8 +442,9 @@ class _FinetuneSession:
     def __del__(self):
         exe, self.exe = getattr(self, 'exe', None), None
         if exe is not None:
-            lib = self.lib
-            _hip.release(self.device, lib, lambda: lib.graph_destroy(exe))
+            lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
+            if rel is not None:              # (None: interpreter shutdown)
+                rel(self.device, lib, lambda: lib.graph_destroy(exe))
 
     def train_step(self):
         # loss = (|rec - x| * m).sum() / cnt (opt_amass_temp.py:199-203); its gradient is closed-form, so the eleven small

@@ -453,8 +453,10 @@ class ProxWindowEngine:
             # The engine's buffers are torch tensors allocated on the default stream but written by graph replays on whatever
             # stream step() ran on.  When the last reference goes, the caching allocator may hand those blocks to the next
             # default-stream allocation at once -- while a replay is still in flight they would be written from two places.
-            lib = self.lib
-            _hip.release(self.device, lib, lambda: lib.prox_destroy(h))
+            lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
+            if rel is None:                  # interpreter shutdown: module globals are gone, the process is about to exit
+                return
+            rel(self.device, lib, lambda: lib.prox_destroy(h))
 
     def _s(self):
         return None if self.lib.is_emu else torch.cuda.current_stream(self.device).cuda_stream

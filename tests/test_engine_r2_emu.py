@@ -163,3 +163,23 @@ def test_run_of_iterations_equals_single_iteration_calls(emu_lib):
         b.step(1, use_graph=False)
     assert torch.equal(a.params75(), b.params75()) and torch.equal(a.params72(), b.params72())
     assert a.losses() == b.losses() and int(a.step_ctr.item()) == int(b.step_ctr.item()) == 3
+
+
+@pytest.mark.timeout(900)
+def test_per_frame_clips_side_by_side_equal_sequential(emu_lib):
+    """fit_clips_per_frame (stage 1 for several clips in lockstep, one PerFrameFitter each) == each clip's fit_clip, bit for bit;
+    clips of different lengths"""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import PerFrameFitter, fit_clips_per_frame
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    betas = [prob['seq']['init_params'][0, 6:16], prob['seq']['init_params'][0, 6:16] * np.float32(0.5)]
+    clips = [markers[:3], markers[4:6]]
+    mk = lambda: PerFrameFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], 'cpu', lib=emu_lib)
+    pfs = [mk(), mk()]
+    got = fit_clips_per_frame(pfs, clips, betas, steps=3, use_graph=False)
+    assert [tuple(g.shape) for g in got] == [(3, 72), (2, 72)]
+    solo = mk()
+    for i in range(2):
+        assert torch.equal(solo.fit_clip(clips[i], betas[i], steps=3, use_graph=False), got[i]), i
+    assert not torch.equal(got[0][:2], got[1])
