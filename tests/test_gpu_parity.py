@@ -481,9 +481,9 @@ def test_prox_full_size_window_runs(dev):
     # eager runs differ in the last bits -- the printed 20-step loss above varies in its 6th digit from run to run -- and the
     # loss has thresholds (contact, friction, sdf < 0.01) that turn a last-bit difference into an Adam-step-sized one in a few
     # entries now and then: one of six full-suite runs of round 2 tripped the former max < 5e-3 bound.  Bounds: the mean, and
-    # the largest drift lr x steps allows.  The NATIVE engine is deterministic and checked bit for bit, tests/test_gpu_r2.py.)
+    # the drift two Adam trajectories can build up in 8 steps of lr 0.005 (they may move in opposite directions).  The NATIVE engine is deterministic and checked bit for bit, tests/test_gpu_r2.py.)
     dpe = (fit_g.pose_embedding.detach() - fit_e.pose_embedding.detach()).abs()
-    assert float(dpe.mean()) < 2e-3 and float(dpe.max()) <= 8 * 0.005 * 1.01
+    assert float(dpe.mean()) < 2e-3 and float(dpe.max()) <= 2 * 8 * 0.005 * 1.25
     assert abs(float(lg['total_loss']) - float(le['total_loss'])) < 1e-2 * abs(float(le['total_loss']))
     n = 103
     torch.cuda.synchronize()
