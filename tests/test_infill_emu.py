@@ -90,3 +90,28 @@ def test_finetune_loop_matches_torch_adam(emu_lib):
     assert rel_err(rec, r[:, :, 1:-1, 8:-8]) < 1e-3 and rel_err(z, zr) < 1e-3
     for k, p in ae.named_parameters():
         assert float((p.detach() - wr[k].detach()).abs().max()) < 2e-5, k
+
+
+def test_finetune_session_carries_nothing_from_clip_to_clip(emu_lib):
+    """The finetune loop keeps its parameters, Adam state, inputs and workspace at fixed addresses across clips of one shape
+    (lemo_amd.infill._FinetuneSession).  A second clip must start from the pretrained weights with a fresh optimiser
+    (opt_amass_temp.py:160-164): its result equals what a brand-new session computes, bit for bit, whatever ran before."""
+    from lemo_amd import infill
+    from lemo_amd.infill import AE, finetune_and_infill
+    w = _weights()
+    g = torch.Generator().manual_seed(4)
+    xa, xb = torch.randn(1, 4, 18, 22, generator=g), torch.randn(1, 4, 18, 22, generator=g)
+    ma, mb = torch.rand(18, 22, generator=g) > 0.3, torch.rand(18, 22, generator=g) > 0.5
+    ae = AE(_lib=emu_lib)
+    infill._SESSIONS.clear()
+    finetune_and_infill(ae, w, xa, ma, steps=3, lr=1e-3)                     # clip A first: the session now holds A's state
+    rec_b, z_b = finetune_and_infill(ae, w, xb, mb, steps=2, lr=1e-3)         # clip B on the SAME session
+    p_b = {k: v.detach().clone() for k, v in ae.state_dict().items()}
+    assert len(infill._SESSIONS) == 1
+    infill._SESSIONS.clear()
+    ae2 = AE(_lib=emu_lib)
+    rec_f, z_f = finetune_and_infill(ae2, w, xb, mb, steps=2, lr=1e-3)        # clip B on a fresh session
+    assert torch.equal(rec_b, rec_f) and torch.equal(z_b, z_f)
+    for k, v in ae2.state_dict().items():
+        assert torch.equal(v, p_b[k]), k
+    infill._SESSIONS.clear()
