@@ -101,3 +101,25 @@ class ConcurrentClips:
     def params72(self) -> torch.Tensor:
         """[clips,B,72] (after :meth:`synchronize`)"""
         return torch.stack([f.params72() for f in self.fitters], 0)
+
+
+def fit_sharded_concurrent(n_seq: int, fitters: Sequence, load_sequence: Callable, steps: int, rank: int, world: int, group=None,
+                           use_graph: bool = True) -> torch.Tensor:
+    """:func:`fit_sharded` with several clips per GPU in flight: this rank's sequences ``rank, rank + world, ...`` are fitted
+    ``len(fitters)`` at a time (:class:`ConcurrentClips`: one engine + stream each), ``load_sequence(fitter, seq_id)`` puts a
+    sequence into an engine (``AmassTemporalFitter.load_sequence`` with that sequence's data), and ALL ``n_seq`` results come
+    back on every rank in sequence order through the one all-gather.  ``n_seq`` must be a multiple of ``world``."""
+    assert n_seq % world == 0, 'pad the sequence list to a multiple of the world size'
+    mine = my_sequences(n_seq, rank, world)
+    k = len(fitters)
+    out = []
+    for i in range(0, len(mine), k):
+        batch = mine[i:i + k]
+        cc = ConcurrentClips(fitters[:len(batch)])
+        for f, s in zip(cc.fitters, batch):
+            load_sequence(f, s)
+        cc.step(steps, use_graph=use_graph)
+        cc.synchronize()
+        out.append(cc.params72().clone())
+    allp = gather_fitted_params(torch.cat(out, 0), group)
+    return allp[torch.tensor(unshard_order(n_seq, world), device=allp.device)]
