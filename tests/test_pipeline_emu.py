@@ -38,7 +38,7 @@ def test_decode_clip_kernel_vs_reference_fixture(emu_lib, which):
 
 @pytest.mark.timeout(1200)
 def test_prox_window_setup_vs_reference_fixture(emu_lib):
-    """fitting_temp_slide.py:776-941 (opt_step == 0) with a 1-step finetune on the emulator vs the oracle restatement
+    """fitting_temp_slide.py:776-941 (opt_step == 0) with a 3-step finetune on the emulator vs the oracle restatement
     (pinned to the reference at 0.0 for the full 60 steps, prox_setup.*); the 60-step fixture is checked on the GPU."""
     from lemo_amd import pipeline as P, synthetic
     from lemo_amd.infill import AE
@@ -49,9 +49,9 @@ def test_prox_window_setup_vs_reference_fixture(emu_lib):
     ae_w = {k: torch.from_numpy(v) for k, v in synthetic.make_ae_weights(7).items()}
     stats = P.load_infill_stats()
     vw, jw, mask = torch.from_numpy(g['vertices_world']), torch.from_numpy(g['smplx_joints_world']), torch.from_numpy(g['marker_mask'])
-    ref = PO.prox_window_setup(vw, jw, mask, ae_w, stats, prob['ids']['markers67'], finetune_steps=1)
+    ref = PO.prox_window_setup(vw, jw, mask, ae_w, stats, prob['ids']['markers67'], finetune_steps=3)
     ae = AE(_lib=emu_lib)
-    got = P.prox_window_setup(vw, jw, mask, ae, ae_w, prob['ids']['markers67'], stats, finetune_steps=1, use_graph=False)
+    got = P.prox_window_setup(vw, jw, mask, ae, ae_w, prob['ids']['markers67'], stats, finetune_steps=3, use_graph=False)
     assert rel_err(got['clip_img_input'], ref['clip_img_input']) < 2e-5
     assert torch.equal(got['train_mask'], ref['train_mask'])
     assert abs(float(got['rot_0_pivot']) - float(np.asarray(ref['rot_0_pivot']).reshape(-1)[0])) < 1e-9

@@ -130,7 +130,7 @@ def test_two_windows_chained_through_the_native_engine(emu_lib, tmp_path):
         prob = dict(base, B=len(fns), params=init, gt_joints=base['gt_joints'][s:s + len(fns)], joints_conf=base['joints_conf'][s:s + len(fns)])
         eng, bm = ge.prox_engine_for(prob, torch.device('cpu'), first_batch_flag=first, lib=emu_lib)
         before = {k: eng.P[k].clone() for k, _ in ENGINE_PARAMS}
-        eng.step(1, use_graph=False)
+        eng.step(2, use_graph=False)
         assert eng.nonfinite_step() == 0
         seen.append((s, first, n_frozen, before, {k: eng.P[k].clone() for k, _ in ENGINE_PARAMS}))
         body = {k: eng.P[k].numpy() for k, _ in ENGINE_PARAMS[:-1]}
