@@ -132,15 +132,15 @@ def test_concurrent_clips_helper_equals_separate_runs(emu_lib):
     for f, ip in zip(fits, inits):
         f.load_sequence(ip, markers, prob['seq']['contact_lbl'])
     cc = ConcurrentClips(fits)
-    cc.prepare(2)
-    cc.step(2, use_graph=False)
+    cc.prepare(1)
+    cc.step(1, use_graph=False)
     cc.synchronize()
     got = cc.params72()
     assert got.shape == (2, prob['B'], 72) and not torch.equal(got[0], got[1])
     solo = mk()
     for i, ip in enumerate(inits):
         solo.load_sequence(ip, markers, prob['seq']['contact_lbl'])
-        solo.step(2, use_graph=False)
+        solo.step(1, use_graph=False)
         assert torch.equal(solo.params72(), got[i])
 
 
