@@ -137,11 +137,14 @@ def test_concurrent_clips_helper_equals_separate_runs(emu_lib):
     cc.synchronize()
     got = cc.params72()
     assert got.shape == (2, prob['B'], 72) and not torch.equal(got[0], got[1])
+    live = [f.params75().clone() for f in fits]            # after the update (params72 is the state the last forward saw)
     solo = mk()
     for i, ip in enumerate(inits):
         solo.load_sequence(ip, markers, prob['seq']['contact_lbl'])
+        before = solo.params75().clone()
         solo.step(1, use_graph=False)
-        assert torch.equal(solo.params72(), got[i])
+        assert torch.equal(solo.params72(), got[i]) and torch.equal(solo.params75(), live[i])
+        assert not torch.equal(solo.params75(), before)
 
 
 @pytest.mark.timeout(900)
