@@ -426,6 +426,10 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
   FitEngine* e = new (std::nothrow) FitEngine();
   if (e) {
     e->d = *d;
+    // stage 1 fits frame after frame on one stream: the device is never idle when a call starts, so the small head graphs
+    // (there to get an idle device going within ~40 us) only cost host time -- 12 hipGraphLaunch per 100-step frame instead of 5,
+    // and the host thread is what limits several clips in lockstep (tools/perframe_concurrent.py)
+    if (d->per_frame) e->head = 0;
     if (const char* h = getenv("LEMO_FIT_HEAD")) e->head = atoi(h);       // diagnostics: A/B of the replay schedule
   }
   return e;
