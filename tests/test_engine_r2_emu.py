@@ -186,3 +186,23 @@ def test_per_frame_clips_side_by_side_equal_sequential(emu_lib):
     for i in range(2):
         assert torch.equal(solo.fit_clip(clips[i], betas[i], steps=3, use_graph=False), got[i]), i
     assert not torch.equal(got[0][:2], got[1])
+
+
+@pytest.mark.timeout(900)
+def test_per_frame_active_vertex_forward_equals_full_forward(emu_lib):
+    """PerFrameFitter forwards only the loss-carrying vertices by default; full_vertices=True regresses all of them like
+    the reference's smplx call does.  Same losses, same fit (the blend GEMM's summation order is the only difference)."""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import PerFrameFitter
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    betas = prob['seq']['init_params'][0, 6:16]
+    mk = lambda full: PerFrameFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], 'cpu',
+                                     lib=emu_lib, full_vertices=full)
+    a, b = mk(False), mk(True)
+    assert not a.first.full and b.first.full and b.first.vertices().shape[1] == prob['V']
+    ra = a.fit_clip(markers[:2], betas, steps=2, use_graph=False)
+    rb = b.fit_clip(markers[:2], betas, steps=2, use_graph=False)
+    assert float((ra - rb).abs().max()) < 5e-5
+    la, lb = a.rest.losses(), b.rest.losses()
+    assert abs(la['total'] - lb['total']) <= 1e-5 * abs(lb['total'])
