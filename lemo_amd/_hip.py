@@ -272,18 +272,56 @@ def quiesce(device, lib=None) -> bool:
     return True
 
 
-def release(device, lib, destroy) -> None:
-    """run `destroy()` (a native handle's destructor) once the device is quiet; during a stream capture it is parked and run
-    by the next release outside one"""
-    if quiesce(device, lib):
-        pending, _DEFERRED[:] = list(_DEFERRED), []
-        for fn in pending + [destroy]:
+def flush_deferred() -> None:
+    """run the destructors that were parked during a stream capture (called from `release` and on every engine launch, so
+    parked handles do not wait for some later object to die)"""
+    if not _DEFERRED:
+        return
+    try:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+    except Exception:
+        return
+    pending, _DEFERRED[:] = list(_DEFERRED), []
+    for fn in pending:
+        try:
+            fn()
+        except Exception:
+            pass
+
+
+def release(device, lib, destroy, event=None) -> None:
+    """run `destroy()` (a native handle's destructor) once the engine's work is done; during a stream capture it is parked
+    and run later (`flush_deferred`).  `event`: the engine's last-launch event (`StreamOrdered._run_ev`) -- only THAT is
+    waited for, so dropping one engine does not stall the device under its peers; without it (an engine that
+    does not track its launches) the whole device is synchronised."""
+    def wait():
+        if event is None:
+            return quiesce(device, lib)
+        try:
+            if torch.cuda.is_current_stream_capturing():
+                return False
+            event.synchronize()
+        except Exception:
+            pass
+        return True
+
+    def run():
+        if event is not None:          # parked during a capture: the event may not have completed yet when it is flushed
             try:
-                fn()
+                event.synchronize()
             except Exception:
                 pass
+        destroy()
+
+    if wait():
+        flush_deferred()
+        try:
+            destroy()
+        except Exception:
+            pass
     else:
-        _DEFERRED.append(destroy)
+        _DEFERRED.append(run)
 
 
 _LIB: Optional[HipLib] = None
@@ -303,3 +341,44 @@ def check_device(lib: HipLib, t: torch.Tensor):
             raise LemoHipError('the host-emulated test library only takes CPU tensors')
     elif not t.is_cuda:
         raise LemoHipError('lemo_amd compute entry points need tensors on a HIP device (no CPU fallback)')
+
+
+class StreamOrdered:
+    """Ordering between an engine's host-side state writes (torch ops on whatever stream is current) and its launches
+    (possibly on another, non-blocking stream), owned by the engine: each side records an event that the other side's
+    stream waits for.  Without it a clip's first Adam update could overtake the zeroing of its own moments."""
+    _gpu = False
+    _setup_ev = _run_ev = None
+
+    def _init_order(self, device, lib):
+        self._gpu = torch.device(device).type == 'cuda' and not lib.is_emu
+        self._odev = torch.device(device)
+        self._setup_ev = self._run_ev = None
+
+    def _cur(self):
+        return torch.cuda.current_stream(self._odev)
+
+    def _before_write(self):
+        if self._gpu and self._run_ev is not None:
+            self._cur().wait_event(self._run_ev)
+
+    def _after_write(self):
+        if self._gpu:
+            if self._setup_ev is None:
+                self._setup_ev = torch.cuda.Event()
+            self._setup_ev.record(self._cur())
+
+    def _before_run(self):
+        if self._gpu:
+            flush_deferred()
+            for ev in (self._setup_ev, self._run_ev):
+                if ev is not None:
+                    self._cur().wait_event(ev)
+
+    def _after_run(self):
+        if self._gpu:
+            if self._run_ev is None:
+                self._run_ev = torch.cuda.Event()
+            self._run_ev.record(self._cur())
+
+    _before_read = _before_write

@@ -184,29 +184,36 @@ class DeviceBody:
         self._sets = {}
 
     def vertex_set(self, key, ids: np.ndarray, vp_row=None, frames: int = 0):
-        """cached device copy of ``BodyModelData.vertex_set`` -> (ctypes struct, tensors).  ``frames``: batch size the
-        deterministic dense backward of a large set must hold partial sums for (scratch grows on demand)."""
+        """device copy of ``BodyModelData.vertex_set`` -> (ctypes struct, tensors).  The index tables and ``Dk`` / ``DkG`` are
+        immutable and cached per model; with ``frames`` > 0 (large sets: the deterministic dense backward) the returned
+        struct is a PRIVATE copy carrying freshly allocated scratch for that many frames -- the partial sums of
+        ``lbs_bwd_chunk`` and the K-slab partials of the feature-gradient GEMM.  Scratch is never shared: an engine copies
+        the struct by value into its descriptor and captured graphs, so a later, larger request must not free it, and two
+        engines on two streams must not write the same partials."""
         if key not in self._sets:
             s = self.data.vertex_set(ids, vp_row)
             tt = {k: torch.from_numpy(v).to(self.device) for k, v in s.items() if isinstance(v, np.ndarray)}
+            if 'jcsr_chunk' in tt:                  # Dk k-chunk major for the split-K GEMM: [NCs/16][512][16] (immutable)
+                tt['DkG'] = tt['Dk'].view(K_PAD, s['NCs'] // 16, 16).permute(1, 0, 2).contiguous()
             st = _hip.VertexSetBwd(s['n'], s['NCs'], ptr(tt['ids']), ptr(tt['vp_row']), ptr(tt['Dk']),
                                    ptr(tt['DkT']) if 'DkT' in tt else None,
                                    ptr(tt['jcsr_start']), ptr(tt['jcsr_u']), ptr(tt['jcsr_w']),
                                    ptr(tt['jcsr_chunk']) if 'jcsr_chunk' in tt else None,
                                    ptr(tt['jc_u']) if 'jc_u' in tt else None, ptr(tt['jc_w']) if 'jc_w' in tt else None, None, 0)
+            st.DkG = ptr(tt['DkG']) if 'DkG' in tt else None
             self._sets[key] = (st, tt)
         st, tt = self._sets[key]
-        if 'jcsr_chunk' in tt and frames > st.part_frames:
-            nchunk = tt['jcsr_chunk'].shape[0]
-            tt['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
-            st.part, st.part_frames = ptr(tt['part']), frames
-            if st.gemm_slabs == 0:                 # K-slab partials of the feature-gradient GEMM (long K): 32 x 128 x 512 floats
-                tt['gemm_part'] = torch.zeros(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)
-                st.gemm_part, st.gemm_slabs = ptr(tt['gemm_part']), GEMM_SLABS
-                # Dk k-chunk major for the split-K GEMM: [NCs/16][512][16]
-                tt['DkG'] = tt['Dk'].view(K_PAD, s['NCs'] // 16, 16).permute(1, 0, 2).contiguous()
-                st.DkG = ptr(tt['DkG'])
-        return self._sets[key]
+        if 'jcsr_chunk' not in tt or frames <= 0:
+            return st, tt
+        mine = _hip.VertexSetBwd()
+        C.memmove(C.byref(mine), C.byref(st), C.sizeof(st))
+        own = dict(tt)                              # same immutable tensors + this caller's scratch (keeps both alive)
+        nchunk = tt['jcsr_chunk'].shape[0]
+        own['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
+        own['gemm_part'] = torch.zeros(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)   # 32 x 128 x 512 floats
+        mine.part, mine.part_frames = ptr(own['part']), frames
+        mine.gemm_part, mine.gemm_slabs = ptr(own['gemm_part']), GEMM_SLABS
+        return mine, own
 
 
 def alloc_pose_ws(B: int, nj: int, device):
@@ -270,7 +277,7 @@ class _SmplxFn(torch.autograd.Function):
             dl = djoints[:, d.nj + ne:]                                             # [B,51,3]
             contrib = dl.unsqueeze(2) * dev.t['lmk_bary'].view(1, -1, 3, 1)          # [B,51,3(f),3]
             dverts.index_add_(1, dev.t['lmk_rows'].long().view(-1), contrib.reshape(B, -1, 3))
-        uset, _ = dev.vertex_set('all', np.arange(d.V), frames=B)
+        uset, _uset_keep = dev.vertex_set('all', np.arange(d.V), frames=B)     # private scratch for this call
         dvp, dA, dtransl, dX = z(B, uset.NCs), z(B, d.nj, 12), z(B, 3), z(B, K_PAD)
         lib.check(lib.lbs_verts_bwd(C.byref(dev.skin), C.byref(uset), ptr(tt['A']), d.nj, ptr(ctx.v_posed), d.V,
                                     ptr(dverts), B, Bp, ptr(dvp), ptr(dA), ptr(dtransl), ptr(dX), s), 'lbs_verts_bwd')

@@ -241,7 +241,6 @@ static const int FIT_UNROLL[FIT_LEVELS] = {20, 5, 1};   // iterations per graph,
 struct FitEngine {
   lemo_fit_desc d;
   hipGraphExec_t exec[FIT_LEVELS] = {nullptr, nullptr, nullptr};   // FIT_UNROLL[l] iterations each, captured on first use
-  hipStream_t graph_stream = nullptr;
   int head = 5;     // replays of the 1-iteration graph that open a call (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
 };
 
@@ -267,10 +266,8 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
 // busy and cost nothing).  A call therefore opens with a few replays of the 32-node graph, continues with the 156-node
 // one, and only then switches to the large graph -- the device starts within ~40 us and the host stays ahead.
 static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
-  if (e->graph_stream != s) {
-    for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) { (void)hipGraphExecDestroy(e->exec[l]); e->exec[l] = nullptr; }
-    e->graph_stream = s;
-  }
+  // a hipGraphExec is not bound to the stream it was captured on: the graphs are kept when the caller changes streams
+  // (round 2 destroyed and re-captured all three -- ~600 nodes -- per stream change, possibly under a replay still in flight)
   int left = n;
   int plan[FIT_LEVELS] = {0, 0, 0};                 // replays per level, in launch order: level 2 (1 it), 1 (5 it), 0 (20 it), then tails
   int tail[FIT_LEVELS] = {0, 0, 0};

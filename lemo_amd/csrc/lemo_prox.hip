@@ -21,7 +21,6 @@ static const int PROX_UNROLL[PROX_LEVELS] = {10, 1};
 struct ProxEngine {
   lemo_prox_desc d;
   hipGraphExec_t exec[PROX_LEVELS] = {nullptr, nullptr};
-  hipStream_t graph_stream = nullptr;
 };
 
 static int conv_layer(const lemo_prox_desc& d, int l, bool bwd, const float* x, const float* aux, float* out, int H, int W, hipStream_t s) {
@@ -134,10 +133,7 @@ int lemo_prox_step(void* h, int n, int use_graph, void* stream) {
     for (int i = 0; i < n; ++i) CHK(prox_iteration(e->d, s));
     return 0;
   }
-  if (e->graph_stream != s) {
-    for (int l = 0; l < PROX_LEVELS; ++l) if (e->exec[l]) { (void)hipGraphExecDestroy(e->exec[l]); e->exec[l] = nullptr; }
-    e->graph_stream = s;
-  }
+  // graphs are stream-agnostic once instantiated: kept across stream changes (see fit_graphs)
   // open with single-iteration replays (the device starts while the host still enqueues), then the 10-iteration graph
   int left = n;
   const int head = left < 3 ? left : 3;

@@ -32,7 +32,7 @@ FOOT_SETS = ('left_heel', 'right_heel', 'left_toe', 'right_toe')
 LOSS_NAMES = ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total')
 
 
-class AmassTemporalFitter:
+class AmassTemporalFitter(_hip.StreamOrdered):
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
@@ -161,7 +161,31 @@ class AmassTemporalFitter:
         self.handle = self.lib.fit_create(C.byref(d))
         if not self.handle:
             raise _hip.LemoHipError('lemo_fit_create rejected the descriptor')
-        self._stream = None
+        # Stream ordering is owned by the engine: state writes (load_sequence / reset_optimizer) and
+        # launches (forward / backward / step) may be issued on DIFFERENT non-blocking streams; each side records an event
+        # and the other side's stream waits for it, so a clip's first Adam update can never overtake the zeroing of its moments
+        self._init_order(self.device, self.lib)
+        self._own = None
+        self._after_write()          # the constructor's fills / uploads sit on its current stream
+
+    def own_stream(self):
+        """the fitter's persistent side stream (None on the emulator): graph capture needs a non-default stream, and a
+        per-clip ``torch.cuda.Stream()`` would walk through torch's stream pool"""
+        if not self._gpu:
+            return None
+        if self._own is None:
+            self._own = torch.cuda.Stream(self.device)
+        return self._own
+
+    def step_async(self, n: int, use_graph: bool = True) -> None:
+        """``n`` iterations on :meth:`own_stream`, ordered after what the current stream holds so far; result readers
+        (``params72`` / ``losses`` / ...) order themselves after it through the engine's events"""
+        s = self.own_stream()
+        if s is None:
+            return self.step(n, use_graph=False)
+        s.wait_stream(self._cur())
+        with torch.cuda.stream(s):
+            self.step(n, use_graph=use_graph)
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None
@@ -172,7 +196,7 @@ class AmassTemporalFitter:
             lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
             if rel is None:                  # interpreter shutdown: module globals are gone, the process is about to exit
                 return
-            rel(self.device, lib, lambda: lib.fit_destroy(h))
+            rel(self.device, lib, lambda: lib.fit_destroy(h), getattr(self, '_run_ev', None))
 
     # -- sequence setup (opt_amass_temp.py:332-345) -------------------------------------------
     @torch.no_grad()
@@ -183,6 +207,7 @@ class AmassTemporalFitter:
                         else torch.as_tensor(np.asarray(a, np.float32), device=self.device))
         p = td(init_params)
         assert p.shape == (self.B, 72)
+        self._before_write()
         self.P['transl'].copy_(p[:, 0:3])
         self.P['rot6d'].copy_(convert_to_6D_all(p[:, 3:6]))
         self.P['shape'].copy_(p[:, 6:16])
@@ -195,11 +220,13 @@ class AmassTemporalFitter:
     def reset_optimizer(self):
         """a fresh ``optim.Adam`` (opt_amass_temp.py:343, opt_amass_perframe.py:312): moments, step count and the
         non-finite-loss latch"""
+        self._before_write()
         for t in self.adam_m + self.adam_v:
             t.zero_()
         self.step_ctr.zero_()
         self.nonfinite.zero_()
         self._stepped = False
+        self._after_write()
 
     # -- execution ---------------------------------------------------------------------------
     def _s(self):
@@ -208,24 +235,32 @@ class AmassTemporalFitter:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def forward(self) -> None:
+        self._before_run()
         self.lib.check(self.lib.fit_forward(self.handle, self._s()), 'fit_forward')
         self._stepped = False
+        self._after_run()
 
     def backward(self) -> None:
+        self._before_run()
         self.lib.check(self.lib.fit_backward(self.handle, self._s()), 'fit_backward')
+        self._after_run()
 
     def step(self, n: int = 1, use_graph: bool = True) -> None:
         """``n`` Adam iterations (forward, backward, update) -- asynchronous on the current stream.
         With ``use_graph`` the iteration is captured once and replayed; capture needs a non-default
-        stream, so call inside ``with torch.cuda.stream(s):``."""
+        stream, so call inside ``with torch.cuda.stream(s):``.  Ordered after the last ``load_sequence`` / ``reset_optimizer``
+        even when those were issued on another stream (the engine's own events)."""
+        self._before_run()
         self.lib.check(self.lib.fit_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()),
                        'fit_step')
         self._stepped = self._stepped or n > 0
+        self._after_run()
 
     def nonfinite_step(self) -> int:
         """1-based index of the first iteration (since the last ``load_sequence`` / ``reset_optimizer``) whose total loss
         was NaN or Inf, 0 if none (synchronises).  From the following iteration on the engine skipped every update --
         the ``break`` of ``FittingMonitor.run_fitting`` (fitting_temp_slide.py:198-204) inside a replayed graph."""
+        self._before_read()
         return int(self.nonfinite[0].item())
 
     def prepare(self, n: int) -> None:
@@ -242,12 +277,14 @@ class AmassTemporalFitter:
 
     # -- results -------------------------------------------------------------------------------
     def losses(self) -> Dict[str, float]:
+        self._before_read()
         v = self.ws['losses'].detach().cpu().numpy()
         return {k: float(v[i]) for i, k in enumerate(LOSS_NAMES)}
 
     def grads(self) -> Dict[str, torch.Tensor]:
         """raw gradients after ``backward()`` (the L2-prior terms on ``other`` are added inside the
         Adam kernel; ``grads_with_priors`` adds them here for comparison with autograd)."""
+        self._before_read()
         return dict(transl=self.ws['g_transl'], rot6d=self.ws['g_rot6d'], other=self.ws['g_other'])
 
     def grads_with_priors(self) -> Dict[str, torch.Tensor]:
@@ -265,6 +302,7 @@ class AmassTemporalFitter:
         reference saves (opt_amass_temp.py:457-458: the parameters the last iteration's forward saw, i.e. after
         n - 1 updates).  After ``step(n)`` every column comes from that iteration: ``go_aa`` from its forward and the
         pre-update snapshot the Adam kernel took; after a bare ``forward()`` the live parameters are those values."""
+        self._before_read()
         if self._stepped:
             B = self.B
             tr, ot = self.snap[:3 * B].view(B, 3), self.snap[9 * B:].view(B, 56)
@@ -273,10 +311,12 @@ class AmassTemporalFitter:
         return torch.cat([tr, self.ws['go_aa'], self.P['shape'], ot], dim=-1)
 
     def vertices(self) -> torch.Tensor:
+        self._before_read()
         return self.ws['verts']
 
     def posed_joints(self) -> torch.Tensor:
         """the 55 posed skeleton joints + transl of the last forward, [B,55,3]."""
+        self._before_read()
         return self._pose_t['Jtr'] + self.P['transl'][:, None, :]
 
 

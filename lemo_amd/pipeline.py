@@ -127,14 +127,8 @@ class AmassClipPipeline:
         rec, _ = finetune_and_infill(self.ae, self.ae_weights, x_in, mask, steps=finetune_steps, use_graph=use_graph)
         lbl, markers = decode_markers(rec[0, 0], clip_img[0], rot_0_pivot, self.stats, _lib=self.ae._lib_override)
         fit.load_sequence(init_params, markers, lbl)
-        if fit.lib.is_emu:
-            fit.step(steps, use_graph=False)
-        else:
-            s = torch.cuda.Stream(fit.device)
-            s.wait_stream(torch.cuda.current_stream(fit.device))
-            with torch.cuda.stream(s):
-                fit.step(steps, use_graph=True if use_graph is None else bool(use_graph))
-            torch.cuda.current_stream(fit.device).wait_stream(s)
+        # the fitter's own persistent stream (its graphs are captured once); params72() orders itself after the run
+        fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
         return dict(p72=fit.params72(), contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in,
                     train_mask=mask)
 

@@ -289,7 +289,7 @@ ENGINE_PARAMS = (('global_orient', 3), ('transl', 3), ('left_hand_pose', 12), ('
 (fit_temp_loadprox_slide.py:511-519)."""
 
 
-class ProxWindowEngine:
+class ProxWindowEngine(_hip.StreamOrdered):
     """One sliding window (B frames) of the PROX temporal fit on the native engine (``lemo_prox_*``): closure
     ``fitting_func`` (fitting_temp_slide.py:239-311), the S2 / S3-active ``SMPLifyLoss`` terms, backward, first-15 % erase
     and Adam (lr 0.005) are a fixed sequence of ~40 HIP kernels captured once and replayed -- no torch op, no host sync,
@@ -446,6 +446,8 @@ class ProxWindowEngine:
         if not self.handle:
             raise _hip.LemoHipError('lemo_prox_create rejected the descriptor')
         self.first_batch_flag = bool(first_batch_flag)
+        self._init_order(self.device, lib)
+        self._after_write()          # the parameter copies above were enqueued on the constructor's current stream
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None
@@ -456,27 +458,33 @@ class ProxWindowEngine:
             lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
             if rel is None:                  # interpreter shutdown: module globals are gone, the process is about to exit
                 return
-            rel(self.device, lib, lambda: lib.prox_destroy(h))
+            rel(self.device, lib, lambda: lib.prox_destroy(h), getattr(self, '_run_ev', None))
 
     def _s(self):
         return None if self.lib.is_emu else torch.cuda.current_stream(self.device).cuda_stream
 
     def closure(self) -> Dict[str, float]:
         """forward + backward (no update, no erase): fills the loss record and the gradient buffers"""
+        self._before_run()
         self.lib.check(self.lib.prox_closure(self.handle, self._s()), 'prox_closure')
+        self._after_run()
         return self.loss_dict()
 
     def step(self, n: int = 1, use_graph: bool = True) -> None:
         """n x ``optimizer.step(closure)``; asynchronous.  Graph capture needs a non-default current stream."""
+        self._before_run()
         self.lib.check(self.lib.prox_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()), 'prox_step')
+        self._after_run()
 
     def loss_dict(self) -> Dict[str, float]:
+        self._before_read()
         v = self.ws['losses'].detach().cpu().numpy()
         return {k: float(v[i]) for i, k in enumerate(LOSS_KEYS)}
 
     def grads(self, erase: bool = True) -> Dict[str, torch.Tensor]:
         """d(total_loss)/d(parameter) of the last closure including the priors' own terms, with the first-15 % erase
         applied like the reference's closure does (:282-289)"""
+        self._before_read()
         g = {'global_orient': self.ws['g_go'], 'transl': self.ws['dtr_v'] + self.ws['dtr_j'], 'left_hand_pose': self.ws['g_lh'],
              'right_hand_pose': self.ws['g_rh'], 'jaw_pose': self.ws['g_jaw'], 'leye_pose': self.ws['g_leye'],
              'reye_pose': self.ws['g_reye'], 'expression': self.ws['g_expr'], 'pose_embedding': self.ws['g_pe']}
@@ -493,11 +501,13 @@ class ProxWindowEngine:
     def nonfinite_step(self) -> int:
         """1-based index of the first iteration with a NaN / Inf total loss (0 = none): FittingMonitor.run_fitting's stop
         (fitting_temp_slide.py:198-204) inside the replayed graph -- later iterations skip their update"""
+        self._before_read()
         return int(self.nonfinite[0].item())
 
     def write_back(self, body_model: SMPLX) -> torch.Tensor:
         """copy the fitted parameters into the smplx-compatible module (what fit_temp_loadprox_slide.py:577-594 pickles);
         returns pose_embedding"""
+        self._before_read()
         with torch.no_grad():
             for k, _ in ENGINE_PARAMS[:-1]:
                 getattr(body_model, k).copy_(self.P[k])

@@ -69,7 +69,7 @@ class ConcurrentClips:
         dev = self.fitters[0].device
         self.device = dev
         self._gpu = dev.type == 'cuda' and not self.fitters[0].lib.is_emu
-        self.streams = [torch.cuda.Stream(dev) for _ in self.fitters] if self._gpu else [None] * len(self.fitters)
+        self.streams = [f.own_stream() for f in self.fitters] if self._gpu else [None] * len(self.fitters)   # persistent, one per engine
 
     def _on(self, i, fn):
         if self._gpu:

@@ -347,8 +347,17 @@ def test_dense_vertex_backward_large_set(emu_lib):
     assert rel_err(out.vertices.detach(), v_ref.detach()) < 1e-4
     for k in p:
         assert rel_err(p[k].grad, q[k].grad) < 1e-4, k
-    st, tt = model._device_body(torch.device('cpu')).vertex_set('all', np.arange(1300), frames=B)
+    db = model._device_body(torch.device('cpu'))
+    st, tt = db.vertex_set('all', np.arange(1300), frames=B)
     assert 'jcsr_chunk' in tt and st.part_frames >= B                   # the deterministic path was the one that ran
+    # scratch is private per caller: the cached struct carries none, two requests never share a buffer, and a
+    # larger request does not touch the smaller one's; the immutable tables are shared
+    shared, stt = db.vertex_set('all', np.arange(1300))
+    assert shared.part_frames == 0 and not shared.part and 'part' not in stt
+    st2, tt2 = db.vertex_set('all', np.arange(1300), frames=4 * B)
+    assert tt2['part'].data_ptr() != tt['part'].data_ptr() and tt2['gemm_part'].data_ptr() != tt['gemm_part'].data_ptr()
+    assert st.part == tt['part'].data_ptr() and st.part_frames == B and tt['part'].shape[0] == B
+    assert tt2['Dk'].data_ptr() == tt['Dk'].data_ptr() and st2.DkG == st.DkG == shared.DkG
 
 
 @pytest.mark.parametrize('ci,co,ks', [(64, 64, 4), (40, 32, 7), (128, 64, 8)])

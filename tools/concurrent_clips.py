@@ -25,11 +25,22 @@ for f, s in zip(fits, streams):
         f.prepare(20)
 bench.clock_ramp(fits[0], streams[0], 250.0, True)
 res = {}
+load = lambda f, p: f.load_sequence(p['seq']['init_params'], p['markers'], p['seq']['contact_lbl'])
+# every clip on its own first: the values the side-by-side runs must reproduce bit for bit
+solo = []
+for f, p, s in zip(fits, probs, streams):
+    load(f, p)
+    with torch.cuda.stream(s):
+        f.step(10); f.step(steps)
+    torch.cuda.synchronize(dev)
+    solo.append((f.losses(), f.params75().clone()))
+print('solo final total losses:', [repr(l['total']) for l, _ in solo], flush=True)
+bad = 0
 for k in range(1, kmax + 1):
     best = 0.0
     for rep in range(3):
         for f, p in zip(fits[:k], probs[:k]):
-            f.load_sequence(p['seq']['init_params'], p['markers'], p['seq']['contact_lbl'])
+            load(f, p)                       # default stream; the engines order their launches behind it (own events)
         for f, s in zip(fits[:k], streams[:k]):
             with torch.cuda.stream(s):
                 f.step(10)
@@ -41,9 +52,16 @@ for k in range(1, kmax + 1):
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
         best = max(best, k * steps / dt)
+        for i, f in enumerate(fits[:k]):
+            same = f.losses() == solo[i][0] and torch.equal(f.params75(), solo[i][1])
+            if not same:
+                bad += 1
+                print(f'MISMATCH k={k} rep={rep} clip={i}: {f.losses()["total"]!r} vs solo {solo[i][0]["total"]!r}', flush=True)
     losses = [f.losses()['total'] for f in fits[:k]]
     assert all(f.nonfinite_step() == 0 for f in fits[:k])
     res[k] = best
     print(f'{k} clip(s) side by side: {best:8.1f} fitting-iterations/s aggregate ({best / k:7.1f} per clip), '
-          f'{1e3 * k / best:.3f} ms per iteration-of-any-clip; final total losses {["%.4f" % l for l in losses]}', flush=True)
-print(json.dumps({'steps': steps, 'aggregate_iterations_per_s': res}))
+          f'{1e3 * k / best:.3f} ms per iteration-of-any-clip; final total losses {[repr(l) for l in losses]} '
+          f'(== solo, every repetition: {bad == 0})', flush=True)
+print(json.dumps({'steps': steps, 'aggregate_iterations_per_s': res, 'bit_identical_to_solo': bad == 0}))
+sys.exit(1 if bad else 0)
