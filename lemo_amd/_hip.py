@@ -351,7 +351,9 @@ class StreamOrdered:
     _setup_ev = _run_ev = None
 
     def _init_order(self, device, lib):
-        self._gpu = torch.device(device).type == 'cuda' and not lib.is_emu
+        # LEMO_UNORDERED=1 (diagnostics only, tools/concurrent_clips.py): run without the events, to reproduce what the
+        # ordering fixes
+        self._gpu = torch.device(device).type == 'cuda' and not lib.is_emu and os.environ.get('LEMO_UNORDERED', '0') != '1'
         self._odev = torch.device(device)
         self._setup_ev = self._run_ev = None
 

@@ -178,6 +178,42 @@ def prox_window_setup(vertices_world: torch.Tensor, smplx_joints_world: torch.Te
 # ------------------------------------------------------------------------------------------------------------------
 # per-frame fit (stage 1): opt_amass_perframe.py:291-363
 # ------------------------------------------------------------------------------------------------------------------
+def perframe_loss_terms(so: O.SmplxOracle, vposer_w, ids: torch.Tensor, w: dict, transl, rot6d, shape_t, other, tgt):
+    """ONE evaluation of the per-frame objective (opt_amass_perframe.py:324-351): returns (total, parts, p72, verts).
+    ``perframe_fit`` below is this in the reference's loop, and that loop is pinned to the reference's own text at 0.0
+    (tests/golden/oracle_vs_reference.txt, row perframe.*), so the single iteration is pinned with it."""
+    p75 = torch.cat([transl, rot6d, shape_t, other], dim=-1)
+    p72 = O.convert_to_3D_rot(p75)
+    body_pose = O.vposer_decode(vposer_w, p72[:, 16:48], 'aa').view(1, -1)
+    verts, _, _ = so.forward(betas=p72[:, 6:16], global_orient=p72[:, 3:6], body_pose=body_pose,
+                             left_hand_pose=p72[:, 48:60], right_hand_pose=p72[:, 60:], transl=p72[:, 0:3])
+    parts = dict(marker=F.l1_loss(verts[:, ids, :], tgt), vposer=torch.mean(p72[:, 16:48] ** 2),
+                 shape=torch.mean(p72[:, 6:16] ** 2), hand=torch.mean(p72[:, 48:] ** 2))
+    loss = (w['rec_markers'] * parts['marker'] + w['vposer'] * parts['vposer'] +
+            w['shape'] * parts['shape'] + w['hand'] * parts['hand'])
+    return loss, parts, p72, verts
+
+
+def perframe_iteration(so: O.SmplxOracle, vposer_w, markers67_ids, p72_aa: np.ndarray, target: np.ndarray,
+                       weights: Optional[dict] = None):
+    """losses and gradients of ONE per-frame iteration at the parameters ``p72_aa`` [72] (axis-angle orientation; converted
+    to the 6-D parameterisation the loop optimises, :303-306) against ``target`` [67,3] -- the GPU gate of BASELINE
+    configs[0].  Returns dict(total, marker, vposer, shape, hand, g_transl, g_rot6d, g_other, rot6d)."""
+    w = dict(O.LOSS_WEIGHTS if weights is None else weights)
+    ids = torch.as_tensor(np.asarray(markers67_ids, np.int64))
+    p = torch.from_numpy(np.asarray(p72_aa, np.float32)).view(1, 72)
+    transl = p[:, 0:3].clone().requires_grad_(True)
+    rot6d = O.convert_to_6D_all(p[:, 3:6]).detach().clone().requires_grad_(True)
+    other = p[:, 16:].clone().requires_grad_(True)
+    tgt = torch.from_numpy(np.asarray(target, np.float32)).view(1, -1, 3)
+    loss, parts, _, verts = perframe_loss_terms(so, vposer_w, ids, w, transl, rot6d, p[:, 6:16], other, tgt)
+    loss.backward()
+    out = {k: float(v.detach()) for k, v in parts.items()}
+    out.update(total=float(loss.detach()), g_transl=transl.grad.numpy().copy(), g_rot6d=rot6d.grad.numpy().copy(),
+               g_other=other.grad.numpy().copy(), rot6d=rot6d.detach().numpy().copy(), verts=verts.detach().numpy().copy())
+    return out
+
+
 def perframe_fit(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec: np.ndarray, betas: np.ndarray, steps: int = 100,
                  weights: Optional[dict] = None):
     """Returns ``body_params_opt_cur_clip`` [T,72] (p72 of each frame's LAST forward) and the per-frame final loss."""
@@ -204,13 +240,7 @@ def perframe_fit(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec: np.nda
                 for g in opt.param_groups:
                     g['lr'] = 0.003
             opt.zero_grad()
-            p75 = torch.cat([transl, rot6d, shape_t, other], dim=-1)
-            p72 = O.convert_to_3D_rot(p75)
-            body_pose = O.vposer_decode(vposer_w, p72[:, 16:48], 'aa').view(1, -1)
-            verts, _, _ = so.forward(betas=p72[:, 6:16], global_orient=p72[:, 3:6], body_pose=body_pose,
-                                     left_hand_pose=p72[:, 48:60], right_hand_pose=p72[:, 60:], transl=p72[:, 0:3])
-            loss = (w['rec_markers'] * F.l1_loss(verts[:, ids, :], tgt) + w['vposer'] * torch.mean(p72[:, 16:48] ** 2) +
-                    w['shape'] * torch.mean(p72[:, 6:16] ** 2) + w['hand'] * torch.mean(p72[:, 48:] ** 2))
+            loss, _, p72, _ = perframe_loss_terms(so, vposer_w, ids, w, transl, rot6d, shape_t, other, tgt)
             loss.backward()
             opt.step()
         out.append(p72[0].detach().numpy().copy())

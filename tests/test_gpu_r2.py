@@ -27,6 +27,51 @@ def dev():
 # ---------------------------------------------------------------------------------------------------------------------
 # per-frame fit (configs[0])
 # ---------------------------------------------------------------------------------------------------------------------
+def test_perframe_single_iteration_full_size_vs_pinned_oracle(dev):
+    """BASELINE configs[0], ONE iteration (VERDICT r02 #4i): B = 1, V = 10475, real marker ids -- marker L1 + the three
+    L2 priors <= 1e-5 and the three gradients <= 1e-4 (max-norm) against ``pipeline_oracle.perframe_iteration``, the same
+    lines ``perframe_fit`` runs, pinned bit-exactly to the reference's loop text (tests/test_oracle.py).  Evaluated at
+    the loop's start point (:298-310) and at three realistic bodies."""
+    from lemo_amd.fitting import AmassTemporalFitter, LOSS_WEIGHTS
+    from lemo_amd.vposer import make_vposer_weights
+    from oracle import lemo_oracle as O, pipeline_oracle as PO
+    A = load_assets()
+    model = synthetic.make_synthetic_smplx(seed=0)
+    g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
+    seq = synthetic.make_synthetic_sequence(0, B=119)
+    vw = make_vposer_weights(2)
+    so, vwt = O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}
+    w = dict(LOSS_WEIGHTS, contact_vel=0.0, smooth=0.0)
+    fit = AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 1, dev, weights=w, full_vertices=False,
+                              lr0=0.1, lr1=0.01, lr_switch=60, lr2=0.003, lr_switch2=80, per_frame=True)
+    start = np.zeros(72, np.float32)
+    start[0:3], start[3:6], start[6:16] = (0.0, 0.4, 1.0), (0.0, 1.6, 3.14), seq['init_params'][0, 6:16]
+    points = [(start, g['markers_rec'][0])] + [(seq['init_params'][t], g['markers_rec'][t]) for t in (0, 57, 118)]
+    worst = dict(loss=0.0, grad=0.0)
+    for p72, tgt in points:
+        ref = PO.perframe_iteration(so, vwt, A['ids']['markers67'], p72, tgt)
+        fit.load_sequence(p72[None], tgt[None], np.zeros((1, 4), np.float32))
+        fit.forward(); fit.backward()
+        torch.cuda.synchronize()
+        L = fit.losses()
+        for k in ('marker', 'vposer', 'shape', 'hand', 'total'):
+            e = abs(L[k] - ref[k]) / max(abs(ref[k]), 1e-12)
+            worst['loss'] = max(worst['loss'], e)
+            assert e <= 1e-5, (k, L[k], ref[k])
+        assert L['contact'] == 0.0 and L['smooth'] == 0.0
+        gg = fit.grads_with_priors()
+        for k in ('transl', 'rot6d', 'other'):
+            r = ref['g_' + k]
+            e = float(np.abs(gg[k].cpu().numpy() - r).max() / np.abs(r).max())
+            worst['grad'] = max(worst['grad'], e)
+            assert e <= 1e-4, (k, e)
+        rows = fit._idx['row67'].long()
+        vm = fit.vertices()[0, rows].cpu().numpy()
+        ids = np.asarray(A['ids']['markers67'])
+        assert np.abs(vm - ref['verts'][0, ids]).max() <= 1e-4 * np.abs(ref['verts']).max()
+    print(f'\nper-frame single iteration, V = 10475, 4 points: worst loss rel err {worst["loss"]:.2e}, worst gradient max-norm err {worst["grad"]:.2e}')
+
+
 def test_perframe_fit_full_size_vs_oracle(dev):
     """opt_amass_perframe.py:291-363 at V = 10475 with the real marker ids: 3 frames x 100 steps (both lr switches) on the
     engine's per_frame mode (graph replay) vs the oracle, whose loop is pinned to the reference text at 0.0."""
@@ -48,9 +93,27 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     print(f'\nper-frame fit, 3 frames x 100 steps: params vs oracle max {d.max():.2e} mean {d.mean():.2e}; final loss gpu {L["total"]:.6f} oracle {last[-1]:.6f}')
     assert L['contact'] == 0.0 and L['smooth'] == 0.0
     # 300 Adam steps with two optimiser restarts (lr 0.1, sign() gradients of the L1 term) are chaotic in the parameters
-    # (measured: mean |diff| 0.12 while the final losses agree to 3 %): the full run is compared through its loss, the
-    # iterates through the 10-step and 2-step runs below and the B = 1 gradient check of the emulator suite
-    assert abs(L['total'] - last[-1]) < 0.1 * last[-1]
+    # (measured: max |diff| 0.99 while both runs fit the same markers): the full run is compared through WHAT IT FITS --
+    # the marker residual of each frame and the distance between the two fitted bodies (MPJPE over the 22 body joints, mm);
+    # the arithmetic of an iteration is gated by test_perframe_single_iteration_full_size_vs_pinned_oracle
+    so = O.SmplxOracle(model)
+    vwt = {k: torch.from_numpy(v) for k, v in vw.items()}
+    ids67 = torch.as_tensor(np.asarray(A['ids']['markers67'], np.int64))
+
+    def body(p72):
+        p = torch.from_numpy(np.asarray(p72, np.float32))
+        bp = O.vposer_decode(vwt, p[:, 16:48], 'aa').view(p.shape[0], -1)
+        v, j, _ = so.forward(betas=p[:, 6:16], global_orient=p[:, 3:6], body_pose=bp, left_hand_pose=p[:, 48:60],
+                             right_hand_pose=p[:, 60:], transl=p[:, 0:3])
+        return v[:, ids67].detach().numpy(), j[:, :22].detach().numpy()
+    mg, jg = body(got)
+    mo, jo = body(ref)
+    res_g = np.abs(mg - mr).mean(axis=(1, 2)) * 1e3                  # per-frame mean |marker residual|, mm
+    res_o = np.abs(mo - mr).mean(axis=(1, 2)) * 1e3
+    mpjpe = np.linalg.norm(jg - jo, axis=-1).mean(axis=1) * 1e3     # per frame, mm
+    print(f'marker residual mm: gpu {np.round(res_g, 3)} oracle {np.round(res_o, 3)}; MPJPE gpu-vs-oracle fits mm {np.round(mpjpe, 3)}')
+    assert np.all(np.abs(res_g - res_o) <= 0.15 * res_o + 0.05), (res_g, res_o)
+    assert mpjpe.max() < 5.0, mpjpe
     ref10, last10 = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr, betas, steps=10)
     got10 = pf.fit_clip(mr, betas, steps=10).cpu().numpy()
     d10 = np.abs(got10 - ref10)

@@ -173,3 +173,22 @@ def test_pipeline_oracle_vs_reference_fixture():
     _, rec2 = PO.finetune(ae_w, x_in, m, steps=2)
     tgt = torch.from_numpy(g['clip_img_rec'])
     assert float((rec2 - tgt).abs().mean()) < float((rec0 - tgt).abs().mean())
+
+
+def test_perframe_oracle_reproduces_the_reference_written_fixture():
+    """configs[0]: ``perframe_fit.npz`` holds what the reference's own loop text (opt_amass_perframe.py:291-364, exec'd by
+    tests/golden/ref_harness.py) produced for 3 frames x 100 steps; the oracle -- whose single evaluation
+    ``perframe_loss_terms`` is also what the GPU gate of one iteration is checked against -- must reproduce it exactly."""
+    import __graft_entry__ as ge
+    from oracle import lemo_oracle as O, pipeline_oracle as PO
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'perframe_fit.npz'))
+    prob = ge.small_problem()
+    so = O.SmplxOracle(prob['model'], extra_joint_ids=list(range(21)))
+    vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
+    o, last = PO.perframe_fit(so, vw, prob['ids']['markers67'], g['markers_rec'], g['betas'], steps=100)
+    assert np.array_equal(o, g['p72']) and np.array_equal(last, g['final_loss'])
+    # the single-iteration entry evaluates the same objective: at the fitted parameters of frame 2 its total equals the
+    # loop's last loss up to the 6-D round trip of the orientation (aa -> 6-D -> aa)
+    it = PO.perframe_iteration(so, vw, prob['ids']['markers67'], g['p72'][2], g['markers_rec'][2])
+    assert abs(it['total'] - float(g['final_loss'][2])) <= 2e-6 * abs(float(g['final_loss'][2])) + 1e-9
+    assert abs(it['total'] - (it['marker'] + 0.02 * it['vposer'] + 0.01 * it['shape'] + 0.01 * it['hand'])) < 1e-7
