@@ -47,3 +47,26 @@ def amass_fit_oracle_f64(model, vposer_w, enc_w, ids, Xmean, Xstd, init_params, 
         fit.other = p[:, 16:].double().clone().requires_grad_(True)
         fit.opt = torch.optim.Adam([fit.transl, fit.rot6d, fit.other], lr=0.01)
     return fit
+
+
+def perframe_iteration_f64(model, vposer_w, markers67_ids, p72_aa, target, weights=None, extra_joint_ids=None):
+    """``pipeline_oracle.perframe_iteration`` (opt_amass_perframe.py:324-351, one evaluation + gradients) in float64, from
+    the SAME float32 start point (the 6-D orientation is converted in float32 like the fit's)."""
+    from . import pipeline_oracle as PO
+    with default_f64():
+        so = O.SmplxOracle(model, extra_joint_ids=extra_joint_ids)
+        _to_double(so)
+        vw = {k: torch.as_tensor(np.asarray(v)).double() for k, v in vposer_w.items()}
+        w = dict(O.LOSS_WEIGHTS if weights is None else weights)
+        ids = torch.as_tensor(np.asarray(markers67_ids, np.int64))
+        p = torch.from_numpy(np.asarray(p72_aa, np.float32)).view(1, 72)
+        transl = p[:, 0:3].double().clone().requires_grad_(True)
+        rot6d = O.convert_to_6D_all(p[:, 3:6].clone()).double().clone().requires_grad_(True)
+        other = p[:, 16:].double().clone().requires_grad_(True)
+        tgt = torch.from_numpy(np.asarray(target, np.float32)).double().view(1, -1, 3)
+        loss, parts, _, verts = PO.perframe_loss_terms(so, vw, ids, w, transl, rot6d, p[:, 6:16].double(), other, tgt)
+        loss.backward()
+        out = {k: float(v.detach()) for k, v in parts.items()}
+        out.update(total=float(loss.detach()), g_transl=transl.grad.numpy().copy(), g_rot6d=rot6d.grad.numpy().copy(),
+                   g_other=other.grad.numpy().copy(), verts=verts.detach().numpy().copy())
+    return out
