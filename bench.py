@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '3'))
+DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '4'))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -68,19 +68,7 @@ def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
 
 def conv_launcher(fit, stream):
     """closure that launches the engine's 64->64 conv (layer 10's shape, the engine's own buffers / scratch output)"""
-    from lemo_amd._hip import ptr
-    lib = fit.lib
-    H, W = fit.H, fit.W
-    if fit.conv_variant == 3:
-        fn = lib.conv3x3_mfma_split
-        args = (ptr(fit.act[9]), ptr(fit.enc.w3[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
-    elif fit.conv_variant == 2:
-        fn = lib.conv3x3_mfma_lds
-        args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.w2[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0)
-    else:
-        fn = lib.conv3x3_mfma
-        args = (ptr(fit.act[9]), ptr(fit.enc.w[9]), ptr(fit.enc.b[9]), None, ptr(fit.dact[1]), H, W, 64, 64, 0, fit.conv_variant)
-    return lambda: lib.check(fn(*args, stream.cuda_stream))
+    return lambda: _conv_layer(fit, 9, False, fit.act[9], fit.dact[1], stream)
 
 
 def events_ms(stream, launch, reps, precondition=None):
@@ -121,9 +109,11 @@ def _conv_layer(fit, l, bwd, src, dst, stream):
     ci, co = (ENC_CHANNELS[l + 1], ENC_CHANNELS[l]) if bwd else (ENC_CHANNELS[l], ENC_CHANNELS[l + 1])
     bias, aux, epi = (None, ptr(fit.act[l]), 1) if bwd else (ptr(e.b[l]), None, 0)
     w, w2, w3 = (e.wbwd, e.wbwd2, e.wbwd3) if bwd else (e.w, e.w2, e.w3)
-    if fit.conv_variant >= 3:
-        rc = fit.launch_split_conv(l, bwd, src, dst, stream.cuda_stream) if hasattr(fit, 'launch_split_conv') else \
-            lib.conv3x3_mfma_split(ptr(src), ptr(w3[l]), ptr(w[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
+    if fit.conv_variant >= 4:
+        pack, winv = e.split_pack(l, bwd, fit.conv_variant)
+        rc = lib.conv3x3_mfma_split_f16(ptr(src), ptr(pack), winv, ptr(w[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
+    elif fit.conv_variant == 3:
+        rc = lib.conv3x3_mfma_split(ptr(src), ptr(w3[l]), ptr(w[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
     elif fit.conv_variant == 2:
         rc = lib.conv3x3_mfma_lds(ptr(src), ptr(w[l]), ptr(w2[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
     else:
@@ -426,7 +416,13 @@ def main():
     vs = time_vertex_stage(fit, stream, use_graph=use_graph)
     lbs_in_chain_ms = (time_conv_chain(fit, stream, use_graph=use_graph, with_lbs=True) - chain_ms) if fit.full else None
     fit.dact[0].zero_(); fit.dact[1].zero_()          # the chain used the gradient maps as scratch (interiors are rewritten each step)
-    if fit.conv_variant == 3:
+    if fit.conv_variant == 4:
+        # every fp32-accurate multiply-accumulate is 3 fp16 MFMA products (two error-compensated fp16 pieces per operand, fp32
+        # accumulate): the pipe that bounds the kernel is the 16-bit matrix pipe at 1/3 of its dense peak
+        peak, kname = PEAK_BF16_MATRIX_TFLOPS / 3.0, 'conv3x3_split_kernel<NP=2> (variant 4: two fp16 pieces per fp32 operand, 3 products on v_mfma_f32_32x32x16_f16)'
+        peak_note = ('algorithmic fp32 FLOP/s against f16 dense MFMA peak %.0f TF / 3 products per fp32-accurate MAC (variant 3, 6 bf16 '
+                     'products: peak / 6; the fp32-MFMA kernel (--conv-variant 2): %.1f TF)' % (PEAK_BF16_MATRIX_TFLOPS, PEAK_FP32_MATRIX_TFLOPS))
+    elif fit.conv_variant == 3:
         # every fp32 multiply-accumulate is 6 bf16 MFMA products (exact 3-way operand split, fp32 accumulate):
         # the pipe that bounds the kernel is the bf16 matrix pipe at 1/6 of its dense peak
         peak, kname = PEAK_BF16_MATRIX_TFLOPS / 6.0, 'conv3x3_split_kernel (variant 3: fp32-exact 3xbf16 operand split on v_mfma_f32_32x32x16_bf16)'
@@ -445,13 +441,16 @@ def main():
                                'encoder 245x134, marker+contact+prior losses, Adam',
                    'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
                    'sequences': world, 'conv_variant': fit.conv_variant,
-                   'arithmetic': 'fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
-                                 'each (6 bf16-MFMA products, fp32 accumulate; error vs float64 <= the fp32-MFMA kernel\'s)'
-                                 if fit.conv_variant == 3 else 'fp32 throughout (fp32-input MFMA)',
+                   'arithmetic': {4: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
+                                     'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured '
+                                     'error vs float64 at the level of an fp32 convolution, conv_split_kernels.hip)',
+                                  3: 'fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
+                                     'each (6 bf16-MFMA products, fp32 accumulate; error vs float64 <= the fp32-MFMA kernel\'s)'}.get(
+                                         fit.conv_variant, 'fp32 throughout (fp32-input MFMA)'),
                    'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant == 3
+                     'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant >= 3
                                                                          else 'lemo::conv3x3_mfma_v2_kernel<0'),
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
                                      'algorithmic minimum 17.1e6)',

@@ -54,25 +54,17 @@ int lemo_conv3x3_mfma_split(const float* in, const void* w3, const float* wt, co
                             float* out, int H, int W, int cin, int cout, int epi, void* stream);
 int lemo_conv3x3_mfma_split_census(const float* in, const void* w3, const float* wt, const float* bias, float* out,
                                    int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
-/* Persistent chain of up to LEMO_CHAIN_MAX consecutive 64 -> 64 layers in ONE launch (layer l reads what layer l-1
- * wrote: in[l] == out[l-1]); results are bit-identical to n calls of lemo_conv3x3_mfma_split.  One workgroup per CU
- * keeps its tile through all layers and waits on per-tile flags of its neighbours instead of a kernel boundary, so
- * every workgroup must be resident at once: lemo_conv3x3_split_chain_supported() checks H*W/128 <= #CUs.
- * sync: device ints, lemo_conv3x3_split_chain_sync_ints(H, W, n) of them, zeroed once by the caller and then owned
- * by this (shape, n); sync[1] != 0 after a launch means a bounded wait timed out (results invalid). */
-#define LEMO_CHAIN_MAX 8
-typedef struct lemo_conv_chain {
-  int n;
-  const float* in[LEMO_CHAIN_MAX];
-  const void* w3[LEMO_CHAIN_MAX];
-  const float* wt[LEMO_CHAIN_MAX];
-  const float* bias[LEMO_CHAIN_MAX];   /* epi 0 / 2 */
-  const float* aux[LEMO_CHAIN_MAX];    /* epi 1 */
-  float* out[LEMO_CHAIN_MAX];
-} lemo_conv_chain;
-int lemo_conv3x3_split_chain_supported(int H, int W);
-int lemo_conv3x3_split_chain_sync_ints(int H, int W, int n);
-int lemo_conv3x3_split_chain(const lemo_conv_chain* c, int H, int W, int epi, int* sync, void* stream);
+/* variant 4 ("split-f16", the engines' default since round 3): the same convolution with TWO fp16 pieces per operand and
+ * three of the four piece products (the error-compensated fp16 scheme of Markidis et al. / Ootomo & Yokota: hi = f16(x s),
+ * lo = f16(x s - hi); a b ~= a_hi b_lo + a_lo b_hi + a_hi b_hi, fp32 accumulate) -- half the matrix-core work of variant 3,
+ * error vs float64 at the level of an fp32 convolution (conv_split_kernels.hip header has the measurements).  The
+ * activations are scaled per workgroup inside the kernel (any fp32 CG8P tensor is a valid input); the weights are scaled
+ * on the host: w2 = f16 w2[Cin/16][tap 9][Cout/32][piece 2][lane 64][8] of weight * 2^k, winv = 2^-k. */
+int lemo_conv3x3_mfma_split_f16(const float* in, const void* w2, float winv, const float* wt, const float* bias, const float* aux,
+                                float* out, int H, int W, int cin, int cout, int epi, void* stream);
+/* census of either variant (pieces = 3: w = w3, winv ignored; pieces = 2: w = w2) */
+int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
+                                    int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
@@ -288,7 +280,7 @@ typedef struct lemo_fit_const {
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
-  int conv_variant;               /* 0/1: lemo_conv3x3_mfma variants ; 2: lemo_conv3x3_mfma_lds ;
+  int conv_variant;               /* 4: split-f16 (default) ; 0/1: lemo_conv3x3_mfma variants ; 2: lemo_conv3x3_mfma_lds ;
                                    * 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;
@@ -303,10 +295,10 @@ typedef struct lemo_fit_desc {
   const float* enc_wbwd[10];      /* backward-data packs (layer 0: same [Cout][9]) */
   const float* enc_w2[10];        /* channel-group-major packs for conv_variant 2 (layer 0 unused) */
   const float* enc_wbwd2[10];
-  const void* enc_w3[10];         /* split-bf16 packs for conv_variant 3 (layer 0: NULL) */
+  const void* enc_w3[10];         /* split packs (layer 0: NULL): bf16 x 3 pieces for conv_variant 3, f16 x 2 pieces for 4 */
   const void* enc_wbwd3[10];
-  int* conv_chain_sync[2];        /* forward / backward encoder chains (lemo_conv3x3_split_chain), or NULL: one launch
-                                   * per layer.  Sized for n = 7 layers each, zeroed by the caller. */
+  float enc_w3_inv[10];           /* conv_variant 4: 2^-k of each pack's host-side weight scale 2^k (lemo_conv3x3_mfma_split_f16) */
+  float enc_wbwd3_inv[10];
   /* sequence data */
   const float* target;            /* [B][n67][3]  markers_rec */
   const float* contact;           /* [B][4] */
@@ -410,6 +402,7 @@ typedef struct lemo_prox_desc {
   const float* enc_w[10]; const float* enc_b[10]; const float* enc_wbwd[10];
   const float* enc_w2[10]; const float* enc_wbwd2[10];
   const void* enc_w3[10]; const void* enc_wbwd3[10];
+  float enc_w3_inv[10]; float enc_wbwd3_inv[10];      /* conv_variant 4 (see lemo_fit_desc) */
   /* scene */
   const float* sdf; int sdf_dim[3];           /* [D][H][W] */
   float grid_min[3], grid_max[3];

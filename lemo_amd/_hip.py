@@ -82,12 +82,6 @@ class FitConst(C.Structure):
 CHAIN_MAX = 8
 
 
-class ConvChain(C.Structure):
-    """lemo_conv_chain"""
-    _fields_ = [('n', C.c_int), ('inp', vp * CHAIN_MAX), ('w3', vp * CHAIN_MAX), ('wt', vp * CHAIN_MAX), ('bias', vp * CHAIN_MAX),
-                ('aux', vp * CHAIN_MAX), ('out', vp * CHAIN_MAX)]
-
-
 class FitDesc(C.Structure):
     _fields_ = [
         ('B', C.c_int), ('Bp', C.c_int), ('V', C.c_int), ('nrows', C.c_int), ('full_vertices', C.c_int),
@@ -95,7 +89,7 @@ class FitDesc(C.Structure):
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst),
         ('fwd_ids', vp),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10),
-        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10), ('conv_chain_sync', vp * 2),
+        ('enc_w2', vp * 10), ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10), ('enc_w3_inv', C.c_float * 10), ('enc_wbwd3_inv', C.c_float * 10),
         ('target', vp), ('contact', vp), ('weights', vp), ('weights_host', C.c_float * 6),
         ('transl', vp), ('rot6d', vp), ('other', vp), ('shape', vp),
         ('adam_m', vp * 3), ('adam_v', vp * 3), ('step_ctr', vp),
@@ -130,7 +124,7 @@ class ProxDesc(C.Structure):
         ('use_infill', C.c_int), ('T', C.c_int),
         ('vposer', VPoserW), ('body', BodyConst), ('skin', SkinConst), ('uset', VertexSetBwd), ('fit', FitConst), ('pc', ProxConst),
         ('enc_ch', C.c_int * 11), ('enc_w', vp * 10), ('enc_b', vp * 10), ('enc_wbwd', vp * 10), ('enc_w2', vp * 10),
-        ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10),
+        ('enc_wbwd2', vp * 10), ('enc_w3', vp * 10), ('enc_wbwd3', vp * 10), ('enc_w3_inv', C.c_float * 10), ('enc_wbwd3_inv', C.c_float * 10),
         ('sdf', vp), ('sdf_dim', C.c_int * 3), ('grid_min', C.c_float * 3), ('grid_max', C.c_float * 3),
         ('cam2world', C.c_float * 12), ('cam', C.c_float * 4),
         ('gt_joints', vp), ('w2', vp), ('marker_mask', vp), ('body_markers_rec', vp), ('contact_lbl_rec', vp),
@@ -174,12 +168,11 @@ _SIGS = {
     'lemo_reconstruct_global_body_dev': (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_local_markers_4chan': (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     'lemo_decode_clip': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
-    'lemo_conv3x3_split_chain_supported': (C.c_int, [C.c_int, C.c_int]),
-    'lemo_conv3x3_split_chain_sync_ints': (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    'lemo_conv3x3_split_chain': (C.c_int, [C.POINTER(ConvChain), C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_split_supported': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'lemo_conv3x3_mfma_split': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_split_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'lemo_conv3x3_mfma_split_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    'lemo_conv3x3_mfma_split_census2': (C.c_int, [vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_mfma_lds_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_c1_bwd': (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -18,12 +18,9 @@ int conv_lds_init();
 // variant 3: fp32-exact 64->64 conv on the bf16 matrix cores (3-way bf16 operand split, 6 products)
 bool conv3x3_split_supported(int H, int W, int cin, int cout);
 int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const float* bias, const float* aux, float* out,
-                       int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
+                       int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr, int pieces = 3,
+                       float winv = 1.f);
 int conv_split_init();
-bool conv3x3_split_chain_supported(int H, int W);
-int conv3x3_split_chain_sync_ints(int H, int W, int n);
-// force: skip the residency check
-int conv3x3_split_chain(const lemo_conv_chain& c, int H, int W, int epi, int* sync, bool force, hipStream_t s);
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);

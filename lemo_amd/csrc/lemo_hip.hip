@@ -12,7 +12,7 @@ using namespace lemo;
 
 extern "C" {
 
-int lemo_abi_version(void) { return 1; }
+int lemo_abi_version(void) { return 2; }
 
 int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W,
                       int cin, int cout, int epi, int variant, void* stream) {
@@ -40,11 +40,15 @@ int lemo_conv3x3_mfma_split_census(const float* in, const void* w3, const float*
   if (!in || !w3 || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
   return conv3x3_mfma_split(in, w3, wt, bias, nullptr, out, H, W, cin, cout, 0, S(stream), dbg);
 }
-int lemo_conv3x3_split_chain_supported(int H, int W) { return conv3x3_split_chain_supported(H, W) ? 1 : 0; }
-int lemo_conv3x3_split_chain_sync_ints(int H, int W, int n) { return conv3x3_split_chain_sync_ints(H, W, n); }
-int lemo_conv3x3_split_chain(const lemo_conv_chain* c, int H, int W, int epi, int* sync, void* stream) {
-  if (!c) return LEMO_ERR_ARG;
-  return conv3x3_split_chain(*c, H, W, epi, sync, false, S(stream));
+int lemo_conv3x3_mfma_split_f16(const float* in, const void* w2, float winv, const float* wt, const float* bias, const float* aux,
+                                float* out, int H, int W, int cin, int cout, int epi, void* stream) {
+  if (!in || !w2 || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
+  return conv3x3_mfma_split(in, w2, wt, bias, aux, out, H, W, cin, cout, epi, S(stream), nullptr, 2, winv);
+}
+int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
+                                    int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
+  if (!in || !w || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
+  return conv3x3_mfma_split(in, w, wt, bias, nullptr, out, H, W, cin, cout, 0, S(stream), dbg, pieces, winv);
 }
 int lemo_conv3x3_mfma_lds_census(const float* in, const float* wt, const float* wt2, const float* bias, float* out,
                                  int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
@@ -230,8 +234,6 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 // ------------------------------------------------------------------------------------------------
 // fitting engine
 // ------------------------------------------------------------------------------------------------
-static const int CHAIN_LAYERS = 7;    // 64 -> 64 layers of the encoder (models/AE_sep.py:77-89): what conv_chain_sync is sized for
-
 // a replay costs ~8 us of device idle time around the graph (tools/ubench/launch_ubench.hip) on top of its nodes:
 // up to FIT_UNROLL[0] iterations are captured into one graph; remainders run on the smaller graphs
 static const int FIT_LEVELS = 3;
@@ -300,6 +302,24 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
   return a;
 }
 
+// one MFMA layer of the smoothness encoder (forward: act[l] -> act[l+1]; backward-data: d(pre-act l+1) -> d(pre-act l) with
+// the saved activation act[l] as epilogue operand) on the kernel family conv_variant selects for its shape
+static int enc_layer(const lemo_fit_desc& d, int l, bool bwd, const float* src, float* dst, int H, int W, hipStream_t s) {
+  const int cin = bwd ? d.enc_ch[l + 1] : d.enc_ch[l], cout = bwd ? d.enc_ch[l] : d.enc_ch[l + 1];
+  const float* wt = bwd ? d.enc_wbwd[l] : d.enc_w[l];
+  const float* wt2 = bwd ? d.enc_wbwd2[l] : d.enc_w2[l];
+  const void* w3 = bwd ? d.enc_wbwd3[l] : d.enc_w3[l];
+  const float* bias = bwd ? nullptr : d.enc_b[l];
+  const float* aux = bwd ? d.act[l] : nullptr;
+  const int epi = bwd ? 1 : 0;
+  if (d.conv_variant >= 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
+    return conv3x3_mfma_split(src, w3, wt, bias, aux, dst, H, W, cin, cout, epi, s, nullptr, d.conv_variant == 4 ? 2 : 3,
+                              bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l]);
+  if (d.conv_variant >= 2 && 127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 <= 416)
+    return conv3x3_mfma_lds(src, wt, wt2, bias, aux, dst, H, W, cin, cout, epi, s);
+  return conv3x3_mfma(src, wt, bias, aux, dst, H, W, cin, cout, epi, d.conv_variant >= 2 ? 1 : d.conv_variant, s);
+}
+
 // compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
 // a run of iterations the previous iteration's tail launch has already produced it from the updated latent
 static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true) {
@@ -329,27 +349,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
   CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  // runs of 64 -> 64 layers go out as ONE persistent chain launch when the caller provided the sync buffer and
-  // every workgroup fits on the device at once; everything else one launch per layer
-  const bool chain_f = d.conv_variant == 3 && d.conv_chain_sync[0] && conv3x3_split_chain_supported(H, W);
-  for (int l = 1; l < 10;) {
-    if (chain_f && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_w3[l]) {
-      lemo_conv_chain c{};
-      while (l < 10 && c.n < LEMO_CHAIN_MAX && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_w3[l]) {
-        c.in[c.n] = d.act[l]; c.w3[c.n] = d.enc_w3[l]; c.wt[c.n] = d.enc_w[l]; c.bias[c.n] = d.enc_b[l]; c.out[c.n] = d.act[l + 1];
-        ++c.n; ++l;
-      }
-      if (c.n == CHAIN_LAYERS) { CHK(conv3x3_split_chain(c, H, W, 0, d.conv_chain_sync[0], false, s)); continue; }
-      l -= c.n;                                       // the sync buffer is sized for CHAIN_LAYERS: fall through
-    }
-    if (d.conv_variant == 3 && d.enc_w3[l] && conv3x3_split_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1]))
-      CHK(conv3x3_mfma_split(d.act[l], d.enc_w3[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
-    else if (d.conv_variant >= 2)
-      CHK(conv3x3_mfma_lds(d.act[l], d.enc_w[l], d.enc_w2[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, s));
-    else
-      CHK(conv3x3_mfma(d.act[l], d.enc_w[l], d.enc_b[l], nullptr, d.act[l + 1], H, W, d.enc_ch[l], d.enc_ch[l + 1], 0, d.conv_variant, s));
-    ++l;
-  }
+  for (int l = 1; l < 10; ++l) CHK(enc_layer(d, l, false, d.act[l], d.act[l + 1], H, W, s));
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
   CHK(fit_losses(d.act[10], d.dact[0], H, W, d.enc_ch[10], coef2, d.loss_acc + 9, d.fit, d.verts, d.nrows, d.target, d.contact,
@@ -367,26 +367,9 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   int cur = 0;
   if (d.per_frame) goto vertex_stage;           // no encoder: d.fit.u_m81 is all -1, dx0 is never read
   {
-  const bool chain_b = d.conv_variant == 3 && d.conv_chain_sync[1] && conv3x3_split_chain_supported(H, W);
-  for (int l = 9; l >= 1;) {       // d(pre-act of layer l+1) -> d(pre-act of layer l)
-    if (chain_b && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_wbwd3[l]) {
-      lemo_conv_chain c{};
-      int cc = cur;
-      while (l >= 1 && c.n < LEMO_CHAIN_MAX && d.enc_ch[l] == 64 && d.enc_ch[l + 1] == 64 && d.enc_wbwd3[l]) {
-        c.in[c.n] = d.dact[cc]; c.w3[c.n] = d.enc_wbwd3[l]; c.wt[c.n] = d.enc_wbwd[l]; c.aux[c.n] = d.act[l]; c.out[c.n] = d.dact[1 - cc];
-        cc = 1 - cc; ++c.n; --l;
-      }
-      if (c.n == CHAIN_LAYERS) { CHK(conv3x3_split_chain(c, H, W, 1, d.conv_chain_sync[1], false, s)); cur = cc; continue; }
-      l += c.n;
-    }
-    if (d.conv_variant == 3 && d.enc_wbwd3[l] && conv3x3_split_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l]))
-      CHK(conv3x3_mfma_split(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
-    else if (d.conv_variant >= 2)
-      CHK(conv3x3_mfma_lds(d.dact[cur], d.enc_wbwd[l], d.enc_wbwd2[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, s));
-    else
-      CHK(conv3x3_mfma(d.dact[cur], d.enc_wbwd[l], nullptr, d.act[l], d.dact[1 - cur], H, W, d.enc_ch[l + 1], d.enc_ch[l], 1, d.conv_variant, s));
+  for (int l = 9; l >= 1; --l) {       // d(pre-act of layer l+1) -> d(pre-act of layer l)
+    CHK(enc_layer(d, l, true, d.dact[cur], d.dact[1 - cur], H, W, s));
     cur = 1 - cur;
-    --l;
   }
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
   }

@@ -30,8 +30,9 @@ static int conv_layer(const lemo_prox_desc& d, int l, bool bwd, const float* x, 
   const void* w3 = bwd ? d.enc_wbwd3[l] : d.enc_w3[l];
   const float* bias = bwd ? nullptr : d.enc_b[l];
   const int epi = bwd ? 1 : 0;
-  if (d.conv_variant == 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
-    return conv3x3_mfma_split(x, w3, wt, bias, aux, out, H, W, cin, cout, epi, s);
+  if (d.conv_variant >= 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
+    return conv3x3_mfma_split(x, w3, wt, bias, aux, out, H, W, cin, cout, epi, s, nullptr, d.conv_variant == 4 ? 2 : 3,
+                              bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l]);
   if (d.conv_variant >= 2 && 127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 <= 416)
     return conv3x3_mfma_lds(x, wt, wt2, bias, aux, out, H, W, cin, cout, epi, s);
   return conv3x3_mfma(x, wt, bias, aux, out, H, W, cin, cout, epi, 1, s);

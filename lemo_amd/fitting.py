@@ -36,7 +36,7 @@ class AmassTemporalFitter(_hip.StreamOrdered):
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
-                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None, use_conv_chain: Optional[bool] = None,
+                 lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None,
                  lbs_blend_fp32: bool = False, per_frame: bool = False, lr2: float = 0.0, lr_switch2: int = 0,
                  lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
@@ -128,17 +128,12 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
         d.fwd_ids = ptr(I['fwd_ids'])
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c
-        # persistent encoder chains (7 x 64->64 forward, 7 backward-data): flags + counters, zeroed once
-        nsync = self.lib.conv3x3_split_chain_sync_ints(H, W, 7)
-        self.chain_sync = [torch.zeros(max(nsync, 1), dtype=torch.int32, device=dev) for _ in range(2)]
-        use_chain = bool(use_conv_chain)           # default off: measured 18.8 vs 16.6 us per layer (conv_split_kernels.hip)
-        for i in range(2):
-            d.conv_chain_sync[i] = ptr(self.chain_sync[i]) if (use_chain and nsync > 0 and not self.lib.is_emu) else None
         for l in range(10):
             d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
             d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
-            d.enc_w3[l] = ptr(self.enc.w3[l]) if self.enc.w3[l] is not None else None
-            d.enc_wbwd3[l] = ptr(self.enc.wbwd3[l]) if self.enc.wbwd3[l] is not None else None
+            for bwd, dst, dinv in ((False, d.enc_w3, d.enc_w3_inv), (True, d.enc_wbwd3, d.enc_wbwd3_inv)):
+                pack, winv = self.enc.split_pack(l, bwd, self.conv_variant)         # bf16 x 3 (variant 3) or f16 x 2 (variant 4)
+                dst[l], dinv[l] = (ptr(pack) if pack is not None else None), float(winv)
         d.target, d.contact, d.weights = ptr(self.target), ptr(self.contact), ptr(self._w_dev)
         for i, v in enumerate(wl): d.weights_host[i] = v
         d.transl, d.rot6d, d.other, d.shape = (ptr(self.P[k]) for k in ('transl', 'rot6d', 'other', 'shape'))
@@ -267,13 +262,6 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         """capture (without running) the hipGraphs an ``n``-iteration :meth:`step` on the current stream replays."""
         if not self.lib.is_emu:
             self.lib.check(self.lib.fit_prepare(self.handle, int(n), self._s()), 'fit_prepare')
-
-    def check_chains(self):
-        """raises if a bounded wait of the persistent encoder kernels timed out (call after a synchronisation)"""
-        for i, name in enumerate(('forward', 'backward')):
-            if int(self.chain_sync[i][1].item()) != 0:
-                raise _hip.LemoHipError(f'{name} encoder chain: a neighbour-tile wait timed out (are all {self.H * self.W // 128} '
-                                        'workgroups resident at once?)')
 
     # -- results -------------------------------------------------------------------------------
     def losses(self) -> Dict[str, float]:

@@ -83,6 +83,36 @@ def pack_conv3x3_bwd_split(w: np.ndarray) -> np.ndarray:
     return pack_conv3x3_split(np.ascontiguousarray(wf))
 
 
+def f16_split2(x: np.ndarray):
+    """x * 2^k = hi + lo (two fp16 pieces, 2 x 11 significand bits) with 2^k chosen so that max|x| lands in [2^14, 2^15):
+    returns (hi, lo, 2^-k).  The conv_variant-4 operand format (conv_split_kernels.hip header)."""
+    x = np.ascontiguousarray(x, np.float32)
+    m = float(np.abs(x).max())
+    k = 14 - int(np.floor(np.log2(m))) if m > 0 else 0
+    xs = x * np.float32(2.0 ** k)                              # exact (power of two)
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    assert np.isfinite(hi).all()
+    return hi, lo, float(2.0 ** -k)
+
+
+def pack_conv3x3_split_f16(w: np.ndarray):
+    """[Cout][Cin][3][3] fp32 -> (uint16 (f16 bits) w2[Cin/16][tap][Cout/32][piece 2][lane 64][8], winv) for
+    lemo_conv3x3_mfma_split_f16: same fragment order as :func:`pack_conv3x3_split`, two pieces of weight * 2^k."""
+    co, ci = w.shape[:2]
+    assert ci % 16 == 0 and co % 32 == 0
+    hi, lo, winv = f16_split2(w)
+    bits = np.stack([hi, lo], 0).view(np.uint16)             # [2][co][ci][3][3]
+    t = bits.reshape(2, co // 32, 32, ci // 16, 2, 8, 9)    # [s][mt][i][kc][h][e][tap]
+    t = t.transpose(3, 6, 1, 0, 4, 2, 5)                    # [kc][tap][mt][s][h][i][e]
+    return np.ascontiguousarray(t).reshape(ci // 16, 9, co // 32, 2, 64, 8), winv
+
+
+def pack_conv3x3_bwd_split_f16(w: np.ndarray):
+    wf = w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)
+    return pack_conv3x3_split_f16(np.ascontiguousarray(wf))
+
+
 def cg8p_alloc(C_: int, H: int, W: int, device) -> torch.Tensor:
     """zeroed CG8P activation buffer [C/8][(H+2)*(W+2)][8] (border stays zero forever)."""
     return torch.zeros(max(C_ // 8, 1), (H + 2) * (W + 2), 8, dtype=torch.float32, device=device)
@@ -104,11 +134,18 @@ def from_cg8p(buf: torch.Tensor, H: int, W: int) -> torch.Tensor:
 class EncWeights:
     """Device-resident packed weights of the 10-layer smoothness encoder."""
 
+    def split_pack(self, l: int, bwd: bool, variant: int):
+        """(device pack, winv) of layer l for the split kernels: f16 x 2 pieces for variant >= 4, bf16 x 3 for 3"""
+        if variant >= 4:
+            return (self.wbwd4[l], self.wbwd4_inv[l]) if bwd else (self.w4[l], self.w4_inv[l])
+        return ((self.wbwd3[l] if bwd else self.w3[l]), 1.0)
+
     def __init__(self, state: Dict[str, np.ndarray], device):
         self.keys = enc_layer_keys()
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
         self.w, self.b, self.wbwd, self.w2, self.wbwd2 = [], [], [], [], []
         self.w3, self.wbwd3 = [], []                       # split-bf16 packs (layer 0: None)
+        self.w4, self.wbwd4, self.w4_inv, self.wbwd4_inv = [], [], [], []     # split-f16 packs + inverse host scales (variant 4)
         t16 = lambda a: torch.from_numpy(a.view(np.int16)).to(device)
         for li, k in enumerate(self.keys):
             w = np.asarray(state[k + '.weight'], np.float32)
@@ -119,6 +156,7 @@ class EncWeights:
                 self.wbwd.append(self.w[0])
                 self.w2.append(self.w[0]); self.wbwd2.append(self.w[0])
                 self.w3.append(None); self.wbwd3.append(None)
+                self.w4.append(None); self.wbwd4.append(None); self.w4_inv.append(1.0); self.wbwd4_inv.append(1.0)
             else:
                 self.w.append(t(pack_conv3x3(w)))
                 self.wbwd.append(t(pack_conv3x3_bwd(w)))
@@ -126,6 +164,9 @@ class EncWeights:
                 self.wbwd2.append(t(pack_conv3x3_bwd_gmajor(w)))
                 self.w3.append(t16(pack_conv3x3_split(w)))
                 self.wbwd3.append(t16(pack_conv3x3_bwd_split(w)))
+                pf, fi = pack_conv3x3_split_f16(w)
+                pb, bi = pack_conv3x3_bwd_split_f16(w)
+                self.w4.append(t16(pf)); self.wbwd4.append(t16(pb)); self.w4_inv.append(fi); self.wbwd4_inv.append(bi)
             self.b.append(t(b))
 
 
@@ -133,9 +174,10 @@ class EncWeights:
 # Encoder as autograd ops over the C ABI
 # ----------------------------------------------------------------------------------------------
 
-DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '3'))
-"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 3 = fp32-exact
-split-bf16 kernel for the 64->64 layers + LDS-tiled fp32-MFMA kernel (2) for the rest; 2 / 1 = fp32 MFMA only.
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '4'))
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 4 = split-f16 kernel (two
+error-compensated fp16 pieces per fp32 operand, 3 products; the default since round 3), 3 = split-bf16 kernel (three
+exact bf16 pieces, 6 products), LDS-tiled fp32-MFMA kernel (2) for shapes they do not take; 2 / 1 = fp32 MFMA only.
 The environment override exists for A/B runs of the parity suite."""
 
 
@@ -146,7 +188,10 @@ def _conv_layer(lib, enc: EncWeights, l: int, bwd: bool, x, out, aux, H, W, vari
     wt, wt2, w3 = (enc.wbwd[l], enc.wbwd2[l], enc.wbwd3[l]) if bwd else (enc.w[l], enc.w2[l], enc.w3[l])
     bias, epi = (None, 1) if bwd else (ptr(enc.b[l]), 0)
     auxp = ptr(aux) if bwd else None
-    if variant >= 3 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
+    if variant >= 4 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
+        w4, winv = enc.split_pack(l, bwd, variant)
+        lib.check(lib.conv3x3_mfma_split_f16(ptr(x), ptr(w4), winv, ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_split_f16')
+    elif variant >= 3 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
         lib.check(lib.conv3x3_mfma_split(ptr(x), ptr(w3), ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_split')
     elif variant >= 2 and 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 <= 416:
         lib.check(lib.conv3x3_mfma_lds(ptr(x), ptr(wt), ptr(wt2), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_lds')

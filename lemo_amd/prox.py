@@ -419,8 +419,9 @@ class ProxWindowEngine(_hip.StreamOrdered):
         for l in range(10):
             d.enc_w[l], d.enc_b[l], d.enc_wbwd[l] = ptr(self.enc.w[l]), ptr(self.enc.b[l]), ptr(self.enc.wbwd[l])
             d.enc_w2[l], d.enc_wbwd2[l] = ptr(self.enc.w2[l]), ptr(self.enc.wbwd2[l])
-            d.enc_w3[l] = ptr(self.enc.w3[l]) if self.enc.w3[l] is not None else None
-            d.enc_wbwd3[l] = ptr(self.enc.wbwd3[l]) if self.enc.wbwd3[l] is not None else None
+            for bwd, dst, dinv in ((False, d.enc_w3, d.enc_w3_inv), (True, d.enc_wbwd3, d.enc_wbwd3_inv)):
+                pack, winv = self.enc.split_pack(l, bwd, cv)                         # bf16 x 3 (variant 3) or f16 x 2 (variant 4)
+                dst[l], dinv[l] = (ptr(pack) if pack is not None else None), float(winv)
         d.sdf = ptr(self.sdf)
         for i in range(3):
             d.sdf_dim[i], d.grid_min[i], d.grid_max[i] = int(self.sdf.shape[i]), float(grid_min[i]), float(grid_max[i])

@@ -70,3 +70,45 @@ def perframe_iteration_f64(model, vposer_w, markers67_ids, p72_aa, target, weigh
         out.update(total=float(loss.detach()), g_transl=transl.grad.numpy().copy(), g_rot6d=rot6d.grad.numpy().copy(),
                    g_other=other.grad.numpy().copy(), verts=verts.detach().numpy().copy())
     return out
+
+
+def perframe_fit_f64(model, vposer_w, markers67_ids, markers_rec, betas, steps=100, weights=None, extra_joint_ids=None):
+    """``pipeline_oracle.perframe_fit`` (opt_amass_perframe.py:291-363) with every tensor in float64 from the same
+    float32 start values: what the loop does when rounding is taken out of it -- the yardstick for how far two
+    correct float32 implementations of this loop may drift apart (the marker term's sign() gradient and Adam's
+    normalisation turn rounding-sized differences into O(lr) steps)."""
+    from . import pipeline_oracle as PO
+    import torch.nn.functional as F  # noqa: F401
+    with default_f64():
+        so = O.SmplxOracle(model, extra_joint_ids=extra_joint_ids)
+        _to_double(so)
+        vw = {k: torch.as_tensor(np.asarray(v)).double() for k, v in vposer_w.items()}
+        w = dict(O.LOSS_WEIGHTS if weights is None else weights)
+        ids = torch.as_tensor(np.asarray(markers67_ids, np.int64))
+        T = markers_rec.shape[0]
+        shape_t = torch.from_numpy(np.asarray(betas, np.float32)).double().view(1, 10)
+        out, last = [], []
+        transl = rot6d = other = None
+        for t in range(T):
+            tgt = torch.from_numpy(np.asarray(markers_rec[t:t + 1], np.float32)).double()
+            if t == 0:
+                transl = torch.tensor([[0.0, 0.4, 1.0]], dtype=torch.float32).double()
+                rot6d = O.convert_to_6D_all(torch.tensor([[0.0, 1.6, 3.14]], dtype=torch.float32)).detach().double().clone()
+                other = torch.zeros(1, 56, dtype=torch.float64)
+                for p in (transl, rot6d, other):
+                    p.requires_grad = True
+            opt = torch.optim.Adam([transl, rot6d, other], lr=0.1 if t == 0 else 0.01)
+            for step in range(steps):
+                if step > 60:
+                    for g in opt.param_groups:
+                        g['lr'] = 0.01
+                if step > 80:
+                    for g in opt.param_groups:
+                        g['lr'] = 0.003
+                opt.zero_grad()
+                loss, _, p72, _ = PO.perframe_loss_terms(so, vw, ids, w, transl, rot6d, shape_t, other, tgt)
+                loss.backward()
+                opt.step()
+            out.append(p72[0].detach().numpy().copy())
+            last.append(float(loss.detach()))
+    return np.asarray(out), np.asarray(last)

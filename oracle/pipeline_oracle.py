@@ -244,5 +244,5 @@ def perframe_fit(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec: np.nda
             loss.backward()
             opt.step()
         out.append(p72[0].detach().numpy().copy())
-        last.append(float(loss))
+        last.append(float(loss.detach()))
     return np.asarray(out), np.asarray(last)

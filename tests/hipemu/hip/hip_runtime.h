@@ -470,6 +470,27 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_bf16x
   return d;
 }
 
+// gfx950 f16 MFMA: same operand / result lane maps as the bf16 form; products of two f16 values are exact in fp32 terms,
+// summed in double here and rounded once per instruction
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int) {
+  hipemu::WaveBuf& w = hipemu::mywave();
+  const int l = hipemu::me().lane;
+  for (int e = 0; e < 8; ++e) { w.a8[l][e] = (float)a[e]; w.b8[l][e] = (float)b[e]; }
+  hipemu::barrier(w.g);
+  hipemu_f32x16 d;
+  const int col = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    double acc = c[r];
+    for (int hh = 0; hh < 2; ++hh)
+      for (int e = 0; e < 8; ++e) acc += (double)w.a8[row + 32 * hh][e] * (double)w.b8[col + 32 * hh][e];
+    d[r] = (float)acc;
+  }
+  hipemu::barrier(w.g);
+  return d;
+}
+
 // ---- atomics: atomicAdd on GLOBAL memory is deferred to the end of the launch (see hipemu::launch); its return value is
 // NOT the old value (no kernel uses it).  Integer fetch-adds whose result IS used (last-block detection) are real atomics.
 template <typename T> static void hipemu_apply_add(void* p, const void* v) { T a; memcpy(&a, v, sizeof(T)); *(T*)p = *(T*)p + a; }

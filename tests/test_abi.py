@@ -23,7 +23,7 @@ def test_gfx950_library_exports_every_declared_symbol(hip_lib_built):
     dll = ctypes.CDLL(hip_lib_built)
     missing = [n for n in _declared() if not hasattr(dll, n)]
     assert not missing, missing
-    assert dll.lemo_abi_version() == 1
+    assert dll.lemo_abi_version() == 2
 
 
 def test_python_binding_covers_header():
@@ -43,3 +43,27 @@ def test_product_refuses_cpu_tensors(hip_lib_built):
     from lemo_amd.rotation import convert_to_3D_all
     with pytest.raises(_hip.LemoHipError):
         convert_to_3D_all(torch.randn(4, 6))            # no CPU fallback
+
+
+def test_descriptor_layouts_match_the_header():
+    """the ctypes mirrors of lemo_fit_desc / lemo_prox_desc must have the C structs' size and field offsets: compiled from
+    include/lemo_hip.h with the host compiler (a mismatch is a silent wrong-pointer bug otherwise)"""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from lemo_amd import _hip
+    fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame']),
+              'lemo_prox_desc': (_hip.ProxDesc, ['enc_w3_inv', 'sdf', 'pose_embedding', 'losses'])}
+    src = '#include <cstdio>\n#include <cstddef>\n#include "lemo_hip.h"\nint main(){\n'
+    for name, (_, fl) in fields.items():
+        src += f'printf("%zu", sizeof({name}));' + ''.join(f'printf(" %zu", offsetof({name}, {f}));' for f in fl) + 'printf("\\n");\n'
+    src += 'return 0;}\n'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, 'o.cpp'), 'w').write(src)
+        subprocess.run(['g++', '-I', os.path.join(root, 'include'), os.path.join(td, 'o.cpp'), '-o', os.path.join(td, 'o')], check=True)
+        lines = subprocess.run([os.path.join(td, 'o')], check=True, capture_output=True, text=True).stdout.strip().split('\n')
+    for line, (name, (cls, fl)) in zip(lines, fields.items()):
+        want = [int(v) for v in line.split()]
+        got = [C.sizeof(cls)] + [getattr(cls, f).offset for f in fl]
+        assert got == want, (name, got, want)

@@ -35,9 +35,8 @@ def full_problem(dev):
     g = np.load(os.path.join(GOLDEN, 'amass_iter.npz'))
     model = synthetic.make_synthetic_smplx(seed=0)
     seq = synthetic.make_synthetic_sequence(0, B=119)
-    mk = lambda full, variant=None, chain=None: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'],
-                                                                    A['Xstd'], 119, dev, full_vertices=full, conv_variant=variant,
-                                                                    use_conv_chain=chain)
+    mk = lambda full, variant=None: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'],
+                                                        A['Xstd'], 119, dev, full_vertices=full, conv_variant=variant)
     return dict(A=A, g=g, model=model, seq=seq, make=mk)
 
 
@@ -160,10 +159,53 @@ def test_split_bf16_conv_error_is_fp32_sized(dev):
     assert float((got[-1, -62:] - refdx[-1, -62:]).abs().max() / refdx.abs().max()) < 2e-6      # the remainder patches
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+def test_split_f16_conv_error_is_fp32_sized(dev):
+    """conv variant 4 multiplies each fp32 operand as two error-compensated fp16 pieces (3 f16-MFMA products, fp32
+    accumulate, per-workgroup power-of-two scaling).  Against a float64 convolution its error must be the size of an fp32
+    convolution's own rounding error: <= 1.5x the fp32-MFMA kernel's on the same data and < 2e-6 of max|out| -- on
+    activation-sized data AND on gradient-sized data (1e-6: deep in fp16's denormal range without the scaling)."""
+    import torch.nn.functional as F
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import (cg8p_alloc, from_cg8p, to_cg8p, pack_conv3x3, pack_conv3x3_gmajor, pack_conv3x3_split_f16,
+                                 pack_conv3x3_bwd, pack_conv3x3_bwd_split_f16)
+    lib = _hip.get_lib()
+    A = load_assets()
+    H, W = 245, 134
+    w, b = np.asarray(A['enc_w']['enc_blc4.main.2.weight'], np.float32), np.asarray(A['enc_w']['enc_blc4.main.2.bias'], np.float32)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, H, W, generator=g).abs() * 0.3
+    ref = F.leaky_relu(F.conv2d(x[None].double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1), 0.2)[0]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    pf, fi = pack_conv3x3_split_f16(w)
+    wt, wt2, w4, bd, xin = t(pack_conv3x3(w)), t(pack_conv3x3_gmajor(w)), t(pf.view(np.int16)), t(b), to_cg8p(x).to(dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    o2, o4 = cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    lib.check(lib.conv3x3_mfma_lds(ptr(xin), ptr(wt), ptr(wt2), ptr(bd), None, ptr(o2), H, W, 64, 64, 0, s))
+    lib.check(lib.conv3x3_mfma_split_f16(ptr(xin), ptr(w4), fi, ptr(wt), ptr(bd), None, ptr(o4), H, W, 64, 64, 0, s))
+    torch.cuda.synchronize()
+    e2 = float((from_cg8p(o2.cpu(), H, W).double() - ref).abs().max() / ref.abs().max())
+    e4 = float((from_cg8p(o4.cpu(), H, W).double() - ref).abs().max() / ref.abs().max())
+    r4 = float((from_cg8p(o4.cpu(), H, W).double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f'\nmax err / max|ref| vs float64: fp32-MFMA {e2:.3e}   split-f16 {e4:.3e} (rms {r4:.3e})')
+    assert e4 < 2e-6 and e4 <= 1.5 * e2 and r4 < 6e-7
+    assert float(o4.reshape(8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0          # zero border untouched
+    dy, aux = torch.randn(64, H, W, generator=g) * 1e-6, torch.randn(64, H, W, generator=g)
+    refdx = F.conv_transpose2d(dy[None].double(), torch.from_numpy(w).double(), padding=1)[0] * torch.where(aux > 0, 1.0, 0.2).double()
+    pb, bi = pack_conv3x3_bwd_split_f16(w)
+    wb, wb4 = t(pack_conv3x3_bwd(w)), t(pb.view(np.int16))
+    dyb, auxb, dxb = to_cg8p(dy).to(dev), to_cg8p(aux).to(dev), cg8p_alloc(64, H, W, dev)
+    lib.check(lib.conv3x3_mfma_split_f16(ptr(dyb), ptr(wb4), bi, ptr(wb), None, ptr(auxb), ptr(dxb), H, W, 64, 64, 1, s))
+    torch.cuda.synchronize()
+    got = from_cg8p(dxb.cpu(), H, W).double()
+    assert float((got - refdx).abs().max() / refdx.abs().max()) < 2e-6
+    assert float((got[-1, -62:] - refdx[-1, -62:]).abs().max() / refdx.abs().max()) < 2e-6      # the remainder patches
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
 def test_encoder_full_size_golden(dev, variant):
     """10-layer MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad.  Variants 0-2 run
-    every layer on the fp32 MFMA; 3 runs the seven 64->64 layers (forward and backward-data) on the split-bf16 kernel."""
+    every layer on the fp32 MFMA; 3 / 4 run the nine MFMA layers (forward and backward-data) on the split-bf16 / split-f16 kernel."""
     from lemo_amd import _hip
     from lemo_amd._hip import ptr
     from lemo_amd.priors import ENC_CHANNELS, EncWeights, cg8p_alloc, from_cg8p, _conv_layer
@@ -263,7 +305,7 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert abs(fit.losses()['total'] - ref_total) < 2e-3 * ref_total
 
 
-@pytest.mark.parametrize('conv_variant', [3, 2])
+@pytest.mark.parametrize('conv_variant', [4, 3, 2])
 def test_fit_full_size_golden(full_problem, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
@@ -575,63 +617,3 @@ def test_marker_image_encode_decode_golden(dev):
     assert rel_err(glob.cpu(), g['global_body']) < 1e-5
     img_np, _ = get_local_markers_4chan(g['body'], g['contact'])          # numpy in -> float64 numpy out, like the reference
     assert isinstance(img_np, np.ndarray) and img_np.dtype == np.float64
-
-
-def test_fit_engine_with_conv_chain_matches_per_layer(full_problem, dev):
-    """the fitting engine with the opt-in persistent encoder chains: same losses and parameters after 3 graph-replayed
-    steps as with one launch per layer (identical arithmetic -> identical bits)"""
-    from lemo_amd import _hip
-    if not _hip.get_lib().conv3x3_split_chain_supported(245, 134):
-        pytest.skip('fewer CUs than tiles')
-    g, seq = full_problem['g'], full_problem['seq']
-    res = []
-    for chain in (False, True):
-        fit = full_problem['make'](False, 3, chain)
-        fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
-        s = torch.cuda.Stream(dev)
-        with torch.cuda.stream(s):
-            fit.step(3, use_graph=True)
-        torch.cuda.synchronize()
-        fit.check_chains()
-        fit.forward(); torch.cuda.synchronize()
-        res.append((fit.params75().clone(), fit.losses()))
-    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
-
-
-def test_conv_chain_is_bit_identical_to_per_layer_launches(dev):
-    """persistent 7-layer encoder chain (neighbour-tile flags, coherent activation accesses) == 7 launches, bit for bit,
-    for the forward epilogue and for the backward-data epilogue with ping-pong buffers; and through the fitting engine."""
-    import ctypes as C
-    from lemo_amd import _hip
-    from lemo_amd._hip import ptr
-    from lemo_amd.priors import EncWeights, cg8p_alloc, to_cg8p
-    lib = _hip.get_lib()
-    H, W = 245, 134
-    if not lib.conv3x3_split_chain_supported(H, W):
-        pytest.skip('fewer CUs than tiles: the chain kernel cannot keep every workgroup resident')
-    enc = EncWeights(load_assets()['enc_w'], dev)
-    s = torch.cuda.current_stream(dev).cuda_stream
-    g = torch.Generator().manual_seed(1)
-    x = to_cg8p(torch.randn(64, H, W, generator=g).abs() * 0.3).to(dev)
-    auxs = [to_cg8p(torch.randn(64, H, W, generator=g)).to(dev) for _ in range(7)]
-    for epi in (0, 1):
-        outs = []
-        for chain in (False, True):
-            layers = list(range(3, 10)) if epi == 0 else list(range(9, 2, -1))
-            pp = [x.clone(), cg8p_alloc(64, H, W, dev)]
-            c = _hip.ConvChain(); c.n = 7
-            for i, l in enumerate(layers):
-                c.inp[i], c.out[i] = ptr(pp[i & 1]), ptr(pp[1 - (i & 1)])
-                c.w3[i], c.wt[i] = (ptr(enc.w3[l]), ptr(enc.w[l])) if epi == 0 else (ptr(enc.wbwd3[l]), ptr(enc.wbwd[l]))
-                if epi == 0: c.bias[i] = ptr(enc.b[l])
-                else: c.aux[i] = ptr(auxs[i])
-            sync = torch.zeros(lib.conv3x3_split_chain_sync_ints(H, W, 7), dtype=torch.int32, device=dev)
-            if chain:
-                lib.check(lib.conv3x3_split_chain(C.byref(c), H, W, epi, ptr(sync), s))
-            else:
-                for i in range(7):
-                    lib.check(lib.conv3x3_mfma_split(c.inp[i], c.w3[i], c.wt[i], c.bias[i], c.aux[i], c.out[i], H, W, 64, 64, epi, s))
-            torch.cuda.synchronize()
-            assert int(sync[1]) == 0
-            outs.append(pp[1].clone())
-        assert torch.equal(outs[0], outs[1]), epi

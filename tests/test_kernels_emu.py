@@ -292,34 +292,59 @@ def test_contact_term_empty_selection_is_exactly_zero(emu_lib):
     assert fit.losses()['contact'] == 0.0                # no contact labels at all
 
 
-def test_conv_chain_single_layer_coherent_path(emu_lib):
-    """the persistent chain kernel's code path (coherent buffer accesses, patch after the K loop, flag publication)
-    with n = 1 layer -- the emulator runs workgroups one after another, so multi-layer chains are GPU-only tests"""
-    import ctypes as C
-    from lemo_amd import _hip
-    from lemo_amd.priors import pack_conv3x3_split
-    H, W = 36, 57
-    g = torch.Generator().manual_seed(7)
-    x, w, b = torch.randn(64, H, W, generator=g), torch.randn(64, 64, 3, 3, generator=g) * 0.1, torch.randn(64, generator=g)
-    ref = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
-    xin, out = to_cg8p(x), cg8p_alloc(64, H, W, 'cpu')
-    wt, w3 = torch.from_numpy(pack_conv3x3(w.numpy())), torch.from_numpy(pack_conv3x3_split(w.numpy()).view(np.int16))
-    n = emu_lib.conv3x3_split_chain_sync_ints(H, W, 1)
-    assert n == 3 + 1 + (H * W) // 128
-    sync = torch.zeros(n, dtype=torch.int32)
-    c = _hip.ConvChain()
-    c.n = 1
-    c.inp[0], c.w3[0], c.wt[0], c.bias[0], c.out[0] = ptr(xin), ptr(w3), ptr(wt), ptr(b), ptr(out)
-    for epoch in (1, 2):                                               # a second launch reuses the sync buffer
-        out.zero_()
-        assert emu_lib.conv3x3_split_chain(C.byref(c), H, W, 0, ptr(sync), None) == 0
-        assert rel_err(from_cg8p(out, H, W), ref) < 2e-6
-        nb = (H * W) // 128
-        assert int(sync[0]) == epoch and int(sync[1]) == 0 and int(sync[2]) == epoch * nb and int(sync[3]) == epoch * nb
-        assert (sync[4:] == epoch).all()
-    one = cg8p_alloc(64, H, W, 'cpu')
-    assert emu_lib.conv3x3_mfma_split(ptr(xin), ptr(w3), ptr(wt), ptr(b), None, ptr(one), H, W, 64, 64, 0, None) == 0
-    assert torch.equal(one, out)                                       # bit-identical to the per-layer kernel
+@pytest.mark.parametrize('H,W,ci,co', [(7, 41, 64, 64), (36, 57, 64, 64), (7, 41, 32, 64), (7, 41, 64, 32), (9, 30, 32, 32)])
+def test_conv3x3_split_f16_forward_and_backward_data(emu_lib, H, W, ci, co):
+    """conv variant 4 (two error-compensated fp16 pieces per operand, three products, per-workgroup power-of-two scaling)
+    against torch fp32 AND float64: its error must be of the size of the fp32 convolution's own rounding error.  The
+    input spans a wide dynamic range ACROSS tiles and ACROSS the two channel phases (one half of the image 1e-9-sized, the
+    other 1e4-sized; channels 32.. scaled by 1e-3) -- what the per-workgroup, per-phase scale is for: a per-tensor scale
+    would flush the small half to fp16 denormals."""
+    from lemo_amd.priors import pack_conv3x3_split_f16, pack_conv3x3_bwd_split_f16, f16_split2
+    g = torch.Generator().manual_seed(H * W + ci + 2 * co + 1)
+    x, w, b = torch.randn(ci, H, W, generator=g), torch.randn(co, ci, 3, 3, generator=g) * 0.1, torch.randn(co, generator=g)
+    hi, lo, winv = f16_split2(w.numpy())
+    assert np.abs(hi.astype(np.float64) + lo.astype(np.float64) - w.numpy().astype(np.float64) / winv).max() <= 2.0 ** -22 * np.abs(w.numpy() / winv).max()
+    assert 2.0 ** 14 <= np.abs(w.numpy() / winv).max() < 2.0 ** 15
+    wt = torch.from_numpy(pack_conv3x3(w.numpy()))
+    pf, fi = pack_conv3x3_split_f16(w.numpy())
+    w4 = torch.from_numpy(pf.view(np.int16))
+    for case in (('plain', 'range') if H >= 30 else ('plain',)):
+        xx = x.clone()
+        if case == 'range':
+            xx[:, : H // 2] *= 1e-9
+            xx[:, H // 2:] *= 1e4
+            xx[32:] *= 1e-3
+        ref64 = F.leaky_relu(F.conv2d(xx[None].double(), w.double(), b.double() * (0 if case == 'range' else 1), padding=1), 0.2)[0]
+        ref32 = F.leaky_relu(F.conv2d(xx[None], w, b * (0 if case == 'range' else 1), padding=1), 0.2)[0]
+        bb = b * (0 if case == 'range' else 1)
+        xin, out = to_cg8p(xx), cg8p_alloc(co, H, W, 'cpu')
+        assert emu_lib.conv3x3_mfma_split_f16(ptr(xin), ptr(w4), fi, ptr(wt), ptr(bb), None, ptr(out), H, W, ci, co, 0, None) == 0
+        got = from_cg8p(out, H, W).double()
+        if case == 'plain':
+            e_split, e_f32 = rel_err(got, ref64), rel_err(ref32.double(), ref64)
+            assert e_split < 2e-6 and e_split < 4 * e_f32, (e_split, e_f32)
+        else:
+            # per region, away from the seam: a workgroup's tile is 128 consecutive pixels (2-3 rows here) + a halo row on
+            # either side, and its scale follows the largest value it staged -- rows that share a tile with the 1e4-sized
+            # half are carried relative to THAT maximum (documented property of the per-workgroup scale)
+            for r0, r1 in ((0, H // 2 - 5), (H // 2 + 5, H)):
+                e = float((got[:, r0:r1] - ref64[:, r0:r1]).abs().max() / ref64[:, r0:r1].abs().max())
+                e32 = float((ref32.double()[:, r0:r1] - ref64[:, r0:r1]).abs().max() / ref64[:, r0:r1].abs().max())
+                assert e < 3e-6 and e < 6 * e32 + 1e-7, (case, r0, e, e32)
+        assert float(out.reshape(co // 8, H + 2, W + 2, 8)[:, 0].abs().max()) == 0.0       # border untouched
+    dy, aux = torch.randn(co, H, W, generator=g) * 1e-6, torch.randn(ci, H, W, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr[None], w, b, padding=1).backward(dy[None])
+    refdx = xr.grad * torch.where(aux > 0, 1.0, 0.2)
+    dyb, auxb, dxb = to_cg8p(dy), to_cg8p(aux), cg8p_alloc(ci, H, W, 'cpu')
+    pb, bi = pack_conv3x3_bwd_split_f16(w.numpy())
+    wtb, wb4 = torch.from_numpy(pack_conv3x3_bwd(w.numpy())), torch.from_numpy(pb.view(np.int16))
+    assert emu_lib.conv3x3_mfma_split_f16(ptr(dyb), ptr(wb4), bi, ptr(wtb), None, ptr(auxb), ptr(dxb), H, W, co, ci, 1, None) == 0
+    assert rel_err(from_cg8p(dxb, H, W), refdx) < 2e-6
+    # all-zero input: scale clamps, output = lrelu(bias) exactly
+    z = cg8p_alloc(ci, H, W, 'cpu')
+    assert emu_lib.conv3x3_mfma_split_f16(ptr(z), ptr(w4), fi, ptr(wt), ptr(b), None, ptr(out), H, W, ci, co, 0, None) == 0
+    assert torch.equal(from_cg8p(out, H, W), F.leaky_relu(b, 0.2)[:, None, None].expand(co, H, W))
 
 
 def test_dense_vertex_backward_large_set(emu_lib):

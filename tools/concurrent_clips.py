@@ -17,7 +17,7 @@ dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
 fits, probs, streams = [], [], []
 for k in range(kmax):
-    f, p = bench.build_problem(k, 119, dev, full_vertices=True, conv_variant=3)
+    f, p = bench.build_problem(k, 119, dev, full_vertices=True, conv_variant=bench.DEFAULT_CONV_VARIANT)
     fits.append(f); probs.append(p); streams.append(torch.cuda.Stream(dev))
 for f, s in zip(fits, streams):
     with torch.cuda.stream(s):

@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device('cuda:0')
-fit, _ = bench.build_problem(0, 119, dev, True, conv_variant=3)
+fit, _ = bench.build_problem(0, 119, dev, True, conv_variant=bench.DEFAULT_CONV_VARIANT)
 lib = fit.lib
 buf = torch.zeros(4 * 32, dtype=torch.int64, device=dev)
 lib._dll.lemo_census_set.argtypes = [C.c_void_p]

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-hammer = (sys.argv[2] if len(sys.argv) > 2 else 'B') != 'none'
+mode = sys.argv[2] if len(sys.argv) > 2 else 'B'         # B: another clip's graphs; torch: big torch matmuls + copies; none
+hammer = mode != 'none'
 dev = torch.device('cuda:0')
 torch.cuda.set_device(dev)
 A, pa = bench.build_problem(0, 119, dev, full_vertices=True, conv_variant=bench.DEFAULT_CONV_VARIANT)
@@ -54,11 +55,37 @@ for _ in range(3):                                   # solo determinism
     run_a(); torch.cuda.synchronize(dev)
     bad = [k for (k, t), (_, b) in zip(buffers(A), base) if not torch.equal(t, b)]
     print('solo repeat differs in:', bad, flush=True)
+X = torch.randn(4096, 4096, device=dev)
+Z = torch.empty_like(X)
+
+
+def where(name, t, b):
+    """which (frame, ...) entries of a [B, ...] buffer differ"""
+    d = (t != b)
+    if d.dim() < 2 or d.shape[0] != 119:
+        return f'{name}: {int(d.sum())} entries'
+    fr = d.reshape(119, -1).any(1).nonzero().flatten().tolist()
+    detail = ''
+    if name in ('pose.R', 'pose.T', 'pose.A', 'pose.Jtr') and fr:
+        f0 = fr[0]
+        nj = 55
+        jd = d[f0].reshape(nj, -1).any(1).nonzero().flatten().tolist()
+        detail = f' frame {f0}: joints {jd}'
+        if name == 'pose.R':
+            detail += f' got {t[f0, jd[0]].flatten().tolist()} base {b[f0, jd[0]].flatten().tolist()}'
+    return f'{name}: frames {fr}{detail}'
+
+
 seen = {}
 for trial in range(trials):
-    if hammer:
+    if mode == 'B':
         with torch.cuda.stream(sb):
             B.step(100); B.step(100)
+    elif mode == 'torch':
+        with torch.cuda.stream(sb):
+            for _ in range(60):
+                Y = X @ X
+                Z.copy_(Y)
     run_a()
     torch.cuda.synchronize(dev)
     bad = []
@@ -66,6 +93,8 @@ for trial in range(trials):
         if not torch.equal(t, b):
             d = (t.double() - b.double()).abs()
             bad.append((k, int((d != 0).sum()), float(d.max()), float(b.double().abs().max())))
+            if k in ('pose.full_pose', 'pose.R', 'pose.T', 'pose.A', 'pose.Xg', 'verts', 'v_posed', 'act[1]', 'act[2]', 'dA', 'dX', 'g_other'):
+                print('   ', where(k, t, b), flush=True)
     if bad:
         first = bad[0][0]
         seen[first] = seen.get(first, 0) + 1
