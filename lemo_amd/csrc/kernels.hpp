@@ -52,6 +52,7 @@ typedef lemo_fit_const FitConst;
 struct DvertsIn {
   const float* verts; int nrows; const float* target; const float* contact; const float* dx0; const float* canon;
   const float* weights; int B;
+  int Bn;       // frames the marker mean runs over: B, or 1 when every row is a fit of its own (lemo_fit_desc.per_frame)
 };
 // the fitting engine's LBS backward computes d(verts) itself instead of reading it (one launch less per iteration)
 struct FitFuse { FitConst fc; DvertsIn in; const double* acc; double smooth_count; float* losses_out; };
@@ -118,7 +119,7 @@ int loss_finalize(const double* acc, int B, int n67, double smooth_count, const 
 // finalises the losses from `acc` in its prologue (block 0 publishes them to `losses`)
 int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
                     const float* dx0, const float* canon, const float* weights, const double* acc, double smooth_count,
-                    float* losses, int B, float* dverts, hipStream_t s);
+                    float* losses, int B, float* dverts, hipStream_t s, int Bn = 0);
 // arguments of fit_tail_kernel (loss_kernels.hip): last VPoser-backward layer + Adam + first VPoser-forward layer of the
 // next iteration, one workgroup per frame
 struct FitTail {
@@ -140,6 +141,7 @@ struct FitTail {
   int* nonfinite;
   const float* losses;
   int B, do_dz, do_adam;
+  int Bn;                          // frames the prior means run over (B; 1 with lemo_fit_desc.per_frame: independent rows)
 };
 int fit_tail(const FitTail& a, hipStream_t s);
 int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float* rot6d, const float* g_rot, float* m1,

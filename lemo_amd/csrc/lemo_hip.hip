@@ -299,6 +299,7 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
   a.lr0 = d.lr0; a.lr1 = d.lr1; a.lr_switch = d.lr_switch; a.lr2 = d.lr2; a.lr_switch2 = d.lr_switch2;
   a.snap = d.snap; a.nonfinite = d.nonfinite; a.losses = d.losses;
   a.B = d.B; a.do_dz = dz; a.do_adam = adam;
+  a.Bn = d.per_frame ? 1 : d.B;       // per_frame: every row is a fit of its own (B > 1 = several clips' frames in lockstep)
   return a;
 }
 
@@ -376,10 +377,10 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
 vertex_stage:
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
     // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two
-    const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B}, d.loss_acc, cnt, d.losses};
+    const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B, d.per_frame ? 1 : B}, d.loss_acc, cnt, d.losses};
     CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, nullptr, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s, &ff));
   } else {
-    CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s));
+    CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s, d.per_frame ? 1 : B));
     CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
   }
   lemo_pose_grad_in gi{d.dA, nullptr, d.dX};

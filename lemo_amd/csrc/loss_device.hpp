@@ -181,7 +181,7 @@ __device__ __forceinline__ void dverts_load(const FitConst& fc, const DvertsIn& 
   for (int k = 0; k < 4; ++k) { r.ct[k] = contact[(size_t)bc * 4 + k]; r.ctm[k] = contact[(size_t)bp * 4 + k]; }
 #pragma unroll
   for (int e = 0; e < 9; ++e) r.cn[e] = canon[e];
-  r.wm = weights[0] / ((float)B * fc.n67 * 3); r.wc = weights[4];
+  r.wm = weights[0] / ((float)in.Bn * fc.n67 * 3); r.wc = weights[4];
   // smoothness-image gradient: feature row d = 3 m81 + c is read by padded rows y = d + 1 (+ one reflected copy for
   // d == 1 or d == D - 2) and, for each of the two time differences, padded columns t' + 8 (+ one reflected copy near
   // either end).  2 x 2 x 2 candidate reads per component, absent ones point at the main one and are switched off.

@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256)
 dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, const float* __restrict__ target,
                        const float* __restrict__ contact, const float* __restrict__ dx0, const float* __restrict__ canon,
                        const float* __restrict__ weights, const double* __restrict__ acc, double smooth_count,
-                       float* __restrict__ losses_out, int B, float* __restrict__ dverts) {
+                       float* __restrict__ losses_out, int B, int Bn, float* __restrict__ dverts) {
   __shared__ float losses[12];
   __shared__ double tots[13];
   const int b = blockIdx.x;
@@ -247,7 +247,7 @@ dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, 
     if (b == 0) for (int i = 0; i < 12; ++i) losses_out[i] = losses[i];
   }
   __syncthreads();
-  const DvertsIn in = {verts, nrows, target, contact, dx0, canon, weights, B};
+  const DvertsIn in = {verts, nrows, target, contact, dx0, canon, weights, B, Bn};
   for (int u = threadIdx.x; u < fc.n; u += 256) {
     float gx, gy, gz;
     dverts_vertex(fc, in, losses, b, dverts_indices(fc, u), gx, gy, gz);
@@ -258,8 +258,8 @@ dverts_assemble_kernel(FitConst fc, const float* __restrict__ verts, int nrows, 
 
 int dverts_assemble(const FitConst& fc, const float* verts, int nrows, const float* target, const float* contact,
                     const float* dx0, const float* canon, const float* weights, const double* acc, double smooth_count,
-                    float* losses, int B, float* dverts, hipStream_t s) {
-  hipLaunchKernelGGL(dverts_assemble_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, dx0, canon, weights, acc, smooth_count, losses, B, dverts);
+                    float* losses, int B, float* dverts, hipStream_t s, int Bn) {
+  hipLaunchKernelGGL(dverts_assemble_kernel, dim3(B), dim3(256), 0, s, fc, verts, nrows, target, contact, dx0, canon, weights, acc, smooth_count, losses, B, Bn > 0 ? Bn : B, dverts);
   return (int)hipGetLastError();
 }
 
@@ -428,7 +428,7 @@ fit_tail_kernel(FitTail a) {
       float grad = g_in;
       if (col >= 0) {
         if (a.do_dz && col < 32) grad = dzs[col];
-        grad += col < 32 ? w_v * 2.f * p_old / ((float)B * 32.f) : w_h * 2.f * p_old / ((float)B * 24.f);
+        grad += col < 32 ? w_v * 2.f * p_old / ((float)a.Bn * 32.f) : w_h * 2.f * p_old / ((float)a.Bn * 24.f);
       }
       if (a.snap) a.snap[flat] = p_old;
       if (nf1 == 0) {

@@ -290,7 +290,7 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
   }
   __syncthreads();
   // target / contact are only dereferenced (clamped reads), never used: m67 = -1, fm = 0 -> any buffer of >= B * max(n67 * 3, 4) floats
-  const DvertsIn din = {in.verts, V, in.verts, in.verts, in.dx0, in.canon, in.weights, B};
+  const DvertsIn din = {in.verts, V, in.verts, in.verts, in.dx0, in.canon, in.weights, B, B};
   for (int u = blockIdx.y * 256 + t; u < pc.n_s; u += 256 * gridDim.y) {     // (frame, quarter of S) per workgroup
     const int vid = pc.s_vid[u];
     const float* p = in.verts + ((size_t)b * V + vid) * 3;

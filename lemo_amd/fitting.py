@@ -385,6 +385,68 @@ class PerFrameFitter:
         return self.end_clip(st)
 
 
+class BatchedPerFrameFitter:
+    """Stage 1 (``opt_amass_perframe.py:293-355``) for N clips AT ONCE through ONE engine: row i of the engine's batch is
+    the current frame of clip i.  With ``lemo_fit_desc.per_frame`` every row is a fit of its own -- the marker mean and
+    the prior means run over that row only, Adam state is per row, nothing in the per-frame objective couples rows -- so
+    N frame fits cost the launches of one (an iteration is ~11 launches of N workgroups instead of one workgroup; the
+    per-frame kernels have one workgroup per row).  One clip alone is bound by its 100 x 119 sequential iterations
+    (~71 us each, ~140 frame fits/s); N clips in lockstep reach N times that until the device fills (VERDICT r02 #4ii).
+    Each clip's result is bit-identical to its solo fit with :class:`PerFrameFitter` (tested: every kernel's arithmetic
+    for a row is independent of the batch size).  Clips may differ in length: rows of finished clips keep fitting their
+    last frame and are ignored.  (The non-finite-loss latch is per engine: a NaN in one clip freezes the batch.)"""
+
+    def __init__(self, body, vposer_weights, enc_state, ids, Xmean, Xstd, device, batch: int, weights: Optional[dict] = None,
+                 lib: Optional[_hip.HipLib] = None, full_vertices: bool = False):
+        w = dict(LOSS_WEIGHTS if weights is None else weights, contact_vel=0.0, smooth=0.0)
+        self.N = int(batch)
+        mk = lambda lr0: AmassTemporalFitter(body, vposer_weights, enc_state, ids, Xmean, Xstd, self.N, device, weights=w,
+                                             full_vertices=full_vertices, lr0=lr0, lr1=0.01, lr_switch=60, lr2=0.003, lr_switch2=80,
+                                             per_frame=True, lib=lib)
+        self.first, self.rest = mk(0.1), mk(0.01)
+        self.device = self.first.device
+
+    @torch.no_grad()
+    def fit_clips(self, markers_list, betas_list, steps: int = 100, use_graph: bool = True):
+        """markers_list[i] [T_i,67,3], betas_list[i] [10] -> list of ``body_params_opt_cur_clip`` [T_i,72] (device tensors)"""
+        n = len(markers_list)
+        assert 1 <= n <= self.N and len(betas_list) == n
+        dev, N = self.device, self.N
+        Ts = [int(np.asarray(m).shape[0]) for m in markers_list]
+        Tmax = max(Ts)
+        mr = torch.zeros(N, Tmax, np.asarray(markers_list[0]).shape[1], 3, device=dev)
+        for i, m in enumerate(markers_list):
+            t = torch.as_tensor(np.asarray(m, np.float32), device=dev)
+            mr[i, :Ts[i]] = t
+            mr[i, Ts[i]:] = t[-1]
+        mr[n:] = mr[0]                                       # unused rows repeat clip 0 (ignored)
+        init = np.zeros((N, 72), np.float32)
+        init[:, 0:3], init[:, 3:6] = PerFrameFitter.INIT_TRANSL, PerFrameFitter.INIT_ORIENT
+        for i in range(N):
+            init[i, 6:16] = np.asarray(betas_list[min(i, n - 1)], np.float32)
+        out = torch.empty(Tmax, N, 72, device=dev)
+        zero_lbl = np.zeros((N, 4), np.float32)
+        graph = bool(use_graph) and not self.first.lib.is_emu
+        for t in range(Tmax):
+            fit = self.first if t == 0 else self.rest
+            if t == 0:
+                fit.load_sequence(init, mr[:, 0], zero_lbl)
+            else:
+                fit._before_write()
+                if t == 1:
+                    for k in ('transl', 'rot6d', 'other', 'shape'):
+                        fit.P[k].copy_(self.first.P[k])
+                    fit.contact.zero_()
+                fit.target.copy_(mr[:, t])
+                fit.reset_optimizer()
+            if graph:
+                fit.step_async(steps, use_graph=True)
+            else:
+                fit.step(steps, use_graph=False)
+            out[t] = fit.params72()
+        return [out[:Ts[i], i] for i in range(n)]
+
+
 def fit_clips_per_frame(fitters, markers_list, betas_list, steps: int = 100, use_graph: bool = True):
     """Stage 1 for several clips SIDE BY SIDE: ``fitters[i]`` (a :class:`PerFrameFitter` each, its own engines and stream) fits
     clip i; the frame loops advance in lockstep so that the device always holds one frame fit of every clip.  A B = 1 fit uses a

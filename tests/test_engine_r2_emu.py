@@ -206,3 +206,22 @@ def test_per_frame_active_vertex_forward_equals_full_forward(emu_lib):
     assert float((ra - rb).abs().max()) < 5e-5
     la, lb = a.rest.losses(), b.rest.losses()
     assert abs(la['total'] - lb['total']) <= 1e-5 * abs(lb['total'])
+
+
+def test_batched_perframe_fit_is_bit_identical_to_solo(emu_lib):
+    """stage 1 for several clips through ONE engine (row i = current frame of clip i, lemo_fit_desc.per_frame: every row a
+    fit of its own) == each clip fitted alone with B = 1, bit for bit -- clips of different lengths, different betas"""
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import PerFrameFitter, BatchedPerFrameFitter
+    prob = ge.small_problem()
+    _, markers = ge.oracle_for(prob)
+    b0 = prob['seq']['init_params'][0, 6:16]
+    clips = [markers[:3], markers[3:5] + 0.01, markers[6:10] * 1.02]
+    betas = [b0, b0 * 0.5, -b0]
+    args = (prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], 'cpu')
+    pf = PerFrameFitter(*args, lib=emu_lib)
+    solo = [pf.fit_clip(m, b, steps=7, use_graph=False).clone() for m, b in zip(clips, betas)]
+    bf = BatchedPerFrameFitter(*args, batch=4, lib=emu_lib)            # one spare row
+    got = bf.fit_clips(clips, betas, steps=7, use_graph=False)
+    for a, b in zip(solo, got):
+        assert a.shape == b.shape and torch.equal(a, b)
