@@ -112,3 +112,168 @@ def perframe_fit_f64(model, vposer_w, markers67_ids, markers_rec, betas, steps=1
             out.append(p72[0].detach().numpy().copy())
             last.append(float(loss.detach()))
     return np.asarray(out), np.asarray(last)
+
+
+class KinkProbe:
+    """Which frames can a rounding-sized difference move by MORE than rounding?  (computed, not narrated: VERDICT r02 #5)
+
+    The AMASS objective has three families of kinks: 21 M LeakyReLU units of the smoothness encoder (slope 0.2 | 1), the L1
+    marker residuals (sign), and the contact term's ``speed > 0.1`` selection.  A unit / residual / speed that sits closer to
+    its kink than the implementation's own error takes the other branch, and the gradient of the frames in its reach then
+    changes by a finite amount however small the error was.  Wrapped around a float64 ``AmassFitOracle`` this probe records,
+    for every evaluation of the objective, the kinks that lie within a stated tolerance of being crossed and the frames
+    their flip can reach:
+
+    * LeakyReLU unit of layer l at image column c with |activation| <= ``tol_act`` x max|activation of layer l|
+      (default 3e-6 = ~8 x the measured error of an fp32-accurate convolution, 4e-7 of the layer maximum) -> reach:
+      image columns c - 10 .. c + 10 (ten 3x3 layers), i.e. velocity columns j = c - 8 (reflect-padded by 8) and frames
+      j, j + 1;
+    * marker residual with |r| <= ``tol_res`` metres (default 3e-6: ~8 x an fp32 vertex at 1.6 m) -> its frame;
+    * contact speed with |s - 0.1| <= ``tol_speed`` m/s (default 2e-4: speeds are 30 x vertex differences) -> frames t, t+1
+      and every frame of that foot set's mean (a changed count rescales the whole term: ALL frames are marked).
+
+    ``events`` lists (evaluation index, kind, frame range); ``frames(i)`` the exposed frames of evaluation i."""
+
+    def __init__(self, fit: O.AmassFitOracle, tol_act: float = 3e-6, tol_res: float = 3e-6, tol_speed: float = 2e-4):
+        self.fit, self.tol_act, self.tol_res, self.tol_speed = fit, tol_act, tol_res, tol_speed
+        self.B = int(fit.markers_rec.shape[0])
+        self.events, self.n_eval = [], 0
+        self._orig_enc, self._orig_losses = None, None
+
+    # -- patching -----------------------------------------------------------------------------------------------
+    def __enter__(self):
+        probe = self
+        self._orig_enc = O.enc_forward
+
+        def enc(w, x, return_all=False):
+            z, acts = probe._orig_enc(w, x, True)
+            probe._scan_acts(acts)
+            return (z, acts) if return_all else z
+        O.enc_forward = enc
+        self._orig_losses = self.fit.losses
+
+        def losses():
+            out = probe._orig_losses()
+            probe._scan_verts(out[3])
+            probe.n_eval += 1
+            return out
+        self.fit.losses = losses
+        return self
+
+    def __exit__(self, *a):
+        O.enc_forward = self._orig_enc
+        self.fit.losses = self._orig_losses
+        return False
+
+    # -- scans ----------------------------------------------------------------------------------------------------
+    def _col_frames(self, c: int, radius: int):
+        """frames a kink at image column c can reach through `radius` 3x3 layers, the temporal difference and the reflect pad"""
+        nd = self.B - 1
+        fr = set()
+        for cc in range(c - radius, c + radius + 1):
+            if cc < 0 or cc > nd + 15:
+                continue
+            j = cc - 8
+            if j < 0:
+                j = -j                       # F.pad(..., 'reflect'): column 8 - k mirrors velocity column k
+            elif j > nd - 1:
+                j = 2 * (nd - 1) - j
+            j = min(max(j, 0), nd - 1)
+            fr.update((j, j + 1))
+        return fr
+
+    def _scan_acts(self, acts):
+        for l, a in enumerate(acts, start=1):
+            a = a.detach()
+            m = float(a.abs().max())
+            if m == 0.0:
+                continue
+            near = (a.abs() <= self.tol_act * m).nonzero()
+            for c in sorted({int(v) for v in near[:, 3].tolist()}):
+                self.events.append((self.n_eval, f'lrelu{l}', c, self._col_frames(c, 10)))
+
+    def _scan_verts(self, verts):
+        f = self.fit
+        v = verts.detach()
+        r = (v[:, f.ids['markers67'], :] - f.markers_rec).abs()
+        for t in sorted({int(x) for x in (r <= self.tol_res).nonzero()[:, 0].tolist()}):
+            self.events.append((self.n_eval, 'l1', t, {t}))
+        if f.w['contact_vel'] > 0:
+            vel = (v[1:] - v[:-1]) * 30
+            for k, name in enumerate(('left_heel', 'right_heel', 'left_toe', 'right_toe')):
+                lbl = f.contact[:, k]
+                s = torch.norm(vel[:, f.ids[name], :], dim=-1)[lbl[0:-1] == 1]
+                if s.numel() and bool(((s - 0.1).abs() <= self.tol_speed).any()):
+                    self.events.append((self.n_eval, 'contact_' + name, -1, set(range(self.B))))
+
+    # -- results ------------------------------------------------------------------------------------------------
+    def frames(self, evaluation: int = 0):
+        out = set()
+        for e, _, _, fr in self.events:
+            if e == evaluation:
+                out |= fr
+        return sorted(out)
+
+    def count(self, upto: int = None):
+        return sum(1 for e, *_ in self.events if upto is None or e <= upto)
+
+    def summary(self, evaluation: int = 0):
+        kinds = {}
+        for e, kind, _, _ in self.events:
+            if e == evaluation:
+                k = 'lrelu' if kind.startswith('lrelu') else ('contact' if kind.startswith('contact') else kind)
+                kinds[k] = kinds.get(k, 0) + 1
+        return kinds
+
+
+def flip_sensitivity(fit: O.AmassFitOracle, tol_act: float = 3e-6, subsets: int = 2, seed: int = 0):
+    """COMPUTED kink exposure of the gradient.  ``KinkProbe`` shows that at BASELINE size hundreds of the
+    encoder's 21 M LeakyReLU units sit within any realistic error band of their kink in EVERY evaluation -- proximity alone
+    marks all frames.  What matters is how much the gradient can move when such units take the other branch.  This function
+    evaluates, in float64 at the oracle's current parameters, the objective's gradient (a) as it is and (b) with the slope
+    of EVERY unit whose pre-activation lies within ``tol_act`` x (layer maximum) of zero swapped (0.2 <-> 1; the value
+    changes by < tol_act x max), plus ``subsets`` random halves of that set (guards against cancellation), and returns
+
+        S[group][frame] = max over the variants of  max_entries |G_variant - G| / max|G_group|
+
+    -- a per-frame, per-parameter-group bound on what rounding-sized differences of an fp32-accurate forward can do to the
+    gradient THROUGH THE ENCODER'S KINKS.  A frame's gradient error beyond ``rounding + 2 S`` is not explained by them.
+    (default tol_act 3e-6 = ~8 x the measured pre-activation error of the fp32-accurate convolutions, 4e-7 of the layer
+    maximum.)  Uses ``torch.autograd.grad``: the oracle's optimiser state and ``.grad`` fields are not touched."""
+    import torch.nn.functional as F
+    orig = O.enc_forward
+    params = (fit.transl, fit.rot6d, fit.other)
+
+    def make_enc(mode, gen):
+        def enc(w, x, return_all=False):
+            acts = []
+            for blk in range(1, 6):
+                for idx in (0, 2):
+                    pre = F.conv2d(x, w[f'enc_blc{blk}.main.{idx}.weight'], w[f'enc_blc{blk}.main.{idx}.bias'], stride=1, padding=1)
+                    y = F.leaky_relu(pre, 0.2)
+                    if mode != 'none':
+                        pa = pre.detach().abs()
+                        m = pa <= tol_act * pa.max()
+                        if mode == 'half':
+                            m = m & (torch.rand(m.shape, generator=gen) < 0.5)
+                        y = y + torch.where(m, torch.where(pre > 0, -0.8 * pre, 0.8 * pre), torch.zeros_like(pre))
+                    x = y
+                    acts.append(x)
+            return (x, acts) if return_all else x
+        return enc
+
+    def grads(mode, gen=None):
+        O.enc_forward = make_enc(mode, gen)
+        try:
+            with default_f64():
+                total = fit.losses()[0]
+                return torch.autograd.grad(total, params)
+        finally:
+            O.enc_forward = orig
+    G0 = grads('none')
+    variants = [grads('all')] + [grads('half', torch.Generator().manual_seed(seed + 1 + i)) for i in range(subsets)]
+    out = {}
+    for name, i in (('transl', 0), ('rot6d', 1), ('other', 2)):
+        n = G0[i].abs().max()
+        out[name] = torch.stack([(g[i] - G0[i]).abs().max(1).values / n for g in variants]).max(0).values
+    return out

@@ -373,6 +373,40 @@ def pin_perframe(report):
     np.savez(os.path.join(HERE, 'perframe_fit.npz'), markers_rec=markers[:3], betas=betas, p72=np.asarray(r), final_loss=last)
 
 
+def pin_dropin_prox(report):
+    """Drop-in proof of the PROX side of the boundary: the reference's own
+    ``FittingMonitor.create_fitting_closure`` + ``SMPLifyLoss.forward`` + ``optim_factory.create_optimizer``
+    (fitting_temp_slide.py:220-311, 564-1062, optimizers/optim_factory.py) run UNMODIFIED on top of the product's modules --
+    ``lemo_amd.compat`` smplx.create, ``lemo_amd.vposer.VPoser``, ``lemo_amd.priors.Enc`` on the host-emulated kernel
+    library -- for S2 / S3 x first / later window; compared with prox_iter.npz, which holds what the same reference code
+    produced on its own stack (pin_prox_and_emit).  Rows ``dropin_prox.*``: 14 loss_dict entries (max rel), the three
+    gradients (max-norm rel) and the parameters after three ``optimizer.step(closure)`` (max abs)."""
+    import __graft_entry__ as ge
+    import ref_harness as RH
+    from lemo_amd import _hip
+    from oracle.prox_oracle import LOSS_KEYS
+    emu = _hip.HipLib(_hip.EMU_LIB_PATH, is_emu=True)
+    g = np.load(os.path.join(HERE, 'prox_iter.npz'))
+    for stage in ('S3', 'S2'):
+        for first in (False, True):
+            tag = f'{stage}_{"first" if first else "later"}'
+            prob = ge.prox_small_problem(stage=stage, real_markers=True)
+            rw = RH.RefProxWindow(prob, first_batch_flag=first, product_lib=emu)
+            h = rw.iterate(1)[0]
+            ref = g[tag + '_loss']
+            report[f'dropin_prox.{tag}.loss_dict'] = max((abs(h[k] - float(r)) / max(abs(float(r)), 1e-30)) if h[k] != float(r) else 0.0
+                                                         for k, r in zip(LOSS_KEYS, ref))
+            gr = rw.grads()
+            for k in ('pose_embedding', 'transl', 'global_orient'):
+                r = g[f'{tag}_g_{k}']
+                report[f'dropin_prox.{tag}.g_{k}'] = float(np.abs(gr[k] - r).max() / np.abs(r).max())
+            rw.iterate(2)
+            worst = 0.0
+            for k, t in (('pose_embedding', rw.pose_embedding), ('transl', rw.body_model.transl), ('global_orient', rw.body_model.global_orient)):
+                worst = max(worst, float(np.abs(t.detach().numpy() - g[f'{tag}_{k}_after3']).max()))
+            report[f'dropin_prox.{tag}.params_after3'] = worst
+
+
 def pin_prox_and_emit(report):
     """(7) Drive the reference's OWN SMPLifyLoss / FittingMonitor closure / PerspectiveCamera / L2Prior /
     SMPLifyAnglePrior / JointMapper / optim_factory (imported under module stubs, tests/golden/ref_harness.py) on the
@@ -490,12 +524,16 @@ if __name__ == '__main__':
     assert not bad, 'oracle disagrees with the reference'
     drop = {}
     pin_dropin(drop)
+    pin_dropin_prox(drop)
     print('reference loop text on the PRODUCT modules (emulator library) vs on the oracle-backed objects:')
     with open(os.path.join(HERE, 'dropin_vs_reference.txt'), 'w') as f:
         for k, v in drop.items():
             print(f'  {k:44s} {v}')
             f.write(f'{k}\t{v}\n')
-    assert max(v for k, v in drop.items() if not k.startswith('dropin.g_') and k != 'dropin.p75_after3') <= 1e-5, 'loss scalars'
+    assert max(v for k, v in drop.items() if k.startswith('dropin.') and not k.startswith('dropin.g_') and k != 'dropin.p75_after3') <= 1e-5, 'loss scalars'
+    assert max(v for k, v in drop.items() if k.startswith('dropin_prox.') and k.endswith('loss_dict')) <= 1e-5, 'PROX drop-in: loss_dict'
+    assert max(v for k, v in drop.items() if k.startswith('dropin_prox.') and '.g_' in k) <= 2e-4, 'PROX drop-in: gradients'
+    assert max(v for k, v in drop.items() if k.startswith('dropin_prox.') and k.endswith('params_after3')) <= 1e-4, 'PROX drop-in: parameters'
     assert max(v for k, v in drop.items() if k.startswith('dropin.g_')) <= 2e-4 and drop['dropin.p75_after3'] <= 1e-5
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

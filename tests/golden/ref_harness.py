@@ -267,15 +267,41 @@ class RefProxWindow:
     the reference's json/npy files at construction are the real (V = 10475) ones; for a reduced synthetic model they
     are overwritten by the problem's ids after construction (plain attributes)."""
 
-    def __init__(self, prob, first_batch_flag=False, ae_weights=None):
+    def __init__(self, prob, first_batch_flag=False, ae_weights=None, product_lib=None):
+        """``product_lib``: None -> the reference's own stack (oracle-backed ``RefSmplx`` around the vendored ``lbs()``, the
+        reference's VPoser and Enc classes).  A ``lemo_amd._hip.HipLib`` (the host-emulated build of the UNMODIFIED kernel
+        sources) -> the drop-in proof of the PROX side of the boundary: ``lemo_amd.compat`` smplx.create,
+        ``lemo_amd.vposer.VPoser`` and ``lemo_amd.priors.Enc`` take their places and the reference's own
+        ``FittingMonitor.create_fitting_closure`` / ``SMPLifyLoss.forward`` / ``optim_factory`` run on top of them,
+        unmodified (``F.grid_sample`` etc. stay torch: they are the reference's own lines)."""
         M = ref_prox_modules()
         B, w = prob['B'], dict(prob['weights'])
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
         so = O.SmplxOracle(prob['model'], extra_joint_ids=list(range(21)) if prob['V'] < 9930 else None)
         self.so = so
         joint_mapper = M.misc.JointMapper(np.asarray(prob['joint_map']))
-        self.body_model = RefSmplx(so, B, joint_mapper=joint_mapper)
-        self.vposer = ref_vposer({k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()})
+        if product_lib is None:
+            self.body_model = RefSmplx(so, B, joint_mapper=joint_mapper)
+            self.vposer = ref_vposer({k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()})
+            smooth_model = ref_enc()
+        else:
+            from lemo_amd.compat import smplx as compat_smplx
+            from lemo_amd.priors import Enc
+            from lemo_amd.vposer import VPoser
+            # main_slide.py:160-179: smplx.create(model_path, joint_mapper=..., create_body_pose=not use_vposer, **args)
+            self.body_model = compat_smplx.create(prob['model'], model_type='smplx', gender='male', ext='npz', num_pca_comps=12,
+                                                  joint_mapper=joint_mapper, create_global_orient=True, create_body_pose=False,
+                                                  create_betas=True, create_left_hand_pose=True, create_right_hand_pose=True,
+                                                  create_expression=True, create_jaw_pose=True, create_leye_pose=True,
+                                                  create_reye_pose=True, create_transl=True, batch_size=B, dtype=torch.float32,
+                                                  extra_joint_ids=list(range(21)) if prob['V'] < 9930 else None, _lib=product_lib)
+            self.vposer = VPoser(_lib=product_lib).eval()
+            self.vposer.load_state_dict({**self.vposer.state_dict(), **{k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}})
+            smooth_model = Enc(_lib=product_lib)
+            smooth_model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in prob['enc_w'].items()})
+            smooth_model.eval()
+            for p_ in smooth_model.parameters():
+                p_.requires_grad = False
         cam = prob.get('cam') or dict(fx=1060.53, fy=1060.38, cx=951.30, cy=536.77)    # PROXD_temp_S2.yaml:111-114
         self.camera = M.camera.create_camera(focal_length_x=cam['fx'], focal_length_y=cam['fy'],
                                              center=torch.tensor([cam['cx'], cam['cy']]).view(-1, 2), batch_size=B,
@@ -298,7 +324,7 @@ class RefProxWindow:
                 grid_min=f(prob['grid_min']).repeat(B, 1).unsqueeze(1), grid_max=f(prob['grid_max']).repeat(B, 1).unsqueeze(1),
                 sdf=sdf.repeat(B, 1, 1, 1).unsqueeze(1), sdf_normals=None, voxel_size=None,
                 R=f(prob['R']), t=f(prob['t']).reshape(1, 3), contact=False, dtype=torch.float32, smooth_acc=False,
-                smooth_vel=False, use_motion_smooth_prior=True, motion_smooth_model=ref_enc(), use_friction=True,
+                smooth_vel=False, use_motion_smooth_prior=True, motion_smooth_model=smooth_model, use_friction=True,
                 contact_fric_verts_ids=np.asarray(prob['fric_ids']), use_motion_infill_prior=use_infill,
                 motion_infill_model=motion_infill_model, infill_pretrain_weights=ae_weights, device=torch.device('cpu'))
         finally:

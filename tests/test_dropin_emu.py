@@ -20,6 +20,16 @@ def test_dropin_report_rows():
     for k in ('g_transl', 'g_rot6d', 'g_other'):
         assert float(rows['dropin.' + k]) <= 2e-4
     assert float(rows['dropin.p75_after3']) <= 1e-5
+    # PROX side of the boundary: the reference's own FittingMonitor closure + SMPLifyLoss + optim_factory
+    # (fitting_temp_slide.py:220-311, 564-1062) ran unmodified on lemo_amd.compat smplx / lemo_amd.vposer.VPoser /
+    # lemo_amd.priors.Enc (emulator library) -- tests/golden/make_golden.py::pin_dropin_prox, vs prox_iter.npz
+    for stage in ('S2', 'S3'):
+        for w in ('first', 'later'):
+            t = f'dropin_prox.{stage}_{w}.'
+            assert float(rows[t + 'loss_dict']) <= 5e-6
+            for k in ('g_pose_embedding', 'g_transl', 'g_global_orient'):
+                assert float(rows[t + k]) <= 2e-4
+            assert float(rows[t + 'params_after3']) <= 1e-4
 
 
 @pytest.mark.timeout(900)

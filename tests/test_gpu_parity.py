@@ -40,6 +40,27 @@ def full_problem(dev):
     return dict(A=A, g=g, model=model, seq=seq, make=mk)
 
 
+@pytest.fixture(scope='module')
+def kink_exposure(full_problem):
+    """COMPUTED per-frame bound on what the objective's kinks can do to the iteration-0 gradient at BASELINE size
+    (oracle/f64.py: flip_sensitivity for the encoder's LeakyReLU units, KinkProbe for L1 residuals / contact speeds),
+    evaluated once in float64 at the golden (6) inputs -- what the gradient gates use instead of a constant (VERDICT r02 #5)"""
+    from oracle.f64 import amass_fit_oracle_f64, default_f64, flip_sensitivity, KinkProbe
+    from lemo_amd.vposer import make_vposer_weights
+    torch.set_num_threads(32)
+    A, g, seq = full_problem['A'], full_problem['g'], full_problem['seq']
+    o64 = amass_fit_oracle_f64(full_problem['model'], make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'],
+                               seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    S = flip_sensitivity(o64)
+    with default_f64(), KinkProbe(o64, tol_act=0.0) as pr:           # residual / speed kinks only (tol_act 0: no unit listed)
+        o64.losses()
+    l1 = sorted({f for e, kind, _, fr in pr.events if kind == 'l1' for f in fr})
+    contact = any(kind.startswith('contact') for _, kind, _, _ in pr.events)
+    print(f'\ncomputed kink exposure at golden (6): S median {max(float(v.median()) for v in S.values()):.1e} max '
+          f'{max(float(v.max()) for v in S.values()):.1e}; frames with an L1 residual within 3e-6 m of zero: {l1}; contact speed near 0.1: {contact}')
+    return dict(S=S, l1=l1, contact=contact)
+
+
 def test_rot6d_vposer_golden(dev):
     from lemo_amd.rotation import convert_to_3D_all
     from lemo_amd.vposer import VPoser, make_vposer_weights
@@ -306,7 +327,7 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
 
 
 @pytest.mark.parametrize('conv_variant', [4, 3, 2])
-def test_fit_full_size_golden(full_problem, dev, conv_variant):
+def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
     g, seq = full_problem['g'], full_problem['seq']
@@ -325,13 +346,24 @@ def test_fit_full_size_golden(full_problem, dev, conv_variant):
     assert abs(float(v.double().sum()) - float(g['verts_sum'])) < 1e-6 * float(v.double().abs().sum())
     assert rel_err(fit.params72().cpu(), g['p72_0']) < 1e-5
     gr = fit.grads_with_priors()
-    # vs the fp32 CPU oracle.  Max norm: both paths sit a few 1e-4 from float64 at this size, in the handful of frames where
-    # one of them crossed a LeakyReLU / L1 kink the other did not (tests/test_gpu_gates.py, tools/grad_vs_golden.py);
-    # everywhere else -- the median over frames of the per-frame maximum -- they agree to ~5e-6
+    # vs the reference's fp32 CPU result, frame by frame, against a COMPUTED bound: both sides are fp32-accurate evaluations of
+    # an objective with kinks, so frame f may differ by  2e-5 (rounding, of the group's largest entry) + 2 x 2 x S[f],
+    # S = how far f's gradient moves when every LeakyReLU unit of the encoder within 3e-6 x layer-max of its kink takes the
+    # other branch (float64, oracle/f64.py::flip_sensitivity; one factor 2 per side).  Frames holding an L1 residual within
+    # 3e-6 m of zero (or any frame, if a contact speed sits at the 0.1 m/s threshold) get the constant 2e-3 instead.  The
+    # median over frames of the per-frame maximum -- the arithmetic where nothing flipped -- stays at 2e-5.
+    KE = kink_exposure
     for k in ('transl', 'rot6d', 'other'):
         a, b = gr[k].cpu().double(), torch.from_numpy(g['g_' + k]).double()
-        e = (a - b).abs() / b.abs().max()
-        assert float(e.max()) < 2e-3 and float(e.max(1).values.median()) < 2e-5, (k, float(e.max()), float(e.max(1).values.median()))
+        e = ((a - b).abs() / b.abs().max()).max(1).values
+        bound = 2e-5 + 4.0 * KE['S'][k]
+        if KE['contact']:
+            bound = torch.full_like(bound, 2e-3)
+        for f in KE['l1']:
+            bound[f] = max(float(bound[f]), 2e-3)
+        bad = (e > bound).nonzero().flatten().tolist()
+        assert not bad, (k, bad, [float(e[i]) for i in bad], [float(bound[i]) for i in bad])
+        assert float(e.median()) < 2e-5, (k, float(e.median()))
     s = torch.cuda.Stream(dev)
     with torch.cuda.stream(s):
         fit.step(1, use_graph=True)
