@@ -311,6 +311,133 @@ def concurrent_probe(fit0, prob0, B, device, k, steps, conv_variant):
                     'bit-identical to a run on its own (tests/test_gpu_r2.py); not the headline config (one clip per GPU)'}
 
 
+def prox_probe(device, steps=300, stage='S3'):
+    """BASELINE configs[3]/[4] on ONE GPU: the native PROX window engine (lemo_prox_*: closure + Adam, captured graphs) at
+    B = 100, V = 10475, 256^3 SDF, S2 / S3 weights -- optimizer.step(closure) iterations per second.  Not the headline."""
+    import __graft_entry__ as ge
+    eng, _ = ge.prox_engine_for(ge.prox_full_problem(stage), device, first_batch_flag=False)
+    s = torch.cuda.Stream(device)
+    with torch.cuda.stream(s):
+        eng.step(100, use_graph=True)
+    torch.cuda.synchronize(device)
+    best = 0.0
+    for _ in range(2):
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s):
+            eng.step(steps, use_graph=True)
+        torch.cuda.synchronize(device)
+        best = max(best, steps / (time.perf_counter() - t0))
+    assert eng.nonfinite_step() == 0
+    return eng, {'value': best, 'unit': 'PROX fitting-iterations/s (optimizer.step(closure), one window)', 'steps': steps,
+                 'workload': f'temp_prox/fitting_temp_slide.py window, PROXD_temp_{stage}.yaml weights: B=100 frames, V=10475, 256^3 synthetic SDF, '
+                             '245x115 smoothness image, native engine (44 launches / iteration, graph replay)',
+                 'total_loss': eng.loss_dict()['total_loss']}
+
+
+def perframe_probe(device, clips=64, frames=4, steps=100):
+    """BASELINE configs[0] (stage 1, opt_amass_perframe.py): frame fits per second with `clips` clips in lockstep through one
+    engine (lemo_amd.fitting.BatchedPerFrameFitter; each clip bit-identical to its solo fit) and for one clip alone."""
+    from lemo_amd import synthetic
+    from lemo_amd.assets import load_assets
+    from lemo_amd.fitting import BatchedPerFrameFitter
+    from lemo_amd.vposer import make_vposer_weights
+    A = load_assets()
+    model, vw = synthetic.make_synthetic_smplx(seed=0), make_vposer_weights(2)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'amass_iter.npz'))
+    base = g['markers_rec']
+    mk = lambda i: (base[(7 * i) % (119 - frames):(7 * i) % (119 - frames) + frames] * (1.0 + 0.002 * (i % 5))).astype(np.float32)
+    betas = synthetic.make_synthetic_sequence(0, B=119)['init_params'][0, 6:16]
+    out = {}
+    for n in (1, clips):
+        bf = BatchedPerFrameFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], device, batch=n)
+        cl, bt = [mk(i) for i in range(n)], [betas] * n
+        bf.fit_clips(cl, bt, steps=steps); torch.cuda.synchronize(device)             # captures the graphs
+        t0 = time.perf_counter()
+        bf.fit_clips(cl, bt, steps=steps); torch.cuda.synchronize(device)
+        out[n] = n * frames / (time.perf_counter() - t0)
+    return {'value': out[clips], 'unit': 'frame fits/s (100 Adam steps each)', 'clips_in_lockstep': clips, 'one_clip_value': out[1],
+            'workload': 'opt_amass_perframe.py stage-1 fit: B=1 objective per frame (marker L1 + three L2 priors), V=10475, frames '
+                        'of a clip sequential (warm start), clips batched as rows of one engine; every clip bit-identical to its solo fit'}
+
+
+def ae_probe(device):
+    """per-clip infilling-AE finetune (opt_amass_temp.py:154-214: 60 training steps + eval forward at [1,4,210,135]) in ms"""
+    from lemo_amd import synthetic
+    from lemo_amd.infill import AE, finetune_and_infill
+    w = {k: torch.from_numpy(v).to(device) for k, v in synthetic.make_ae_weights(7).items()}
+    ae = AE().to(device)
+    ae.load_state_dict(w)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 210, 135, generator=g).to(device)
+    mask = (torch.ones(210, 135) > 0).to(device)
+    finetune_and_infill(ae, w, x, mask, steps=60)
+    torch.cuda.synchronize(device)
+    best = 1e30
+    for _ in range(2):
+        t0 = time.perf_counter()
+        finetune_and_infill(ae, w, x, mask, steps=60)
+        torch.cuda.synchronize(device)
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    return {'value': best, 'unit': 'ms per clip (60 finetune steps + eval forward)', 'higher_is_better': False,
+            'workload': 'models/AE.py infilling autoencoder, [1,4,210,135] clip image, masked L1, Adam 3e-6 (opt_amass_temp.py:154-214)'}
+
+
+def main_prox(args, world, rank, device):
+    """--workload prox: BASELINE configs[4]'s per-GPU leg.  Recordings shard over ranks (windows of one recording are
+    sequential: temp_prox/main_slide.py:257); every rank fits the current window of ITS recording -- B = 100, V = 10475,
+    256^3 SDF, S3 -- for K timed iterations; one all-gather of the fitted per-frame rows (lemo_amd.sharding)."""
+    import __graft_entry__ as ge
+    from lemo_amd.prox import ENGINE_PARAMS
+    from lemo_amd.sharding import gather_fitted_params
+    prob = ge.prox_full_problem('S3')
+    rng = np.random.default_rng(100 + rank)                    # rank r's own recording: perturbed initial fit and keypoints
+    prob['params'] = {k: (np.asarray(v, np.float32) + (rng.standard_normal(np.shape(v)).astype(np.float32) * 0.01 if k != 'betas' else 0))
+                      for k, v in prob['params'].items()}
+    eng, _ = ge.prox_engine_for(prob, device, first_batch_flag=False)
+    s = torch.cuda.Stream(device)
+    rows = lambda: torch.cat([eng.P[k] for k, _ in ENGINE_PARAMS], dim=1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    with torch.cuda.stream(s):
+        eng.step(max(args.warmup, 100), use_graph=True)          # graphs captured + clocks up
+    torch.cuda.synchronize(device)
+    gather_fitted_params(rows()[None])
+    torch.cuda.synchronize(device)
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(s):
+        eng.step(args.steps, use_graph=True)
+        s.synchronize()
+    local = rows()
+    gathered = gather_fitted_params(local[None])
+    torch.cuda.synchronize(device)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    assert gathered.shape[0] == world and torch.equal(gathered[rank], local) and bool(torch.isfinite(gathered).all())
+    for r in range(world):
+        if r != rank:
+            assert not torch.equal(gathered[r], local), 'ranks fitted the same recording'
+    assert eng.nonfinite_step() == 0
+    out = {'metric': 'PROX fitting-iterations/sec (100-frame window, PROXD_temp_S3)', 'value': world * args.steps / dt,
+           'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 100),
+           'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+           'data': 'synthetic',
+           'config': {'workload': 'temp_prox/main_slide.py PROXD_temp_S3.yaml: one 100-frame sliding window per GPU (recordings shard '
+                                  'over ranks, windows of a recording are sequential), V=10475, 256^3 synthetic SDF, smoothness + '
+                                  'infilling priors, native PROX engine', 'frames': 100, 'recordings': world,
+                      'parallelism': f'recording-shard x{world} + 1 all_gather'},
+           'total_loss': eng.loss_dict()['total_loss']}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -323,6 +450,9 @@ def main():
     ap.add_argument('--conv-variant', type=int, default=DEFAULT_CONV_VARIANT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ramp-ms', type=float, default=250.0, help='untimed replay of the iteration before the warm-up steps (0 = off)')
+    ap.add_argument('--workload', choices=('amass', 'prox'), default='amass',
+                    help="amass (default, the headline: BASELINE configs[1]/[2]) or prox (configs[4]'s per-GPU leg: one S3 window per GPU)")
+    ap.add_argument('--no-extras', action='store_true', help='skip the non-headline objects (prox_window, perframe, ae_finetune)')
     ap.add_argument('--concurrent-clips', type=int, default=3,
                     help='after the headline measurement (one clip per GPU), also time this many independent clips fitted side by '
                          'side on GPU 0 (reported as "concurrent_clips", never as "value"; 0 = off)')
@@ -339,6 +469,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if args.workload == 'prox':
+        main_prox(args, world, rank, device)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from lemo_amd.sharding import gather_fitted_params
     B = args.frames
@@ -486,6 +621,15 @@ def main():
             out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, max(args.steps, 100), args.conv_variant)
         except Exception as e:       # noqa: BLE001
             out['concurrent_clips'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not args.no_extras and use_graph:
+        # the other workloads of BASELINE.json on this GPU (never the headline value; a failure must not cost the line)
+        del fit
+        for key, fn in (('prox_window', lambda: prox_probe(device)[1]), ('perframe', lambda: perframe_probe(device)),
+                        ('ae_finetune', lambda: ae_probe(device))):
+            try:
+                out[key] = fn()
+            except Exception as e:       # noqa: BLE001
+                out[key] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(prob, B)
         out['speedup_vs_cpu_baseline'] = out['value'] / out['cpu_baseline']['value']

@@ -123,3 +123,41 @@ def fit_sharded_concurrent(n_seq: int, fitters: Sequence, load_sequence: Callabl
         out.append(cc.params72().clone())
     allp = gather_fitted_params(torch.cat(out, 0), group)
     return allp[torch.tensor(unshard_order(n_seq, world), device=allp.device)]
+
+
+def fit_recordings_sharded(n_rec: int, fit_recording: Callable[[int], torch.Tensor], rank: int, world: int, group=None,
+                           max_frames: int = None) -> List[torch.Tensor]:
+    """The PROX leg of the multi-GPU path (BASELINE configs[4]; VERDICT r02 missing #1).
+
+    The reference walks the windows of ONE recording strictly in order -- window w+1 is initialised from the per-frame
+    results window w has just written on their 30-frame overlap (``temp_prox/main_slide.py:257``,
+    ``data_parser_slide.py:199-212, 329-331``) -- so windows cannot be spread over GPUs; recordings share nothing.  The shard
+    axis is therefore the RECORDING: recording r -> rank r mod world, its windows sequential on that rank
+    (``fit_recording(r)`` runs :func:`lemo_amd.prox_windows.run_recording` or any equivalent and returns the per-frame result
+    rows ``[n_frames_r, D]``), and ONE collective at the end hands every rank every recording's rows.  Recordings differ in
+    length: rows are padded with NaN to ``max_frames`` (default: the longest local recording, made common with one tiny
+    all-reduce -- pass it to skip that) and trimmed again after the gather.  ``n_rec`` must be a multiple of ``world``.
+    Returns the list of ``[n_frames_r, D]`` tensors in recording order."""
+    assert n_rec % world == 0, 'pad the recording list to a multiple of the world size'
+    mine = [fit_recording(r) for r in my_sequences(n_rec, rank, world)]
+    D = int(mine[0].shape[1])
+    assert all(m.dim() == 2 and int(m.shape[1]) == D for m in mine)
+    tmax = max(int(m.shape[0]) for m in mine)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if max_frames is None and multi:
+        t = torch.tensor([tmax], dtype=torch.int64, device=mine[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        tmax = int(t.item())
+    elif max_frames is not None:
+        assert max_frames >= tmax
+        tmax = int(max_frames)
+    pad = torch.full((len(mine), tmax, D), float('nan'), dtype=mine[0].dtype, device=mine[0].device)
+    for i, m in enumerate(mine):
+        pad[i, :m.shape[0]] = m
+    allp = gather_fitted_params(pad, group)                       # the path's one data collective
+    allp = allp[torch.tensor(unshard_order(n_rec, world), device=allp.device)]
+    out = []
+    for r in range(n_rec):
+        valid = ~torch.isnan(allp[r, :, 0])
+        out.append(allp[r][valid])
+    return out

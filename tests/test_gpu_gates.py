@@ -131,7 +131,7 @@ def _check(r, tag, flips=False, grad_flips=None):
             # that moves by a fraction S changes an Adam update by at most ~lr x S (kink_budget = lr x sum over the steps
             # so far of the mean computed exposure; 0 when no unit is near its kink)
             assert t['gpu_mean'] <= 3.0 * max(x['cpu_mean'] for x in r['traj'][:i + 1]) + 2e-6 + 3.0 * t['kink_budget'], (i, t)
-            assert t['tot_gpu'] <= 1e-4, (i, t)
+            assert t['tot_gpu'] <= 1e-4 + 10.0 * t['kink_budget'], (i, t)      # (the 1e6-weighted smoothness term follows the parameters)
 
 
 def test_small_problem_vs_float64(dev):
@@ -151,7 +151,7 @@ def test_small_problem_vs_float64(dev):
     # within 1e-5
     r = _run(dev, small, mk, dict(O.LOSS_WEIGHTS, contact_vel=0.0, rec_markers=0.0), 10)
     _check(r, 'small problem, contact and marker terms off')
-    assert max(t['tot_gpu'] for t in r['traj']) < 1e-5
+    assert max(t['tot_gpu'] - 10.0 * t['kink_budget'] for t in r['traj']) < 1e-5
     # single entries: within 2e-5 of float64 unless the computed exposure of the encoder's kinks explains more (an entry whose
     # gradient is moved across zero by a flipped unit takes an update of the other sign: 2 lr)
     assert max(t['gpu_max'] for t in r['traj']) < 2e-5 + (2 * 0.01 if r['traj'][-1]['kink_budget'] > 1e-7 else 0.0)

@@ -175,7 +175,8 @@ def test_finetune_60_steps_vs_reference_fixture(dev):
     rec0, _ = finetune_and_infill(ae, ae_w, x_in, m, steps=0)
     moved = float((rec0.cpu() - ref).abs().max() / ref.abs().max())
     print(f'\nfinetuned reconstruction vs the reference run: max rel {e:.2e} (the 60 steps moved it by {moved:.2e})')
-    assert e < 2e-3 and e < 0.2 * moved                      # 60 Adam steps at lr 3e-6 through max-pool argmax ties
+    # measured 2.5e-7 (r02, r03); a max-pool argmax tie broken the other way would show as ~1e-4: gate at 4x the measurement
+    assert e < 1e-6 and e < 1e-3 * moved
     lbl, mk = P.decode_markers(rec[0, 0], torch.from_numpy(g['clip_img'])[0].to(dev), torch.from_numpy(g['rot_0_pivot']).to(dev))
     assert float((lbl.cpu() - torch.from_numpy(g['contact_lbl_rec'])).abs().mean()) < 0.01
     assert float((mk.cpu() - torch.from_numpy(g['markers_rec'])).abs().max()) < 5e-3          # metres
@@ -219,7 +220,7 @@ def test_amass_clip_pipeline_end_to_end_vs_oracle(dev):
     mpjpe = O.mpjpe_mm(j_gpu, j_ref)
     lg, lo = fit.losses()['total'], ref['hist'][-1]['total']
     print(f'\nclip pipeline ({steps} steps): MPJPE gpu-vs-oracle {mpjpe:.3f} mm; final total gpu {lg:.4f} oracle {lo:.4f}')
-    assert mpjpe < 2.0 and abs(lg - lo) < 2e-2 * abs(lo)
+    assert mpjpe < 1.2 and abs(lg - lo) < 2e-3 * abs(lo)          # measured 0.29 - 0.39 mm, |loss difference| 3e-4 of the loss
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -251,21 +252,7 @@ def test_prox_iteration_vs_reference_generated_golden(dev, stage, first):
 
 def _prox_full_problem(stage, B=100):
     import __graft_entry__ as ge
-    from lemo_amd.prox import S2_WEIGHTS, S3_WEIGHTS, load_prox_tables
-    A = load_assets()
-    small = ge.prox_small_problem(B=B, stage=stage)
-    rng = np.random.default_rng(3)
-    D = 256
-    zz = np.linspace(-3, 6, D, dtype=np.float32)
-    sdf = (np.broadcast_to(zz[None, None, :], (D, D, D)) - 1.40).astype(np.float32).copy()
-    sdf += (rng.standard_normal((D // 8, D // 8, D // 8)).astype(np.float32) * 0.02).repeat(8, 0).repeat(8, 1).repeat(8, 2)
-    prob = dict(small, model=synthetic.make_synthetic_smplx(seed=0), V=10475, ids=A['ids'], Xmean=A['Xmean'], Xstd=A['Xstd'],
-                fric_ids=load_prox_tables()['contact_fric_verts_ids'], sdf=sdf, weights=S3_WEIGHTS if stage == 'S3' else S2_WEIGHTS)
-    if stage == 'S3':
-        mask = np.ones((B, 67), np.float32); mask[40:60, :22] = 0
-        prob['infill'] = dict(marker_mask=mask, body_markers_rec=(rng.standard_normal((B - 1, 67, 3)) * 0.3).astype(np.float32),
-                              contact_lbl_rec=(rng.random((B - 1, 4)) < 0.7).astype(np.float32))
-    return prob
+    return ge.prox_full_problem(stage, B)
 
 
 @pytest.mark.parametrize('stage', ['S2', 'S3'])
@@ -487,7 +474,7 @@ def test_prox_engine_baseline_size(dev, stage):
     torch.cuda.synchronize()
     dt = time.time() - t0
     print(f'PROX engine {stage} window B=100 V=10475: {n / dt:.1f} iterations/s ({dt / n * 1e3:.3f} ms/iteration), total {l0:.2f} -> {e1.loss_dict()["total_loss"]:.2f}')
-    assert n / dt > 800
+    assert n / dt > 1300                                           # measured 1805 - 1945 it/s (r02 boxes); a lost graph replay or fusion shows as < 1000
 
 
 def test_concurrent_clips_bit_identical_to_solo_runs(dev):

@@ -112,3 +112,88 @@ def test_two_rank_gloo_concurrent_clips():
     for p in procs:
         p.join(30)
     assert res == [(0, True), (1, True)]
+
+
+def _prox_recording_rows(rec_id, tmp):
+    """fit one small synthetic recording (17 frames, batch 10 -> two chained windows) with the native PROX engine on the
+    emulator through lemo_amd.prox_windows.run_recording; rows = [transl | global_orient | pose_embedding] per frame"""
+    import numpy as np
+    import __graft_entry__ as ge
+    from lemo_amd import _hip, prox_windows as PW
+    from lemo_amd.prox import ENGINE_PARAMS
+    emu = _hip.HipLib(_hip.EMU_LIB_PATH, is_emu=True)
+    n, B = 17, 10
+    base = ge.prox_small_problem(B=n, stage='S2', seed=5 + rec_id)
+    names = [f'rec{rec_id}_frame_{i:05d}' for i in range(n)]
+    cur, prox = os.path.join(tmp, f'cur{rec_id}'), os.path.join(tmp, f'prox{rec_id}')
+    P0 = base['params']
+    body0 = {k: np.asarray(P0[k], np.float32) for k in ('transl', 'global_orient', 'betas', 'left_hand_pose', 'right_hand_pose', 'jaw_pose',
+                                                       'leye_pose', 'reye_pose', 'expression')}
+    for i, fn in enumerate(names):
+        PW.write_result_pkl(PW.result_path(prox, fn), {}, body0, np.asarray(P0['pose_embedding'], np.float32), np.zeros((n, 63), np.float32), i)
+    emb = {}
+
+    def fit_window(fns, init, first, n_frozen):
+        s = names.index(fns[0])
+        prob = dict(base, B=len(fns), params=init, gt_joints=base['gt_joints'][s:s + len(fns)], joints_conf=base['joints_conf'][s:s + len(fns)])
+        eng, _ = ge.prox_engine_for(prob, torch.device('cpu'), first_batch_flag=first, lib=emu)
+        eng.step(2, use_graph=False)
+        body = {k: eng.P[k].numpy() for k, _ in ENGINE_PARAMS[:-1]}
+        body['betas'] = np.asarray(init['betas'], np.float32)
+        for i, fn in enumerate(fns):
+            emb[fn] = eng.P['pose_embedding'][i].clone()
+        return {}, body, eng.P['pose_embedding'].numpy(), np.zeros((len(fns), 63), np.float32)
+
+    assert PW.run_recording(names, B, cur, prox, fit_window) == 2
+    rows = []
+    for fn in names:
+        r = PW.read_prox_pkl(PW.result_path(cur, fn))
+        rows.append(torch.cat([torch.from_numpy(np.asarray(r['transl'], np.float32)).reshape(-1),
+                               torch.from_numpy(np.asarray(r['global_orient'], np.float32)).reshape(-1), emb[fn]]))
+    return torch.stack(rows)
+
+
+def _worker_prox(rank, world, port, tmp, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lemo_amd.sharding import fit_recordings_sharded
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(4)
+    calls = []
+
+    def fit_recording(r):
+        calls.append(r)
+        rows = _prox_recording_rows(r, tmp)
+        return rows if r == 0 else rows[:15]              # recordings of different lengths: 17 and 15 result rows
+    out = fit_recordings_sharded(2, fit_recording, rank, world)
+    torch.save([o.clone() for o in out], os.path.join(tmp, f'out_rank{rank}.pt'))
+    q.put((rank, calls == [rank] and [int(o.shape[0]) for o in out] == [17, 15] and all(bool(torch.isfinite(o).all()) for o in out)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_prox_recordings(tmp_path):
+    """the PROX multi-GPU leg: recording r -> rank r, each rank walks ITS recording's two chained windows with the native
+    PROX engine (emulator library, lemo_amd.prox_windows.run_recording), ONE all-gather returns every recording's per-frame
+    rows to every rank, padded / trimmed for the different lengths; equal on both ranks and equal to a single-process run"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_prox, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=800) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
+    a, b = torch.load(tmp_path / 'out_rank0.pt'), torch.load(tmp_path / 'out_rank1.pt')
+    solo = [_prox_recording_rows(0, str(tmp_path / 'solo')), _prox_recording_rows(1, str(tmp_path / 'solo'))[:15]]
+    for r in range(2):
+        assert torch.equal(a[r], b[r]) and torch.equal(a[r], solo[r]), r
+    assert not torch.equal(a[0][:15], a[1])

@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import __graft_entry__ as ge
-from test_gpu_r2 import _prox_full_problem
+_prox_full_problem = ge.prox_full_problem
 dev = torch.device('cuda:0')
 stage = sys.argv[1] if len(sys.argv) > 1 else 'S3'
 eng, _ = ge.prox_engine_for(_prox_full_problem(stage), dev, first_batch_flag=False)
