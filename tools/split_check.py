@@ -1,4 +1,4 @@
-"""conv variant 3 (split-bf16) on the GPU: accuracy against float64 next to the fp32-MFMA kernel, wall time
+"""conv variants 3 (split-bf16) and 4 (split-f16) on the GPU: accuracy against float64 next to the fp32-MFMA kernel, wall time
 of both (HIP events around 20 launches) and the per-wave census of the split kernel.  Diagnostic, GPU box only."""
 import os, sys, collections
 import numpy as np, torch
@@ -8,7 +8,7 @@ from lemo_amd import _hip
 from lemo_amd._hip import ptr
 from lemo_amd.assets import load_assets
 from lemo_amd.priors import (cg8p_alloc, to_cg8p, from_cg8p, pack_conv3x3, pack_conv3x3_gmajor, pack_conv3x3_split,
-                             pack_conv3x3_bwd, pack_conv3x3_bwd_split)
+                             pack_conv3x3_bwd, pack_conv3x3_bwd_split, pack_conv3x3_split_f16)
 
 lib = _hip.get_lib(); dev = torch.device('cuda:0')
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (245, 134)
@@ -20,15 +20,18 @@ x = torch.randn(64, H, W, generator=g).abs() * 0.3
 ref64 = F.leaky_relu(F.conv2d(x[None].double(), torch.from_numpy(w).double(), torch.from_numpy(bnp).double(), padding=1), 0.2)[0]
 t = lambda a: torch.from_numpy(a).to(dev)
 wt, wt2, w3 = t(pack_conv3x3(w)), t(pack_conv3x3_gmajor(w)), t(pack_conv3x3_split(w).view(np.int16))
+_p4, w4inv = pack_conv3x3_split_f16(w); w4 = t(_p4.view(np.int16))
 b = t(bnp); xin = to_cg8p(x).to(dev); s = torch.cuda.current_stream(dev).cuda_stream
 res = {}
-for name in ('fp32-mfma (variant 2)', 'split-bf16 (variant 3)'):
+for name in ('fp32-mfma (variant 2)', 'split-bf16 (variant 3)', 'split-f16 (variant 4)'):
     out = cg8p_alloc(64, H, W, dev)
     def run():
         if name.startswith('fp32'):
             lib.check(lib.conv3x3_mfma_lds(ptr(xin), ptr(wt), ptr(wt2), ptr(b), None, ptr(out), H, W, 64, 64, 0, s))
-        else:
+        elif name.startswith('split-bf16'):
             lib.check(lib.conv3x3_mfma_split(ptr(xin), ptr(w3), ptr(wt), ptr(b), None, ptr(out), H, W, 64, 64, 0, s))
+        else:
+            lib.check(lib.conv3x3_mfma_split_f16(ptr(xin), ptr(w4), w4inv, ptr(wt), ptr(b), None, ptr(out), H, W, 64, 64, 0, s))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,28 +58,17 @@ torch.cuda.synchronize()
 e = (from_cg8p(dxb.cpu(), H, W).double() - refdx).abs().max() / refdx.abs().max()
 print('backward-data (epi 1): max err / max|ref| %.3e' % e)
 
-# census
+# census of both split variants
 nblk = H * W // 128
-dbg = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
-out = cg8p_alloc(64, H, W, dev)
-for it in range(3):
-    dbg.zero_()
-    lib.check(lib.conv3x3_mfma_split_census(ptr(xin), ptr(w3), ptr(wt), ptr(b), ptr(out), H, W, 64, 64, ptr(dbg), s))
-    torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nblk, 8, 8)
-hw, xcc, t0, t1, tp, tl = d[..., 0], d[..., 1] & 0xf, d[..., 2], d[..., 3], d[..., 4], d[..., 5]
-tm0, tm1 = d[..., 6], d[..., 7]
-cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
-cuid = (xcc * 8 + se) * 32 + sh * 16 + cu
-print('distinct CUs used:', len(set(cuid[:, 0].tolist())), 'of', nblk, 'blocks')
-print('per-wave cycles: median %d max %d' % (np.median(t1 - t0), (t1 - t0).max()))
-# s_memtime bases differ between XCDs: cluster the records by start time (a launch lasts < 1e5 ticks)
-order = np.argsort(t0.ravel()); ts = t0.ravel()[order]
-cuts = np.nonzero(np.diff(ts) > 1_000_000)[0] + 1
-spans, sskew, eskew = [], [], []
-for idx in np.split(order, cuts):
-    a0, a1 = t0.ravel()[idx], t1.ravel()[idx]
-    spans.append(int(a1.max() - a0.min())); sskew.append(int(a0.max() - a0.min())); eskew.append(int(a1.max() - a1.min()))
-print('%d clock domains; per-domain span first-start -> last-end %s ; start skew %s ; end skew %s' % (len(spans), spans, sskew, eskew))
-print('breakdown (median ticks): prologue %d  loop %d [chunk0 %d, barrier %d, chunk1+barrier %d]  epilogue %d' % (
-    np.median(tp - t0), np.median(tl - tp), np.median(tm0 - tp), np.median(tm1 - tm0), np.median(tl - tm1), np.median(t1 - tl)))
+for pieces, pack, winv in ((3, w3, 1.0), (2, w4, w4inv)):
+    dbg = torch.zeros(nblk * 8 * 8, dtype=torch.int64, device=dev)
+    out = cg8p_alloc(64, H, W, dev)
+    for it in range(3):
+        dbg.zero_()
+        lib.check(lib.conv3x3_mfma_split_census2(ptr(xin), ptr(pack), winv, pieces, ptr(wt), ptr(b), ptr(out), H, W, 64, 64, ptr(dbg), s))
+        torch.cuda.synchronize()
+    d = dbg.cpu().numpy().reshape(nblk, 8, 8)
+    hw, xcc, t0, t1, tp, tl = d[..., 0], d[..., 1] & 0xf, d[..., 2], d[..., 3], d[..., 4], d[..., 5]
+    tm0, tm1 = d[..., 6], d[..., 7]
+    print('pieces %d: per-wave cycles median %d max %d; breakdown (median ticks): prologue %d  loop %d [chunk0 %d, barrier %d, chunk1+barrier %d]  epilogue %d' % (
+        pieces, np.median(t1 - t0), (t1 - t0).max(), np.median(tp - t0), np.median(tl - tp), np.median(tm0 - tp), np.median(tm1 - tm0), np.median(tl - tm1), np.median(t1 - tl)))
