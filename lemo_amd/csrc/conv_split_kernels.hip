@@ -65,34 +65,9 @@ template <int CIN, int COUT, int NP> struct Cv3Cfg {
   static constexpr int NTI = CIN == 64 ? 9 : 5;                 // patch: taps per lane (Cin 32: lane half = tap parity)
 };
 
-// ---- tile geometry: vertical strips ---------------------------------------------------------------------------
-// A workgroup's tile is 128 consecutive pixels of a LINEAR ORDER of the image.  Rounds 1-2 used the row-major order: a tile
-// was ~one image row and its 3x3 halo two more -- 404 staged pixels for 128 outputs (3.2x), and the census of round 3
-// showed the kernel waiting for exactly that fill (all 103 KB of a workgroup's input land ~9.4k cycles after the launch,
-// 11-12 B/clk/CU, while the MFMA work of the split-f16 kernel is 6.9k).  The order is now STRIP-MAJOR: the image is cut
-// into ns vertical strips (widths wb = ceil(W / ns) for the first `nbig`, ws = floor(W / ns) for the rest), pixels run
-// row-major inside a strip and strips follow one another.  A tile is then ~128 / w rows of one strip -- a near-square patch
-// whose halo is one pixel all around: ~200 staged pixels at w = 17 (1.6x).  A tile that runs off the bottom of a strip
-// continues at the top of the next one and stages TWO regions.  The remainder pixels (P % 128) are the last pixels of
-// the order, as before.  Divisions by the strip constants are magic multiplies (host: 2^32 / d + 1; exact while
-// p * d < 2^32, checked on the host; magic 0 = "one strip", quotient 0).
-struct StripGeo {
-  int H, ns, nbig, wb, ws, nbigpx;        // nbigpx = nbig * wb * H: pixels in the wide strips
-  unsigned m_bh, m_b, m_sh, m_s;          // / (wb H), / wb, / (ws H), / ws
-  unsigned m_rb, m_rs;                    // / (wb + 2), / (ws + 2): staged row length of a region
-};
-__device__ __forceinline__ int mdiv(int p, unsigned magic) { return (int)__umulhi((unsigned)p, magic); }
-// pixel p of the strip-major order -> image (y, x), and its strip's first column x0 / width w
-__device__ __forceinline__ void strip_px(const StripGeo& g, int p, int& y, int& x, int& x0, int& w) {
-  const bool big = p < g.nbigpx;
-  const int pp = big ? p : p - g.nbigpx;
-  w = big ? g.wb : g.ws;
-  const int sidx = mdiv(pp, big ? g.m_bh : g.m_sh);
-  const int r = pp - sidx * w * g.H;
-  y = mdiv(r, big ? g.m_b : g.m_s);
-  x0 = (big ? 0 : g.nbig * g.wb) + sidx * w;
-  x = x0 + r - y * w;
-}
+// p / W for 0 <= p < 2^24 with magic = 2^32 / W + 1 (host): one v_mul_hi instead of the ~40-instruction
+// runtime division (the prologue had 13 of them per thread: 3.6k of its 6.9k cycles were address math)
+__device__ __forceinline__ int div_w(int p, unsigned magic) { return (int)__umulhi((unsigned)p, magic); }
 
 // ---- split-f16 helpers (NP = 2) ---------------------------------------------------------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -148,15 +123,14 @@ template <int CIN> struct SplitPatch {
 template <int EPI, int CIN, int COUT, int NP>
 __device__ __forceinline__ void split_patch_load(SplitPatch<CIN>& pt, const float* __restrict__ in, const float* __restrict__ wt,
                                                  const float* __restrict__ bias, const float* __restrict__ aux,
-                                                 const StripGeo& geo, int Wp, int HWp, int P, int rem0, int patch) {
+                                                 int W, unsigned wmagic, int Wp, int HWp, int P, int rem0, int patch) {
   typedef Cv3Cfg<CIN, COUT, NP> Cfg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pq = patch / Cfg::CQ, cq = patch - pq * Cfg::CQ;
   int p = rem0 + pq * Cfg::PPX + (wave >> 1);
   pt.valid = p < P;
   p = p < P ? p : P - 1;
-  int y, x, x0_, w_;
-  strip_px(geo, p, y, x, x0_, w_);
+  const int y = div_w(p, wmagic), x = p - y * W;
   pt.poff = (y + 1) * Wp + (x + 1);
   pt.co = cq * 4 + 2 * (wave & 1);
   const int c = lane & (CIN - 1);
@@ -239,7 +213,7 @@ __device__ __forceinline__ void split_reduce_store(const f32x16& give, const f32
 template <int EPI, int CIN, int COUT, int NP, bool DBG>
 __device__ __forceinline__ void split_layer(const float* __restrict__ in, const uint4* __restrict__ w3, float winv, const float* __restrict__ wt,
                                             const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                                            int H, int W, const StripGeo& geo, int full_blocks, int tile,
+                                            int H, int W, unsigned wmagic, int full_blocks, int tile,
                                             unsigned long long* __restrict__ dbg) {
   unsigned long long t_start = 0, t_pro = 0, t_loop = 0, t_mid0 = 0, t_mid1 = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
@@ -268,7 +242,7 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
   _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
     _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_)                                              \
       rb[SET][nt_][s_] = *reinterpret_cast<const uint4*>(                                         \
-          smem + (2 * (NCC * kh + (U) / 9) + h) * GRP + s_ * PLANE + (li[nt_] + (((U) % 9) / 3 - 1) * pitch + (((U) % 9) % 3 - 1)) * 16);
+          smem + (2 * (NCC * kh + (U) / 9) + h) * GRP + s_ * PLANE + (li[nt_] + (((U) % 9) / 3 - 1) * Wp + (((U) % 9) % 3 - 1)) * 16);
 #define CV3_MFMA1(SA, SETA, SB, SETB)                                                              \
   _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) {                                            \
     if (NP == 3)                                                                                   \
@@ -303,44 +277,28 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
   SplitPatch<CIN> pt;
 
   // ---- staging plan ---------------------------------------------------------------------------------
-  // region 1: the tile's rows in the strip of its first pixel (+ a halo row above and below, a halo column left and right);
-  // region 2 (tiles that run off the bottom of their strip): the rows at the top of the next strip, same shape.
-  // LDS pixel index = region base + (row in region) * pitch + (column in region), pitch = wb + 2 for every strip.
   const int pfirst = tile * 128, plast = pfirst + 127;
-  int yf, xf, x0f, wf, yl, xl, x0l, wl;
-  strip_px(geo, pfirst, yf, xf, x0f, wf);
-  strip_px(geo, plast, yl, xl, x0l, wl);
-  const bool two = x0l != x0f;                                   // uniform
-  const int pitch = geo.wb + 2;
-  const int rows1 = (two ? H - 1 : yl) - yf + 3;                 // staged rows of region 1 (padded rows yf .. )
-  const int rows2 = two ? yl + 3 : 0;                            // region 2: padded rows 0 .. yl + 2
-  const int cw1 = wf + 2, cw2 = wl + 2;                          // staged columns per row
-  const int n1 = rows1 * cw1, npx = n1 + rows2 * cw2;            // staged pixels (<= CV3_NPX, checked on host)
-  const int base2 = rows1 * pitch;                               // LDS pixel index where region 2 starts
-  const unsigned mr1 = wf == geo.wb ? geo.m_rb : geo.m_rs, mr2 = wl == geo.wb ? geo.m_rb : geo.m_rs;
+  const int yf = div_w(pfirst, wmagic), yl = div_w(plast, wmagic);
+  const int q0 = (yf + 1) * Wp + (pfirst - yf * W + 1), q1 = (yl + 1) * Wp + (plast - yl * W + 1);
+  const int qin = q0 - Wp - 1;                                   // first staged padded pixel
+  const int npx = q1 - q0 + 2 * Wp + 3;                          // staged pixels (<= CV3_NPX, checked on host)
+  const int nchB = 2 * npx;                                      // 16-B chunks (4 floats) per channel group
   // phase f stages groups {2f, 2f+1, GH+2f, GH+2f+1}: the f-th k-chunk of both K halves.
-  // Slot c0 = tid + NT k covers 16-B chunk c0 % (2 NPX) of group c0 / (2 NPX); chunk c = (staged pixel q, half); slots past
-  // the tile's own 2 npx chunks redo its last one (same data, same place).  No predicates anywhere: a load whose only
+  // Slot c = tid + NT k covers chunk c % 816 of group c / 816 (constant stride = the LDS plane size, so the
+  // map costs a handful of VALU ops: every prologue instruction is paid twice per SIMD with the MFMA pipe
+  // idle); chunks past the tile's own nchB re-read its last one.  No predicates anywhere: a load whose only
   // use sits inside an `if` is sunk into it by hipcc and then waited for with vmcnt(0).
   unsigned offB[NB];
   int dstB[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     int c0 = (int)threadIdx.x + k * NT;
-    c0 = c0 < 4 * 2 * CV3_NPX ? c0 : 4 * 2 * CV3_NPX - 1;
-    const int gg = c0 / (2 * CV3_NPX);
-    int c = c0 - gg * (2 * CV3_NPX);
+    c0 = c0 < 4 * 2 * CV3_NPX ? c0 : 4 * 2 * CV3_NPX - 1;        // surplus slots redo the last chunk (same data, same place)
+    const int gg = c0 / (2 * CV3_NPX), c = c0 - gg * (2 * CV3_NPX);
     const int g0 = (gg >> 1) * GH + (gg & 1);
-    c = c < 2 * npx ? c : 2 * npx - 1;
-    const int q = c >> 1, half = c & 1;
-    const bool r2 = q >= n1;
-    const int qq = r2 ? q - n1 : q;
-    const int cw = r2 ? cw2 : cw1;
-    const int row = mdiv(qq, r2 ? mr2 : mr1), col = qq - row * cw;
-    const int gpix = ((r2 ? 0 : yf) + row) * Wp + (r2 ? x0l : x0f) + col;          // padded coordinates
-    const int lpix = (r2 ? base2 : 0) + row * pitch + col;
-    offB[k] = (unsigned)g0 * in_gstride + (unsigned)gpix * 8u + (unsigned)half * 4u;
-    dstB[k] = g0 * GRP + (lpix * 2 + half) * 8;
+    const int cl = c < nchB ? c : nchB - 1;
+    offB[k] = (unsigned)g0 * in_gstride + (unsigned)qin * 8u + (unsigned)cl * 4u;
+    dstB[k] = g0 * GRP + c * 8;
   }
   float4 stB[NB];
 #pragma unroll
@@ -390,11 +348,9 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int p = pfirst + ph * 64 + nt * 32 + j;
-    int y, x, x0, w;
-    strip_px(geo, p, y, x, x0, w);
+    const int y = div_w(p, wmagic), x = p - y * W;
     poffn[nt] = (y + 1) * Wp + (x + 1);
-    const bool r2 = two && x0 != x0f;
-    li[nt] = (r2 ? base2 + (y + 1) * pitch : (y - yf + 1) * pitch) + (x - x0 + 1);
+    li[nt] = poffn[nt] - qin;
   }
   f32x16 acc[2];
 #pragma unroll
@@ -411,7 +367,7 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
       if (u + 2 < NU) { CV3_LOAD_A((u + 2) % 3, u + 2) }
       if (tap + 1 < 9) { CV3_LOAD_B((u + 1) & 1, u + 1) }
       if (u == 0) {
-        split_patch_load<EPI, CIN, COUT, NP>(pt, in, wt, bias, aux, geo, Wp, HWp, P, rem0, has_patch ? tile : 0);
+        split_patch_load<EPI, CIN, COUT, NP>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, has_patch ? tile : 0);
         pt.valid = pt.valid && has_patch;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -493,7 +449,7 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
   }
   // shapes with more remainder patches than blocks: the rest, round-robin (not on the headline shapes)
   for (int patch = tile + full_blocks; patch < npatch; patch += full_blocks) {
-    split_patch_load<EPI, CIN, COUT, NP>(pt, in, wt, bias, aux, geo, Wp, HWp, P, rem0, patch);
+    split_patch_load<EPI, CIN, COUT, NP>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, patch);
     split_patch_finish<EPI, CIN>(pt, out, HWp);
   }
   if (DBG && lane == 0) {           // census record, same format as conv3x3_mfma_v2_kernel
@@ -508,7 +464,7 @@ template <int EPI, int CIN, int COUT, int NP, bool DBG>
 __global__ void __launch_bounds__((Cv3Cfg<CIN, COUT, NP>::NT))
 conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3, float winv, const float* __restrict__ wt,
                      const float* __restrict__ bias, const float* __restrict__ aux, float* __restrict__ out,
-                     int H, int W, StripGeo geo, int full_blocks, unsigned long long* __restrict__ dbg) {
+                     int H, int W, unsigned wmagic, int full_blocks, unsigned long long* __restrict__ dbg) {
   // XCD-aware tile order (workgroup b runs on XCD b % 8): XCD x owns a contiguous run of tiles so that
   // vertically adjacent tiles share their halo rows in one L2
   int tile = (int)blockIdx.x;
@@ -516,7 +472,7 @@ conv3x3_split_kernel(const float* __restrict__ in, const uint4* __restrict__ w3,
     const int q = full_blocks >> 3, r = full_blocks & 7, xcd = tile & 7, k = tile >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
-  split_layer<EPI, CIN, COUT, NP, DBG>(in, w3, winv, wt, bias, aux, out, H, W, geo, full_blocks, tile, dbg);
+  split_layer<EPI, CIN, COUT, NP, DBG>(in, w3, winv, wt, bias, aux, out, H, W, wmagic, full_blocks, tile, dbg);
 }
 
 int conv_split_init() {
@@ -532,43 +488,14 @@ int conv_split_init() {
   return rc;
 }
 
-// Strip geometry for an H x W image: the number of strips that minimises the average staged pixels per tile,
-// (128 / w + 1 + 2) rows x (w + 2) columns, subject to (a) a tile never spans three strips (w H >= 256), (b) the worst
-// two-region tile fits the LDS planes (CV3_NPX), (c) the magic divisions are exact (p d < 2^32).  false: no geometry fits.
-static bool strip_geometry(int H, int W, StripGeo& g) {
-  const long P = (long)H * W;
-  double best = 1e30;
-  bool found = false;
-  for (int ns = 1; ns <= 32 && ns <= W; ++ns) {
-    const int ws = W / ns, wb = (W + ns - 1) / ns, nbig = W - ns * ws;
-    if ((long)ws * H < 256) break;
-    const int rows = (128 + ws - 1) / ws + 1;                       // rows a tile can touch in one strip
-    const int worst1 = (rows + 2) * (wb + 2), worst2 = (rows + 1 + 4) * (wb + 2);   // one region / two regions
-    if ((ns > 1 ? (worst1 > worst2 ? worst1 : worst2) : worst1) > CV3_NPX) continue;
-    if (ns > 1 && P * ((long)wb * H) >= (1l << 32)) continue;
-    if (P * (long)(wb + 2) >= (1l << 32)) continue;
-    const double wavg = (double)W / ns, cost = (128.0 / wavg + 3.0) * (wavg + 2.0);
-    if (cost < best) {
-      best = cost; found = true;
-      auto magic = [](long d) { return (unsigned)((1ull << 32) / (unsigned long long)d + 1); };
-      g.H = H; g.ns = ns; g.nbig = nbig; g.wb = wb; g.ws = ws; g.nbigpx = nbig * wb * H;
-      g.m_bh = ns > 1 ? magic((long)wb * H) : 0u; g.m_b = magic(wb);
-      g.m_sh = ns > 1 ? magic((long)ws * H) : 0u; g.m_s = magic(ws);
-      g.m_rb = magic(wb + 2); g.m_rs = magic(ws + 2);
-      if (nbig == 0) { g.nbigpx = 0; }                              // all strips have width ws == wb
-    }
-  }
-  return found;
-}
-
 // shapes the split kernel takes; everything else stays on conv3x3_mfma_lds
 bool conv3x3_split_supported(int H, int W, int cin, int cout) {
   if ((cin != 32 && cin != 64) || (cout != 32 && cout != 64) || H <= 0 || W <= 0) return false;
   const long P = (long)H * W;
   const long full = P / 128;
   if (full < 1 || P > (1l << 24)) return false;
-  StripGeo g;
-  return strip_geometry(H, W, g);
+  if (127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 > CV3_NPX) return false;
+  return true;
 }
 
 // pieces = 3: w3 = bf16 pack (pack_conv3x3_split), winv ignored.  pieces = 2: w3 = f16 pack of weight * 2^k, winv = 2^-k.
@@ -579,15 +506,14 @@ int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const f
   const int full = (H * W) / 128;
   if (int rc = conv_split_init()) return rc;
   const uint4* w3v = reinterpret_cast<const uint4*>(w3);
-  StripGeo geo;
-  if (!strip_geometry(H, W, geo)) return LEMO_ERR_SHAPE;
+  const unsigned wmagic = (unsigned)((1ull << 32) / (unsigned)W + 1);       // exact for p < 2^32 / W (P <= 2^24 checked)
   if (dbg) {
     if (epi != 0 || cin != 64 || cout != 64) return LEMO_ERR_ARG;
-    if (pieces == 3) hipLaunchKernelGGL((conv3x3_split_kernel<0, 64, 64, 3, true>), dim3(full), dim3(512), (Cv3Cfg<64, 64, 3>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, geo, full, dbg);
-    else hipLaunchKernelGGL((conv3x3_split_kernel<0, 64, 64, 2, true>), dim3(full), dim3(512), (Cv3Cfg<64, 64, 2>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, geo, full, dbg);
+    if (pieces == 3) hipLaunchKernelGGL((conv3x3_split_kernel<0, 64, 64, 3, true>), dim3(full), dim3(512), (Cv3Cfg<64, 64, 3>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, wmagic, full, dbg);
+    else hipLaunchKernelGGL((conv3x3_split_kernel<0, 64, 64, 2, true>), dim3(full), dim3(512), (Cv3Cfg<64, 64, 2>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, wmagic, full, dbg);
     return (int)hipGetLastError();
   }
-#define LAUNCH3(EPI_, CI_, CO_, NP_) hipLaunchKernelGGL((conv3x3_split_kernel<EPI_, CI_, CO_, NP_, false>), dim3(full), dim3((Cv3Cfg<CI_, CO_, NP_>::NT)), (Cv3Cfg<CI_, CO_, NP_>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, geo, full, (unsigned long long*)nullptr)
+#define LAUNCH3(EPI_, CI_, CO_, NP_) hipLaunchKernelGGL((conv3x3_split_kernel<EPI_, CI_, CO_, NP_, false>), dim3(full), dim3((Cv3Cfg<CI_, CO_, NP_>::NT)), (Cv3Cfg<CI_, CO_, NP_>::SMEM_BYTES), s, in, w3v, winv, wt, bias, aux, out, H, W, wmagic, full, (unsigned long long*)nullptr)
 #define LAUNCH_E(CI_, CO_, NP_) { if (epi == 0) LAUNCH3(0, CI_, CO_, NP_); else if (epi == 1) LAUNCH3(1, CI_, CO_, NP_); else LAUNCH3(2, CI_, CO_, NP_); }
 #define LAUNCH_S(NP_) { if (cin == 64 && cout == 64) LAUNCH_E(64, 64, NP_) else if (cin == 64) LAUNCH_E(64, 32, NP_) else if (cout == 64) LAUNCH_E(32, 64, NP_) else LAUNCH_E(32, 32, NP_) }
   if (pieces == 3) LAUNCH_S(3) else LAUNCH_S(2)
