@@ -394,7 +394,17 @@ def ae_probe(device):
         finetune_and_infill(ae, w, x, mask, steps=60)
         torch.cuda.synchronize(device)
         best = min(best, (time.perf_counter() - t0) * 1e3)
+    from lemo_amd.infill import finetune_and_infill_many
+    k = 4
+    xs = [torch.randn(1, 4, 210, 135, generator=g).to(device) for _ in range(k)]
+    finetune_and_infill_many(ae, w, xs, [mask] * k, steps=60)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    finetune_and_infill_many(ae, w, xs, [mask] * k, steps=60)
+    torch.cuda.synchronize(device)
+    many = (time.perf_counter() - t0) * 1e3 / k
     return {'value': best, 'unit': 'ms per clip (60 finetune steps + eval forward)', 'higher_is_better': False,
+            'clips_side_by_side': k, 'side_by_side_ms_per_clip': many,
             'workload': 'models/AE.py infilling autoencoder, [1,4,210,135] clip image, masked L1, Adam 3e-6 (opt_amass_temp.py:154-214)'}
 
 

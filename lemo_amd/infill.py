@@ -454,7 +454,7 @@ class _FinetuneSession:
         rec.backward(torch.sign(rec.detach() - self.x[0, 0]) * self.moc)
         self.opt.step()
 
-    def run(self, flat0, x, m_over_cnt, steps, use_graph):
+    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True):
         import ctypes as C
         lib = self.lib
         if self.gpu:
@@ -492,12 +492,32 @@ class _FinetuneSession:
             else:
                 for _ in range(left):
                     self.train_step()
-        if self.gpu:
+        if self.gpu and join:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return self.flat.detach()
 
+    def join(self):
+        """make the current stream wait for this session's work (``run(..., join=False)`` leaves that to the caller, so that
+        several sessions can be enqueued before anything waits for any of them)"""
+        if self.gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
 
 _SESSIONS: Dict[tuple, _FinetuneSession] = {}
+_MAX_SESSIONS = 8
+"""sessions kept alive at once (LRU): each pins ~45 workspace buffers, a stream, a private memory pool and an instantiated
+graph; PROX tail windows and recordings of varying length would otherwise add one per clip shape without bound (ADVICE r02)."""
+
+
+def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0) -> _FinetuneSession:
+    key = (str(device), tuple(shape), float(lr), id(lib), int(slot))
+    ses = _SESSIONS.pop(key, None)
+    if ses is None:
+        ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
+    _SESSIONS[key] = ses                                   # most recently used last
+    while len(_SESSIONS) > _MAX_SESSIONS:
+        _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for the device and releases the graph
+    return ses
 
 
 def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, train_mask: torch.Tensor, steps: int = 60,
@@ -521,10 +541,7 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
         use_graph = clip_img_input.is_cuda
     use_graph = bool(use_graph) and clip_img_input.is_cuda and not lib.is_emu
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
-    key = (str(clip_img_input.device), tuple(clip_img_input.shape), float(lr), id(lib))
-    ses = _SESSIONS.get(key)
-    if ses is None:
-        ses = _SESSIONS[key] = _FinetuneSession(lib, flat0.numel(), tuple(clip_img_input.shape), lr, clip_img_input.device)
+    ses = _session(lib, flat0.numel(), clip_img_input.shape, lr, clip_img_input.device)
     flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
     with torch.no_grad():
         o = 0
@@ -534,3 +551,39 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     with torch.no_grad():
         rec, z = model(clip_img_input)
     return rec[:, :, 1:-1, 8:-8], z
+
+
+def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor], train_masks: List[torch.Tensor], steps: int = 60,
+                             lr: float = 3e-6, use_graph: Optional[bool] = None):
+    """:func:`finetune_and_infill` for several clips SIDE BY SIDE (the dataset-scale form, like
+    ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1): every clip's
+    60-step finetune runs on its own session -- own stream, own flat parameter copy, Adam state, workspace and captured
+    graph -- so the k loops advance concurrently.  One training step is ~150 short launches (the deep layers are 27 x 17 and
+    14 x 9 pixel images: a handful of workgroups each) whose time is mostly kernel-boundary latency; a second and third clip
+    fill the idle device.  Each clip's result is bit-identical to its solo ``finetune_and_infill`` (same kernels, same order,
+    no shared state; tested).  Returns the list of ``(clip_img_rec, z)``; at most ``_MAX_SESSIONS`` clips per call."""
+    assert 1 <= len(clips) == len(train_masks) <= _MAX_SESSIONS
+    lib = model._lib_override or _hip.get_lib()
+    if use_graph is None:
+        use_graph = clips[0].is_cuda
+    use_graph = bool(use_graph) and clips[0].is_cuda and not lib.is_emu
+    model.load_state_dict(weights)
+    flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
+    flats, sessions = [], []
+    mocs = [tm.to(x.dtype) * (1.0 / tm.to(x.dtype).sum()) for x, tm in zip(clips, train_masks)]     # (on the current stream, before any fork)
+    for i, (x, moc) in enumerate(zip(clips, mocs)):                          # enqueue: clip i's loop on session i's stream
+        ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i)
+        flats.append(ses.run(flat0, x, moc, steps, use_graph, join=False))   # the current stream waits for nobody yet
+        sessions.append(ses)
+    for ses in sessions:
+        ses.join()
+    out = []
+    for x, flat in zip(clips, flats):                                        # eval forwards, one after the other
+        with torch.no_grad():
+            o = 0
+            for p in model.ordered_parameters():
+                p.copy_(flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            rec, z = model(x)
+        out.append((rec[:, :, 1:-1, 8:-8].clone(), z.clone()))
+    return out

@@ -145,6 +145,35 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     assert np.abs(got2 - ref2).max() < 5e-5
 
 
+def test_finetune_many_clips_side_by_side_bit_identical(dev):
+    """four clips' 60-step AE finetunes side by side (finetune_and_infill_many: one session = stream + parameters + Adam state
+    + workspace + captured graph per clip) == each clip through finetune_and_infill on its own, bit for bit; and the
+    aggregate time per clip (printed: the per-clip cost a dataset-scale run pays)"""
+    import time
+    from lemo_amd import infill
+    from lemo_amd.infill import AE, finetune_and_infill, finetune_and_infill_many
+    ae_w = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_ae_weights(7).items()}
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(1, 4, 210, 135, generator=g).to(dev) for _ in range(4)]
+    ms = [(torch.rand(210, 135, generator=g) > 0.2).to(dev) for _ in range(4)]
+    ae = AE().to(dev)
+    solo = []
+    for x, m in zip(xs, ms):
+        r, z = finetune_and_infill(ae, ae_w, x, m, steps=60)
+        solo.append((r.clone(), z.clone()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); finetune_and_infill(ae, ae_w, xs[0], ms[0], steps=60); torch.cuda.synchronize()
+    t_solo = (time.perf_counter() - t0) * 1e3
+    many = finetune_and_infill_many(ae, ae_w, xs, ms, steps=60)             # captures the four graphs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); many = finetune_and_infill_many(ae, ae_w, xs, ms, steps=60); torch.cuda.synchronize()
+    t_many = (time.perf_counter() - t0) * 1e3
+    print(f'\ninfilling AE finetune: one clip {t_solo:.1f} ms; four clips side by side {t_many:.1f} ms = {t_many / 4:.1f} ms per clip')
+    for (ra, za), (rb, zb) in zip(solo, many):
+        assert torch.equal(ra, rb) and torch.equal(za, zb)
+    infill._SESSIONS.clear()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # per-clip pipeline: fixtures written by the reference's own text (tests/golden/make_golden.py)
 # ---------------------------------------------------------------------------------------------------------------------

@@ -115,3 +115,26 @@ def test_finetune_session_carries_nothing_from_clip_to_clip(emu_lib):
     for k, v in ae2.state_dict().items():
         assert torch.equal(v, p_b[k]), k
     infill._SESSIONS.clear()
+
+
+def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
+    """finetune_and_infill_many: clip i on session slot i (own parameters / Adam state / workspace) == clip i through
+    finetune_and_infill, bit for bit; and the session cache is an LRU of at most _MAX_SESSIONS entries"""
+    from lemo_amd import infill
+    from lemo_amd.infill import AE, finetune_and_infill, finetune_and_infill_many
+    w = _weights()
+    g = torch.Generator().manual_seed(6)
+    xs = [torch.randn(1, 4, 18, 22, generator=g) for _ in range(3)]
+    ms = [torch.rand(18, 22, generator=g) > 0.3 for _ in range(3)]
+    infill._SESSIONS.clear()
+    ae = AE(_lib=emu_lib)
+    solo = [tuple(t.clone() for t in finetune_and_infill(ae, w, x, m, steps=2, lr=1e-3)) for x, m in zip(xs, ms)]
+    infill._SESSIONS.clear()
+    many = finetune_and_infill_many(AE(_lib=emu_lib), w, xs, ms, steps=2, lr=1e-3)
+    assert len(infill._SESSIONS) == 3
+    for (ra, za), (rb, zb) in zip(solo, many):
+        assert torch.equal(ra, rb) and torch.equal(za, zb)
+    for t in range(infill._MAX_SESSIONS + 3):                          # other clip shapes: the cache stays bounded
+        finetune_and_infill(ae, w, torch.randn(1, 4, 18, 24 + 2 * t, generator=g), torch.ones(18, 24 + 2 * t) > 0, steps=0)
+    assert len(infill._SESSIONS) == infill._MAX_SESSIONS
+    infill._SESSIONS.clear()

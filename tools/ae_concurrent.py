@@ -1,0 +1,25 @@
+"""k clips' infilling-AE finetunes side by side (lemo_amd.infill.finetune_and_infill_many): ms per clip for k = 1..4, graph replay and
+eager launches (diagnostic, GPU box only).  Usage: python tools/ae_concurrent.py"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lemo_amd import synthetic, infill
+from lemo_amd.infill import AE, finetune_and_infill_many
+dev = torch.device('cuda:0')
+w = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_ae_weights(7).items()}
+ae = AE().to(dev); ae.load_state_dict(w)
+g = torch.Generator().manual_seed(0)
+xs = [torch.randn(1, 4, 210, 135, generator=g).to(dev) for _ in range(4)]
+mask = (torch.ones(210, 135) > 0).to(dev)
+for use_graph in (True, False):
+    for k in (1, 2, 4):
+        finetune_and_infill_many(ae, w, xs[:k], [mask] * k, steps=60, use_graph=use_graph); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        finetune_and_infill_many(ae, w, xs[:k], [mask] * k, steps=60, use_graph=use_graph); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        # host time to ENQUEUE (no sync): how long the launches alone take
+        t0 = time.perf_counter()
+        finetune_and_infill_many(ae, w, xs[:k], [mask] * k, steps=60, use_graph=use_graph)
+        th = (time.perf_counter() - t0) * 1e3
+        torch.cuda.synchronize()
+        print(f'graph={use_graph} k={k}: {dt:7.1f} ms total = {dt / k:6.1f} ms per clip; host enqueue time {th:7.1f} ms', flush=True)
