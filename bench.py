@@ -395,7 +395,7 @@ def ae_probe(device):
         torch.cuda.synchronize(device)
         best = min(best, (time.perf_counter() - t0) * 1e3)
     from lemo_amd.infill import finetune_and_infill_many
-    k = 4
+    k = 2
     xs = [torch.randn(1, 4, 210, 135, generator=g).to(device) for _ in range(k)]
     finetune_and_infill_many(ae, w, xs, [mask] * k, steps=60)
     torch.cuda.synchronize(device)

@@ -150,6 +150,15 @@ class _FlatTables:
         return cls._cache[k]
 
 
+WGRAD_SECOND_STREAM = __import__('os').environ.get('LEMO_AE_SECOND_STREAM', '0') != '0'
+"""Round 2 ran the weight gradients of the training step on a second stream beside the backward-data chain.  Round 3 measured what
+that costs a GRAPH (tools/ae_concurrent.py, profiles/r03_ae_concurrent.txt): the 20 fork / join pairs make ``hipGraphLaunch`` of the
+captured step ~0.9 ms of HOST time -- 55 of a clip's 88 ms were spent enqueueing, the finetune was host-bound and k clips side by side
+did not overlap at all.  On ONE stream the 60 launches cost 4.7 ms of host time; a clip takes 81 ms (GPU-bound now) and two clips
+side by side 53 ms each.  Default off since round 3 (``LEMO_AE_SECOND_STREAM=1`` or set this to True before the first clip restores
+the second stream; read when a workspace is created).  Same kernels either way: identical results."""
+
+
 class AEWorkspace:
     """Activation / gradient buffers of one training step, allocated and zeroed ONCE and handed out in call order.  A
     step asks for the same ~45 CG8P buffers in the same order every time and the kernels only ever write interiors (the
@@ -160,8 +169,9 @@ class AEWorkspace:
     def __init__(self, device):
         self.device, self.bufs, self.pos = torch.device(device), [], 0
         self.flats, self.fpos = [], 0
-        # weight gradients run on a second stream, next to the backward-data chain that does not depend on them
-        self.side = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+        # weight gradients may run on a second stream, next to the backward-data chain that does not depend on them (see
+        # WGRAD_SECOND_STREAM below)
+        self.side = torch.cuda.Stream(self.device) if (self.device.type == 'cuda' and WGRAD_SECOND_STREAM) else None
 
     def reset(self):
         self.pos = self.fpos = 0

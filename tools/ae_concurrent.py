@@ -11,6 +11,7 @@ ae = AE().to(dev); ae.load_state_dict(w)
 g = torch.Generator().manual_seed(0)
 xs = [torch.randn(1, 4, 210, 135, generator=g).to(dev) for _ in range(4)]
 mask = (torch.ones(210, 135) > 0).to(dev)
+print('second stream for the weight gradients:', infill.WGRAD_SECOND_STREAM, flush=True)
 for use_graph in (True, False):
     for k in (1, 2, 4):
         finetune_and_infill_many(ae, w, xs[:k], [mask] * k, steps=60, use_graph=use_graph); torch.cuda.synchronize()

@@ -1,4 +1,4 @@
 #!/bin/bash
-OUT=gpurun_out/r03j; mkdir -p $OUT
-timeout 600 python tools/ae_concurrent.py > $OUT/ae_concurrent.txt 2>&1; grep -v amdgpu $OUT/ae_concurrent.txt | cut -c1-200
-GPU_MAX_HW_QUEUES=8 timeout 600 python tools/ae_concurrent.py > $OUT/ae_concurrent_q8.txt 2>&1; echo "--- GPU_MAX_HW_QUEUES=8"; grep -v amdgpu $OUT/ae_concurrent_q8.txt | cut -c1-200
+OUT=gpurun_out/r03k; mkdir -p $OUT
+LEMO_AE_SECOND_STREAM=0 timeout 600 python tools/ae_concurrent.py > $OUT/ae_concurrent_single.txt 2>&1; grep -v amdgpu $OUT/ae_concurrent_single.txt | cut -c1-200
+timeout 600 python tools/ae_concurrent.py > $OUT/ae_concurrent_two.txt 2>&1; grep -v amdgpu $OUT/ae_concurrent_two.txt | cut -c1-200
