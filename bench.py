@@ -44,7 +44,7 @@ PEAK_HBM_TBS = 8.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_FILE = os.path.join('profiles', 'r03_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
 
 
-def build_problem(seq_id, B, device, full_vertices, conv_variant=1, side_forward=False):
+def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
     from lemo_amd import synthetic
     from lemo_amd.assets import load_assets
     from lemo_amd.fitting import AmassTemporalFitter
@@ -53,7 +53,7 @@ def build_problem(seq_id, B, device, full_vertices, conv_variant=1, side_forward
     model = synthetic.make_synthetic_smplx(seed=0)
     vw = make_vposer_weights(2)
     fit = AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], B, device,
-                              full_vertices=full_vertices, conv_variant=conv_variant, side_forward=side_forward)
+                              full_vertices=full_vertices, conv_variant=conv_variant)
     seq = synthetic.make_synthetic_sequence(seq_id, B=B)
     # target markers = model markers of the perturbed trajectory, via the product path
     fit.load_sequence(seq['target_params'], np.zeros((B, 67, 3), np.float32), seq['contact_lbl'])
@@ -471,9 +471,6 @@ def main():
     ap.add_argument('--frames', type=int, default=119, help='B = clip_seconds*30-1 (the "T=120" clip)')
     ap.add_argument('--active-vertices-only', action='store_true',
                     help='forward only the 253 vertices the losses read (NOT the headline config)')
-    ap.add_argument('--side-forward', action='store_true',
-                    help='experiment (DESIGN 9.7): all vertices still forwarded every iteration, but on a parallel graph branch; the '
-                         'losses run on the forward of the loss-carrying vertices (NOT the default configuration)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--conv-variant', type=int, default=DEFAULT_CONV_VARIANT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -505,8 +502,7 @@ def main():
 
     from lemo_amd.sharding import gather_fitted_params
     B = args.frames
-    fit, prob = build_problem(rank, B, device, full_vertices=not args.active_vertices_only, conv_variant=args.conv_variant,
-                              side_forward=args.side_forward)
+    fit, prob = build_problem(rank, B, device, full_vertices=not args.active_vertices_only, conv_variant=args.conv_variant)
     stream = torch.cuda.Stream(device)
     use_graph = not args.no_graph
 
@@ -579,8 +575,6 @@ def main():
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12
     vs = time_vertex_stage(fit, stream, use_graph=use_graph)
     lbs_in_chain_ms = (time_conv_chain(fit, stream, use_graph=use_graph, with_lbs=True) - chain_ms) if fit.full else None
-    if args.side_forward:
-        out_side = True
     fit.dact[0].zero_(); fit.dact[1].zero_()          # the chain used the gradient maps as scratch (interiors are rewritten each step)
     if fit.conv_variant == 4:
         # every fp32-accurate multiply-accumulate is 3 fp16 MFMA products (two error-compensated fp16 pieces per operand, fp32
@@ -606,7 +600,7 @@ def main():
                                '(the T=120 clip), SMPL-X-shaped synthetic model V=10475, VPoser decode, smoothness '
                                'encoder 245x134, marker+contact+prior losses, Adam',
                    'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
-                   'sequences': world, 'conv_variant': fit.conv_variant, 'side_forward': bool(args.side_forward),
+                   'sequences': world, 'conv_variant': fit.conv_variant,
                    'arithmetic': {4: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
                                      'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured '
                                      'error vs float64 at the level of an fp32 convolution, conv_split_kernels.hip)',

@@ -334,14 +334,6 @@ typedef struct lemo_fit_desc {
                                    * encoder, no contact term), any B >= 1 */
   float lr2;                      /* third learning-rate level: lr = lr2 when step > lr_switch2 > 0 (opt_amass_perframe.py:316-321) */
   int lr_switch2;
-  /* ---- round-3 addition ---- */
-  int side_forward;               /* 1 (with full_vertices == 0 and verts_full != NULL): the losses run on the forward of the
-                                   * loss-carrying vertices only (identical losses and gradients), and the ALL-vertex forward of the
-                                   * same iteration (lbs.py:94-117 for the 10475 vertices: what the reference's output.vertices holds)
-                                   * is launched on an engine-owned side stream forked after the pose stage and joined before the
-                                   * next pose stage / at the end of the call -- a parallel branch of the captured graph */
-  float* verts_full;              /* [B][V][3] */
-  float* v_posed_full;            /* [B][V][3] */
 } lemo_fit_desc;
 
 /* Opaque engine: holds a copy of the descriptor (pointers only) and, optionally, a captured hipGraph. */

@@ -244,37 +244,15 @@ struct FitEngine {
   lemo_fit_desc d;
   hipGraphExec_t exec[FIT_LEVELS] = {nullptr, nullptr, nullptr};   // FIT_UNROLL[l] iterations each, captured on first use
   int head = 5;     // replays of the 1-iteration graph that open a call (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
-  // side_forward: the all-vertex forward runs on `side`, forked from / joined into the caller's stream with these events
-  // (inside a capture they become a parallel branch of the graph)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool pending = false;       // a side launch has been forked and not joined yet (host-side bookkeeping of the launch ORDER)
-  int fork_late = 0;          // LEMO_SIDE_FORK=1: fork before the per-frame backward kernels instead of right after the pose stage
 };
 
-// all-vertex forward of the current pose on the engine's side stream (fork now, join later)
-static int side_fork(FitEngine* e, hipStream_t s) {
-  const lemo_fit_desc& d = e->d;
-  CHK((int)hipEventRecord(e->ev_fork, s));
-  CHK((int)hipStreamWaitEvent(e->side, e->ev_fork, 0));
-  CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, d.body.nj, d.transl, nullptr, d.V, d.B, d.verts_full, d.v_posed_full, e->side, nullptr, d.pose.XgS));
-  CHK((int)hipEventRecord(e->ev_join, e->side));
-  e->pending = true;
-  return 0;
-}
-static int side_join(FitEngine* e, hipStream_t s) {
-  if (!e || !e->pending) return 0;
-  e->pending = false;
-  return (int)hipStreamWaitEvent(s, e->ev_join, 0);
-}
-
-static int fit_iteration(FitEngine* e, hipStream_t s, bool first, bool last);
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last);
 
 static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e, s, i == 0, i == iters - 1);
+  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s, i == 0, i == iters - 1);
   const int ec = (int)hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   CHK(ec);
@@ -345,7 +323,7 @@ static int enc_layer(const lemo_fit_desc& d, int l, bool bwd, const float* src, 
 
 // compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
 // a run of iterations the previous iteration's tail launch has already produced it from the updated latent
-static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true, FitEngine* e = nullptr) {
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   // VPoser MLP (3 MFMA GEMMs); its rotation head and the 6-D -> axis-angle conversion of the global
@@ -360,9 +338,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   in.betas = d.shape; in.betas_stride = 10;
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   in.nonfinite = d.nonfinite;
-  CHK(side_join(e, s));                     // the previous iteration's all-vertex forward still reads the pose workspace
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
-  if (e && d.side_forward && (finalize || !e->fork_late)) CHK(side_fork(e, s));
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
     CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
@@ -385,7 +361,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
 
 // update = false: gradients only (lemo_fit_backward).  update = true: the tail launch also runs Adam and, with next_h1,
 // the first VPoser layer of the next iteration.
-static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false, FitEngine* e = nullptr) {
+static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
@@ -399,7 +375,6 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
   }
 vertex_stage:
-  if (e && d.side_forward && e->fork_late && !e->pending) CHK(side_fork(e, s));
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
     // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two
     const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B, d.per_frame ? 1 : B}, d.loss_acc, cnt, d.losses};
@@ -420,11 +395,9 @@ vertex_stage:
 }
 
 // first / last: position inside the run of iterations issued together (one graph, or one eager call)
-static int fit_iteration(FitEngine* e, hipStream_t s, bool first, bool last) {
-  const lemo_fit_desc& d = e->d;
-  CHK(fit_forward(d, s, false, first, e));
-  CHK(fit_backward(d, s, true, !last, e));
-  if (last) CHK(side_join(e, s));            // a call / a captured graph ends joined
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last) {
+  CHK(fit_forward(d, s, false, first));
+  CHK(fit_backward(d, s, true, !last));
   return 0;
 }
 
@@ -439,13 +412,6 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
     // and the host thread is what limits several clips in lockstep (tools/perframe_concurrent.py)
     if (d->per_frame) e->head = 0;
     if (const char* h = getenv("LEMO_FIT_HEAD")) e->head = atoi(h);       // diagnostics: A/B of the replay schedule
-    if (d->side_forward) {
-      if (d->full_vertices || !d->verts_full || !d->v_posed_full) { delete e; return nullptr; }
-      if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) { delete e; return nullptr; }
-      if (const char* f = getenv("LEMO_SIDE_FORK")) e->fork_late = atoi(f);
-    }
   }
   return e;
 }
@@ -454,23 +420,19 @@ void lemo_fit_destroy(void* h) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return;
   for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 
 int lemo_fit_forward(void* h, void* stream) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return LEMO_ERR_ARG;
-  CHK(fit_forward(e->d, S(stream), true, true, e));
-  return side_join(e, S(stream));            // a bare forward returns with the all-vertex result ordered on the caller's stream
+  return fit_forward(e->d, S(stream), true);
 }
 
 int lemo_fit_backward(void* h, void* stream) {       // after lemo_fit_forward: gradients only, no Adam
   FitEngine* e = (FitEngine*)h;
   if (!e) return LEMO_ERR_ARG;
-  return fit_backward(e->d, S(stream), false, false, nullptr);
+  return fit_backward(e->d, S(stream));
 }
 
 int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
@@ -478,7 +440,7 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
   if (!e || n < 0) return LEMO_ERR_ARG;
   hipStream_t s = S(stream);
   if (!use_graph) {
-    for (int i = 0; i < n; ++i) CHK(fit_iteration(e, s, i == 0, i == n - 1));
+    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s, i == 0, i == n - 1));
     return 0;
   }
   CHK(fit_graphs(e, s, n, false));

@@ -38,16 +38,12 @@ class AmassTemporalFitter(_hip.StreamOrdered):
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
                  lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None,
                  lbs_blend_fp32: bool = False, per_frame: bool = False, lr2: float = 0.0, lr_switch2: int = 0,
-                 lib: Optional[_hip.HipLib] = None, side_forward: bool = False):
+                 lib: Optional[_hip.HipLib] = None):
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
         if not self.lib.is_emu and self.device.type != 'cuda':
             raise _hip.LemoHipError('AmassTemporalFitter needs a HIP device (no CPU fallback)')
-        # side_forward (round-3 experiment): all 10475 vertices are still forwarded every iteration, but on a parallel
-        # branch -- the losses run on the forward of the loss-carrying vertices (identical losses and gradients) and the
-        # all-vertex launch overlaps whatever the device has idle; `vertices()` returns the all-vertex result
-        self.side_forward = bool(side_forward) and bool(full_vertices)
-        self.B, self.full = int(B), bool(full_vertices) and not self.side_forward
+        self.B, self.full = int(B), bool(full_vertices)
         data = body if isinstance(body, BodyModelData) else BodyModelData(load_model_dict(body), num_pca_comps=num_pca_comps)
         assert data.ncomp == 12, 'the AMASS parameter vector carries 12 PCA coefficients per hand'
         self.data = data
@@ -153,9 +149,6 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         self.nonfinite = torch.zeros(2, dtype=torch.int32, device=dev)   # first iteration with a NaN / Inf total loss
         d.snap, d.nonfinite = ptr(self.snap), ptr(self.nonfinite)
         d.per_frame, d.lr2, d.lr_switch2 = int(self.per_frame), float(lr2), int(lr_switch2)
-        if self.side_forward:
-            self.ws['verts_full'], self.ws['v_posed_full'] = z(B, data.V, 3), z(B, data.V, 3)
-            d.side_forward, d.verts_full, d.v_posed_full = 1, ptr(self.ws['verts_full']), ptr(self.ws['v_posed_full'])
         self._stepped = False
         for l in range(1, 11): d.act[l] = ptr(self.act[l])
         d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
@@ -307,7 +300,7 @@ class AmassTemporalFitter(_hip.StreamOrdered):
 
     def vertices(self) -> torch.Tensor:
         self._before_read()
-        return self.ws['verts_full'] if self.side_forward else self.ws['verts']
+        return self.ws['verts']
 
     def marker_vertices(self) -> torch.Tensor:
         """the 67 marker vertices of the last forward, [B,67,3] (whatever the vertex layout of the loss path is)"""

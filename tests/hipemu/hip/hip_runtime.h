@@ -76,16 +76,6 @@ static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-// streams / events: launches execute synchronously in program order here, so forks and joins are no-ops
-typedef void* hipEvent_t;
-#define hipStreamNonBlocking 1
-#define hipEventDisableTiming 2
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)1; return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }

@@ -52,7 +52,7 @@ def test_descriptor_layouts_match_the_header():
     import subprocess
     import tempfile
     from lemo_amd import _hip
-    fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame', 'side_forward', 'v_posed_full']),
+    fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame']),
               'lemo_prox_desc': (_hip.ProxDesc, ['enc_w3_inv', 'sdf', 'pose_embedding', 'losses'])}
     src = '#include <cstdio>\n#include <cstddef>\n#include "lemo_hip.h"\nint main(){\n'
     for name, (_, fl) in fields.items():

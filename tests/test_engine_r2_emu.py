@@ -225,32 +225,3 @@ def test_batched_perframe_fit_is_bit_identical_to_solo(emu_lib):
     got = bf.fit_clips(clips, betas, steps=7, use_graph=False)
     for a, b in zip(solo, got):
         assert a.shape == b.shape and torch.equal(a, b)
-
-
-def test_side_forward_engine_equals_full_engine(emu_lib):
-    """lemo_fit_desc.side_forward: the all-vertex forward on the engine's side stream + the losses on the forward of the
-    loss-carrying vertices vs the all-vertex engine: the SAME vertices bit for bit (same kernel, same pose), losses /
-    gradients / parameters equal up to the rounding of the two blend paths (the small-set forward is an fp32 FMA chain, the
-    all-vertex one the split MFMA GEMM -- like full_vertices=False, tests/test_gpu_parity.py::test_active_vertex_forward_is_identical)"""
-    import __graft_entry__ as ge
-    from lemo_amd.fitting import AmassTemporalFitter
-    prob = ge.small_problem()
-    _, markers = ge.oracle_for(prob)
-    res = []
-    for side in (False, True):
-        fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], prob['B'], 'cpu',
-                                  full_vertices=True, side_forward=side, lib=emu_lib)
-        assert fit.side_forward == side
-        fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
-        fit.forward(); fit.backward()
-        L, g, v, mv = fit.losses(), {k: t.clone() for k, t in fit.grads().items()}, fit.vertices().clone(), fit.marker_vertices().clone()
-        fit.step(3, use_graph=False)
-        res.append((L, g, v, mv, fit.params75().clone(), fit.vertices().clone()))
-    (La, ga, va, ma, pa, v3a), (Lb, gb, vb, mb, pb, v3b) = res
-    for k in La:
-        assert abs(La[k] - Lb[k]) <= 1e-6 * abs(La[k]) + 1e-12, k
-    for k in ga:
-        assert float((ga[k] - gb[k]).abs().max()) <= 5e-5 * float(ga[k].abs().max()), k
-    assert float((pa - pb).abs().max()) < 1e-4
-    assert va.shape == vb.shape == (prob['B'], prob['V'], 3) and torch.equal(va, vb)          # iteration 0: same pose, same kernel
-    assert float((ma - mb).abs().max()) <= 1e-6 * float(ma.abs().max()) and float((v3a - v3b).abs().max()) < 1e-4
