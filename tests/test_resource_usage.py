@@ -14,8 +14,10 @@ HIPCC = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
 
 # kernel-name fragment -> (file, max VGPRs, threads per block that budget comes from)
 BUDGETS = {
-    'conv3x3_split_kernelILi0ELi64ELi64ELb0E': ('conv_split_kernels.hip', 256, 512),   # one 8-wave block per CU: 2 waves per SIMD, 512 / 2 registers
-    'conv3x3_split_kernelILi1ELi64ELi64ELb0E': ('conv_split_kernels.hip', 256, 512),
+    'conv3x3_split_kernelILi0ELi64ELi64ELi2ELb0E': ('conv_split_kernels.hip', 256, 512),   # one 8-wave block per CU: 2 waves per SIMD, 512 / 2 registers
+    'conv3x3_split_kernelILi1ELi64ELi64ELi2ELb0E': ('conv_split_kernels.hip', 256, 512),   # (NP = 2: split-f16, the default)
+    'conv3x3_split_kernelILi0ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),   # (NP = 3: split-bf16)
+    'conv3x3_split_kernelILi1ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),
@@ -27,7 +29,8 @@ BUDGETS = {
 
 
 def _usage(fname):
-    out = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
+    out = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-fno-vectorize',    # the Makefile's flags
+                          '-I' + os.path.join(ROOT, 'include'),
                           '-Wno-unused-function', '-Rpass-analysis=kernel-resource-usage', '-c', fname, '-o', os.devnull],
                          cwd=CSRC, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -49,10 +52,14 @@ def test_hot_kernels_fit_their_register_budget_without_scratch():
     files = sorted({f for f, _, _ in BUDGETS.values()})
     with ThreadPoolExecutor(len(files)) as ex:
         usage = dict(zip(files, ex.map(_usage, files)))
+    # lbs_bwd_frame<staged, fused> (1024 threads: 128 registers is the hard limit) keeps 4 values in scratch since the library is
+    # built without the SLP vectoriser (packed fp32 held pairs in fewer live ranges; DESIGN 9.3 says why it is off): 4 stores + 4
+    # reloads per thread outside any loop, 10.4 -> 10.7 us for the launch.  Everything else stays at zero.
+    SCRATCH_OK = {'lbs_bwd_frame_kernelILb1ELb1E': 32}
     for frag, (fname, max_vgpr, _) in BUDGETS.items():
         hits = {k: v for k, v in usage[fname].items() if frag in k}
         assert hits, (frag, sorted(usage[fname])[:5])
         for name, u in hits.items():
-            assert u.get('ScratchSize [bytes/lane]', 0) == 0 and u.get('VGPRs Spill', 0) == 0, (name, u)
+            assert u.get('ScratchSize [bytes/lane]', 0) <= SCRATCH_OK.get(frag, 0) and u.get('VGPRs Spill', 0) <= SCRATCH_OK.get(frag, 0) // 4, (name, u)
             assert u['VGPRs'] <= max_vgpr, (name, u)
             assert u.get('LDS Size [bytes/block]', 0) <= 160 * 1024, (name, u)
