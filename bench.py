@@ -622,6 +622,15 @@ def main():
                                          '/ 14: the in-iteration duration incl. the kernel boundary, comparable with the rocprofv3 '
                                          'average of the same kernel in profiles/ (kernel stats of this round)',
                      'kernel_ms_back_to_back': b2b_ms,
+                     'memory_view': {
+                         'algorithmic_bytes_per_launch': 17.1e6, 'achieved_TBps': 17.1e6 / (kern_ms * 1e-3) / 1e12,
+                         'frac_of_hbm_peak': 17.1e6 / (kern_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         'copy_layer_floor_ms': 0.00507,
+                         'frac_of_copy_layer_floor': 0.00507 / kern_ms,
+                         'note': 'since round 3 the layer is bound by data movement + launch boundary, not by the matrix pipe (DESIGN 9.2): '
+                                 'a kernel of the same launch geometry that only reads the 8.4 MB the previous launch wrote and writes 8.4 MB '
+                                 'takes 5.07 us in a dependent chain (tools/ubench/boundary_ubench.hip, profiles/r03_boundary_ubench.txt); '
+                                 'frac_of_copy_layer_floor = that floor / kernel_ms'},
                      'frac_back_to_back': kern_flops / (b2b_ms * 1e-3) / 1e12 / peak,
                      'traffic_source': 'committed PMC file ' + PMC_FILE + ' (counters cannot be read from inside the process)'},
     }

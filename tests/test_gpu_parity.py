@@ -557,8 +557,20 @@ def test_prox_full_size_window_runs(dev):
     # entries now and then: one of six full-suite runs of round 2 tripped the former max < 5e-3 bound.  Bounds: the mean, and
     # the drift two Adam trajectories can build up in 8 steps of lr 0.005 (they may move in opposite directions).  The NATIVE engine is deterministic and checked bit for bit, tests/test_gpu_r2.py.)
     dpe = (fit_g.pose_embedding.detach() - fit_e.pose_embedding.detach()).abs()
-    assert float(dpe.mean()) < 2e-3 and float(dpe.max()) <= 2 * 8 * 0.005 * 1.25
-    assert abs(float(lg['total_loss']) - float(le['total_loss'])) < 1e-2 * abs(float(le['total_loss']))
+    # against the spread of TWO EAGER runs (the former max bound, 0.1, was vacuous): the graph run may not be further
+    # from an eager run than 3x what a second eager run is, in the mean and in the 99 % quantile; a capture bug in a few frames
+    # (3200 entries, 32 per frame) shows in the quantile long before it shows in the mean
+    fit_e2, _ = ge.prox_fitter_for(prob, dev, first_batch_flag=False)
+    le2 = fit_e2.step(8, use_graph=False)
+    torch.cuda.synchronize()
+    dee = (fit_e2.pose_embedding.detach() - fit_e.pose_embedding.detach()).abs()
+    q = lambda t: float(torch.quantile(t.flatten().float(), 0.99))
+    print(f'module path, 8 steps: |graph - eager| mean {float(dpe.mean()):.2e} q99 {q(dpe):.2e} max {float(dpe.max()):.2e}; '
+          f'|eager - eager| mean {float(dee.mean()):.2e} q99 {q(dee):.2e} max {float(dee.max()):.2e}')
+    assert float(dpe.mean()) <= 3 * float(dee.mean()) + 2e-5 and q(dpe) <= 3 * q(dee) + 2e-4
+    assert float(dpe.max()) <= 2 * 8 * 0.005 * 1.25              # (what two Adam trajectories can drift apart at all)
+    spread = abs(float(le2['total_loss']) - float(le['total_loss']))
+    assert abs(float(lg['total_loss']) - float(le['total_loss'])) <= 3 * spread + 1e-3 * abs(float(le['total_loss']))
     n = 103
     torch.cuda.synchronize()
     t0 = time.time()
