@@ -30,7 +30,7 @@ EXTRA_JOINT_VERTEX_IDS = [9120, 9929, 9448, 616, 6, 5770, 5780, 8846, 8463, 8474
                           5361, 4933, 5058, 5169, 5286, 8079, 7669, 7794, 7905, 8022]
 K_PAD = 512          # blend-shape GEMM depth: 20 shape/expression + 486 pose features, padded
 DENSE_CHUNK = 512    # LBS_DENSE_CHUNK of lbs_kernels.hip
-GEMM_SLABS = 96      # K slabs of the all-vertex feature-gradient GEMM (gemm_nt16_splitk): 768 workgroups
+GEMM_SLABS = int(os.environ.get('LEMO_GEMM_SLABS', '64'))      # K slabs of the all-vertex feature-gradient GEMM (gemm_nt16_splitk): x 4 M-blocks of 128 rows = 256 workgroups (round 3; 96 x 8 before)
 
 
 def _roundup(x, m):

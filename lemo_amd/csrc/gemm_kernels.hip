@@ -105,6 +105,7 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
 __global__ void __launch_bounds__(256)
 gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
                         float* __restrict__ part) {
+  constexpr int NTHR = 256, NSLOT = 2;                          // (same staging roles as the bf16 kernel with MW = 2)
   __shared__ __attribute__((aligned(16))) float Bs[2][4][GEMM_SK_NT * 16][4];      // [buffer][k quarter][frame][4 k]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -116,11 +117,11 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
   const int nst = c1 - c0;
   const float* ap = Am + (size_t)(mt * 16 + i) * lda + 4 * q;
   // staging role of this thread: float4 idx = tid + 256 r -> frame idx >> 2, k quarter idx & 3
-  const float* bsrc[2];
-  int bdst[2];
+  const float* bsrc[NSLOT];
+  int bdst[NSLOT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int idx = tid + 256 * r, n = idx >> 2, kq = idx & 3;
+  for (int r = 0; r < NSLOT; ++r) {
+    const int idx = tid + NTHR * r, n = idx >> 2, kq = idx & 3;
     bsrc[r] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * kq;
     bdst[r] = (kq * (GEMM_SK_NT * 16) + n) * 4;
   }
@@ -133,13 +134,13 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
 #pragma unroll
     for (int u = 0; u < 3; ++u) a[u] = ld4(ap + (size_t)clampc(c0 + u) * 16);
     {                                                          // step 0 straight into LDS buffer 0, steps 1 and 2 into registers
-      float4 b0[2];
+      float4 b0[NSLOT];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
+      for (int r = 0; r < NSLOT; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
+        for (int r = 0; r < NSLOT; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
 #pragma unroll
       for (int r = 0; r < 2; ++r) st4(&Bs[0][0][0][0] + bdst[r], b0[r]);
     }
@@ -180,28 +181,35 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
 // 157 TFLOP/s = 26 us) was above its HBM floor (64 MB of A: ~12 us).  Wave = one 32-row M-tile x two 32-frame N-tiles; A fragments
 // (8 consecutive k of one row per lane) straight from global memory three steps ahead and split in registers, the B tile of a
 // step split ONCE per workgroup on its way into LDS ([piece][k half][frame][8 bf16]: every fragment one conflict-free b128).
-__global__ void __launch_bounds__(256)
+// MW = 32-row M-tiles per workgroup (round 3).  The workgroup stages the B tile of a step (128 frames x 16 k = 8 KB) once and
+// every M-tile wave pair consumes it: with MW = 2 (64 rows, rounds 1-2) the eight M-blocks of the PROX GEMM (M = 512) each
+// re-read all of dvp -- 8 x 12.6 MB against 64 MB of A -- and a workgroup pulled 16 KB per step into its CU for 64 rows; a CU
+// takes in cold data at ~10 B/clk whatever is asked of it, so the launch lasted 42 us for a 12 us HBM floor.
+// MW = 4: 128 rows per workgroup, 8 waves, dvp read 4 times, half the partial slabs for the same number of workgroups.
+template <int MW>
+__global__ void __launch_bounds__(128 * MW)
 gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
                              float* __restrict__ part, int a_grouped) {
+  constexpr int NTHR = 128 * MW, NSLOT = 512 / NTHR;             // staging slots per thread: 512 float4 per step
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][2][GEMM_SK_NT * 16][16];   // [buffer][piece][k half][frame][8 bf16]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int mblocks = M >> 6;
+  const int mblocks = M / (32 * MW);
   const int mb = blockIdx.x % mblocks, slab = blockIdx.x / mblocks;
-  const int mtile = wave & 1, npair = wave >> 1;                 // rows mb*64 + mtile*32 .. +31 ; frames npair*64 .. +63
+  const int mtile = wave % MW, npair = wave / MW;                // rows mb*32*MW + mtile*32 .. +31 ; frames npair*64 .. +63
   const int k16 = K >> 4, per = (k16 + S - 1) / S;
   const int c0 = slab * per, c1 = (c0 + per < k16) ? c0 + per : k16;
   const int nst = c1 - c0;
   // A element (row, k): row-major [M][lda], or k-chunk major [K/16][M][16] (a_grouped: a step's 64 x 16 tile is contiguous)
-  const int arow = mb * 64 + mtile * 32 + j;
+  const int arow = mb * (32 * MW) + mtile * 32 + j;
   const float* ap = a_grouped ? Am + (size_t)arow * 16 + 8 * h : Am + (size_t)arow * lda + 8 * h;
   const size_t astep = a_grouped ? (size_t)M * 16 : 16;
   // staging role: float4 idx = tid + 256 r -> frame idx >> 2, k quarter idx & 3 (4 k each)
-  const float* bsrc[2];
-  int bdst[2];
+  const float* bsrc[NSLOT];
+  int bdst[NSLOT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int idx = tid + 256 * r, n = idx >> 2, kq = idx & 3;
+  for (int r = 0; r < NSLOT; ++r) {
+    const int idx = tid + NTHR * r, n = idx >> 2, kq = idx & 3;
     bsrc[r] = Bm + (size_t)(n < N ? n : N - 1) * ldb + 4 * kq;
     bdst[r] = (((kq >> 1) * (GEMM_SK_NT * 16) + n) * 16) + (kq & 1) * 8;       // + piece * (2 * 128 * 16)
   }
@@ -214,24 +222,24 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   if (nst > 0) {
     auto clampc = [&](int c) { return c < c1 ? c : c1 - 1; };
-    float4 a[3][2], bg[2][2];                                  // A of steps s, s+1, s+2 ; B (global) of steps s+1, s+2
+    float4 a[3][2], bg[2][NSLOT];                              // A of steps s, s+1, s+2 ; B (global) of steps s+1, s+2
 #pragma unroll
     for (int u = 0; u < 3; ++u) { a[u][0] = ld4(ap + (size_t)clampc(c0 + u) * astep); a[u][1] = ld4(ap + (size_t)clampc(c0 + u) * astep + 4); }
 #define SK_STORE_B(BUFI, V)                                                                          \
-    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                                                \
+    _Pragma("unroll") for (int r = 0; r < NSLOT; ++r) {                                            \
       uint2 p0, p1, p2;                                                                            \
       split3x4(V[r], p0, p1, p2);                                                                  \
       unsigned char* d = bs + (BUFI) * BUF + bdst[r];                                              \
       *reinterpret_cast<uint2*>(d) = p0; *reinterpret_cast<uint2*>(d + PIECE) = p1; *reinterpret_cast<uint2*>(d + 2 * PIECE) = p2; \
     }
     {
-      float4 b0[2];
+      float4 b0[NSLOT];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
+      for (int r = 0; r < NSLOT; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
+        for (int r = 0; r < NSLOT; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
       SK_STORE_B(0, b0)
     }
     __syncthreads();
@@ -254,7 +262,7 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
       // publish step s+1 (held in registers since two steps ago) to the other buffer, refill the registers with step s+3
       if (s_ + 1 < nst) { SK_STORE_B(buf ^ 1, bg[0]) }
 #pragma unroll
-      for (int r = 0; r < 2; ++r) { bg[0][r] = bg[1][r]; bg[1][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + 3) * 16); }
+      for (int r = 0; r < NSLOT; ++r) { bg[0][r] = bg[1][r]; bg[1][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + 3) * 16); }
       a[0][0] = a[1][0]; a[0][1] = a[1][1]; a[1][0] = a[2][0]; a[1][1] = a[2][1];
       a[2][0] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep); a[2][1] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep + 4);
 #define SK_MFMA1(SA, SB)                                                                             \
@@ -272,39 +280,55 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq)
-      st4(pp + (size_t)(npair * 64 + t * 32 + j) * M + mb * 64 + mtile * 32 + 8 * rq + 4 * h,
-          make_float4(acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]));
+      if (npair * 64 + t * 32 + j < N)                       // frames past N are padding: nobody reads their partials
+        st4(pp + (size_t)(npair * 64 + t * 32 + j) * M + mb * (32 * MW) + mtile * 32 + 8 * rq + 4 * h,
+            make_float4(acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]));
 }
+// C = sum over the S slab partials, in a FIXED order (deterministic).  32 outputs (float4) x 8 slab groups per workgroup: group g adds
+// slabs g, g + 8, ... in order with eight loads in flight, the eight group sums are added in group order through LDS.  (Rounds 1-2:
+// one thread per output walking all S slabs -- 50 workgroups reading 25 MB: 11.7 us.)
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ part, int M, int N, int S, float* __restrict__ C, int ldc) {
-  const int i = blockIdx.x * 256 + threadIdx.x;           // float4 index over [N][M / 4]
-  const int m4 = M >> 2;
-  if (i >= N * m4) return;
-  const int n = i / m4, mq = i - n * m4;
+  __shared__ float4 red[8][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;                       // float4 index over [N][M / 4]
+  const int m4 = M >> 2, tot = N * m4;
+  const int ic = i < tot ? i : tot - 1;
+  const int n = ic / m4, mq = ic - n * m4;
   const size_t stride = (size_t)(GEMM_SK_NT * 16) * M;
   const float* p = part + (size_t)n * M + mq * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s0 = 0; s0 < S; s0 += 8) {                      // 8 loads in flight, added in slab order
+  for (int s0 = g; s0 < S; s0 += 64) {                     // slabs g, g + 8, ..., eight in flight
     float4 r[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = ld4(p + (size_t)(s0 + u < S ? s0 + u : S - 1) * stride);
+    for (int u = 0; u < 8; ++u) r[u] = ld4(p + (size_t)(s0 + 8 * u < S ? s0 + 8 * u : g) * stride);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) if (s0 + u < S) { v.x += r[u].x; v.y += r[u].y; v.z += r[u].z; v.w += r[u].w; }
+    for (int u = 0; u < 8; ++u) if (s0 + 8 * u < S) { v.x += r[u].x; v.y += r[u].y; v.z += r[u].z; v.w += r[u].w; }
   }
-  st4(C + (size_t)n * ldc + mq * 4, v);
+  red[g][o] = v;
+  __syncthreads();
+  if (g == 0 && i < tot) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { const float4 w = red[k][o]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    st4(C + (size_t)n * ldc + mq * 4, v);
+  }
 }
 
 int gemm_nt16_splitk_part_floats(int M, int S) { return S * GEMM_SK_NT * 16 * M; }
 
 int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
                      hipStream_t s, const float* A_grouped) {
-  if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || (ldc & 3) || S < 1 || !part)
+  if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || (ldc & 3) || S < 1 || S > (K >> 4) || !part)
     return LEMO_ERR_SHAPE;
   static const bool fp32_mfma = getenv("LEMO_SPLITK_FP32") != nullptr;       // A/B switch (diagnostics): v3, the fp32-MFMA kernel
   if (fp32_mfma) hipLaunchKernelGGL(gemm_nt16_splitk_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part);
-  else if (A_grouped) hipLaunchKernelGGL(gemm_nt16_splitk_bf16_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A_grouped, lda, B, ldb, M, N, K, S, part, 1);
-  else hipLaunchKernelGGL(gemm_nt16_splitk_bf16_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part, 0);
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((N * (M >> 2) + 255) / 256), dim3(256), 0, s, part, M, N, S, C, ldc);
+  else if ((M & 127) == 0) {                                 // 128 rows per workgroup (M % 128 == 0: the PROX feature-gradient GEMM)
+    if (A_grouped) hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<4>), dim3((M >> 7) * S), dim3(512), 0, s, A_grouped, lda, B, ldb, M, N, K, S, part, 1);
+    else hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<4>), dim3((M >> 7) * S), dim3(512), 0, s, A, lda, B, ldb, M, N, K, S, part, 0);
+  }
+  else if (A_grouped) hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<2>), dim3((M >> 6) * S), dim3(256), 0, s, A_grouped, lda, B, ldb, M, N, K, S, part, 1);
+  else hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<2>), dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part, 0);
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((N * (M >> 2) + 31) / 32), dim3(256), 0, s, part, M, N, S, C, ldc);
   return (int)hipGetLastError();
 }
 

@@ -495,7 +495,12 @@ def test_splitk_gemm_matches_float64(emu_lib, grouped):
     from lemo_amd._hip import ptr
     lib = emu_lib
     g = torch.Generator().manual_seed(5)
-    M, N, K, S = 128, 37, 16 * 41, 6
+    for M, N, K, S in ((128, 37, 16 * 41, 6), (192, 100, 16 * 23, 11), (512, 7, 16 * 67, 64)):
+        _splitk_case(lib, g, M, N, K, S, grouped)          # 128-row workgroups (M % 128 == 0) and the 64-row form; S > 8 * 8: several reduce rounds
+
+
+def _splitk_case(lib, g, M, N, K, S, grouped):
+    from lemo_amd._hip import ptr
     A = torch.randn(M, K, generator=g)
     B = torch.randn(N, K, generator=g) * 0.5
     ref = (B.double() @ A.double().t())                                            # C[n][m]
