@@ -253,6 +253,40 @@ int lemo_adam_flat(float* p, const float* g, float* m, float* v, int n, float lr
  * captured graph of a whole training step can be replayed */
 int lemo_adam_flat_ctr(float* p, const float* g, float* m, float* v, int n, float lr, int* step_ctr, void* stream);
 
+/* ---- native training-step engine of the infilling autoencoder (lemo_amd/csrc/ae_engine.hip) ------------------------
+ * Replaces, for one clip, the block opt_amass_temp.py:160-214 (= temp_prox/fitting_temp_slide.py:861-893): "reload the
+ * pretrained AE, optimizer = Adam(lr 3e-6), 60 x [rec = AE(x); loss = sum(|rec - x| * mask) / count; backward; step],
+ * eval forward".  One step is 53 launches (20 + 19 convolutions with fused epilogues, pooling, ONE launch for all 20 weight
+ * gradients, ONE for slab reduction + Adam + re-packing), captured into 5-step and 1-step graphs on first use.
+ *   ws / ws_floats: caller-owned ZEROED device workspace of lemo_ae_ws_floats(H, W) floats, alive as long as the engine;
+ *   H x W: the clip image [1,4,H,W] (H = 3 * markers + contacts + 2 pads, W = frames + 16), H, W >= 2, H * W <= 2^22.
+ * lemo_ae_load: `flat` = the model's 40 tensors back to back in state_dict order per layer (weight, bias; enc_blc1.main.0,
+ *   enc_blc1.main.2, ..., dec_blc5.deconv2; each in its own layout: Conv2d [out][in][3][3], ConvTranspose2d [in][out][3][3]),
+ *   lemo_ae_n_param() floats; x = clip image [4][H][W]; moc = train mask / count, [H][W] (d loss / d rec = sign(rec - x) * moc).
+ *   Resets the optimizer state (a fresh Adam per clip, as the reference builds one).
+ * lemo_ae_step: n training steps on `stream` (use_graph: replay captured steps; same kernels, same results).
+ * lemo_ae_forward: eval forward with the current parameters -> rec [H][W], z [256][h5][w5] (may be NULL; h5, w5 = five times
+ *   (n - 1) / 2 + 1).   lemo_ae_params: the current parameters in `flat` order. */
+typedef struct lemo_ae_desc {
+  int H, W;
+  float lr;
+  float* ws;
+  long long ws_floats;
+} lemo_ae_desc;
+long long lemo_ae_ws_floats(int H, int W);
+int lemo_ae_n_param(void);
+void* lemo_ae_create(const lemo_ae_desc* d);
+void lemo_ae_destroy(void* h);
+int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream);
+int lemo_ae_step(void* h, int n, int use_graph, void* stream);
+int lemo_ae_forward(void* h, float* rec, float* z, void* stream);
+int lemo_ae_params(void* h, float* flat_out, void* stream);
+/* one convolution of the engine on its own (tests, tools).  Enumerates an H x W pixel grid; in_s = 2: the input (and the
+ * epi-1 operand) is a fineH x fineW image read at its even pixels; out_s = 2: the output is written to the even pixels of a
+ * fineH x fineW image (zero-stuffing geometry).  mt / nw = 0: the engine's own launch shape. */
+int lemo_ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
+                 int in_s, int out_s, int cin, int cout, int epi, int mt, int nw, void* stream);
+
 /* ---- stream capture helpers: record everything a host-side step enqueues on `stream` (HIP kernels of this library
  * and the caller's own device work alike) into an executable graph, replay it with one call.  Relaxed capture mode;
  * the caller guarantees that the step does not synchronise and that every buffer it touches outlives the replays. */

@@ -62,6 +62,11 @@ class WgradJob(C.Structure):
                 ('cin_real', C.c_int), ('cout_real', C.c_int), ('H', C.c_int), ('W', C.c_int)]
 
 
+class AeDesc(C.Structure):
+    """lemo_ae_desc"""
+    _fields_ = [('H', C.c_int), ('W', C.c_int), ('lr', C.c_float), ('ws', vp), ('ws_floats', C.c_longlong)]
+
+
 class SkinConst(C.Structure):
     _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int), ('blend_fp32', C.c_int)] + \
         [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val')]
@@ -205,6 +210,15 @@ _SIGS = {
     'lemo_conv3x3_wgrad_reduce_multi': (C.c_int, [C.POINTER(WgradJob), C.c_int, vp]),
     'lemo_adam_flat': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, C.c_int, vp]),
     'lemo_adam_flat_ctr': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_float, vp, vp]),
+    'lemo_ae_ws_floats': (C.c_longlong, [C.c_int, C.c_int]),
+    'lemo_ae_n_param': (C.c_int, []),
+    'lemo_ae_create': (vp, [C.POINTER(AeDesc)]),
+    'lemo_ae_destroy': (None, [vp]),
+    'lemo_ae_load': (C.c_int, [vp, vp, vp, vp, vp]),
+    'lemo_ae_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
+    'lemo_ae_forward': (C.c_int, [vp, vp, vp, vp]),
+    'lemo_ae_params': (C.c_int, [vp, vp, vp]),
+    'lemo_ae_conv': (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 11 + [vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
     'lemo_fit_destroy': (None, [vp]),

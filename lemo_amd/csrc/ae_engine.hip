@@ -1,0 +1,744 @@
+// Native training-step engine of the motion-infilling autoencoder (models/AE.py:11-108) for its per-clip self-supervised
+// finetune (opt_amass_temp.py:154-214, temp_prox/fitting_temp_slide.py:861-893: 60 x [forward, L1 on the unmasked rows,
+// backward, Adam lr 3e-6] + one eval forward at [1,4,210,135]).
+//
+// Why an engine: the step is 20 convolutions of 126 .. 28350 pixels with 32 .. 256 channels -- 17 GFLOP, ~0.1 ms of fp32
+// MFMA time -- so its cost is the NUMBER of dependent launches and what each leaves idle.  Round 2 ran it as ~150 launches
+// (autograd function + packing gathers, 1.3 ms); here one step is 53:
+//   * one convolution kernel for every layer and direction: the workgroup's 4 .. 16 waves split K = 9 Cin between them and
+//     reduce through LDS in wave order (no split-K partials in HBM, no combine launch), epilogue fused; the kernel takes
+//     separate input / output / epilogue-operand geometries, so that a decoder block's output is written straight into the
+//     zero-stuffed input of the next block's stride-2 transposed convolution, and the adjoint of the stuffing (gather of the
+//     even pixels, times lrelu') is the epilogue of a backward convolution that only enumerates those pixels;
+//   * the 20 weight gradients need d(pre-activation) of every layer and nothing else: they run after the backward-data
+//     chain as ONE launch over all layers' (slab, tap, tile) work items (the chip is full; 20 launches of 126..576
+//     workgroups each were not), writing slab partials in the layout of the parameter vector;
+//   * parameters, Adam moments and gradients live in the kernels' packed forward layout (Adam is elementwise: the order
+//     is free), so the optimizer launch sums the slab partials in slab order, updates, and scatters the new value into the
+//     backward pack: no gathers between "the model's tensors" and "the kernels' operands" inside the loop;
+//   * loss gradient sign(rec - x) * mask / count in closed form (one launch, which also advances Adam's step counter and
+//     bias corrections on the device so that a captured step can be replayed).
+// Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), every sum in a fixed order -> results do not depend on concurrency.
+#include "conv_common.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#define CHK_(e) do { int _e = (e); if (_e) return _e; } while (0)
+
+namespace lemo {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// convolution, K split over the waves of the workgroup
+// ---------------------------------------------------------------------------------------------------------------------
+// A pixel (y, x) of the H x W grid the launch enumerates sits at padded pixel ((s y + 1) Wp + s x + 1) of a buffer with
+// row pitch Wp and stride s (1: plain CG8P of an H x W image; 2: the even pixels of a twice finer image = zero-stuffing
+// geometry).  Taps always address neighbouring pixels of the INPUT buffer.
+struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; int aux_Wp, aux_HWp, aux_s; };
+
+template <int MT, int EPI>          // MT x 32 couts per workgroup; EPI: conv_common.hpp (0 lrelu(acc + bias), 1 acc * lrelu'(aux), 2 acc + bias)
+__global__ void __launch_bounds__(1024)
+ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout) {
+  LEMO_DYN_SMEM(red);                                          // [wave][MT][4][64 lanes] float4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int P = g.H * g.W;
+  const int m_base = blockIdx.y * (MT * 32);
+  const int p = blockIdx.x * 32 + j;
+  const int pc = p < P ? p : P - 1;
+  const int y = pc / g.W, x = pc - y * g.W;
+  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + 4 * h;
+  const float* wt_l = wt + (size_t)(m_base + j) * 8 + 4 * h;
+  const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
+  const int gm = (1 << cin_lg) - 1, nit = 9 << cin_lg;
+  const int lo = nit * wave / NW, hi = nit * (wave + 1) / NW;    // this wave's (tap, channel group) steps; host: NW <= nit
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  // operands two steps ahead through a 3-deep register ring (a step is 4 MT MFMAs = 256 MT cycles; an L2 round trip is
+  // several of those)
+#define AE_LD(IT, A_, B_)                                                                                   \
+  {                                                                                                         \
+    const int it_ = (IT) < hi ? (IT) : hi - 1;                                                              \
+    const int tap_ = it_ >> cin_lg, g_ = it_ & gm;                                                          \
+    const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
+    B_ = ld4(in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)g_ * in_gstride);                   \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) A_[m_] = ld4(wt_l + (size_t)it_ * wt_itstride + (size_t)m_ * 256); \
+  }
+#define AE_MF(A_, B_)                                                                                       \
+  _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                      \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].x, B_.x, acc[m_], 0, 0, 0);                       \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].y, B_.y, acc[m_], 0, 0, 0);                       \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].z, B_.z, acc[m_], 0, 0, 0);                       \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].w, B_.w, acc[m_], 0, 0, 0);                       \
+  }
+  float4 a0[MT], a1[MT], a2[MT], b0, b1, b2;
+  AE_LD(lo, a0, b0)
+  AE_LD(lo + 1, a1, b1)
+  for (int it = lo; it < hi; it += 3) {
+    AE_LD(it + 2, a2, b2)
+    AE_MF(a0, b0)
+    if (it + 1 < hi) {
+      AE_LD(it + 3, a0, b0)
+      AE_MF(a1, b1)
+    }
+    if (it + 2 < hi) {
+      AE_LD(it + 4, a1, b1)
+      AE_MF(a2, b2)
+    }
+  }
+#undef AE_LD
+#undef AE_MF
+
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      r4[((wave * MT + m) * 4 + q) * 64 + lane] = make_float4(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]);
+  __syncthreads();
+  if (p >= P) return;
+  // unit u -> (cout tile m, row quad q) of this lane's pixel; the block's waves share the 4 MT units
+  for (int u = wave; u < 4 * MT; u += NW) {
+    const int m = u >> 2, q = u & 3;
+    float4 v = r4[(m * 4 + q) * 64 + lane];
+    for (int w = 1; w < NW; ++w) {                               // wave order: deterministic
+      const float4 t = r4[((w * MT + m) * 4 + q) * 64 + lane];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const int c0 = m_base + m * 32 + q * 8 + 4 * h;              // first of 4 consecutive couts
+    const size_t o = ((size_t)(c0 >> 3) * g.out_HWp + (size_t)((g.out_s * y + 1) * g.out_Wp + g.out_s * x + 1)) * 8 + (c0 & 7);
+    if (EPI == 0 || EPI == 2) {
+      const float4 bb = ld4(bias + c0);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+    } else {
+      const size_t oa = ((size_t)(c0 >> 3) * g.aux_HWp + (size_t)((g.aux_s * y + 1) * g.aux_Wp + g.aux_s * x + 1)) * 8 + (c0 & 7);
+      const float4 yy = ld4(aux + oa);
+      v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
+      v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
+    }
+    st4(out + o, v);
+  }
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+static int ae_conv_init() {
+  static int rc = -1;
+  if (rc >= 0) return rc;
+  rc = 0;
+#define OPTIN(MT_, EPI_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ae_conv_kernel<MT_, EPI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); if (e != hipSuccess) rc = (int)e; }
+  OPTIN(1, 0) OPTIN(1, 1) OPTIN(1, 2) OPTIN(2, 0) OPTIN(2, 1) OPTIN(2, 2)
+#undef OPTIN
+  return rc;
+}
+
+// launch shape (MT, NW).  All waves of a SIMD share its MFMA pipe, so the pipe time of a layer does not depend on how its work is
+// cut; what the cut decides is how many waves per SIMD hide each other's load latency and how long one wave's dependent chain
+// is.  Per cout-tile width MT: the largest NW (power of two, <= steps, NW MT <= 16 for 64 KB of LDS) that keeps the launch at
+// <= 4096 waves (4 per SIMD); then the MT with the smaller makespan estimate -- rounds of 1024 waves x steps per wave x MFMAs
+// per step -- ties to the wider tile (fewer activation loads).
+static void ae_conv_shape(int P, int cin, int cout, int* mt_out, int* nw_out) {
+  const int nit = 9 * (cin / 8), ptiles = (P + 31) / 32;
+  long best = -1;
+  for (int mt = 2; mt >= 1; --mt) {
+    if (cout % (32 * mt)) continue;
+    const int tiles = ptiles * (cout / (32 * mt));
+    int nw = 1;
+    while (nw * 2 <= 16 / mt && nw * 2 <= nit && (long)tiles * nw * 2 <= 4096) nw *= 2;
+    const long est = (((long)tiles * nw + 1023) / 1024) * ((nit + nw - 1) / nw) * mt;
+    if (best < 0 || est < best) { best = est; *mt_out = mt; *nw_out = nw; }
+  }
+}
+
+int ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, const AeGeo& g, int cin, int cout,
+            int epi, hipStream_t s, int force_mt = 0, int force_nw = 0) {
+  if (cin % 8 || (cin & (cin - 1)) || cout % 32 || g.H < 1 || g.W < 1 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
+  int mt = 1, nw = 1;
+  ae_conv_shape(g.H * g.W, cin, cout, &mt, &nw);
+  if (force_mt) mt = force_mt;
+  if (force_nw) nw = force_nw;
+  if (cout % (32 * mt) || nw < 1 || nw > 16 || nw * mt > 16 || nw > 9 * (cin / 8)) return LEMO_ERR_ARG;
+  const dim3 grid((g.H * g.W + 31) / 32, cout / (32 * mt));
+  const size_t lds = (size_t)nw * mt * 4096;
+  const int lg = ilog2(cin / 8);
+#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout)
+  if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
+  else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// all weight gradients of a step in one launch
+// ---------------------------------------------------------------------------------------------------------------------
+//   dW[co][ci][tap] = sum_p dY[co][p] X[ci][p + tap]        (X zero-padded: CG8P border)
+// GEMM per tap: M = ci (A = X shifted), N = co (B = dY), K = pixels; one workgroup = one 32 (ci) x 32 (co) tile of one tap
+// over a slab of 512 pixels, its four waves a quarter of the slab each, summed through LDS in wave order.  With ci on the
+// MFMA's row axis a lane holds 4 consecutive ci of one co per accumulator quad: the slab partial is stored with dwordx4
+// stores, 1 KiB contiguous per wave, directly in the forward pack wt[tap][ci/8][co][8] -- the layout of the parameter
+// vector, so the optimizer reads it with unit stride.
+#define AE_SLAB 512
+struct AeWgradJob {
+  const float* dy; const float* x; float* partial; float* db;        // db: [cout] bias gradient (entries >= cout_real untouched)
+  int H, W; unsigned wmagic; int cin, cout, cout_real, nslab, ntile, first_block;
+};
+#define AE_NLAYER 20
+struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int n; };
+
+__global__ void __launch_bounds__(256)
+ae_wgrad_multi_kernel(AeWgradJobs J) {
+  __shared__ float red[3][16][64];
+  int k = 0;
+  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].first_block) ++k;       // block -> layer (uniform)
+  const AeWgradJob& q = J.j[k];
+  const int blk = (int)blockIdx.x - q.first_block;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int W = q.W, Wp = W + 2, HWp = (q.H + 2) * Wp, P = q.H * W;
+  if (blk >= q.ntile) {
+    // bias gradient of one channel: db[co] = sum_p dY[co][p], eight independent loads in flight per thread
+    const int co = blk - q.ntile;
+    const float* base = q.dy + (size_t)(co >> 3) * HWp * 8 + (co & 7);
+    float a = 0.f;
+    for (int p0 = threadIdx.x; p0 < P; p0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = p0 + 256 * u, pc = p < P ? p : P - 1;
+        const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;
+        v[u] = base[(size_t)((y + 1) * Wp + (xx + 1)) * 8];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += (p0 + 256 * u < P) ? v[u] : 0.f;
+    }
+    a = block_sum(a, &red[0][0][0]);
+    if (threadIdx.x == 0) q.db[co] = a;
+    return;
+  }
+  const int i = lane & 31, kk = lane >> 5;
+  const int cin = q.cin, cout = q.cout;
+  const int cot = cout >> 5, cit = (cin + 31) >> 5;
+  int tile = blk;                                                  // (slab, tap, co tile, ci tile)
+  const int ct = tile % cit; tile /= cit;
+  const int mt = tile % cot; tile /= cot;
+  const int tap = tile % 9, slab = tile / 9;
+  const int dyo = tap / 3 - 1, dxo = tap % 3 - 1;
+  const int co = mt * 32 + i;
+  int ci = ct * 32 + i;
+  const bool ci_ok = ci < cin;
+  if (!ci_ok) ci = cin - 1;
+  const float* bp = q.dy + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
+  const float* ap = q.x + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int q0 = slab * AE_SLAB + wave * (AE_SLAB / 4);            // this wave's quarter (empty past the image end)
+  const int p0 = q0 < P ? q0 : P, p1 = (q0 + AE_SLAB / 4 < P) ? q0 + AE_SLAB / 4 : P;
+  // operands of pixels pb+16.. are requested before the 8 MFMAs of pixels pb.. (two register sets)
+  float a[2][8], b[2][8];
+#define WG_LOAD(SET, PB)                                                                           \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
+    const int p = (PB) + 2 * u + kk;                                                               \
+    const bool ok = p < p1;                                                                        \
+    const int pc = ok ? p : p1 - 1;                                                                \
+    const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;   /* p / W, host-made magic */ \
+    const int o = (y + 1) * Wp + (xx + 1);                                                         \
+    const float bv = bp[(size_t)o * 8];                                                            \
+    const float av = ap[(size_t)(o + dyo * Wp + dxo) * 8];                                         \
+    b[SET][u] = ok ? bv : 0.f;                                                                     \
+    a[SET][u] = (ok && ci_ok) ? av : 0.f;                                                          \
+  }
+#define WG_MFMA(SET)                                                                               \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SET][u], b[SET][u], acc, 0, 0, 0);
+  if (p0 < p1) {
+    WG_LOAD(0, p0)
+    for (int pb = p0; pb < p1; pb += 32) {
+      if (pb + 16 < p1) { WG_LOAD(1, pb + 16) }
+      __builtin_amdgcn_sched_barrier(0);
+      WG_MFMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (pb + 16 < p1) {
+        if (pb + 32 < p1) { WG_LOAD(0, pb + 32) }
+        __builtin_amdgcn_sched_barrier(0);
+        WG_MFMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#undef WG_LOAD
+#undef WG_MFMA
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+  // D: col = lane & 31 -> co, rows (r & 3) + 8 (r >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
+  float* outp = q.partial + (size_t)slab * (9 * (size_t)cin * cout);
+  const int CG = cin >> 3;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int cg = ct * 4 + qd;
+    if (cg < CG)
+      st4(outp + (((size_t)tap * CG + cg) * cout + co) * 8 + 4 * kk, make_float4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// optimizer: slab reduction + Adam + backward pack, one launch over the packed parameter vector
+// ---------------------------------------------------------------------------------------------------------------------
+// theta = [weights of layer 0 | ... | weights of layer 19 | biases of layer 0 | ... ], weights in the forward pack
+// wt[tap][cin_pad/8][cout_pad][8] (each a multiple of 256 floats: a block never straddles layers), biases padded to
+// cout_pad.  Padded entries have zero gradient (their operands are zero) and are masked here as well, so they stay zero.
+struct AeAdamLayer { const float* partial; int nslab, w_off, wb_off, cin_lg /*log2(cin_pad/8)*/, cout_lg, cin, cout; };
+struct AeAdamArgs {
+  AeAdamLayer L[AE_NLAYER];
+  float* theta; float* m; float* v; float* wb; const float* dbias; const float* ctr;    // ctr: [1] = bc1, [2] = bc2s (floats)
+  int n_w, n_all; float lr;
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr, float bc1, float bc2s) {
+  const float mi = m + (g - m) * (1.f - 0.9f);                      // torch.optim.Adam defaults (adam_flat_kernel's arithmetic)
+  const float vi = v * 0.999f + (1.f - 0.999f) * g * g;
+  m = mi; v = vi;
+  return p - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + 1e-8f));
+}
+
+__global__ void __launch_bounds__(256)
+ae_adam_kernel(AeAdamArgs A) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= A.n_all) return;
+  const float bc1 = A.ctr[1], bc2s = A.ctr[2];
+  float g;
+  int wb_idx = -1;
+  if (idx < A.n_w) {
+    int k = 0;
+    while (k + 1 < AE_NLAYER && idx >= A.L[k + 1].w_off) ++k;       // uniform per block
+    const AeAdamLayer& q = A.L[k];
+    const int i = idx - q.w_off;
+    const int c8 = i & 7, co = (i >> 3) & ((1 << q.cout_lg) - 1);
+    const int t = i >> (3 + q.cout_lg);
+    const int cg = t & ((1 << q.cin_lg) - 1), tap = t >> q.cin_lg;
+    const int ci = cg * 8 + c8;
+    const int n_w = 9 << (q.cin_lg + 3 + q.cout_lg);
+    float a = 0.f;
+    if (ci < q.cin && co < q.cout)
+      for (int s = 0; s < q.nslab; ++s) a += q.partial[(size_t)s * n_w + i];     // slab order: deterministic
+    g = a;
+    if (q.wb_off >= 0)        // backward-data pack of the same convolution: wtb[8 - tap][co/8][ci][co%8]
+      wb_idx = q.wb_off + ((((8 - tap) << (q.cout_lg - 3)) + (co >> 3)) << (q.cin_lg + 3)) * 8 + ci * 8 + (co & 7);
+  } else {
+    g = A.dbias[idx - A.n_w];
+  }
+  float m = A.m[idx], v = A.v[idx];
+  const float p = adam_update(A.theta[idx], g, m, v, A.lr, bc1, bc2s);
+  A.m[idx] = m; A.v[idx] = v; A.theta[idx] = p;
+  if (wb_idx >= 0) A.wb[wb_idx] = p;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small kernels: loss gradient, (un)packing
+// ---------------------------------------------------------------------------------------------------------------------
+// d(loss)/d(rec) of loss = sum(|rec - x| * mask) / count (opt_amass_temp.py:199-203) = sign(rec - x) * (mask / count), into
+// channel 0 of the last layer's d(pre-activation) (the layer has no activation); thread 0 advances the step counter and
+// the bias corrections Adam reads later in the same step.
+__global__ void __launch_bounds__(256)
+ae_loss_grad_kernel(const float* __restrict__ rec, const float* __restrict__ x8, const float* __restrict__ moc,
+                    float* __restrict__ dpre, int H, int W, float* __restrict__ ctr) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) {
+    int* ci = reinterpret_cast<int*>(ctr);
+    const int step = ci[0] + 1;
+    ci[0] = step;
+    ctr[1] = (float)(1.0 - pow(0.9, (double)step));
+    ctr[2] = (float)sqrt(1.0 - pow(0.999, (double)step));
+  }
+  if (p >= H * W) return;
+  const int y = p / W, x = p - y * W;
+  const size_t o = (size_t)((y + 1) * (W + 2) + x + 1) * 8;
+  const float d = rec[o] - x8[o];
+  const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);            // torch.sign; NaN -> 0 like the comparison chain
+  dpre[o] = sg * moc[p];
+}
+
+// plain [C][H][W] -> CG8P (channels >= C of the last group stay as they are: zero)
+__global__ void __launch_bounds__(256)
+ae_to_cg8p_kernel(const float* __restrict__ src, int C, int H, int W, float* __restrict__ dst) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C * H * W) return;
+  const int c = t / (H * W), p = t - c * H * W, y = p / W, x = p - y * W;
+  dst[((size_t)(c >> 3) * (H + 2) * (W + 2) + (size_t)((y + 1) * (W + 2) + x + 1)) * 8 + (c & 7)] = src[t];
+}
+__global__ void __launch_bounds__(256)
+ae_from_cg8p_kernel(const float* __restrict__ src, int C, int H, int W, float* __restrict__ dst) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C * H * W) return;
+  const int c = t / (H * W), p = t - c * H * W, y = p / W, x = p - y * W;
+  dst[t] = src[((size_t)(c >> 3) * (H + 2) * (W + 2) + (size_t)((y + 1) * (W + 2) + x + 1)) * 8 + (c & 7)];
+}
+
+// the model's own tensors (state_dict order: per layer weight then bias; Conv2d weight [out][in][3][3], ConvTranspose2d
+// weight [in][out][3][3]) <-> theta (+ the backward pack).  The conv-equivalent weight of a stride-1 transposed convolution
+// is the flipped transpose: cw[co][ci][tap] = w[ci][co][8 - tap].
+struct AePackLayer { int w_off, wb_off, b_off, flat_w, flat_b, cin_lg, cout_lg, cin, cout, deconv; };
+struct AePackArgs { AePackLayer L[AE_NLAYER]; int n_w, n_all; };
+
+__device__ __forceinline__ int ae_flat_index(const AePackLayer& q, int tap, int ci, int co) {
+  return q.deconv ? q.flat_w + (ci * q.cout + co) * 9 + (8 - tap) : q.flat_w + (co * q.cin + ci) * 9 + tap;
+}
+
+template <bool UNPACK>
+__global__ void __launch_bounds__(256)
+ae_pack_kernel(AePackArgs A, const float* __restrict__ src, float* __restrict__ theta, float* __restrict__ wb) {
+  // UNPACK = false: src = flat -> theta, wb.  UNPACK = true: src = theta -> `theta` argument = flat output
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= A.n_all) return;
+  if (idx < A.n_w) {
+    int k = 0;
+    while (k + 1 < AE_NLAYER && idx >= A.L[k + 1].w_off) ++k;
+    const AePackLayer& q = A.L[k];
+    const int i = idx - q.w_off;
+    const int c8 = i & 7, co = (i >> 3) & ((1 << q.cout_lg) - 1);
+    const int t = i >> (3 + q.cout_lg);
+    const int cg = t & ((1 << q.cin_lg) - 1), tap = t >> q.cin_lg;
+    const int ci = cg * 8 + c8;
+    const bool real = ci < q.cin && co < q.cout;
+    if (UNPACK) {
+      if (real) theta[ae_flat_index(q, tap, ci, co)] = src[idx];
+    } else {
+      const float v = real ? src[ae_flat_index(q, tap, ci, co)] : 0.f;
+      theta[idx] = v;
+      if (q.wb_off >= 0)
+        wb[q.wb_off + ((((8 - tap) << (q.cout_lg - 3)) + (co >> 3)) << (q.cin_lg + 3)) * 8 + ci * 8 + (co & 7)] = v;
+    }
+  } else {
+    const int b = idx - A.n_w;
+    int k = 0;
+    while (k + 1 < AE_NLAYER && b >= A.L[k + 1].b_off) ++k;
+    const AePackLayer& q = A.L[k];
+    const int co = b - q.b_off;
+    if (UNPACK) { if (co < q.cout) theta[q.flat_b + co] = src[idx]; }
+    else theta[idx] = co < q.cout ? src[q.flat_b + co] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the engine
+// ---------------------------------------------------------------------------------------------------------------------
+static const int AE_ENC[5][2] = {{4, 32}, {32, 64}, {64, 128}, {128, 256}, {256, 256}};      // models/AE.py:81-91, in_channel = 4
+static const int AE_DEC[5][2] = {{256, 256}, {256, 128}, {128, 64}, {64, 32}, {32, 1}};
+
+struct AeLayer { int cin, cout, cin_pad, cout_pad, deconv, level, w_off, b_off, wb_off, flat_w, flat_b, nslab; size_t part_off; };
+
+static int pad8(int c) { return (c + 7) / 8 * 8; }
+static int pad32(int c) { return (c + 31) / 32 * 32; }
+static size_t cg8p_floats(int C, int H, int W) { return (size_t)(C / 8 > 0 ? C / 8 : 1) * (H + 2) * (W + 2) * 8; }
+
+struct AeEngine {
+  int H[6], W[6];
+  AeLayer L[AE_NLAYER];
+  int n_w = 0, n_b = 0, n_wb = 0, n_flat = 0;
+  size_t n_part = 0;
+  float lr = 0.f;
+  // carved from the caller's workspace
+  float *theta = nullptr, *m = nullptr, *v = nullptr, *wb = nullptr, *dbias = nullptr, *zero_bias = nullptr, *ctr = nullptr,
+        *part = nullptr, *moc = nullptr, *x8 = nullptr;
+  float* act[AE_NLAYER];       // output of layer i (decoder blocks 0..3: their second layer's output lives stuffed in S[b + 1])
+  float* xin[AE_NLAYER];       // input of layer i
+  float* dp[AE_NLAYER];        // d(pre-activation) of layer i
+  float *P[5], *dP[5], *S[5];
+  unsigned char* idx[5];
+  hipGraphExec_t exec[2] = {nullptr, nullptr};      // 5 steps, 1 step
+  int loaded = 0;
+};
+
+struct Bump {
+  float* base; size_t off = 0;
+  float* take(size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; }
+};
+
+// the same routine sizes the workspace (base == nullptr) and carves it
+static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
+  e->H[0] = H0; e->W[0] = W0;
+  for (int k = 0; k < 5; ++k) { e->H[k + 1] = (e->H[k] - 1) / 2 + 1; e->W[k + 1] = (e->W[k] - 1) / 2 + 1; }
+  int n = 0;
+  for (int b = 0; b < 5; ++b) {
+    const int ci = AE_ENC[b][0], co = AE_ENC[b][1];
+    e->L[n++] = AeLayer{ci, co, pad8(ci), pad32(co), 0, b};
+    e->L[n++] = AeLayer{co, co, pad32(co), pad32(co), 0, b};
+  }
+  for (int b = 0; b < 5; ++b) {
+    const int ci = AE_DEC[b][0], co = AE_DEC[b][1];
+    e->L[n++] = AeLayer{ci, co, pad32(ci), pad32(co), 1, 4 - b};
+    e->L[n++] = AeLayer{co, co, pad32(co), pad32(co), 1, 4 - b};
+  }
+  int w = 0, wbo = 0, flat = 0;
+  size_t part = 0;
+  for (int i = 0; i < AE_NLAYER; ++i) {
+    AeLayer& l = e->L[i];
+    l.w_off = w; w += 9 * l.cin_pad * l.cout_pad;
+    l.wb_off = i == 0 ? -1 : wbo; if (i) wbo += 9 * l.cin_pad * l.cout_pad;      // the first layer needs no backward-data
+    l.flat_w = flat; flat += 9 * l.cin * l.cout;
+    l.flat_b = flat; flat += l.cout;
+    l.nslab = (e->H[l.level] * e->W[l.level] + AE_SLAB - 1) / AE_SLAB;
+    l.part_off = part; part += (size_t)l.nslab * 9 * l.cin_pad * l.cout_pad;
+  }
+  e->n_w = w; e->n_wb = wbo; e->n_flat = flat; e->n_part = part;
+  int b = 0;
+  for (int i = 0; i < AE_NLAYER; ++i) { e->L[i].b_off = b; b += e->L[i].cout_pad; }
+  e->n_b = b;
+  Bump B{base};
+  e->theta = B.take(e->n_w + e->n_b); e->m = B.take(e->n_w + e->n_b); e->v = B.take(e->n_w + e->n_b);
+  e->wb = B.take(e->n_wb); e->dbias = B.take(e->n_b); e->zero_bias = B.take(256); e->ctr = B.take(64);
+  e->part = B.take(e->n_part); e->moc = B.take((size_t)H0 * W0);
+  e->x8 = B.take(cg8p_floats(8, H0, W0));
+  for (int bk = 0; bk < 5; ++bk) {
+    const int lv = bk, i0 = 2 * bk, i2 = 2 * bk + 1;
+    e->act[i0] = B.take(cg8p_floats(e->L[i0].cout_pad, e->H[lv], e->W[lv]));
+    e->act[i2] = B.take(cg8p_floats(e->L[i2].cout_pad, e->H[lv], e->W[lv]));
+    e->P[bk] = B.take(cg8p_floats(e->L[i2].cout_pad, e->H[lv + 1], e->W[lv + 1]));
+    e->dP[bk] = B.take(cg8p_floats(e->L[i2].cout_pad, e->H[lv + 1], e->W[lv + 1]));
+    e->idx[bk] = reinterpret_cast<unsigned char*>(B.take(((size_t)e->L[i2].cout_pad * e->H[lv + 1] * e->W[lv + 1] + 3) / 4));
+    e->xin[i0] = bk == 0 ? e->x8 : e->P[bk - 1];
+    e->xin[i2] = e->act[i0];
+  }
+  for (int bk = 0; bk < 5; ++bk) {
+    const int lv = 4 - bk, i1 = 10 + 2 * bk;
+    e->S[bk] = B.take(cg8p_floats(e->L[i1].cin_pad, e->H[lv], e->W[lv]));
+  }
+  for (int bk = 0; bk < 5; ++bk) {
+    const int lv = 4 - bk, i1 = 10 + 2 * bk, i2 = 11 + 2 * bk;
+    e->act[i1] = B.take(cg8p_floats(e->L[i1].cout_pad, e->H[lv], e->W[lv]));
+    e->act[i2] = bk < 4 ? e->S[bk + 1] : B.take(cg8p_floats(e->L[i2].cout_pad, e->H[lv], e->W[lv]));
+    e->xin[i1] = e->S[bk];
+    e->xin[i2] = e->act[i1];
+  }
+  for (int i = 0; i < AE_NLAYER; ++i) e->dp[i] = B.take(cg8p_floats(e->L[i].cout_pad, e->H[e->L[i].level], e->W[e->L[i].level]));
+  *total = B.off;
+}
+
+static AeGeo geo_plain(int H, int W) { const int Wp = W + 2, HWp = (H + 2) * Wp; return AeGeo{H, W, Wp, HWp, 1, Wp, HWp, 1, Wp, HWp, 1}; }
+
+static int ae_forward(AeEngine* e, hipStream_t s) {
+  for (int b = 0; b < 5; ++b) {
+    const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
+    const AeGeo g = geo_plain(H, W);
+    CHK_(ae_conv(e->xin[i0], e->theta + e->L[i0].w_off, e->theta + e->n_w + e->L[i0].b_off, nullptr, e->act[i0], g, e->L[i0].cin_pad, e->L[i0].cout_pad, 0, s));
+    CHK_(ae_conv(e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, 0, s));
+    CHK_(maxpool3s2_fwd(e->act[i2], H, W, e->P[b], e->idx[b], e->L[i2].cout_pad, s));
+  }
+  CHK_(stuff2_fwd(e->P[4], e->H[5], e->W[5], e->S[0], e->H[4], e->W[4], e->L[10].cin_pad, s));
+  for (int b = 0; b < 5; ++b) {
+    const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
+    AeGeo g = geo_plain(H, W);
+    CHK_(ae_conv(e->xin[i1], e->theta + e->L[i1].w_off, e->theta + e->n_w + e->L[i1].b_off, nullptr, e->act[i1], g, e->L[i1].cin_pad, e->L[i1].cout_pad, 0, s));
+    if (b < 4) {       // straight into the stuffed input of the next block: pixel (y, x) -> (2y, 2x) of the next finer level
+      g.out_Wp = e->W[lv - 1] + 2; g.out_HWp = (e->H[lv - 1] + 2) * g.out_Wp; g.out_s = 2;
+    }
+    CHK_(ae_conv(e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, b < 4 ? 0 : 2, s));
+  }
+  return 0;
+}
+
+static int ae_train_step(AeEngine* e, hipStream_t s) {
+  CHK_(ae_forward(e, s));
+  const int H0 = e->H[0], W0 = e->W[0];
+  hipLaunchKernelGGL(ae_loss_grad_kernel, dim3((H0 * W0 + 255) / 256), dim3(256), 0, s, (const float*)e->act[19], (const float*)e->x8,
+                     (const float*)e->moc, e->dp[19], H0, W0, e->ctr);
+  CHK_((int)hipGetLastError());
+  // ---- decoder, last block first
+  for (int b = 4; b >= 0; --b) {
+    const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
+    const AeGeo g = geo_plain(H, W);
+    CHK_(ae_conv(e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i1], e->dp[i1], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));     // * lrelu'(act[i1])
+    // adjoint of (stuffing, transposed conv): only the even pixels of d(stuffed input) exist downstream -> enumerate the
+    // coarse grid, centre taps at (2i, 2j); times lrelu' of the previous block's output (read where it lives: stuffed in S[b])
+    const int h = e->H[lv + 1], w = e->W[lv + 1];
+    AeGeo gs = geo_plain(h, w);
+    gs.in_Wp = W + 2; gs.in_HWp = (H + 2) * (W + 2); gs.in_s = 2;
+    gs.aux_Wp = gs.in_Wp; gs.aux_HWp = gs.in_HWp; gs.aux_s = 2;
+    float* dst = b > 0 ? e->dp[i1 - 1] : e->dP[4];
+    if (b > 0) CHK_(ae_conv(e->dp[i1], e->wb + e->L[i1].wb_off, nullptr, e->S[b], dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 1, s));
+    else       CHK_(ae_conv(e->dp[i1], e->wb + e->L[i1].wb_off, e->zero_bias, nullptr, dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 2, s));   // the latent has no activation
+  }
+  // ---- encoder, last block first
+  for (int b = 4; b >= 0; --b) {
+    const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
+    const AeGeo g = geo_plain(H, W);
+    CHK_(maxpool3s2_bwd(e->dP[b], e->idx[b], e->act[i2], e->dp[i2], H, W, e->L[i2].cout_pad, s));
+    CHK_(ae_conv(e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i0], e->dp[i0], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));
+    if (b > 0) CHK_(ae_conv(e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
+  }
+  // ---- all weight and bias gradients
+  AeWgradJobs J;
+  J.n = AE_NLAYER;
+  int nb = 0;
+  for (int i = 0; i < AE_NLAYER; ++i) {
+    const AeLayer& l = e->L[i];
+    AeWgradJob& q = J.j[i];
+    q.dy = e->dp[i]; q.x = e->xin[i]; q.partial = e->part + l.part_off; q.db = e->dbias + l.b_off;
+    q.H = e->H[l.level]; q.W = e->W[l.level]; q.wmagic = (unsigned)((1ull << 32) / (unsigned)q.W + 1);
+    q.cin = l.cin_pad; q.cout = l.cout_pad; q.cout_real = l.cout; q.nslab = l.nslab;
+    q.ntile = l.nslab * 9 * (l.cout_pad / 32) * ((l.cin_pad + 31) / 32);
+    q.first_block = nb;
+    nb += q.ntile + l.cout;
+  }
+  hipLaunchKernelGGL(ae_wgrad_multi_kernel, dim3(nb), dim3(256), 0, s, J);
+  CHK_((int)hipGetLastError());
+  // ---- Adam
+  AeAdamArgs A;
+  for (int i = 0; i < AE_NLAYER; ++i) {
+    const AeLayer& l = e->L[i];
+    A.L[i] = AeAdamLayer{e->part + l.part_off, l.nslab, l.w_off, l.wb_off, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout};
+  }
+  A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.dbias = e->dbias; A.ctr = e->ctr;
+  A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr;
+  hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all + 255) / 256), dim3(256), 0, s, A);
+  return (int)hipGetLastError();
+}
+
+static AePackArgs ae_pack_args(const AeEngine* e) {
+  AePackArgs A;
+  for (int i = 0; i < AE_NLAYER; ++i) {
+    const AeLayer& l = e->L[i];
+    A.L[i] = AePackLayer{l.w_off, l.wb_off, l.b_off, l.flat_w, l.flat_b, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout, l.deconv};
+  }
+  A.n_w = e->n_w; A.n_all = e->n_w + e->n_b;
+  return A;
+}
+
+static int ae_capture(AeEngine* e, hipStream_t s, int steps, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  int rc = (int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (rc) return rc;
+  for (int i = 0; i < steps && !rc; ++i) rc = ae_train_step(e, s);
+  const int ec = (int)hipStreamEndCapture(s, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (ec) return ec;
+  const int ic = (int)hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (!ic) (void)hipGraphUpload(*out, s);
+  return ic;
+}
+
+}  // namespace lemo
+
+using namespace lemo;
+
+extern "C" {
+
+long long lemo_ae_ws_floats(int H, int W) {
+  if (H < 2 || W < 2 || (long)H * W > (1l << 22)) return 0;
+  AeEngine e;
+  size_t total = 0;
+  ae_layout(&e, H, W, nullptr, &total);
+  return (long long)total;
+}
+
+int lemo_ae_n_param(void) {
+  AeEngine e;
+  size_t total = 0;
+  ae_layout(&e, 64, 64, nullptr, &total);
+  return e.n_flat;
+}
+
+void* lemo_ae_create(const lemo_ae_desc* d) {
+  if (!d || !d->ws || d->H < 2 || d->W < 2 || (long)d->H * d->W > (1l << 22) || !(d->lr > 0.f)) return nullptr;
+  if (ae_conv_init()) return nullptr;
+  AeEngine* e = new (std::nothrow) AeEngine();
+  if (!e) return nullptr;
+  size_t total = 0;
+  ae_layout(e, d->H, d->W, d->ws, &total);
+  if ((long long)total > d->ws_floats) { delete e; return nullptr; }
+  e->lr = d->lr;
+  return e;
+}
+
+void lemo_ae_destroy(void* h) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e) return;
+  for (int l = 0; l < 2; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
+  delete e;
+}
+
+int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e || !flat || !x || !moc) return LEMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int n_all = e->n_w + e->n_b, H = e->H[0], W = e->W[0];
+  hipLaunchKernelGGL((ae_pack_kernel<false>), dim3((n_all + 255) / 256), dim3(256), 0, s, ae_pack_args(e), flat, e->theta, e->wb);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  if ((rc = (int)hipMemsetAsync(e->m, 0, sizeof(float) * n_all, s))) return rc;            // a fresh optimizer (opt_amass_temp.py:160-164)
+  if ((rc = (int)hipMemsetAsync(e->v, 0, sizeof(float) * n_all, s))) return rc;
+  if ((rc = (int)hipMemsetAsync(e->ctr, 0, sizeof(float) * 64, s))) return rc;
+  if ((rc = (int)hipMemcpyAsync(e->moc, moc, sizeof(float) * H * W, hipMemcpyDeviceToDevice, s))) return rc;
+  hipLaunchKernelGGL(ae_to_cg8p_kernel, dim3((4 * H * W + 255) / 256), dim3(256), 0, s, x, 4, H, W, e->x8);
+  e->loaded = 1;
+  return (int)hipGetLastError();
+}
+
+int lemo_ae_step(void* h, int n, int use_graph, void* stream) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e || n < 0) return LEMO_ERR_ARG;
+  if (!e->loaded) return LEMO_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  if (!use_graph) {
+    for (int i = 0; i < n; ++i) { const int rc = ae_train_step(e, s); if (rc) return rc; }
+    return 0;
+  }
+  const int unroll[2] = {5, 1};
+  int plan[2], left = n;
+  for (int l = 0; l < 2; ++l) { plan[l] = left / unroll[l]; left -= plan[l] * unroll[l]; }
+  for (int l = 0; l < 2; ++l)
+    if (plan[l] && !e->exec[l]) { const int rc = ae_capture(e, s, unroll[l], &e->exec[l]); if (rc) return rc; }
+  for (int l = 0; l < 2; ++l)
+    for (int i = 0; i < plan[l]; ++i) { const int rc = (int)hipGraphLaunch(e->exec[l], s); if (rc) return rc; }
+  return 0;
+}
+
+int lemo_ae_forward(void* h, float* rec, float* z, void* stream) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e || !rec) return LEMO_ERR_ARG;
+  if (!e->loaded) return LEMO_ERR_STATE;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ae_forward(e, s);
+  if (rc) return rc;
+  const int H = e->H[0], W = e->W[0];
+  hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, (const float*)e->act[19], 1, H, W, rec);
+  if (z) hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((256 * e->H[5] * e->W[5] + 255) / 256), dim3(256), 0, s, (const float*)e->P[4], 256, e->H[5], e->W[5], z);
+  return (int)hipGetLastError();
+}
+
+int lemo_ae_params(void* h, float* flat_out, void* stream) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e || !flat_out) return LEMO_ERR_ARG;
+  if (!e->loaded) return LEMO_ERR_STATE;
+  const int n_all = e->n_w + e->n_b;
+  hipLaunchKernelGGL((ae_pack_kernel<true>), dim3((n_all + 255) / 256), dim3(256), 0, (hipStream_t)stream, ae_pack_args(e), (const float*)e->theta, flat_out, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+/* one convolution of the engine on its own (tests, tools): plain geometry unless in_s / out_s = 2 (see AeGeo) */
+int lemo_ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
+                 int in_s, int out_s, int cin, int cout, int epi, int mt, int nw, void* stream) {
+  if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux) || (in_s != 1 && in_s != 2) || (out_s != 1 && out_s != 2)) return LEMO_ERR_ARG;
+  if (ae_conv_init()) return LEMO_ERR_STATE;
+  AeGeo g = geo_plain(H, W);
+  if (in_s == 2) { g.in_Wp = fineW + 2; g.in_HWp = (fineH + 2) * (fineW + 2); g.in_s = 2; g.aux_Wp = g.in_Wp; g.aux_HWp = g.in_HWp; g.aux_s = 2; }
+  if (out_s == 2) { g.out_Wp = fineW + 2; g.out_HWp = (fineH + 2) * (fineW + 2); g.out_s = 2; }
+  return ae_conv(in, wt, bias, aux, out, g, cin, cout, epi, (hipStream_t)stream, mt, nw);
+}
+
+}  // extern "C"

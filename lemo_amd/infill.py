@@ -513,36 +513,115 @@ class _FinetuneSession:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
 
-_SESSIONS: Dict[tuple, _FinetuneSession] = {}
+class _EngineSession:
+    """One clip shape's native finetune engine (``lemo_ae_*``, csrc/ae_engine.hip): the workspace it carves its parameters,
+    Adam state, activations and gradients from, its stream, and the output buffers of the eval forward.  Kept across clips
+    of the same shape like :class:`_FinetuneSession` (the captured graphs live inside the engine)."""
+
+    def __init__(self, lib, x_shape, lr, device):
+        self.lib, self.device = lib, torch.device(device)
+        self.gpu = self.device.type == 'cuda' and not lib.is_emu
+        H, W = int(x_shape[-2]), int(x_shape[-1])
+        n = int(lib.ae_ws_floats(H, W))
+        if n <= 0:
+            raise _hip.LemoHipError(f'lemo_ae_ws_floats refuses a {H} x {W} clip image')
+        self.stream = torch.cuda.Stream(self.device) if self.gpu else None
+        self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
+        h5, w5 = H, W
+        for _ in range(5):
+            h5, w5 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
+        self.rec = torch.empty(H, W, dtype=torch.float32, device=self.device)
+        self.z = torch.empty(256, h5, w5, dtype=torch.float32, device=self.device)
+        self.flat = torch.empty(int(lib.ae_n_param()), dtype=torch.float32, device=self.device)
+        if self.gpu:
+            torch.cuda.current_stream(self.device).synchronize()            # the zero fill, before another stream uses ws
+        desc = _hip.AeDesc(H, W, float(lr), ptr(self.ws), n)
+        self.h = lib.ae_create(C.byref(desc))
+        if not self.h:
+            raise _hip.LemoHipError('lemo_ae_create failed')
+        self._ev = None
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            lib, rel = self.lib, getattr(_hip, 'release', None) if _hip is not None else None
+            if rel is not None:              # (None: interpreter shutdown)
+                def destroy(h=h, ws=self.ws):            # (the workspace outlives the engine's last launch)
+                    lib.ae_destroy(h)
+                rel(self.device, lib, destroy, self._ev)
+
+    def _s(self):
+        return self.stream.cuda_stream if self.gpu else None
+
+    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True):
+        """load the pretrained parameters and the clip, `steps` training steps, eval forward, parameters back out -- all on
+        this session's stream; returns views of the session's output buffers (valid until its next run)"""
+        lib = self.lib
+        flat0, x, moc = flat0.contiguous().float(), x.reshape(4, *x.shape[-2:]).contiguous().float(), m_over_cnt.contiguous().float()
+        assert flat0.numel() == self.flat.numel() and tuple(moc.shape) == tuple(self.rec.shape)
+        if self.gpu:
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            _hip.flush_deferred()
+        lib.check(lib.ae_load(self.h, ptr(flat0), ptr(x), ptr(moc), self._s()), 'ae_load')
+        lib.check(lib.ae_step(self.h, int(steps), 1 if (use_graph and self.gpu) else 0, self._s()), 'ae_step')
+        lib.check(lib.ae_forward(self.h, ptr(self.rec), ptr(self.z), self._s()), 'ae_forward')
+        lib.check(lib.ae_params(self.h, ptr(self.flat), self._s()), 'ae_params')
+        if self.gpu:
+            if self._ev is None:
+                self._ev = torch.cuda.Event()
+            self._ev.record(self.stream)
+            self._keep = (flat0, x, moc)                 # read by the launches above: alive until the next run replaces them
+            if join:
+                self.join()
+        return self.flat, self.rec, self.z
+
+    def join(self):
+        if self.gpu:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
+USE_ENGINE = __import__('os').environ.get('LEMO_AE_ENGINE', '1') != '0'
+"""the finetune loop runs on the native step engine (round 3: 53 launches per step instead of ~150; csrc/ae_engine.hip).
+``LEMO_AE_ENGINE=0`` (or ``engine=False``) keeps the round-2 path -- the autograd function + flat Adam under a captured graph
+(:class:`_FinetuneSession`) -- which is also what ``AE.forward`` under autograd runs; tests compare the two."""
+
+_SESSIONS: Dict[tuple, object] = {}
 _MAX_SESSIONS = 8
-"""sessions kept alive at once (LRU): each pins ~45 workspace buffers, a stream, a private memory pool and an instantiated
-graph; PROX tail windows and recordings of varying length would otherwise add one per clip shape without bound (ADVICE r02)."""
+"""sessions kept alive at once (LRU): each pins a workspace (or ~45 workspace buffers), a stream and instantiated graphs; PROX
+tail windows and recordings of varying length would otherwise add one per clip shape without bound (ADVICE r02)."""
 
 
-def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0) -> _FinetuneSession:
-    key = (str(device), tuple(shape), float(lr), id(lib), int(slot))
+def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine: bool = False):
+    key = (str(device), tuple(shape), float(lr), id(lib), int(slot), bool(engine))
     ses = _SESSIONS.pop(key, None)
     if ses is None:
-        ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
+        ses = _EngineSession(lib, tuple(shape), lr, device) if engine else _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
     while len(_SESSIONS) > _MAX_SESSIONS:
-        _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for the device and releases the graph
+        _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for its last launch and releases the graphs
     return ses
 
 
+def _store_params(model: 'AE', flat: torch.Tensor):
+    with torch.no_grad():
+        o = 0
+        for p in model.ordered_parameters():
+            p.copy_(flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+
 def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, train_mask: torch.Tensor, steps: int = 60,
-                        lr: float = 3e-6, use_graph: Optional[bool] = None):
+                        lr: float = 3e-6, use_graph: Optional[bool] = None, engine: Optional[bool] = None):
     """The per-clip block of opt_amass_temp.py:160-215: reload the pretrained weights, ``steps`` x [forward, L1 on
     ``train_mask`` (bool [d+2, T+16] over channel 0), backward, Adam], then one eval forward.  Returns
-    ``(clip_img_rec [1,1,d,T] un-padded, z)``.
+    ``(clip_img_rec [1,1,d,T] un-padded, z)``; the model holds the finetuned weights afterwards, as in the reference.
 
-    ``use_graph`` (default: on a HIP device): the training step -- ~110 HIP kernels plus ~40 small packing ops -- is captured
-    ONCE per process and clip shape into a graph (after 3 eager steps that also warm the allocator) and replayed for every
-    later step and clip (:class:`_FinetuneSession`), which takes the host out of the loop; Adam's bias-correction step lives
-    on the device (``lemo_adam_flat_ctr``) so the replays advance it.  Same kernels, same order: results are bit-identical
-    to eager launches (tested).  Round 2 (tools/ae_prof.py, profiles/r02_ae_kernel_stats.csv): 2.0 -> 1.26 ms of kernel
-    time per step -- weight gradients one tile per workgroup (29 -> 12 us per layer) on a second stream, their 20
-    reductions in one launch, no per-step zero fills, closed-form loss gradient."""
+    ``engine`` (default :data:`USE_ENGINE`): the whole loop runs inside the native step engine (``lemo_ae_*``: 53 launches per
+    step, captured into graphs on first use).  ``engine=False`` is the round-2 path: the training step -- ~110 HIP kernels plus
+    ~40 small packing ops through the autograd function -- captured ONCE per process and clip shape into a graph (after 3 eager
+    steps that also warm the allocator) and replayed (:class:`_FinetuneSession`); Adam's bias-correction step lives on the
+    device (``lemo_adam_flat_ctr``) so the replays advance it.  ``use_graph`` (default: on a HIP device) applies to both; same
+    kernels, same order: results are bit-identical to eager launches (tested)."""
     model.load_state_dict(weights)
     lib = model._lib_override or _hip.get_lib()
     m = train_mask.to(clip_img_input.dtype)
@@ -550,50 +629,56 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     if use_graph is None:
         use_graph = clip_img_input.is_cuda
     use_graph = bool(use_graph) and clip_img_input.is_cuda and not lib.is_emu
+    engine = USE_ENGINE if engine is None else bool(engine)
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
-    ses = _session(lib, flat0.numel(), clip_img_input.shape, lr, clip_img_input.device)
-    flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
-    with torch.no_grad():
-        o = 0
-        for p in model.ordered_parameters():
-            p.copy_(flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+    ses = _session(lib, flat0.numel(), clip_img_input.shape, lr, clip_img_input.device, engine=engine)
+    if engine:
+        _hip.check_device(lib, clip_img_input)
+        flat, rec, z = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
+        _store_params(model, flat)
+        return rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()
+    flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)
+    _store_params(model, flat)
     with torch.no_grad():
         rec, z = model(clip_img_input)
     return rec[:, :, 1:-1, 8:-8], z
 
 
 def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor], train_masks: List[torch.Tensor], steps: int = 60,
-                             lr: float = 3e-6, use_graph: Optional[bool] = None):
+                             lr: float = 3e-6, use_graph: Optional[bool] = None, engine: Optional[bool] = None):
     """:func:`finetune_and_infill` for several clips SIDE BY SIDE (the dataset-scale form, like
     ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1): every clip's
-    60-step finetune runs on its own session -- own stream, own flat parameter copy, Adam state, workspace and captured
-    graph -- so the k loops advance concurrently.  One training step is ~150 short launches (the deep layers are 27 x 17 and
-    14 x 9 pixel images: a handful of workgroups each) whose time is mostly kernel-boundary latency; a second and third clip
-    fill the idle device.  Each clip's result is bit-identical to its solo ``finetune_and_infill`` (same kernels, same order,
-    no shared state; tested).  Returns the list of ``(clip_img_rec, z)``; at most ``_MAX_SESSIONS`` clips per call."""
+    60-step finetune runs on its own session -- own stream, own parameters, Adam state, workspace and captured graphs -- so
+    the k loops advance concurrently.  One training step is a chain of short launches (the deep layers are 27 x 17 and 14 x 9
+    pixel images: a handful of workgroups each) whose time is mostly latency; a second and third clip fill the idle device.
+    Each clip's result is bit-identical to its solo ``finetune_and_infill`` (same kernels, same order, no shared state;
+    tested).  Returns the list of ``(clip_img_rec, z)``; at most ``_MAX_SESSIONS`` clips per call; the model is left with the
+    LAST clip's finetuned weights."""
     assert 1 <= len(clips) == len(train_masks) <= _MAX_SESSIONS
     lib = model._lib_override or _hip.get_lib()
     if use_graph is None:
         use_graph = clips[0].is_cuda
     use_graph = bool(use_graph) and clips[0].is_cuda and not lib.is_emu
+    engine = USE_ENGINE if engine is None else bool(engine)
     model.load_state_dict(weights)
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
-    flats, sessions = [], []
+    results, sessions = [], []
     mocs = [tm.to(x.dtype) * (1.0 / tm.to(x.dtype).sum()) for x, tm in zip(clips, train_masks)]     # (on the current stream, before any fork)
     for i, (x, moc) in enumerate(zip(clips, mocs)):                          # enqueue: clip i's loop on session i's stream
-        ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i)
-        flats.append(ses.run(flat0, x, moc, steps, use_graph, join=False))   # the current stream waits for nobody yet
+        ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i, engine=engine)
+        results.append(ses.run(flat0, x, moc, steps, use_graph, join=False))   # the current stream waits for nobody yet
         sessions.append(ses)
     for ses in sessions:
         ses.join()
     out = []
-    for x, flat in zip(clips, flats):                                        # eval forwards, one after the other
+    if engine:
+        for flat, rec, z in results:
+            out.append((rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()))
+        _store_params(model, results[-1][0])
+        return out
+    for x, flat in zip(clips, results):                                      # eval forwards, one after the other
+        _store_params(model, flat)
         with torch.no_grad():
-            o = 0
-            for p in model.ordered_parameters():
-                p.copy_(flat[o:o + p.numel()].view_as(p))
-                o += p.numel()
             rec, z = model(x)
         out.append((rec[:, :, 1:-1, 8:-8].clone(), z.clone()))
     return out

@@ -138,3 +138,76 @@ def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
         finetune_and_infill(ae, w, torch.randn(1, 4, 18, 24 + 2 * t, generator=g), torch.ones(18, 24 + 2 * t) > 0, steps=0)
     assert len(infill._SESSIONS) == infill._MAX_SESSIONS
     infill._SESSIONS.clear()
+
+
+@pytest.mark.parametrize('mt,nw', [(0, 0), (1, 1), (1, 4), (2, 2), (1, 16), (2, 8)])
+def test_engine_conv_all_geometries(emu_lib, mt, nw):
+    """lemo_ae_conv (K split over the waves of a workgroup, summed in wave order) against torch in its three geometries: plain;
+    output written into the even pixels of a twice finer image (= zero-stuffed input of the next stride-2 transposed conv);
+    input read at the even pixels of a finer image with the epilogue operand read there too (= adjoint of the stuffing fused
+    into the backward-data convolution).  Ragged pixel counts, every epilogue."""
+    import torch.nn.functional as F
+    from lemo_amd.priors import cg8p_alloc, from_cg8p, to_cg8p, pack_conv3x3
+    g = torch.Generator().manual_seed(11)
+    cin, cout, H, W = 32, 64, 7, 9                                     # 63 pixels: one full tile + a ragged one
+    x = torch.randn(cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    wt = torch.from_numpy(pack_conv3x3(w.numpy()))
+    ref = F.conv2d(x[None], w, b, padding=1)[0]
+    # plain, epilogues 0 / 2 / 1
+    aux = torch.randn(cout, H, W, generator=g)
+    for epi, want in ((0, F.leaky_relu(ref, 0.2)), (2, ref),
+                      (1, F.conv2d(x[None], w, None, padding=1)[0] * torch.where(aux > 0, 1.0, 0.2))):
+        out = cg8p_alloc(cout, H, W, 'cpu')
+        assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), ptr(to_cg8p(aux)), ptr(out), H, W, 0, 0, 1, 1, cin, cout, epi, mt, nw, None) == 0
+        assert rel_err(from_cg8p(out, H, W), want) < 2e-6, epi
+    # stuffed output: (y, x) -> (2y, 2x) of a 14 x 17 image; everything else stays zero
+    fH, fW = 14, 17
+    out = cg8p_alloc(cout, fH, fW, 'cpu')
+    assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, fH, fW, 1, 2, cin, cout, 0, mt, nw, None) == 0
+    S = from_cg8p(out, fH, fW)
+    want = torch.zeros(cout, fH, fW)
+    want[:, 0:2 * H:2, 0:2 * W:2] = F.leaky_relu(ref, 0.2)
+    assert rel_err(S, want) < 2e-6 and float(S[:, 1::2].abs().max()) == 0.0 and float(S[:, :, 1::2].abs().max()) == 0.0
+    # strided input: the conv of a fine image evaluated at its even pixels only, times lrelu' of a stuffed operand
+    xf = torch.randn(cin, fH, fW, generator=g)
+    auxf = torch.zeros(cout, fH, fW)
+    auxf[:, 0:2 * H:2, 0:2 * W:2] = aux
+    full = F.conv2d(xf[None], w, None, padding=1)[0]
+    want = full[:, 0:2 * H:2, 0:2 * W:2] * torch.where(aux > 0, 1.0, 0.2)
+    out = cg8p_alloc(cout, H, W, 'cpu')
+    assert emu_lib.ae_conv(ptr(to_cg8p(xf)), ptr(wt), None, ptr(to_cg8p(auxf)), ptr(out), H, W, fH, fW, 2, 1, cin, cout, 1, mt, nw, None) == 0
+    assert rel_err(from_cg8p(out, H, W), want) < 2e-6
+
+
+@pytest.mark.timeout(900)
+def test_engine_equals_autograd_path(emu_lib):
+    """the native step engine (packed parameter vector, fused stuffing, one weight-gradient launch, fused reduce + Adam) and the
+    round-2 path (autograd function + gather tables + flat Adam) are two implementations of the same arithmetic with different
+    K-summation splits: same reconstruction, latent and finetuned parameters after 3 visible steps, to fp32 rounding; and the
+    engine's padded parameter entries stay exactly zero"""
+    from lemo_amd import infill
+    from lemo_amd.infill import AE, finetune_and_infill
+    w = _weights()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(1, 4, 34, 21, generator=g)                       # odd sizes at every level
+    mask = torch.rand(34, 21, generator=g) > 0.3
+    infill._SESSIONS.clear()
+    a, b = AE(_lib=emu_lib), AE(_lib=emu_lib)
+    ra, za = finetune_and_infill(a, w, x, mask, steps=3, lr=1e-3, engine=True)
+    ses = next(iter(infill._SESSIONS.values()))
+    assert isinstance(ses, infill._EngineSession)
+    rb, zb = finetune_and_infill(b, w, x, mask, steps=3, lr=1e-3, engine=False)
+    assert ra.shape == rb.shape and za.shape == zb.shape
+    assert rel_err(ra, rb) < 2e-5 and rel_err(za, zb) < 2e-5
+    moved = 0.0
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) < 2e-5, k                  # lr 1e-3: an Adam step moves every entry by ~1e-3
+        moved = max(moved, float((p.detach() - w[k]).abs().max()))
+    assert moved > 1e-3
+    # theta's padded entries: layer 0 has 4 real input channels of 8 (forward pack [tap][cin/8][cout][8], cout 32)
+    n0 = 9 * 1 * 32 * 8
+    th0 = ses.ws[:n0].reshape(9, 1, 32, 8)
+    assert float(th0[..., 4:].abs().max()) == 0.0 and float(th0[..., :4].abs().max()) > 0.0
+    infill._SESSIONS.clear()
