@@ -402,8 +402,16 @@ def ae_probe(device):
     finetune_and_infill_many(ae, w, xs, [mask] * k, steps=60)
     torch.cuda.synchronize(device)
     many = (time.perf_counter() - t0) * 1e3 / k
+    # the round-2 path (autograd function + flat Adam under a captured graph), same clip: what the step engine replaced
+    finetune_and_infill(ae, w, x, mask, steps=60, engine=False)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    finetune_and_infill(ae, w, x, mask, steps=60, engine=False)
+    torch.cuda.synchronize(device)
+    old = (time.perf_counter() - t0) * 1e3
     return {'value': best, 'unit': 'ms per clip (60 finetune steps + eval forward)', 'higher_is_better': False,
-            'clips_side_by_side': k, 'side_by_side_ms_per_clip': many,
+            'clips_side_by_side': k, 'side_by_side_ms_per_clip': many, 'path': 'native step engine (lemo_ae_*), 53 launches per step',
+            'autograd_path_ms': old,
             'workload': 'models/AE.py infilling autoencoder, [1,4,210,135] clip image, masked L1, Adam 3e-6 (opt_amass_temp.py:154-214)'}
 
 

@@ -283,9 +283,10 @@ int lemo_ae_forward(void* h, float* rec, float* z, void* stream);
 int lemo_ae_params(void* h, float* flat_out, void* stream);
 /* one convolution of the engine on its own (tests, tools).  Enumerates an H x W pixel grid; in_s = 2: the input (and the
  * epi-1 operand) is a fineH x fineW image read at its even pixels; out_s = 2: the output is written to the even pixels of a
- * fineH x fineW image (zero-stuffing geometry).  mt / nw = 0: the engine's own launch shape. */
+ * fineH x fineW image (zero-stuffing geometry).  mt = 0: the engine's own launch shape; else tile mt (1: 32 px x 32 cout,
+ * 2: 32 x 64, 3: 16 x 16) with pt pixel tiles x ks K-slices = pt * ks <= 16 waves per workgroup. */
 int lemo_ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
-                 int in_s, int out_s, int cin, int cout, int epi, int mt, int nw, void* stream);
+                 int in_s, int out_s, int cin, int cout, int epi, int mt, int pt, int ks, void* stream);
 
 /* ---- stream capture helpers: record everything a host-side step enqueues on `stream` (HIP kernels of this library
  * and the caller's own device work alike) into an executable graph, replay it with one call.  Relaxed capture mode;

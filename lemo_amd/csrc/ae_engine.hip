@@ -40,20 +40,23 @@ struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; in
 template <int MT, int EPI>          // MT x 32 couts per workgroup; EPI: conv_common.hpp (0 lrelu(acc + bias), 1 acc * lrelu'(aux), 2 acc + bias)
 __global__ void __launch_bounds__(1024)
 ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout) {
+               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg) {
   LEMO_DYN_SMEM(red);                                          // [wave][MT][4][64 lanes] float4
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // (scalar: see the ring below)
+  // wave -> (pixel tile pt of the workgroup's 2^pt_lg, K slice ks of KS): the waves of one slice share the weights they load
+  // (one L2 -> L1 fill per workgroup instead of one per 32 pixels), the waves of one tile split K
+  const int PT = 1 << pt_lg, pt = wave & (PT - 1), ks = wave >> pt_lg, KS = NW >> pt_lg;
   const int j = lane & 31, h = lane >> 5;
   const int P = g.H * g.W;
   const int m_base = blockIdx.y * (MT * 32);
-  const int p = blockIdx.x * 32 + j;
+  const int p = (blockIdx.x * PT + pt) * 32 + j;
   const int pc = p < P ? p : P - 1;
   const int y = pc / g.W, x = pc - y * g.W;
   const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + 4 * h;
   const float* wt_l = wt + (size_t)(m_base + j) * 8 + 4 * h;
   const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
   const int gm = (1 << cin_lg) - 1, nit = 9 << cin_lg;
-  const int lo = nit * wave / NW, hi = nit * (wave + 1) / NW;    // this wave's (tap, channel group) steps; host: NW <= nit
+  const int lo = nit * ks / KS, hi = nit * (ks + 1) / KS;        // this wave's (tap, channel group) steps; host: KS <= nit
 
   f32x16 acc[MT];
 #pragma unroll
@@ -61,38 +64,44 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  // operands two steps ahead through a 3-deep register ring (a step is 4 MT MFMAs = 256 MT cycles; an L2 round trip is
-  // several of those)
-#define AE_LD(IT, A_, B_)                                                                                   \
+  // Operands D - 1 steps ahead through a D-deep register ring (slots are compile-time indices: the step loop is unrolled by D).
+  // A step is 4 MT MFMAs = 256 MT cycles of pipe time but its operands come from L2 / the fabric (every workgroup reads its own
+  // slice of the weights once): ~1.4 us per round trip measured -- with two loads in flight (round 3's first version) a wave
+  // advanced one step per 0.7 us whatever its MFMAs cost, 16 us for the 18-step waves of the 256-channel layers.
+  constexpr int D = MT == 1 ? 8 : 5;
+  float4 ra[D][MT], rb[D];
+#define AE_LD(IT, SLOT)                                                                                     \
   {                                                                                                         \
-    const int it_ = (IT) < hi ? (IT) : hi - 1;                                                              \
+    const int it_ = (IT);                                                                                   \
     const int tap_ = it_ >> cin_lg, g_ = it_ & gm;                                                          \
     const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
-    B_ = ld4(in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)g_ * in_gstride);                   \
-    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) A_[m_] = ld4(wt_l + (size_t)it_ * wt_itstride + (size_t)m_ * 256); \
+    rb[SLOT] = ld4(in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)g_ * in_gstride);             \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) ra[SLOT][m_] = ld4(wt_l + (size_t)it_ * wt_itstride + (size_t)m_ * 256); \
   }
-#define AE_MF(A_, B_)                                                                                       \
+#define AE_MF(SLOT)                                                                                         \
   _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                      \
-    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].x, B_.x, acc[m_], 0, 0, 0);                       \
-    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].y, B_.y, acc[m_], 0, 0, 0);                       \
-    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].z, B_.z, acc[m_], 0, 0, 0);                       \
-    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[m_].w, B_.w, acc[m_], 0, 0, 0);                       \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SLOT][m_].x, rb[SLOT].x, acc[m_], 0, 0, 0);           \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SLOT][m_].y, rb[SLOT].y, acc[m_], 0, 0, 0);           \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SLOT][m_].z, rb[SLOT].z, acc[m_], 0, 0, 0);           \
+    acc[m_] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[SLOT][m_].w, rb[SLOT].w, acc[m_], 0, 0, 0);           \
   }
-  float4 a0[MT], a1[MT], a2[MT], b0, b1, b2;
-  AE_LD(lo, a0, b0)
-  AE_LD(lo + 1, a1, b1)
-  for (int it = lo; it < hi; it += 3) {
-    AE_LD(it + 2, a2, b2)
-    AE_MF(a0, b0)
-    if (it + 1 < hi) {
-      AE_LD(it + 3, a0, b0)
-      AE_MF(a1, b1)
-    }
-    if (it + 2 < hi) {
-      AE_LD(it + 4, a1, b1)
-      AE_MF(a2, b2)
+  // Every load is unconditional (indices past the wave's last step re-read that step: at most D - 1 redundant L1 hits) and the
+  // branches are scalar, so that hipcc can count the loads in flight and wait for exactly the oldest (vmcnt(N)); loads under
+  // an exec-mask branch made it drain the whole ring (vmcnt(0)) once per trip.
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) AE_LD(lo + d < hi ? lo + d : hi - 1, d)
+  int it = lo;
+  for (; it + D <= hi; it += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      AE_LD(it + u + D - 1 < hi ? it + u + D - 1 : hi - 1, (u + D - 1) % D)
+      __builtin_amdgcn_sched_barrier(0);                         // the load above is issued before these MFMAs, not sunk below them
+      AE_MF(u)
     }
   }
+#pragma unroll
+  for (int u = 0; u < D - 1; ++u)                                // the last < D steps: their operands are already in the ring
+    if (it + u < hi) AE_MF(u)
 #undef AE_LD
 #undef AE_MF
 
@@ -104,12 +113,12 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
       r4[((wave * MT + m) * 4 + q) * 64 + lane] = make_float4(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]);
   __syncthreads();
   if (p >= P) return;
-  // unit u -> (cout tile m, row quad q) of this lane's pixel; the block's waves share the 4 MT units
-  for (int u = wave; u < 4 * MT; u += NW) {
+  // unit u -> (cout tile m, row quad q) of this lane's pixel; the KS waves of the pixel tile share its 4 MT units
+  for (int u = ks; u < 4 * MT; u += KS) {
     const int m = u >> 2, q = u & 3;
-    float4 v = r4[(m * 4 + q) * 64 + lane];
-    for (int w = 1; w < NW; ++w) {                               // wave order: deterministic
-      const float4 t = r4[((w * MT + m) * 4 + q) * 64 + lane];
+    float4 v = r4[((pt * MT + m) * 4 + q) * 64 + lane];
+    for (int k2 = 1; k2 < KS; ++k2) {                            // slice order: deterministic
+      const float4 t = r4[((((k2 << pt_lg) + pt) * MT + m) * 4 + q) * 64 + lane];
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     const int c0 = m_base + m * 32 + q * 8 + 4 * h;              // first of 4 consecutive couts
@@ -128,6 +137,87 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
   }
 }
 
+// The same convolution on 16 px x 16 cout tiles (v_mfma_f32_16x16x4_f32, same flops per cycle): the 256-channel layers at
+// 27 x 17 and 14 x 9 pixels are 120 and 32 tiles of 32 x 32 -- their waves share 120 / 32 of the 256 CUs' MFMA pipes however K
+// is cut (measured 15 us per layer, 7.7 of them pipe time on an eighth of the chip) -- and 464 / 128 tiles of 16 x 16.
+// Lane map as conv_kernels.hip's tail units: one step = two 8-channel groups, lane quarter q4 reads group 2 gp + (q4 >> 1),
+// floats 4 (q4 & 1)..; D: col = lane & 15 -> pixel, rows 4 q4 + r -> cout.
+template <int EPI>
+__global__ void __launch_bounds__(1024)
+ae_conv16_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                 const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg) {
+  LEMO_DYN_SMEM(red);                                          // [wave][64 lanes] float4
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int PT = 1 << pt_lg, pt = wave & (PT - 1), ks = wave >> pt_lg, KS = NW >> pt_lg;
+  const int j = lane & 15, q4 = lane >> 4;
+  const int P = g.H * g.W;
+  const int m_base = blockIdx.y * 16;
+  const int p = (blockIdx.x * PT + pt) * 16 + j;
+  const int pc = p < P ? p : P - 1;
+  const int y = pc / g.W, x = pc - y * g.W;
+  const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
+  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + (size_t)(q4 >> 1) * in_gstride + 4 * (q4 & 1);
+  const float* wt_l = wt + ((size_t)(q4 >> 1) * cout + (m_base + j)) * 8 + 4 * (q4 & 1);
+  const int gp_lg = cin_lg - 1, gm = (1 << gp_lg) - 1, nit = 9 << gp_lg;         // steps of 16 channels
+  const int lo = nit * ks / KS, hi = nit * (ks + 1) / KS;
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 10;
+  float4 ra[D], rb[D];
+#define AE_LD(IT, SLOT)                                                                                     \
+  {                                                                                                         \
+    const int it_ = (IT);                                                                                   \
+    const int tap_ = it_ >> gp_lg, gp_ = it_ & gm;                                                          \
+    const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
+    rb[SLOT] = ld4(in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)(2 * gp_) * in_gstride);      \
+    ra[SLOT] = ld4(wt_l + (size_t)((tap_ << cin_lg) + 2 * gp_) * wt_itstride);                              \
+  }
+#define AE_MF(SLOT)                                                                                         \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[SLOT].x, rb[SLOT].x, acc, 0, 0, 0);                         \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[SLOT].y, rb[SLOT].y, acc, 0, 0, 0);                         \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[SLOT].z, rb[SLOT].z, acc, 0, 0, 0);                         \
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[SLOT].w, rb[SLOT].w, acc, 0, 0, 0);
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) AE_LD(lo + d < hi ? lo + d : hi - 1, d)
+  int it = lo;
+  for (; it + D <= hi; it += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      AE_LD(it + u + D - 1 < hi ? it + u + D - 1 : hi - 1, (u + D - 1) % D)
+      __builtin_amdgcn_sched_barrier(0);
+      AE_MF(u)
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < D - 1; ++u)
+    if (it + u < hi) { AE_MF(u) }
+#undef AE_LD
+#undef AE_MF
+
+  float4* r4 = reinterpret_cast<float4*>(red);
+  r4[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (ks != 0 || p >= P) return;
+  float4 v = r4[pt * 64 + lane];
+  for (int k2 = 1; k2 < KS; ++k2) {                              // slice order: deterministic
+    const float4 t = r4[((k2 << pt_lg) + pt) * 64 + lane];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const int c0 = m_base + 4 * q4;
+  const size_t o = ((size_t)(c0 >> 3) * g.out_HWp + (size_t)((g.out_s * y + 1) * g.out_Wp + g.out_s * x + 1)) * 8 + (c0 & 7);
+  if (EPI == 0 || EPI == 2) {
+    const float4 bb = ld4(bias + c0);
+    v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+    if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+  } else {
+    const size_t oa = ((size_t)(c0 >> 3) * g.aux_HWp + (size_t)((g.aux_s * y + 1) * g.aux_Wp + g.aux_s * x + 1)) * 8 + (c0 & 7);
+    const float4 yy = ld4(aux + oa);
+    v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
+    v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
+  }
+  st4(out + o, v);
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 static int ae_conv_init() {
@@ -140,36 +230,58 @@ static int ae_conv_init() {
   return rc;
 }
 
-// launch shape (MT, NW).  All waves of a SIMD share its MFMA pipe, so the pipe time of a layer does not depend on how its work is
-// cut; what the cut decides is how many waves per SIMD hide each other's load latency and how long one wave's dependent chain
-// is.  Per cout-tile width MT: the largest NW (power of two, <= steps, NW MT <= 16 for 64 KB of LDS) that keeps the launch at
-// <= 4096 waves (4 per SIMD); then the MT with the smaller makespan estimate -- rounds of 1024 waves x steps per wave x MFMAs
-// per step -- ties to the wider tile (fewer activation loads).
-static void ae_conv_shape(int P, int cin, int cout, int* mt_out, int* nw_out) {
-  const int nit = 9 * (cin / 8), ptiles = (P + 31) / 32;
-  long best = -1;
-  for (int mt = 2; mt >= 1; --mt) {
-    if (cout % (32 * mt)) continue;
-    const int tiles = ptiles * (cout / (32 * mt));
-    int nw = 1;
-    while (nw * 2 <= 16 / mt && nw * 2 <= nit && (long)tiles * nw * 2 <= 4096) nw *= 2;
-    const long est = (((long)tiles * nw + 1023) / 1024) * ((nit + nw - 1) / nw) * mt;
-    if (best < 0 || est < best) { best = est; *mt_out = mt; *nw_out = nw; }
+// Launch shape: tile (mt = 2: 32 px x 64 cout, 1: 32 x 32, 3: 16 x 16), pixel tiles per workgroup PT and K slices KS
+// (PT KS waves), from the sweep tools/ae_conv_tune.py (profiles/r03_ae_conv_tune.txt).  The waves of a workgroup share one
+// CU's four MFMA pipes, so a layer's makespan is (workgroups per CU) x (a workgroup's MFMA cycles / the pipes its waves
+// cover): the tile decides how many CUs a small layer reaches -- pick the tile with the smallest estimate, a 16 x 16 tile only
+// if it wins by 15 % (it loads twice the operands per flop).  PT: as many tiles per workgroup (<= 4) as leave >= 200
+// workgroups (they share their weight loads).  KS: four waves per workgroup (one per pipe) -- with the 8-deep operand ring a
+// wave keeps its pipe busy on its own, and every further slice only adds to the LDS reduction (8 or 16 waves measured 10-25 %
+// slower) -- unless a wave's chain would exceed ~36 steps' worth of MFMAs, which is what the deep 256-channel layers need.
+static void ae_conv_shape(int P, int cin, int cout, int* mt_out, int* pt_out, int* ks_out) {
+  double best = -1;
+  for (int mt = 3; mt >= 1; --mt) {
+    const int px = mt == 3 ? 16 : 32, co = mt == 3 ? 16 : 32 * mt;
+    if (cout % co || (mt == 3 && cin < 16)) continue;
+    const int nit = mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8);
+    const long tiles = (long)((P + px - 1) / px) * (cout / co);
+    int pt = 1;
+    while (pt < 4 && tiles / (2 * pt) >= 200) pt *= 2;
+    const int max_nw = mt == 2 ? 8 : 16;
+    int ks = 1;
+    while (pt * ks < 4 && pt * ks * 2 <= max_nw && ks * 2 <= nit) ks *= 2;
+    const int chain = mt == 3 ? 36 : 36 / mt;                    // steps per wave worth ~36 x 4 fp32 32x32x2 MFMAs
+    while ((nit + ks - 1) / ks > chain && pt * ks * 2 <= max_nw) ks *= 2;
+    const int nw = pt * ks;
+    const double per_wg = pt * (mt == 3 ? nit * 4.0 * 32 : nit * 4.0 * mt * 64) / (nw < 4 ? nw : 4);
+    const long wgs = (tiles + pt - 1) / pt;
+    const double est = (wgs > 256 ? wgs / 256.0 : 1.0) * per_wg * (mt == 3 ? 1.15 : 1.0);
+    if (best < 0 || est < best) { best = est; *mt_out = mt; *pt_out = pt; *ks_out = ks; }
   }
 }
 
 int ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, const AeGeo& g, int cin, int cout,
-            int epi, hipStream_t s, int force_mt = 0, int force_nw = 0) {
+            int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0) {
   if (cin % 8 || (cin & (cin - 1)) || cout % 32 || g.H < 1 || g.W < 1 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
-  int mt = 1, nw = 1;
-  ae_conv_shape(g.H * g.W, cin, cout, &mt, &nw);
-  if (force_mt) mt = force_mt;
-  if (force_nw) nw = force_nw;
-  if (cout % (32 * mt) || nw < 1 || nw > 16 || nw * mt > 16 || nw > 9 * (cin / 8)) return LEMO_ERR_ARG;
-  const dim3 grid((g.H * g.W + 31) / 32, cout / (32 * mt));
+  int mt = 1, pt = 1, ks = 1;
+  ae_conv_shape(g.H * g.W, cin, cout, &mt, &pt, &ks);
+  if (force_mt) { mt = force_mt; pt = force_pt; ks = force_ks; }
+  const int lg = ilog2(cin / 8), nw = pt * ks;
+  if (pt < 1 || (pt & (pt - 1)) || ks < 1 || nw > 16) return LEMO_ERR_ARG;
+  const int pt_lg = ilog2(pt);
+  if (mt == 3) {
+    if (cin < 16 || ks > 9 * (cin / 16)) return LEMO_ERR_ARG;
+    const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16);
+    const size_t lds = (size_t)nw * 1024;
+#define LAUNCH16(EPI_) hipLaunchKernelGGL((ae_conv16_kernel<EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg)
+    if (epi == 0) LAUNCH16(0); else if (epi == 1) LAUNCH16(1); else LAUNCH16(2);
+#undef LAUNCH16
+    return (int)hipGetLastError();
+  }
+  if ((mt != 1 && mt != 2) || cout % (32 * mt) || nw * mt > 16 || ks > 9 * (cin / 8)) return LEMO_ERR_ARG;
+  const dim3 grid(((g.H * g.W + 31) / 32 + pt - 1) / pt, cout / (32 * mt));
   const size_t lds = (size_t)nw * mt * 4096;
-  const int lg = ilog2(cin / 8);
-#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout)
+#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg)
   if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
   else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
 #undef LAUNCH
@@ -732,13 +844,13 @@ int lemo_ae_params(void* h, float* flat_out, void* stream) {
 
 /* one convolution of the engine on its own (tests, tools): plain geometry unless in_s / out_s = 2 (see AeGeo) */
 int lemo_ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
-                 int in_s, int out_s, int cin, int cout, int epi, int mt, int nw, void* stream) {
+                 int in_s, int out_s, int cin, int cout, int epi, int mt, int pt, int ks, void* stream) {
   if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux) || (in_s != 1 && in_s != 2) || (out_s != 1 && out_s != 2)) return LEMO_ERR_ARG;
   if (ae_conv_init()) return LEMO_ERR_STATE;
   AeGeo g = geo_plain(H, W);
   if (in_s == 2) { g.in_Wp = fineW + 2; g.in_HWp = (fineH + 2) * (fineW + 2); g.in_s = 2; g.aux_Wp = g.in_Wp; g.aux_HWp = g.in_HWp; g.aux_s = 2; }
   if (out_s == 2) { g.out_Wp = fineW + 2; g.out_HWp = (fineH + 2) * (fineW + 2); g.out_s = 2; }
-  return ae_conv(in, wt, bias, aux, out, g, cin, cout, epi, (hipStream_t)stream, mt, nw);
+  return ae_conv(in, wt, bias, aux, out, g, cin, cout, epi, (hipStream_t)stream, mt, pt, ks);
 }
 
 }  // extern "C"

@@ -140,8 +140,8 @@ def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
     infill._SESSIONS.clear()
 
 
-@pytest.mark.parametrize('mt,nw', [(0, 0), (1, 1), (1, 4), (2, 2), (1, 16), (2, 8)])
-def test_engine_conv_all_geometries(emu_lib, mt, nw):
+@pytest.mark.parametrize('mt,pt,ks', [(0, 0, 0), (1, 1, 1), (1, 1, 4), (1, 4, 2), (2, 2, 2), (1, 2, 8), (2, 1, 8), (3, 1, 1), (3, 4, 1), (3, 2, 8)])
+def test_engine_conv_all_geometries(emu_lib, mt, pt, ks):
     """lemo_ae_conv (K split over the waves of a workgroup, summed in wave order) against torch in its three geometries: plain;
     output written into the even pixels of a twice finer image (= zero-stuffed input of the next stride-2 transposed conv);
     input read at the even pixels of a finer image with the epilogue operand read there too (= adjoint of the stuffing fused
@@ -160,12 +160,12 @@ def test_engine_conv_all_geometries(emu_lib, mt, nw):
     for epi, want in ((0, F.leaky_relu(ref, 0.2)), (2, ref),
                       (1, F.conv2d(x[None], w, None, padding=1)[0] * torch.where(aux > 0, 1.0, 0.2))):
         out = cg8p_alloc(cout, H, W, 'cpu')
-        assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), ptr(to_cg8p(aux)), ptr(out), H, W, 0, 0, 1, 1, cin, cout, epi, mt, nw, None) == 0
+        assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), ptr(to_cg8p(aux)), ptr(out), H, W, 0, 0, 1, 1, cin, cout, epi, mt, pt, ks, None) == 0
         assert rel_err(from_cg8p(out, H, W), want) < 2e-6, epi
     # stuffed output: (y, x) -> (2y, 2x) of a 14 x 17 image; everything else stays zero
     fH, fW = 14, 17
     out = cg8p_alloc(cout, fH, fW, 'cpu')
-    assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, fH, fW, 1, 2, cin, cout, 0, mt, nw, None) == 0
+    assert emu_lib.ae_conv(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, fH, fW, 1, 2, cin, cout, 0, mt, pt, ks, None) == 0
     S = from_cg8p(out, fH, fW)
     want = torch.zeros(cout, fH, fW)
     want[:, 0:2 * H:2, 0:2 * W:2] = F.leaky_relu(ref, 0.2)
@@ -177,7 +177,7 @@ def test_engine_conv_all_geometries(emu_lib, mt, nw):
     full = F.conv2d(xf[None], w, None, padding=1)[0]
     want = full[:, 0:2 * H:2, 0:2 * W:2] * torch.where(aux > 0, 1.0, 0.2)
     out = cg8p_alloc(cout, H, W, 'cpu')
-    assert emu_lib.ae_conv(ptr(to_cg8p(xf)), ptr(wt), None, ptr(to_cg8p(auxf)), ptr(out), H, W, fH, fW, 2, 1, cin, cout, 1, mt, nw, None) == 0
+    assert emu_lib.ae_conv(ptr(to_cg8p(xf)), ptr(wt), None, ptr(to_cg8p(auxf)), ptr(out), H, W, fH, fW, 2, 1, cin, cout, 1, mt, pt, ks, None) == 0
     assert rel_err(from_cg8p(out, H, W), want) < 2e-6
 
 
