@@ -176,9 +176,9 @@ def test_finetune_many_clips_side_by_side_bit_identical(dev):
 
 def test_step_engine_equals_autograd_path_at_full_size(dev):
     """the native step engine (lemo_ae_*) and the round-2 path (autograd function + flat Adam) after the reference's 60 steps at
-    [1,4,210,135]: two summation splits of the same arithmetic.  A parameter moves by <= 60 * 3e-6 = 1.8e-4 in the finetune
-    (Adam's normalised step), so 'the same optimisation' means parameter differences far below that; measured 6e-7 (an entry
-    whose gradient is ~1e-8, Adam's eps, can differ in direction for a few steps), reconstruction 3e-8 of 0.24."""
+    [1,4,210,135]: two summation splits of the same arithmetic.  A parameter moves by ~60 * 3e-6 = 2e-4 in the finetune
+    (Adam's normalised step; measured 2.2e-4), so 'the same optimisation' means parameter differences far below that; measured
+    6e-7 .. 2e-6 (an entry whose gradient is ~1e-8, Adam's eps, can differ in direction for a few steps), reconstruction 3e-8 of 0.24."""
     import time
     from lemo_amd import infill
     from lemo_amd.infill import AE, finetune_and_infill
@@ -192,7 +192,7 @@ def test_step_engine_equals_autograd_path_at_full_size(dev):
     assert float((ra - rb).abs().max()) < 1e-6 * max(1.0, float(rb.abs().max())) and float((za - zb).abs().max()) < 2e-6 * max(1.0, float(zb.abs().max()))
     worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(a.parameters(), b.parameters()))
     moved = max(float((p.detach() - ae_w[k]).abs().max()) for k, p in a.named_parameters())
-    assert worst < 5e-6 and 1e-5 < moved < 2e-4, (worst, moved)
+    assert worst < 5e-6 and 1e-5 < moved < 4e-4, (worst, moved)
     # eager launches == graph replays, bit for bit (same kernels, same order)
     re_, ze = finetune_and_infill(a, ae_w, x, m, steps=60, engine=True, use_graph=False)
     assert torch.equal(ra, re_) and torch.equal(za, ze)
