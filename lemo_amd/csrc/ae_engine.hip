@@ -292,15 +292,10 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
 // all weight gradients of a step in one launch
 // ---------------------------------------------------------------------------------------------------------------------
 //   dW[co][ci][tap] = sum_p dY[co][p] X[ci][p + tap]        (X zero-padded: CG8P border)
-// GEMM per tap: M = ci (A = X shifted), N = co (B = dY), K = pixels.  K runs over the PADDED linear pixel index q of the
-// interior rows (border columns included: dY is zero there, so they add nothing and the taps of q are simply q + dy Wp + dx
-// with no row arithmetic).  One workgroup = one 32 (ci) x 32 (co) tile over a slab of 512 padded pixels for ALL nine taps:
-// six waves = three kernel rows dy x two halves of the slab; a wave keeps three accumulators (dx = -1, 0, +1) and, per step
-// of two pixels, multiplies ONE dY operand with three X operands out of a sliding 17-pixel window per 8 steps -- one scalar
-// load per MFMA.  (Round 3's first version ran one tap per workgroup: two loads per MFMA, each touching 8 cache lines; the
-// launch took 134 us for 70 us of MFMA pipe time, bound by the texture-address path.)  The halves are summed through LDS.
-// With ci on the MFMA's row axis a lane holds 4 consecutive ci of one co per accumulator quad: the slab partial is stored with
-// dwordx4 stores, 1 KiB contiguous per wave, directly in the forward pack wt[tap][ci/8][co][8] -- the layout of the parameter
+// GEMM per tap: M = ci (A = X shifted), N = co (B = dY), K = pixels; one workgroup = one 32 (ci) x 32 (co) tile of one tap
+// over a slab of 512 pixels, its four waves a quarter of the slab each, summed through LDS in wave order.  With ci on the
+// MFMA's row axis a lane holds 4 consecutive ci of one co per accumulator quad: the slab partial is stored with dwordx4
+// stores, 1 KiB contiguous per wave, directly in the forward pack wt[tap][ci/8][co][8] -- the layout of the parameter
 // vector, so the optimizer reads it with unit stride.
 #define AE_SLAB 512
 struct AeWgradJob {
@@ -310,85 +305,79 @@ struct AeWgradJob {
 #define AE_NLAYER 20
 struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int n; };
 
-__global__ void __launch_bounds__(384)
+__global__ void __launch_bounds__(256)
 ae_wgrad_multi_kernel(AeWgradJobs J) {
-  __shared__ float red[3][48][64];
+  __shared__ float red[3][16][64];
   int k = 0;
   while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].first_block) ++k;       // block -> layer (uniform)
   const AeWgradJob& q = J.j[k];
   const int blk = (int)blockIdx.x - q.first_block;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int W = q.W, Wp = W + 2, HWp = (q.H + 2) * Wp, P = q.H * W;
   if (blk >= q.ntile) {
     // bias gradient of one channel: db[co] = sum_p dY[co][p], eight independent loads in flight per thread
     const int co = blk - q.ntile;
     const float* base = q.dy + (size_t)(co >> 3) * HWp * 8 + (co & 7);
     float a = 0.f;
-    for (int p0 = threadIdx.x; p0 < P; p0 += 384 * 8) {
+    for (int p0 = threadIdx.x; p0 < P; p0 += 256 * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int p = p0 + 384 * u, pc = p < P ? p : P - 1;
+        const int p = p0 + 256 * u, pc = p < P ? p : P - 1;
         const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;
         v[u] = base[(size_t)((y + 1) * Wp + (xx + 1)) * 8];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a += (p0 + 384 * u < P) ? v[u] : 0.f;
+      for (int u = 0; u < 8; ++u) a += (p0 + 256 * u < P) ? v[u] : 0.f;
     }
     a = block_sum(a, &red[0][0][0]);
     if (threadIdx.x == 0) q.db[co] = a;
     return;
   }
   const int i = lane & 31, kk = lane >> 5;
-  const int r = wave % 3, hq = wave / 3;                           // kernel row dy = r - 1; half of the slab
   const int cin = q.cin, cout = q.cout;
   const int cot = cout >> 5, cit = (cin + 31) >> 5;
-  int tile = blk;                                                  // (slab, co tile, ci tile)
+  int tile = blk;                                                  // (slab, tap, co tile, ci tile)
   const int ct = tile % cit; tile /= cit;
-  const int mt = tile % cot;
-  const int slab = tile / cot;
+  const int mt = tile % cot; tile /= cot;
+  const int tap = tile % 9, slab = tile / 9;
+  const int dyo = tap / 3 - 1, dxo = tap % 3 - 1;
   const int co = mt * 32 + i;
   int ci = ct * 32 + i;
-  if (ci >= cin) ci = cin - 1;                                     // rows past cin are computed and never stored
+  const bool ci_ok = ci < cin;
+  if (!ci_ok) ci = cin - 1;
   const float* bp = q.dy + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
   const float* ap = q.x + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
-  const int Q1 = (q.H + 1) * Wp;                                   // interior rows: padded pixels [Wp, (H + 1) Wp)
-  const int qs0 = Wp + slab * AE_SLAB + hq * (AE_SLAB / 2);
-  const int qs = qs0 < Q1 ? qs0 : Q1, qe = qs0 + AE_SLAB / 2 < Q1 ? qs0 + AE_SLAB / 2 : Q1;
-  const int off = (r - 1) * Wp + kk - 1;                           // window origin of this lane relative to the group's first pixel
-  f32x16 acc0, acc1, acc2;
+  f32x16 acc;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; }
-  // a group = 8 steps = 16 pixels: dY of pixel qb + 2u + kk, X of pixels qb + off + 0..16 (clamped into the plane: the two
-  // positions that can fall outside belong to border pixels, whose dY is zero).  Group g + 1 is requested before the 24
-  // MFMAs of group g (two register sets).
-  float b[2][8], xw[2][17];
-#define WG_LOAD(SET, QB)                                                                           \
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int q0 = slab * AE_SLAB + wave * (AE_SLAB / 4);            // this wave's quarter (empty past the image end)
+  const int p0 = q0 < P ? q0 : P, p1 = (q0 + AE_SLAB / 4 < P) ? q0 + AE_SLAB / 4 : P;
+  // operands of pixels pb+16.. are requested before the 8 MFMAs of pixels pb.. (two register sets)
+  float a[2][8], b[2][8];
+#define WG_LOAD(SET, PB)                                                                           \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
-    const int p = (QB) + 2 * u + kk;                                                               \
-    const float bv = bp[(size_t)(p < qe ? p : qe - 1) * 8];                                        \
-    b[SET][u] = p < qe ? bv : 0.f;                                                                 \
-  }                                                                                                \
-  _Pragma("unroll") for (int t = 0; t < 17; ++t) {                                                 \
-    int o = (QB) + off + t;                                                                        \
-    o = o < 0 ? 0 : (o < HWp ? o : HWp - 1);                                                       \
-    xw[SET][t] = ap[(size_t)o * 8];                                                                \
+    const int p = (PB) + 2 * u + kk;                                                               \
+    const bool ok = p < p1;                                                                        \
+    const int pc = ok ? p : p1 - 1;                                                                \
+    const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;   /* p / W, host-made magic */ \
+    const int o = (y + 1) * Wp + (xx + 1);                                                         \
+    const float bv = bp[(size_t)o * 8];                                                            \
+    const float av = ap[(size_t)(o + dyo * Wp + dxo) * 8];                                         \
+    b[SET][u] = ok ? bv : 0.f;                                                                     \
+    a[SET][u] = (ok && ci_ok) ? av : 0.f;                                                          \
   }
 #define WG_MFMA(SET)                                                                               \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u], b[SET][u], acc0, 0, 0, 0);         \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u + 1], b[SET][u], acc1, 0, 0, 0);     \
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u + 2], b[SET][u], acc2, 0, 0, 0);     \
-  }
-  if (qs < qe) {
-    WG_LOAD(0, qs)
-    for (int qb = qs; qb < qe; qb += 32) {
-      if (qb + 16 < qe) { WG_LOAD(1, qb + 16) }
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SET][u], b[SET][u], acc, 0, 0, 0);
+  if (p0 < p1) {
+    WG_LOAD(0, p0)
+    for (int pb = p0; pb < p1; pb += 32) {
+      if (pb + 16 < p1) { WG_LOAD(1, pb + 16) }
       __builtin_amdgcn_sched_barrier(0);
       WG_MFMA(0)
       __builtin_amdgcn_sched_barrier(0);
-      if (qb + 16 < qe) {
-        if (qb + 32 < qe) { WG_LOAD(0, qb + 32) }
+      if (pb + 16 < p1) {
+        if (pb + 32 < p1) { WG_LOAD(0, pb + 32) }
         __builtin_amdgcn_sched_barrier(0);
         WG_MFMA(1)
         __builtin_amdgcn_sched_barrier(0);
@@ -397,27 +386,24 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
   }
 #undef WG_LOAD
 #undef WG_MFMA
-  if (hq == 1) {
+  if (wave > 0) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { red[r][e][lane] = acc0[e]; red[r][16 + e][lane] = acc1[e]; red[r][32 + e][lane] = acc2[e]; }
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
   }
   __syncthreads();
-  if (hq == 1) return;
+  if (wave > 0) return;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { acc0[e] += red[r][e][lane]; acc1[e] += red[r][16 + e][lane]; acc2[e] += red[r][32 + e][lane]; }
-  // D: col = lane & 31 -> co, rows (e & 3) + 8 (e >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
+  // D: col = lane & 31 -> co, rows (r & 3) + 8 (r >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
   float* outp = q.partial + (size_t)slab * (9 * (size_t)cin * cout);
   const int CG = cin >> 3;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int cg = ct * 4 + qd;
-    if (cg < CG) {
-      float* o = outp + (((size_t)(3 * r) * CG + cg) * cout + co) * 8 + 4 * kk;
-      const size_t tap_stride = (size_t)CG * cout * 8;
-      st4(o, make_float4(acc0[4 * qd], acc0[4 * qd + 1], acc0[4 * qd + 2], acc0[4 * qd + 3]));
-      st4(o + tap_stride, make_float4(acc1[4 * qd], acc1[4 * qd + 1], acc1[4 * qd + 2], acc1[4 * qd + 3]));
-      st4(o + 2 * tap_stride, make_float4(acc2[4 * qd], acc2[4 * qd + 1], acc2[4 * qd + 2], acc2[4 * qd + 3]));
-    }
+    if (cg < CG)
+      st4(outp + (((size_t)tap * CG + cg) * cout + co) * 8 + 4 * kk, make_float4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]));
   }
 }
 
@@ -617,7 +603,7 @@ static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
     l.wb_off = i == 0 ? -1 : wbo; if (i) wbo += 9 * l.cin_pad * l.cout_pad;      // the first layer needs no backward-data
     l.flat_w = flat; flat += 9 * l.cin * l.cout;
     l.flat_b = flat; flat += l.cout;
-    l.nslab = (e->H[l.level] * (e->W[l.level] + 2) + AE_SLAB - 1) / AE_SLAB;       // slabs of padded interior pixels
+    l.nslab = (e->H[l.level] * e->W[l.level] + AE_SLAB - 1) / AE_SLAB;
     l.part_off = part; part += (size_t)l.nslab * 9 * l.cin_pad * l.cout_pad;
   }
   e->n_w = w; e->n_wb = wbo; e->n_flat = flat; e->n_part = part;
@@ -716,11 +702,11 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     q.dy = e->dp[i]; q.x = e->xin[i]; q.partial = e->part + l.part_off; q.db = e->dbias + l.b_off;
     q.H = e->H[l.level]; q.W = e->W[l.level]; q.wmagic = (unsigned)((1ull << 32) / (unsigned)q.W + 1);
     q.cin = l.cin_pad; q.cout = l.cout_pad; q.cout_real = l.cout; q.nslab = l.nslab;
-    q.ntile = l.nslab * (l.cout_pad / 32) * ((l.cin_pad + 31) / 32);
+    q.ntile = l.nslab * 9 * (l.cout_pad / 32) * ((l.cin_pad + 31) / 32);
     q.first_block = nb;
     nb += q.ntile + l.cout;
   }
-  hipLaunchKernelGGL(ae_wgrad_multi_kernel, dim3(nb), dim3(384), 0, s, J);
+  hipLaunchKernelGGL(ae_wgrad_multi_kernel, dim3(nb), dim3(256), 0, s, J);
   CHK_((int)hipGetLastError());
   // ---- Adam
   AeAdamArgs A;
