@@ -429,10 +429,12 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
 
 __global__ void __launch_bounds__(256)
 ae_adam_kernel(AeAdamArgs A) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  // one thread = four consecutive entries (one half of an 8-channel group of one (tap, cout)): dwordx4 everywhere but the
+  // scatter into the backward pack
+  const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= A.n_all) return;
   const float bc1 = A.ctr[1], bc2s = A.ctr[2];
-  float g;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int wb_idx = -1;
   if (idx < A.n_w) {
     int k = 0;
@@ -444,19 +446,27 @@ ae_adam_kernel(AeAdamArgs A) {
     const int cg = t & ((1 << q.cin_lg) - 1), tap = t >> q.cin_lg;
     const int ci = cg * 8 + c8;
     const int n_w = 9 << (q.cin_lg + 3 + q.cout_lg);
-    float a = 0.f;
-    if (ci < q.cin && co < q.cout)
-      for (int s = 0; s < q.nslab; ++s) a += q.partial[(size_t)s * n_w + i];     // slab order: deterministic
-    g = a;
+    if (ci < q.cin && co < q.cout) {
+      for (int s = 0; s < q.nslab; ++s) {                           // slab order: deterministic
+        const float4 pv = ld4(q.partial + (size_t)s * n_w + i);
+        g.x += pv.x; g.y += pv.y; g.z += pv.z; g.w += pv.w;
+      }
+      if (ci + 1 >= q.cin) g.y = 0.f;                               // padded input channels keep a zero gradient
+      if (ci + 2 >= q.cin) g.z = 0.f;
+      if (ci + 3 >= q.cin) g.w = 0.f;
+    }
     if (q.wb_off >= 0)        // backward-data pack of the same convolution: wtb[8 - tap][co/8][ci][co%8]
       wb_idx = q.wb_off + ((((8 - tap) << (q.cout_lg - 3)) + (co >> 3)) << (q.cin_lg + 3)) * 8 + ci * 8 + (co & 7);
   } else {
-    g = A.dbias[idx - A.n_w];
+    g = ld4(A.dbias + (idx - A.n_w));
   }
-  float m = A.m[idx], v = A.v[idx];
-  const float p = adam_update(A.theta[idx], g, m, v, A.lr, bc1, bc2s);
-  A.m[idx] = m; A.v[idx] = v; A.theta[idx] = p;
-  if (wb_idx >= 0) A.wb[wb_idx] = p;
+  float4 m = ld4(A.m + idx), v = ld4(A.v + idx), p = ld4(A.theta + idx);
+  p.x = adam_update(p.x, g.x, m.x, v.x, A.lr, bc1, bc2s);
+  p.y = adam_update(p.y, g.y, m.y, v.y, A.lr, bc1, bc2s);
+  p.z = adam_update(p.z, g.z, m.z, v.z, A.lr, bc1, bc2s);
+  p.w = adam_update(p.w, g.w, m.w, v.w, A.lr, bc1, bc2s);
+  st4(A.m + idx, m); st4(A.v + idx, v); st4(A.theta + idx, p);
+  if (wb_idx >= 0) { A.wb[wb_idx] = p.x; A.wb[wb_idx + 8] = p.y; A.wb[wb_idx + 16] = p.z; A.wb[wb_idx + 24] = p.w; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -716,7 +726,7 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
   }
   A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.dbias = e->dbias; A.ctr = e->ctr;
   A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr;
-  hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all + 255) / 256), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all / 4 + 255) / 256), dim3(256), 0, s, A);        // (n_w and n_b are multiples of 4)
   return (int)hipGetLastError();
 }
 

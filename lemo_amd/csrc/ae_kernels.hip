@@ -39,9 +39,10 @@ maxpool3s2_fwd_kernel(const float* __restrict__ in, int H, int W, float* __restr
   float* o = out + ((size_t)g * HWop + (yo + 1) * Wop + (xo + 1)) * 8;
   st4(o, make_float4(best[0], best[1], best[2], best[3]));
   st4(o + 4, make_float4(best[4], best[5], best[6], best[7]));
-  unsigned char* io = idx + ((size_t)g * Ho * Wo + p) * 8;
+  uint2 iw = make_uint2(0u, 0u);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) io[c] = bi[c];
+  for (int c = 0; c < 4; ++c) { iw.x |= (unsigned)bi[c] << (8 * c); iw.y |= (unsigned)bi[4 + c] << (8 * c); }
+  *reinterpret_cast<uint2*>(idx + ((size_t)g * Ho * Wo + p) * 8) = iw;            // (little-endian: byte c = channel c)
 }
 
 // din[y][x] = sum over the <= 4 windows covering (y,x) whose argmax is (y,x) of dout ; optionally
@@ -65,17 +66,25 @@ maxpool3s2_bwd_kernel(const float* __restrict__ dout, const unsigned char* __res
       if (xo < 0 || xo >= Wo) continue;
       const int kx = x - (2 * xo - 1);
       if (kx < 0 || kx > 2) continue;
-      const unsigned char want = (unsigned char)(ky * 3 + kx);
-      const unsigned char* io = idx + ((size_t)g * Ho * Wo + yo * Wo + xo) * 8;
+      const unsigned want = (unsigned)(ky * 3 + kx);
+      // the window's 8 winners and 8 gradients in three loads (8 byte loads + 8 dword loads measured 8.6 us per launch)
+      const uint2 iw = *reinterpret_cast<const uint2*>(idx + ((size_t)g * Ho * Wo + yo * Wo + xo) * 8);
       const float* q = dout + ((size_t)g * HWop + (yo + 1) * Wop + (xo + 1)) * 8;
+      const float4 q0 = ld4(q), q1 = ld4(q + 4);
+      const float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-      for (int c = 0; c < 8; ++c) if (io[c] == want) acc[c] += q[c];
+      for (int c = 0; c < 8; ++c) {
+        const unsigned w8 = ((c < 4 ? iw.x : iw.y) >> (8 * (c & 3))) & 0xffu;
+        if (w8 == want) acc[c] += qv[c];
+      }
     }
   }
   const size_t o = ((size_t)g * HWp + (y + 1) * Wp + (x + 1)) * 8;
   if (act) {
+    const float4 a0 = ld4(act + o), a1 = ld4(act + o + 4);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] *= lrelu_grad_from_out(act[o + c]);
+    for (int c = 0; c < 8; ++c) acc[c] *= lrelu_grad_from_out(av[c]);
   }
   st4(din + o, make_float4(acc[0], acc[1], acc[2], acc[3]));
   st4(din + o + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
