@@ -53,7 +53,8 @@ def test_descriptor_layouts_match_the_header():
     import tempfile
     from lemo_amd import _hip
     fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame']),
-              'lemo_prox_desc': (_hip.ProxDesc, ['enc_w3_inv', 'sdf', 'pose_embedding', 'losses'])}
+              'lemo_prox_desc': (_hip.ProxDesc, ['enc_w3_inv', 'sdf', 'pose_embedding', 'losses']),
+              'lemo_ae_desc': (_hip.AeDesc, ['lr', 'ws', 'ws_floats'])}
     src = '#include <cstdio>\n#include <cstddef>\n#include "lemo_hip.h"\nint main(){\n'
     for name, (_, fl) in fields.items():
         src += f'printf("%zu", sizeof({name}));' + ''.join(f'printf(" %zu", offsetof({name}, {f}));' for f in fl) + 'printf("\\n");\n'

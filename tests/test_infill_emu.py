@@ -211,3 +211,22 @@ def test_engine_equals_autograd_path(emu_lib):
     th0 = ses.ws[:n0].reshape(9, 1, 32, 8)
     assert float(th0[..., 4:].abs().max()) == 0.0 and float(th0[..., :4].abs().max()) > 0.0
     infill._SESSIONS.clear()
+
+
+def test_engine_refuses_bad_use(emu_lib):
+    """error behaviour of the lemo_ae_* entry points: shapes the engine does not take, a workspace that is too small, steps before
+    a clip is loaded (LEMO_ERR_STATE = 10003), null arguments (LEMO_ERR_ARG = 10002)"""
+    import ctypes as C
+    from lemo_amd import _hip
+    assert emu_lib.ae_ws_floats(1, 40) == 0 and emu_lib.ae_ws_floats(4096, 4096) == 0
+    n = int(emu_lib.ae_ws_floats(18, 22))
+    assert n > 0 and emu_lib.ae_n_param() == sum(v.numel() for v in _weights().values())
+    ws = torch.zeros(n)
+    assert not emu_lib.ae_create(C.byref(_hip.AeDesc(18, 22, 3e-6, ptr(ws), n - 64)))          # workspace too small
+    assert not emu_lib.ae_create(C.byref(_hip.AeDesc(18, 22, 0.0, ptr(ws), n)))               # lr must be positive
+    h = emu_lib.ae_create(C.byref(_hip.AeDesc(18, 22, 3e-6, ptr(ws), n)))
+    assert h
+    rec = torch.empty(18, 22)
+    assert emu_lib.ae_step(h, 1, 0, None) == 10003 and emu_lib.ae_forward(h, ptr(rec), None, None) == 10003
+    assert emu_lib.ae_load(h, None, None, None, None) == 10002 and emu_lib.ae_step(h, -1, 0, None) == 10002
+    emu_lib.ae_destroy(h)

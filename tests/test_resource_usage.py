@@ -25,6 +25,10 @@ BUDGETS = {
     'smplx_pose_bwd_kernel': ('pose_kernels.hip', 256, 256),
     'fit_losses_kernel': ('loss_kernels.hip', 128, 256),
     'marker_c1_kernel': ('loss_kernels.hip', 128, 256),
+    'ae_conv_kernelILi1ELi0E': ('ae_engine.hip', 128, 1024),                            # AE step engine: up to 16 waves per workgroup
+    'ae_conv_kernelILi2ELi1E': ('ae_engine.hip', 128, 1024),
+    'ae_conv16_kernelILi0E': ('ae_engine.hip', 128, 1024),
+    'ae_wgrad_multi_kernel': ('ae_engine.hip', 128, 256),                               # 8 workgroups of 4 waves per CU
 }
 
 
