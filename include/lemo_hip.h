@@ -281,6 +281,9 @@ int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, v
 int lemo_ae_step(void* h, int n, int use_graph, void* stream);
 int lemo_ae_forward(void* h, float* rec, float* z, void* stream);
 int lemo_ae_params(void* h, float* flat_out, void* stream);
+/* diagnostics (tools/ae_wgrad_probe.py): the step's weight-gradient launch alone on the engine's current buffers; mode 0 = as in
+ * a step, 1 = operands loaded once per wave, 2 = loads without MFMAs (1 and 2 leave garbage in the slab partials). */
+int lemo_ae_wgrad_probe(void* h, int mode, void* stream);
 /* one convolution of the engine on its own (tests, tools).  Enumerates an H x W pixel grid; in_s = 2: the input (and the
  * epi-1 operand) is a fineH x fineW image read at its even pixels; out_s = 2: the output is written to the even pixels of a
  * fineH x fineW image (zero-stuffing geometry).  mt = 0: the engine's own launch shape; else tile mt (1: 32 px x 32 cout,

@@ -292,119 +292,126 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
 // all weight gradients of a step in one launch
 // ---------------------------------------------------------------------------------------------------------------------
 //   dW[co][ci][tap] = sum_p dY[co][p] X[ci][p + tap]        (X zero-padded: CG8P border)
-// GEMM per tap: M = ci (A = X shifted), N = co (B = dY), K = pixels; one workgroup = one 32 (ci) x 32 (co) tile of one tap
-// over a slab of 512 pixels, its four waves a quarter of the slab each, summed through LDS in wave order.  With ci on the
-// MFMA's row axis a lane holds 4 consecutive ci of one co per accumulator quad: the slab partial is stored with dwordx4
-// stores, 1 KiB contiguous per wave, directly in the forward pack wt[tap][ci/8][co][8] -- the layout of the parameter
+// GEMM per tap: M = ci (A = X shifted), N = co (B = dY), K = pixels.  K runs over the PADDED linear pixel index q of the
+// interior rows (border columns included: dY is zero there, so they add nothing and the taps of q are simply q + dy Wp + dx
+// with no row arithmetic).  One WAVE = one workgroup = one 32 (ci) x 32 (co) tile, one kernel row dy, one slab of <= 576 padded
+// pixels: three accumulators (dx = -1, 0, +1) and, per step of two pixels, ONE dY operand times three X operands out of a
+// sliding 17-pixel window per 8 steps -- one scalar load per MFMA, every one of them `base + immediate` (consecutive pixels are
+// 32 bytes apart; nothing is clamped: the two window positions that can fall outside a channel-group plane belong to border
+// pixels (dY = 0) and land in the neighbouring plane or in the zeroed guard floats every engine buffer is wrapped in).  No LDS,
+// no barrier; the wave of the centre row and first ci tile also sums its dY operands: the bias gradient's slab partial.
+// How it got here (tools/ae_wgrad_probe.py, profiles/r03_ae_wgrad_probe.txt): one tap per 4-wave workgroup with per-load index
+// arithmetic took 134 us for 70 us of MFMA pipe time; all taps per 6-wave workgroup (3 rows x 2 halves, LDS reduction) 150 us --
+// 120 us of it with the loads REMOVED: six waves on a CU's four matrix pipes load two of them twice as much as the others,
+// and 36 KB of LDS + 112 registers held a CU at two such workgroups.  Single-wave workgroups leave the placement to the
+// dispatcher, which balances waves over the pipes.
+// With ci on the MFMA's row axis a lane holds 4 consecutive ci of one co per accumulator quad: the slab partial is stored with
+// dwordx4 stores, 1 KiB contiguous per wave, directly in the forward pack wt[tap][ci/8][co][8] -- the layout of the parameter
 // vector, so the optimizer reads it with unit stride.
-#define AE_SLAB 512
+#define AE_SLAB 576               // padded pixels per slab, at most (a layer's slabs are equal parts: ae_slabs)
 struct AeWgradJob {
-  const float* dy; const float* x; float* partial; float* db;        // db: [cout] bias gradient (entries >= cout_real untouched)
-  int H, W; unsigned wmagic; int cin, cout, cout_real, nslab, ntile, first_block;
+  const float* dy; const float* x; float* partial; float* dbp;       // dbp: [nslab][2][cout] bias-gradient partials (pixel parity kept apart)
+  int H, W; int cin, cout, nslab, slab_len, nwave;
 };
 #define AE_NLAYER 20
-struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int n; };
+// the grid is the layers' waves in the order the host wants them DISPATCHED: the long ones first (full 576-pixel slabs run 23 us),
+// the short ones of the 14 x 9 layers last, so that the launch does not end on a few long waves
+struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int first[AE_NLAYER + 1]; int n; };
 
-__global__ void __launch_bounds__(256)
+template <int MODE>        // 0: the product; diagnostics (tools/ae_wgrad_probe.py): 1 = operands loaded once per wave, 2 = no MFMAs
+__global__ void __launch_bounds__(64)
 ae_wgrad_multi_kernel(AeWgradJobs J) {
-  __shared__ float red[3][16][64];
   int k = 0;
-  while (k + 1 < J.n && (int)blockIdx.x >= J.j[k + 1].first_block) ++k;       // block -> layer (uniform)
+  while (k + 1 < J.n && (int)blockIdx.x >= J.first[k + 1]) ++k;               // block -> layer (uniform)
   const AeWgradJob& q = J.j[k];
-  const int blk = (int)blockIdx.x - q.first_block;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int W = q.W, Wp = W + 2, HWp = (q.H + 2) * Wp, P = q.H * W;
-  if (blk >= q.ntile) {
-    // bias gradient of one channel: db[co] = sum_p dY[co][p], eight independent loads in flight per thread
-    const int co = blk - q.ntile;
-    const float* base = q.dy + (size_t)(co >> 3) * HWp * 8 + (co & 7);
-    float a = 0.f;
-    for (int p0 = threadIdx.x; p0 < P; p0 += 256 * 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int p = p0 + 256 * u, pc = p < P ? p : P - 1;
-        const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;
-        v[u] = base[(size_t)((y + 1) * Wp + (xx + 1)) * 8];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += (p0 + 256 * u < P) ? v[u] : 0.f;
-    }
-    a = block_sum(a, &red[0][0][0]);
-    if (threadIdx.x == 0) q.db[co] = a;
-    return;
-  }
+  int tile = (int)blockIdx.x - J.first[k];                         // (slab, co tile, ci tile, kernel row)
+  const int lane = threadIdx.x;
+  const int Wp = q.W + 2, HWp = (q.H + 2) * Wp;
   const int i = lane & 31, kk = lane >> 5;
   const int cin = q.cin, cout = q.cout;
   const int cot = cout >> 5, cit = (cin + 31) >> 5;
-  int tile = blk;                                                  // (slab, tap, co tile, ci tile)
+  const int r = tile % 3; tile /= 3;                               // kernel row dy = r - 1
   const int ct = tile % cit; tile /= cit;
-  const int mt = tile % cot; tile /= cot;
-  const int tap = tile % 9, slab = tile / 9;
-  const int dyo = tap / 3 - 1, dxo = tap % 3 - 1;
+  const int mt = tile % cot;
+  const int slab = tile / cot;
   const int co = mt * 32 + i;
   int ci = ct * 32 + i;
-  const bool ci_ok = ci < cin;
-  if (!ci_ok) ci = cin - 1;
+  if (ci >= cin) ci = cin - 1;                                     // rows past cin are computed and never stored
   const float* bp = q.dy + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
   const float* ap = q.x + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
-  f32x16 acc;
+  const int Q1 = (q.H + 1) * Wp;                                   // interior rows: padded pixels [Wp, (H + 1) Wp)
+  const int qs = Wp + slab * q.slab_len;
+  const int qe = qs + q.slab_len < Q1 ? qs + q.slab_len : Q1;      // (host: qs < Q1)
+  const int off = (r - 1) * Wp + kk - 1;                           // window origin of this lane relative to the group's first pixel
+  f32x16 acc0, acc1, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int q0 = slab * AE_SLAB + wave * (AE_SLAB / 4);            // this wave's quarter (empty past the image end)
-  const int p0 = q0 < P ? q0 : P, p1 = (q0 + AE_SLAB / 4 < P) ? q0 + AE_SLAB / 4 : P;
-  // operands of pixels pb+16.. are requested before the 8 MFMAs of pixels pb.. (two register sets)
-  float a[2][8], b[2][8];
-#define WG_LOAD(SET, PB)                                                                           \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
-    const int p = (PB) + 2 * u + kk;                                                               \
-    const bool ok = p < p1;                                                                        \
-    const int pc = ok ? p : p1 - 1;                                                                \
-    const int y = (int)__umulhi((unsigned)pc, q.wmagic), xx = pc - y * W;   /* p / W, host-made magic */ \
-    const int o = (y + 1) * Wp + (xx + 1);                                                         \
-    const float bv = bp[(size_t)o * 8];                                                            \
-    const float av = ap[(size_t)(o + dyo * Wp + dxo) * 8];                                         \
-    b[SET][u] = ok ? bv : 0.f;                                                                     \
-    a[SET][u] = (ok && ci_ok) ? av : 0.f;                                                          \
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; acc2[e] = 0.f; }
+  float bsum = 0.f;
+  // a group = 8 steps = 16 pixels: dY of pixel qb + 2u + kk, X of pixels qb + off + 0..16.  Group g + 1 is requested before
+  // the 24 MFMAs of group g (two register sets).
+  float b[2][8], xw[2][17];
+#define WG_LOAD(SET, QB)                                                                           \
+  {                                                                                                \
+    const float* bq = bp + (std::ptrdiff_t)((QB) + kk) * 8;                                        \
+    const float* aq = ap + (std::ptrdiff_t)((QB) + off) * 8;                                       \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) b[SET][u] = bq[16 * u];                          \
+    _Pragma("unroll") for (int t = 0; t < 17; ++t) xw[SET][t] = aq[8 * t];                         \
+    if ((QB) + 16 > qe) {                      /* last group of the slab: pixels past its end */    \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) if ((QB) + 2 * u + kk >= qe) b[SET][u] = 0.f;  \
+    }                                                                                              \
   }
 #define WG_MFMA(SET)                                                                               \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SET][u], b[SET][u], acc, 0, 0, 0);
-  if (p0 < p1) {
-    WG_LOAD(0, p0)
-    for (int pb = p0; pb < p1; pb += 32) {
-      if (pb + 16 < p1) { WG_LOAD(1, pb + 16) }
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                  \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u], b[SET][u], acc0, 0, 0, 0);         \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u + 1], b[SET][u], acc1, 0, 0, 0);     \
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xw[SET][2 * u + 2], b[SET][u], acc2, 0, 0, 0);     \
+    bsum += b[SET][u];                                                                             \
+  }
+#define WG_FAKE(SET)                                                                               \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) { acc0[u] += b[SET][u] + xw[SET][2 * u]; acc1[u] += xw[SET][2 * u + 1]; } \
+  acc2[0] += xw[SET][16];
+  if (MODE == 3) {
+    // single register set: more waves per SIMD (83 instead of 112 registers) cover each other's load phases
+    for (int qb = qs; qb < qe; qb += 16) {
+      WG_LOAD(0, qb)
       __builtin_amdgcn_sched_barrier(0);
       WG_MFMA(0)
       __builtin_amdgcn_sched_barrier(0);
-      if (pb + 16 < p1) {
-        if (pb + 32 < p1) { WG_LOAD(0, pb + 32) }
-        __builtin_amdgcn_sched_barrier(0);
-        WG_MFMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-      }
     }
+  } else {
+  WG_LOAD(0, qs)
+  if (MODE == 1) { WG_LOAD(1, qs) }
+  for (int qb = qs; qb < qe; qb += 32) {
+    if (MODE != 1 && qb + 16 < qe) { WG_LOAD(1, qb + 16) }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE != 2) { WG_MFMA(0) } else { WG_FAKE(0) }
+    __builtin_amdgcn_sched_barrier(0);
+    if (qb + 16 < qe) {
+      if (MODE != 1 && qb + 32 < qe) { WG_LOAD(0, qb + 32) }
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE != 2) { WG_MFMA(1) } else { WG_FAKE(1) }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   }
 #undef WG_LOAD
 #undef WG_MFMA
-  if (wave > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[w][r][lane];
-  // D: col = lane & 31 -> co, rows (r & 3) + 8 (r >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
+#undef WG_FAKE
+  // D: col = lane & 31 -> co, rows (e & 3) + 8 (e >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
   float* outp = q.partial + (size_t)slab * (9 * (size_t)cin * cout);
   const int CG = cin >> 3;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const int cg = ct * 4 + qd;
-    if (cg < CG)
-      st4(outp + (((size_t)tap * CG + cg) * cout + co) * 8 + 4 * kk, make_float4(acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]));
+    if (cg < CG) {
+      float* o = outp + (((size_t)(3 * r) * CG + cg) * cout + co) * 8 + 4 * kk;
+      const size_t tap_stride = (size_t)CG * cout * 8;
+      st4(o, make_float4(acc0[4 * qd], acc0[4 * qd + 1], acc0[4 * qd + 2], acc0[4 * qd + 3]));
+      st4(o + tap_stride, make_float4(acc1[4 * qd], acc1[4 * qd + 1], acc1[4 * qd + 2], acc1[4 * qd + 3]));
+      st4(o + 2 * tap_stride, make_float4(acc2[4 * qd], acc2[4 * qd + 1], acc2[4 * qd + 2], acc2[4 * qd + 3]));
+    }
   }
+  if (r == 1 && ct == 0) q.dbp[((size_t)slab * 2 + kk) * cout + co] = bsum;   // sum over this slab's pixels of parity kk, in pixel order
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -413,10 +420,10 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
 // theta = [weights of layer 0 | ... | weights of layer 19 | biases of layer 0 | ... ], weights in the forward pack
 // wt[tap][cin_pad/8][cout_pad][8] (each a multiple of 256 floats: a block never straddles layers), biases padded to
 // cout_pad.  Padded entries have zero gradient (their operands are zero) and are masked here as well, so they stay zero.
-struct AeAdamLayer { const float* partial; int nslab, w_off, wb_off, cin_lg /*log2(cin_pad/8)*/, cout_lg, cin, cout; };
+struct AeAdamLayer { const float* partial; const float* dbp; int nslab, w_off, b_off, wb_off, cin_lg /*log2(cin_pad/8)*/, cout_lg, cin, cout; };
 struct AeAdamArgs {
   AeAdamLayer L[AE_NLAYER];
-  float* theta; float* m; float* v; float* wb; const float* dbias; const float* ctr;    // ctr: [1] = bc1, [2] = bc2s (floats)
+  float* theta; float* m; float* v; float* wb; const float* ctr;    // ctr: [1] = bc1, [2] = bc2s (floats)
   int n_w, n_all; float lr;
 };
 
@@ -447,9 +454,13 @@ ae_adam_kernel(AeAdamArgs A) {
     const int ci = cg * 8 + c8;
     const int n_w = 9 << (q.cin_lg + 3 + q.cout_lg);
     if (ci < q.cin && co < q.cout) {
-      for (int s = 0; s < q.nslab; ++s) {                           // slab order: deterministic
-        const float4 pv = ld4(q.partial + (size_t)s * n_w + i);
-        g.x += pv.x; g.y += pv.y; g.z += pv.z; g.w += pv.w;
+      for (int s0 = 0; s0 < q.nslab; s0 += 8) {                     // slab order: deterministic; 8 loads in flight
+        float4 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.partial + (size_t)(s0 + u < q.nslab ? s0 + u : q.nslab - 1) * n_w + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < q.nslab) { g.x += pv[u].x; g.y += pv[u].y; g.z += pv[u].z; g.w += pv[u].w; }
       }
       if (ci + 1 >= q.cin) g.y = 0.f;                               // padded input channels keep a zero gradient
       if (ci + 2 >= q.cin) g.z = 0.f;
@@ -458,7 +469,25 @@ ae_adam_kernel(AeAdamArgs A) {
     if (q.wb_off >= 0)        // backward-data pack of the same convolution: wtb[8 - tap][co/8][ci][co%8]
       wb_idx = q.wb_off + ((((8 - tap) << (q.cout_lg - 3)) + (co >> 3)) << (q.cin_lg + 3)) * 8 + ci * 8 + (co & 7);
   } else {
-    g = ld4(A.dbias + (idx - A.n_w));
+    const int bi = idx - A.n_w;
+    int k = 0;
+    while (k + 1 < AE_NLAYER && bi >= A.L[k + 1].b_off) ++k;
+    const AeAdamLayer& q = A.L[k];
+    const int co = bi - q.b_off, cop = 1 << q.cout_lg;
+    if (co < q.cout) {
+      const int ns = 2 * q.nslab;
+      for (int s0 = 0; s0 < ns; s0 += 8) {                          // slab order, even pixels then odd: deterministic
+        float4 pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.dbp + (size_t)(s0 + u < ns ? s0 + u : ns - 1) * cop + co);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + u < ns) { g.x += pv[u].x; g.y += pv[u].y; g.z += pv[u].z; g.w += pv[u].w; }
+      }
+      if (co + 1 >= q.cout) g.y = 0.f;
+      if (co + 2 >= q.cout) g.z = 0.f;
+      if (co + 3 >= q.cout) g.w = 0.f;
+    }
   }
   float4 m = ld4(A.m + idx), v = ld4(A.v + idx), p = ld4(A.theta + idx);
   p.x = adam_update(p.x, g.x, m.x, v.x, A.lr, bc1, bc2s);
@@ -561,7 +590,15 @@ ae_pack_kernel(AePackArgs A, const float* __restrict__ src, float* __restrict__ 
 static const int AE_ENC[5][2] = {{4, 32}, {32, 64}, {64, 128}, {128, 256}, {256, 256}};      // models/AE.py:81-91, in_channel = 4
 static const int AE_DEC[5][2] = {{256, 256}, {256, 128}, {128, 64}, {64, 32}, {32, 1}};
 
-struct AeLayer { int cin, cout, cin_pad, cout_pad, deconv, level, w_off, b_off, wb_off, flat_w, flat_b, nslab; size_t part_off; };
+struct AeLayer { int cin, cout, cin_pad, cout_pad, deconv, level, w_off, b_off, wb_off, flat_w, flat_b, nslab, slab_len; size_t part_off, dbp_off; };
+
+// slabs of padded interior pixels for the weight gradients: equal parts of at most AE_SLAB pixels, a multiple of 32 long (27 x 19
+// = 513 padded pixels is ONE slab, not 512 + 1)
+static int ae_slabs(int H, int W, int* len) {
+  const int n_px = H * (W + 2), n = (n_px + AE_SLAB - 1) / AE_SLAB;
+  *len = ((n_px + n - 1) / n + 31) / 32 * 32;
+  return (n_px + *len - 1) / *len;
+}
 
 static int pad8(int c) { return (c + 7) / 8 * 8; }
 static int pad32(int c) { return (c + 31) / 32 * 32; }
@@ -571,10 +608,10 @@ struct AeEngine {
   int H[6], W[6];
   AeLayer L[AE_NLAYER];
   int n_w = 0, n_b = 0, n_wb = 0, n_flat = 0;
-  size_t n_part = 0;
+  size_t n_part = 0, n_dbp = 0;
   float lr = 0.f;
   // carved from the caller's workspace
-  float *theta = nullptr, *m = nullptr, *v = nullptr, *wb = nullptr, *dbias = nullptr, *zero_bias = nullptr, *ctr = nullptr,
+  float *theta = nullptr, *m = nullptr, *v = nullptr, *wb = nullptr, *dbp = nullptr, *zero_bias = nullptr, *ctr = nullptr,
         *part = nullptr, *moc = nullptr, *x8 = nullptr;
   float* act[AE_NLAYER];       // output of layer i (decoder blocks 0..3: their second layer's output lives stuffed in S[b + 1])
   float* xin[AE_NLAYER];       // input of layer i
@@ -585,9 +622,12 @@ struct AeEngine {
   int loaded = 0;
 };
 
+// every buffer is wrapped in AE_GUARD zeroed floats that nothing writes: the weight-gradient kernel's operand windows may
+// reach up to 17 pixels (136 floats) past either end of a CG8P buffer, at positions whose products are multiplied by zero
+#define AE_GUARD 256
 struct Bump {
   float* base; size_t off = 0;
-  float* take(size_t n) { float* p = base ? base + off : nullptr; off += (n + 63) / 64 * 64; return p; }
+  float* take(size_t n) { float* p = base ? base + off + AE_GUARD : nullptr; off += (n + 2 * AE_GUARD + 63) / 64 * 64; return p; }
 };
 
 // the same routine sizes the workspace (base == nullptr) and carves it
@@ -606,23 +646,24 @@ static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
     e->L[n++] = AeLayer{co, co, pad32(co), pad32(co), 1, 4 - b};
   }
   int w = 0, wbo = 0, flat = 0;
-  size_t part = 0;
+  size_t part = 0, dbp = 0;
   for (int i = 0; i < AE_NLAYER; ++i) {
     AeLayer& l = e->L[i];
     l.w_off = w; w += 9 * l.cin_pad * l.cout_pad;
     l.wb_off = i == 0 ? -1 : wbo; if (i) wbo += 9 * l.cin_pad * l.cout_pad;      // the first layer needs no backward-data
     l.flat_w = flat; flat += 9 * l.cin * l.cout;
     l.flat_b = flat; flat += l.cout;
-    l.nslab = (e->H[l.level] * e->W[l.level] + AE_SLAB - 1) / AE_SLAB;
+    l.nslab = ae_slabs(e->H[l.level], e->W[l.level], &l.slab_len);
     l.part_off = part; part += (size_t)l.nslab * 9 * l.cin_pad * l.cout_pad;
+    l.dbp_off = dbp; dbp += (size_t)l.nslab * 2 * l.cout_pad;
   }
-  e->n_w = w; e->n_wb = wbo; e->n_flat = flat; e->n_part = part;
+  e->n_w = w; e->n_wb = wbo; e->n_flat = flat; e->n_part = part; e->n_dbp = dbp;
   int b = 0;
   for (int i = 0; i < AE_NLAYER; ++i) { e->L[i].b_off = b; b += e->L[i].cout_pad; }
   e->n_b = b;
   Bump B{base};
   e->theta = B.take(e->n_w + e->n_b); e->m = B.take(e->n_w + e->n_b); e->v = B.take(e->n_w + e->n_b);
-  e->wb = B.take(e->n_wb); e->dbias = B.take(e->n_b); e->zero_bias = B.take(256); e->ctr = B.take(64);
+  e->wb = B.take(e->n_wb); e->dbp = B.take(e->n_dbp); e->zero_bias = B.take(256); e->ctr = B.take(64);
   e->part = B.take(e->n_part); e->moc = B.take((size_t)H0 * W0);
   e->x8 = B.take(cg8p_floats(8, H0, W0));
   for (int bk = 0; bk < 5; ++bk) {
@@ -673,6 +714,8 @@ static int ae_forward(AeEngine* e, hipStream_t s) {
   return 0;
 }
 
+static int ae_wgrad_launch(AeEngine* e, hipStream_t s, int mode);
+
 static int ae_train_step(AeEngine* e, hipStream_t s) {
   CHK_(ae_forward(e, s));
   const int H0 = e->H[0], W0 = e->W[0];
@@ -703,30 +746,39 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     if (b > 0) CHK_(ae_conv(e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
   }
   // ---- all weight and bias gradients
-  AeWgradJobs J;
-  J.n = AE_NLAYER;
-  int nb = 0;
-  for (int i = 0; i < AE_NLAYER; ++i) {
-    const AeLayer& l = e->L[i];
-    AeWgradJob& q = J.j[i];
-    q.dy = e->dp[i]; q.x = e->xin[i]; q.partial = e->part + l.part_off; q.db = e->dbias + l.b_off;
-    q.H = e->H[l.level]; q.W = e->W[l.level]; q.wmagic = (unsigned)((1ull << 32) / (unsigned)q.W + 1);
-    q.cin = l.cin_pad; q.cout = l.cout_pad; q.cout_real = l.cout; q.nslab = l.nslab;
-    q.ntile = l.nslab * 9 * (l.cout_pad / 32) * ((l.cin_pad + 31) / 32);
-    q.first_block = nb;
-    nb += q.ntile + l.cout;
-  }
-  hipLaunchKernelGGL(ae_wgrad_multi_kernel, dim3(nb), dim3(256), 0, s, J);
-  CHK_((int)hipGetLastError());
+  CHK_(ae_wgrad_launch(e, s, 0));
   // ---- Adam
   AeAdamArgs A;
   for (int i = 0; i < AE_NLAYER; ++i) {
     const AeLayer& l = e->L[i];
-    A.L[i] = AeAdamLayer{e->part + l.part_off, l.nslab, l.w_off, l.wb_off, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout};
+    A.L[i] = AeAdamLayer{e->part + l.part_off, e->dbp + l.dbp_off, l.nslab, l.w_off, l.b_off, l.wb_off, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout};
   }
-  A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.dbias = e->dbias; A.ctr = e->ctr;
+  A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.ctr = e->ctr;
   A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr;
   hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all / 4 + 255) / 256), dim3(256), 0, s, A);        // (n_w and n_b are multiples of 4)
+  return (int)hipGetLastError();
+}
+
+static int ae_wgrad_launch(AeEngine* e, hipStream_t s, int mode) {
+  AeWgradJobs J;
+  int nb = 0, n = 0;
+  for (int lv = 0; lv < 5; ++lv)                                // dispatch order: big images (long waves) first
+    for (int i = 0; i < AE_NLAYER; ++i) {
+      const AeLayer& l = e->L[i];
+      if (l.level != lv) continue;
+      AeWgradJob& q = J.j[n];
+      q.dy = e->dp[i]; q.x = e->xin[i]; q.partial = e->part + l.part_off; q.dbp = e->dbp + l.dbp_off;
+      q.H = e->H[l.level]; q.W = e->W[l.level];
+      q.cin = l.cin_pad; q.cout = l.cout_pad; q.nslab = l.nslab; q.slab_len = l.slab_len;
+      q.nwave = 3 * l.nslab * (l.cout_pad / 32) * ((l.cin_pad + 31) / 32);
+      J.first[n++] = nb;
+      nb += q.nwave;
+    }
+  J.first[n] = nb; J.n = n;
+  if (mode == 1) hipLaunchKernelGGL(ae_wgrad_multi_kernel<1>, dim3(nb), dim3(64), 0, s, J);
+  else if (mode == 2) hipLaunchKernelGGL(ae_wgrad_multi_kernel<2>, dim3(nb), dim3(64), 0, s, J);
+  else if (mode == 3) hipLaunchKernelGGL(ae_wgrad_multi_kernel<3>, dim3(nb), dim3(64), 0, s, J);
+  else hipLaunchKernelGGL(ae_wgrad_multi_kernel<0>, dim3(nb), dim3(64), 0, s, J);
   return (int)hipGetLastError();
 }
 
@@ -850,6 +902,15 @@ int lemo_ae_params(void* h, float* flat_out, void* stream) {
   const int n_all = e->n_w + e->n_b;
   hipLaunchKernelGGL((ae_pack_kernel<true>), dim3((n_all + 255) / 256), dim3(256), 0, (hipStream_t)stream, ae_pack_args(e), (const float*)e->theta, flat_out, (float*)nullptr);
   return (int)hipGetLastError();
+}
+
+/* diagnostics: the weight-gradient launch alone on the engine's current buffers (mode 0 product, 1 operands loaded once per wave,
+   2 no MFMAs) */
+int lemo_ae_wgrad_probe(void* h, int mode, void* stream) {
+  AeEngine* e = (AeEngine*)h;
+  if (!e || mode < 0 || mode > 3) return LEMO_ERR_ARG;
+  if (!e->loaded) return LEMO_ERR_STATE;
+  return ae_wgrad_launch(e, (hipStream_t)stream, mode);
 }
 
 /* one convolution of the engine on its own (tests, tools): plain geometry unless in_s / out_s = 2 (see AeGeo) */
