@@ -655,7 +655,8 @@ def main():
             'kernel_ms_source': 'replay of [lbs_verts_fwd + the 14-conv chain] minus replay of [the 14-conv chain]: the launch with '
                                 'the caches in the state the encoder leaves them in (blend directions not MALL-hot)',
             'kernel_ms_back_to_back': vms_b2b,
-            'mfma_frac': vflops / (vms * 1e-3) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS / 6.0), 'flop_per_launch': vflops}
+            'blend_operands': 'two fp16 pieces each, pre-split (3 MFMA products per MAC)' if fit.dev.blend_f16 else 'three bf16 pieces each, split in the kernel (6 MFMA products per MAC)',
+            'mfma_frac': vflops / (vms * 1e-3) / 1e12 / (PEAK_BF16_MATRIX_TFLOPS / (3.0 if fit.dev.blend_f16 else 6.0)), 'flop_per_launch': vflops}
     if per_rank is not None:
         out['per_rank_iterations_per_s'] = per_rank
     if rank == 0 and world == 1 and args.concurrent_clips > 1 and use_graph and not args.active_vertices_only:

@@ -129,6 +129,8 @@ typedef struct lemo_pose_ws {
   int Bp;
   unsigned short* XgS;   /* optional [512/16][3][Bp][2][8] bf16: Xg split into its three exact bf16 pieces, in the fragment order of
                             lemo_lbs_verts_fwd_xs's blend GEMM (written by lemo_smplx_pose_fwd when non-NULL; pad entries stay 0) */
+  int xgs_f16;           /* 1: XgS holds TWO fp16 pieces instead, [512/16][2][Bp][2][8] (hi = f16(x), lo = f16(x - hi)): the B operand
+                            of the blend GEMM on the fp16 matrix cores; goes with lemo_skin_const.DgH (both or neither) */
 } lemo_pose_ws;
 typedef struct lemo_pose_grad_in {
   const float *dA, *dJtr, *dX;
@@ -158,6 +160,11 @@ typedef struct lemo_skin_const {
   const float* v_template;  /* [V][3] */
   const int* w_idx;         /* [V][KW] ELL skinning weights */
   const float* w_val;
+  const unsigned short* DgH; /* optional: Dg * 2^k pre-split on the host into two fp16 pieces, [64][NC][2 halves][hi 4 | lo 4] (the same
+                             * 32 bytes per (8-feature group, column) as Dg: HBM sees the same traffic, the kernel converts nothing).
+                             * With it (and blend_fp32 == 0, XgS in its fp16 form) the blend GEMM is 3 fp16 MFMA products per 16-deep
+                             * k-chunk (hi hi + hi lo + lo hi: operands carried to 2^-22, fp32 accumulate) instead of 6 bf16 ones. */
+  float dgh_inv;            /* 2^-k */
 } lemo_skin_const;
 typedef struct lemo_vertex_set_bwd {
   int n, NCs;
@@ -184,7 +191,8 @@ typedef struct lemo_vertex_set_bwd {
 int lemo_lbs_verts_fwd(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                        const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 /* diagnostics (tools/lbs_census.py): same launch, per wave {start, after prologue, after GEMM, end} clock stamps */
-/* same, with the per-frame features also given pre-split (lemo_pose_ws.XgS): the blend GEMM reads its B operand from there */
+/* same, with the per-frame features also given pre-split (lemo_pose_ws.XgS): the blend GEMM reads its B operand from there.
+ * XgS must be in the form c selects: two fp16 pieces when c->DgH is set (lemo_pose_ws.xgs_f16 = 1), three bf16 pieces otherwise */
 int lemo_lbs_verts_fwd_xs(const lemo_skin_const* c, const float* Xg, const unsigned short* XgS, int Bp, const float* A, int nj,
                           const float* transl, const int* ids, int n, int B, float* verts, float* v_posed, void* stream);
 int lemo_lbs_verts_fwd_census(const lemo_skin_const* c, const float* Xg, int Bp, const float* A, int nj, const float* transl,

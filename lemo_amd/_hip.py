@@ -41,7 +41,7 @@ class PoseIn(C.Structure):
 
 
 class PoseWs(C.Structure):
-    _fields_ = [(n, vp) for n in ('full_pose', 'R', 'J', 'T', 'A', 'Jtr', 'Xg')] + [('Bp', C.c_int), ('XgS', vp)]
+    _fields_ = [(n, vp) for n in ('full_pose', 'R', 'J', 'T', 'A', 'Jtr', 'Xg')] + [('Bp', C.c_int), ('XgS', vp), ('xgs_f16', C.c_int)]
 
 
 class PoseGradIn(C.Structure):
@@ -69,7 +69,7 @@ class AeDesc(C.Structure):
 
 class SkinConst(C.Structure):
     _fields_ = [('V', C.c_int), ('NC', C.c_int), ('KW', C.c_int), ('blend_fp32', C.c_int)] + \
-        [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val')]
+        [(n, vp) for n in ('Dg', 'v_template', 'w_idx', 'w_val', 'DgH')] + [('dgh_inv', C.c_float)]
 
 
 class VertexSetBwd(C.Structure):

@@ -169,7 +169,7 @@ class BodyModelData:
 class DeviceBody:
     """Device copies of :class:`BodyModelData` + the ctypes constant blocks of the C ABI."""
 
-    def __init__(self, data: BodyModelData, device):
+    def __init__(self, data: BodyModelData, device, blend_f16: Optional[bool] = None):
         self.data, self.device = data, torch.device(device)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         self.t = {k: t(getattr(data, k)) for k in (
@@ -180,7 +180,16 @@ class DeviceBody:
                                    ptr(T['level_joints']), ptr(T['child_start']), ptr(T['child_list']),
                                    ptr(T['J_template']), ptr(T['J_dirs']), ptr(T['pose_mean']),
                                    ptr(T['lh_comp']), ptr(T['rh_comp']))
-        self.skin = _hip.SkinConst(d.V, d.NC, d.KW, 0, ptr(T['Dg']), ptr(T['v_template']), ptr(T['w_idx']), ptr(T['w_val']))
+        # blend directions pre-split into two fp16 pieces (lemo_skin_const.DgH): the blend GEMM of lbs_verts_fwd then runs 3 fp16 MFMA
+        # products per k-chunk on operands it only has to move (LEMO_BLEND_F16=0: the 3-piece bf16 split of the fp32 copy, converted
+        # in the kernel -- round 2's form, kept for A/B)
+        self.blend_f16 = BLEND_F16 if blend_f16 is None else bool(blend_f16)
+        dgh, inv = (None, 0.0)
+        if self.blend_f16:
+            h, inv = split_f16_pairs(d.Dg)
+            T['DgH'] = dgh = t(h)
+        self.skin = _hip.SkinConst(d.V, d.NC, d.KW, 0, ptr(T['Dg']), ptr(T['v_template']), ptr(T['w_idx']), ptr(T['w_val']),
+                                   ptr(dgh) if dgh is not None else None, inv)
         self._sets = {}
 
     def vertex_set(self, key, ids: np.ndarray, vp_row=None, frames: int = 0):
@@ -216,16 +225,37 @@ class DeviceBody:
         return mine, own
 
 
-def alloc_pose_ws(B: int, nj: int, device):
-    """Workspace of the pose stage (saved for backward).  Xg pad rows/cols must stay zero."""
+BLEND_F16 = os.environ.get('LEMO_BLEND_F16', '1') != '0'
+
+
+def split_f16_pairs(Dg: np.ndarray):
+    """Dg [K/8][NC][8] fp32 -> ([K/8][NC][2 halves][hi 4 | lo 4] as uint16, 2^-k): x * 2^k = hi + lo with hi = f16(x 2^k),
+    lo = f16(x 2^k - hi) (round to nearest even), k the largest power that keeps max|x| 2^k <= 2^15 (fp16 overflows at 65504;
+    small entries go denormal in `lo` only below 2^-24 of the largest, i.e. below fp32's own resolution of the sums)."""
+    m = float(np.abs(Dg).max())
+    k = int(np.floor(np.log2(32768.0 / m))) if m > 0 else 0
+    k = max(-14, min(k, 30))
+    xs = Dg.astype(np.float32) * np.float32(2.0 ** k)
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float32)).astype(np.float16)
+    G, NC, _ = Dg.shape
+    out = np.empty((G, NC, 2, 2, 4), np.float16)                    # [group][column][half][piece][4]
+    out[:, :, :, 0, :] = hi.reshape(G, NC, 2, 4)
+    out[:, :, :, 1, :] = lo.reshape(G, NC, 2, 4)
+    return out.view(np.uint16).reshape(G, NC, 16).view(np.int16), float(2.0 ** -k)
+
+
+def alloc_pose_ws(B: int, nj: int, device, f16: bool):
+    """Workspace of the pose stage (saved for backward).  Xg pad rows/cols must stay zero.  ``f16``: the form of the pre-split
+    features XgS -- two fp16 pieces (goes with ``DeviceBody.blend_f16`` / ``lemo_skin_const.DgH``) or three bf16 pieces."""
     Bp = _roundup(B, 32)
     z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
     tt = dict(full_pose=z(B, nj * 3), R=z(B, nj, 9), J=z(B, nj, 3), T=z(B, nj, 12), A=z(B, nj, 12),
               Jtr=z(B, nj, 3), Xg=z(K_PAD // 8, Bp, 8),
-              # Xg again as three exact bf16 pieces in MFMA-fragment order (lemo_pose_ws.XgS): the blend GEMM's B operand
-              XgS=torch.zeros(K_PAD // 16, 3, Bp, 2, 8, dtype=torch.int16, device=device))
+              # Xg again as two fp16 (or three exact bf16) pieces in MFMA-fragment order (lemo_pose_ws.XgS): the blend GEMM's B operand
+              XgS=torch.zeros(K_PAD // 16, 2 if f16 else 3, Bp, 2, 8, dtype=torch.int16, device=device))
     ws = _hip.PoseWs(ptr(tt['full_pose']), ptr(tt['R']), ptr(tt['J']), ptr(tt['T']), ptr(tt['A']), ptr(tt['Jtr']),
-                     ptr(tt['Xg']), Bp, ptr(tt['XgS']))
+                     ptr(tt['Xg']), Bp, ptr(tt['XgS']), 1 if f16 else 0)
     return ws, tt, Bp
 
 
@@ -242,7 +272,7 @@ class _SmplxFn(torch.autograd.Function):
         device = go.device
         _hip.check_device(lib, go)
         s = lib.stream(device)
-        ws, tt, Bp = alloc_pose_ws(B, d.nj, device)
+        ws, tt, Bp = alloc_pose_ws(B, d.nj, device, dev.blend_f16)
         pin = _hip.PoseIn(ptr(go), ptr(body), ptr(jaw), ptr(leye), ptr(reye), ptr(lh), ptr(rh), lh.shape[1],
                           ptr(betas), betas.shape[1], ptr(expr))
         lib.check(lib.smplx_pose_fwd(C.byref(dev.body), C.byref(pin), C.byref(ws), B, s), 'smplx_pose_fwd')

@@ -370,7 +370,18 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
 #define WG_FAKE(SET)                                                                               \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) { acc0[u] += b[SET][u] + xw[SET][2 * u]; acc1[u] += xw[SET][2 * u + 1]; } \
   acc2[0] += xw[SET][16];
-  if (MODE == 3) {
+  if (MODE == 4) {
+    // no scheduling fences: the compiler is free to spread group g + 1's loads between group g's MFMAs
+    WG_LOAD(0, qs)
+    for (int qb = qs; qb < qe; qb += 32) {
+      if (qb + 16 < qe) { WG_LOAD(1, qb + 16) }
+      WG_MFMA(0)
+      if (qb + 16 < qe) {
+        if (qb + 32 < qe) { WG_LOAD(0, qb + 32) }
+        WG_MFMA(1)
+      }
+    }
+  } else if (MODE == 3) {
     // single register set: more waves per SIMD (83 instead of 112 registers) cover each other's load phases
     for (int qb = qs; qb < qe; qb += 16) {
       WG_LOAD(0, qb)
@@ -778,6 +789,7 @@ static int ae_wgrad_launch(AeEngine* e, hipStream_t s, int mode) {
   if (mode == 1) hipLaunchKernelGGL(ae_wgrad_multi_kernel<1>, dim3(nb), dim3(64), 0, s, J);
   else if (mode == 2) hipLaunchKernelGGL(ae_wgrad_multi_kernel<2>, dim3(nb), dim3(64), 0, s, J);
   else if (mode == 3) hipLaunchKernelGGL(ae_wgrad_multi_kernel<3>, dim3(nb), dim3(64), 0, s, J);
+  else if (mode == 4) hipLaunchKernelGGL(ae_wgrad_multi_kernel<4>, dim3(nb), dim3(64), 0, s, J);
   else hipLaunchKernelGGL(ae_wgrad_multi_kernel<0>, dim3(nb), dim3(64), 0, s, J);
   return (int)hipGetLastError();
 }
@@ -908,7 +920,7 @@ int lemo_ae_params(void* h, float* flat_out, void* stream) {
    2 no MFMAs) */
 int lemo_ae_wgrad_probe(void* h, int mode, void* stream) {
   AeEngine* e = (AeEngine*)h;
-  if (!e || mode < 0 || mode > 3) return LEMO_ERR_ARG;
+  if (!e || mode < 0 || mode > 4) return LEMO_ERR_ARG;
   if (!e->loaded) return LEMO_ERR_STATE;
   return ae_wgrad_launch(e, (hipStream_t)stream, mode);
 }

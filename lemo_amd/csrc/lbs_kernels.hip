@@ -34,7 +34,14 @@ static inline int lbs_smem_bytes(int nj) { const int b = (LBS_FR * LBS_PITCH + 2
 // their B fragments straight from L2 (1 KiB coalesced per fragment, one stage ahead) and only the streamed D operand goes
 // through registers -> split -> LDS.  Without it every one of the 250 workgroups converted the same 128 x 512 features and
 // both operands shared the LDS port: 196 KB of LDS traffic per 32-feature stage = as many cycles as its 48 MFMAs.
-template <bool DBG, bool SPLIT, bool PRE = false>
+typedef _Float16 lbs_f16x8 __attribute__((ext_vector_type(8)));
+
+// F16 (with SPLIT and PRE): BOTH operands arrive pre-split into two fp16 pieces -- D once on the host (SkinConst.DgH: the same 32
+// bytes per (group, column) as the fp32 copy, [hi 4 | lo 4] per lane half, scaled by a power of two), the features by the pose
+// kernel (XgS in its fp16 form) -- so the staging threads only move bytes (no conversion: the 3-piece bf16 split of the streamed
+// operand was ~130 vector-ALU instructions per thread and 64-feature stage) and a 16-deep k-chunk is THREE fp16 MFMA products
+// (hi hi + hi lo + lo hi, operands carried to 2^-22, fp32 accumulate) instead of six bf16 ones.
+template <bool DBG, bool SPLIT, bool PRE = false, bool F16 = false>
 __global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
@@ -75,7 +82,80 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
     constexpr int SG = 4, PL = 128 * 16, OPB = SG * 3 * PL, BUFB = 2 * OPB, NSTS = 64 / SG;
     unsigned char* sm = reinterpret_cast<unsigned char*>(smem);
     const int dstb = scol * 16 + shalf * 8;                       // + (group * 3 + piece) * PL
-    if (PRE) {
+    if (PRE && F16) {
+      const int fr = (f0 + nt * 32 + j < Bp) ? f0 + nt * 32 + j : Bp - 1;
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(XgS) + ((size_t)fr * 2 + h) * 16;
+      const size_t piece_b = (size_t)Bp * 32, chunk_b = 2 * piece_b;          // bytes per piece / per 16-feature chunk
+      const float* DgH = reinterpret_cast<const float*>(c.DgH);               // same offsets as Dg: 32 B per (group, column)
+      // one LDS stage = 64 features (8 groups x 2 pieces x 2 KB = 32 KB per buffer); D loads one stage ahead, B fragments one
+      // 32-feature half ahead -- the schedule of the bf16 path below with a third fewer planes and half the MFMAs
+      constexpr int SGB = 8, BUFA = SGB * 2 * PL, NSTB = 64 / SGB;
+      float4 sa[4];
+      uint4 rbg[2][2][2];                                                     // [half parity][chunk of the half][piece]
+#define LBS_H_LOAD_A(ST)                                                                           \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                \
+        sa[k] = ld4(DgH + (size_t)((ST) * SGB + sg0 + 2 * k) * dg_stride + a_off);
+#define LBS_H_LOAD_B(SET, G)                                                                       \
+      _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                             \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                           \
+          rbg[SET][c_][s_] = *reinterpret_cast<const uint4*>(xb + (size_t)((G) * 2 + c_) * chunk_b + s_ * piece_b);
+#define LBS_H_STORE_A(BUF)                                                                         \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                              \
+        unsigned char* d = sm + (BUF) * BUFA + (sg0 + 2 * k) * 2 * PL + dstb;                      \
+        *reinterpret_cast<float2*>(d) = make_float2(sa[k].x, sa[k].y);                             \
+        *reinterpret_cast<float2*>(d + PL) = make_float2(sa[k].z, sa[k].w);                        \
+      }
+      LBS_H_LOAD_A(0)
+      LBS_H_LOAD_B(0, 0)
+      LBS_H_STORE_A(0)
+      LBS_H_LOAD_A(1)
+      __syncthreads();
+      if (DBG) t_pro = __builtin_amdgcn_s_memtime();
+      const int a_rdb = (mp * 64 + j) * 16;
+#define LBS_H_READ(P, C)                                                                           \
+        _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                         \
+          ra[C][0][s_] = *reinterpret_cast<const uint4*>(base + ((P) * 2 + (C)) * 4 * PL + s_ * PL + a_rdb);   \
+          ra[C][1][s_] = *reinterpret_cast<const uint4*>(base + ((P) * 2 + (C)) * 4 * PL + s_ * PL + a_rdb + 32 * 16); \
+        }
+#define LBS_H_MFMA1(P, C, SA, SB)                                                                  \
+        _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                           \
+          acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lbs_f16x8, ra[C][m_][SA]), \
+                                                           __builtin_bit_cast(lbs_f16x8, rbg[P][C][SB]), acc[m_], 0, 0, 0);
+#define LBS_H_MFMA(P, C) LBS_H_MFMA1(P, C, 1, 0) LBS_H_MFMA1(P, C, 0, 1) LBS_H_MFMA1(P, C, 0, 0)      /* small terms first */
+#define LBS_H_HALF(P, ST) {                                                                        \
+        if (2 * (ST) + (P) + 1 < 2 * NSTB) { LBS_H_LOAD_B(1 - (P), 2 * (ST) + (P) + 1) }           \
+        uint4 ra[2][2][2];                                                                         \
+        LBS_H_READ(P, 0)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_H_READ(P, 1)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_H_MFMA(P, 0)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        LBS_H_MFMA(P, 1)                                                                           \
+      }
+      for (int st = 0; st < NSTB; ++st) {
+        const unsigned char* base = sm + (st & 1) * BUFA + h * 2 * PL;
+        LBS_H_HALF(0, st)
+        __builtin_amdgcn_sched_barrier(0);
+        LBS_H_HALF(1, st)
+        if (st + 1 < NSTB) {
+          LBS_H_STORE_A((st + 1) & 1)
+          if (st + 2 < NSTB) { LBS_H_LOAD_A(st + 2) }
+        }
+        __syncthreads();
+      }
+#undef LBS_H_HALF
+#undef LBS_H_READ
+#undef LBS_H_MFMA1
+#undef LBS_H_MFMA
+#undef LBS_H_LOAD_A
+#undef LBS_H_LOAD_B
+#undef LBS_H_STORE_A
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] *= c.dgh_inv;       // D was scaled by a power of two: exact
+    } else if (PRE) {
       // ---- D through LDS (as below), B fragments from the pre-split copy in L2 ----
       const int fr = (f0 + nt * 32 + j < Bp) ? f0 + nt * 32 + j : Bp - 1;
       const unsigned char* xb = reinterpret_cast<const unsigned char*>(XgS) + ((size_t)fr * 2 + h) * 16;
@@ -409,6 +489,9 @@ int lbs_init() {
 #define OPTIN(DBG_, SPLIT_, PRE_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
   OPTIN(false, false, false) OPTIN(true, false, false) OPTIN(false, true, false) OPTIN(true, true, false) OPTIN(false, true, true) OPTIN(true, true, true)
 #undef OPTIN
+#define OPTINH(DBG_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
+  OPTINH(false) OPTINH(true)
+#undef OPTINH
   return rc;
 }
 
@@ -421,10 +504,13 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
 #define LAUNCH(DBG_, SPLIT_, PRE_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
-  if (!c.blend_fp32 && XgS) { if (dbg) LAUNCH(true, true, true); else LAUNCH(false, true, true); }
+#define LAUNCHH(DBG_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, true, true, true>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
+  if (!c.blend_fp32 && XgS && c.DgH) { if (dbg) LAUNCHH(true); else LAUNCHH(false); }      // (XgS in its fp16 form: lemo_pose_ws.xgs_f16)
+  else if (!c.blend_fp32 && XgS) { if (dbg) LAUNCH(true, true, true); else LAUNCH(false, true, true); }
   else if (!c.blend_fp32) { if (dbg) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
   else { if (dbg) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
 #undef LAUNCH
+#undef LAUNCHH
   return (int)hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ using namespace lemo;
 
 extern "C" {
 
-int lemo_abi_version(void) { return 2; }
+int lemo_abi_version(void) { return 3; }
 
 int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W,
                       int cin, int cout, int epi, int variant, void* stream) {
@@ -404,6 +404,7 @@ static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool
 void* lemo_fit_create(const lemo_fit_desc* d) {
   if (!d || d->B < (d->per_frame ? 1 : 10) || d->B > d->Bp || !d->verts || !d->transl) return nullptr;
   if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
+  if (d->pose.XgS && (d->skin.DgH != nullptr) != (d->pose.xgs_f16 != 0)) return nullptr;     // both operands of the blend GEMM in one form
   FitEngine* e = new (std::nothrow) FitEngine();
   if (e) {
     e->d = *d;

@@ -108,6 +108,7 @@ void* lemo_prox_create(const lemo_prox_desc* d) {
     return nullptr;
   if (d->use_infill && (!d->marker_mask || !d->body_markers_rec || !d->contact_lbl_rec || d->T > d->B - 1 || d->T < 1)) return nullptr;
   if (conv_lds_init() || conv_split_init() || lbs_init()) return nullptr;
+  if (d->pose.XgS && (d->skin.DgH != nullptr) != (d->pose.xgs_f16 != 0)) return nullptr;     // both operands of the blend GEMM in one form
   ProxEngine* e = new (std::nothrow) ProxEngine();
   if (e) e->d = *d;
   return e;

@@ -263,7 +263,14 @@ smplx_pose_fwd_kernel(BodyConst c, PoseIn in, PoseWs ws) {
         v = Rs[9 + f] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
       }
       ws.Xg[((size_t)(k >> 3) * ws.Bp + b) * 8 + (k & 7)] = v;
-      if (ws.XgS) {
+      if (ws.XgS && ws.xgs_f16) {
+        // the same value as two fp16 pieces (hi = f16(v), lo = f16(v - hi): 22 significand bits; |v| <= ~3, no scaling needed),
+        // same fragment order with two planes per chunk: XgS[k >> 4][piece][frame][(k >> 3) & 1][k & 7]
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* q = reinterpret_cast<_Float16*>(ws.XgS) + ((((size_t)(k >> 4) * 2) * ws.Bp + b) * 2 + ((k >> 3) & 1)) * 8 + (k & 7);
+        q[0] = hi; q[(size_t)ws.Bp * 16] = lo;
+      } else if (ws.XgS) {
         // the same value as its three exact bf16 pieces, in the B-fragment order of the blend GEMM of lbs_verts_fwd
         // (chunk = 16 features, lane half = 8-feature group parity): XgS[k >> 4][piece][frame][(k >> 3) & 1][k & 7]
         const __bf16 hi = (__bf16)v;

@@ -107,7 +107,7 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         self.step_cur = torch.zeros(1, dtype=torch.int32, device=dev)
         self.loss_acc = torch.zeros(32 * 16, dtype=torch.float64, device=dev)
         self.target, self.contact = z(B, self.n67, 3), z(B, 4)
-        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
+        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev, self.dev.blend_f16)
         self.Bp = Bp
         nsp = self.lib.smooth_loss_blocks(H, W, ENC_CHANNELS[10])
         self.ws = dict(go_aa=z(B, 3), body_aa=z(B, 63), h1=z(B, 512), h2=z(B, 512), vo=z(B, 128), vp_scratch=z(B, 1152),

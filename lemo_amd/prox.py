@@ -396,7 +396,7 @@ class ProxWindowEngine(_hip.StreamOrdered):
         # workspace
         self.H, self.W = 3 * n81 + 2, B - 1 + 16
         H, W = self.H, self.W
-        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev)
+        pose_ws, self._pose_t, Bp = alloc_pose_ws(B, nj, dev, self.dbody.blend_f16)
         uset, self._uset_t = self.dbody.vertex_set('all', np.arange(V), frames=B)
         self.ws = dict(h1=z(B, 512), h2=z(B, 512), vo=z(B, 128), vp_scratch=z(B, 1152), verts=z(B, V, 3), v_posed=z(B, V, 3),
                        dverts=z(B, V, 3), x0=z((H + 2) * (W + 2)), canon=z(12), dx0=z(H * W), dJtr=z(B, nj, 3), dJv=z(B, nvj, 3),

@@ -457,9 +457,9 @@ def test_presplit_blend_operand_is_bit_identical(emu_lib):
     from lemo_amd.body_model import BodyModelData, DeviceBody, alloc_pose_ws
     lib = emu_lib
     data = BodyModelData(synthetic.make_synthetic_smplx(seed=3, V=200, F=300))
-    db = DeviceBody(data, 'cpu')
+    db = DeviceBody(data, 'cpu', blend_f16=False)
     B = 5
-    ws, tt, Bp = alloc_pose_ws(B, data.nj, 'cpu')
+    ws, tt, Bp = alloc_pose_ws(B, data.nj, 'cpu', False)
     g = torch.Generator().manual_seed(1)
     r = lambda *s: (torch.randn(*s, generator=g) * 0.3).contiguous()
     go, body, lh, rh, betas = r(B, 3), r(B, 63), r(B, 12), r(B, 12), r(B, 10)
@@ -484,6 +484,60 @@ def test_presplit_blend_operand_is_bit_identical(emu_lib):
         out.append((v, vp))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert float(out[0][0].abs().max()) > 0
+
+
+def test_f16_presplit_blend_is_fp32_sized(emu_lib):
+    """the blend GEMM with BOTH operands pre-split into two fp16 pieces (lemo_skin_const.DgH made on the host, XgS written in its
+    fp16 form by the pose kernel; 3 fp16 MFMA products per k-chunk) against a float64 evaluation of the same blend + skinning:
+    the error is the fp32 kernel's (fp32-MFMA path, blend_fp32 = 1) to within a small factor, far inside the 1e-4 vertex gate;
+    the pieces carry their operands to 2^-22; ragged frame count, all vertices and a vertex subset"""
+    import ctypes as C
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.body_model import BodyModelData, DeviceBody, alloc_pose_ws, split_f16_pairs
+    lib = emu_lib
+    data = BodyModelData(synthetic.make_synthetic_smplx(seed=3, V=200, F=300))
+    h, inv = split_f16_pairs(data.Dg)
+    hp = h.view(np.float16).reshape(data.Dg.shape[0], data.Dg.shape[1], 2, 2, 4).astype(np.float64)
+    back = (hp[:, :, :, 0, :] + hp[:, :, :, 1, :]).reshape(data.Dg.shape) * inv
+    assert np.abs(back - data.Dg).max() <= np.abs(data.Dg).max() * 2.0 ** -21
+    B = 5
+    res = {}
+    for f16 in (True, False):
+        db = DeviceBody(data, 'cpu', blend_f16=f16)
+        assert (db.skin.DgH is not None) == f16
+        ws, tt, Bp = alloc_pose_ws(B, data.nj, 'cpu', f16)
+        g = torch.Generator().manual_seed(1)
+        r = lambda *s: (torch.randn(*s, generator=g) * 0.3).contiguous()
+        go, body, lh, rh, betas = r(B, 3), r(B, 63), r(B, 12), r(B, 12), r(B, 10)
+        z3, expr, tr = torch.zeros(B, 3), r(B, 10), r(B, 3)
+        pin = _hip.PoseIn(ptr(go), ptr(body), ptr(z3), ptr(z3), ptr(z3), ptr(lh), ptr(rh), 12, ptr(betas), 10, ptr(expr))
+        lib.check(lib.smplx_pose_fwd(C.byref(db.body), C.byref(pin), C.byref(ws), B, None))
+        if f16:                                            # XgS[k >> 4][piece][frame][half][8] (fp16 bits) sums back to Xg to 2^-22
+            pc = tt['XgS'].view(torch.float16).double().sum(1)
+            xg = tt['Xg'].view(-1, 2, Bp, 8).permute(0, 2, 1, 3).double()
+            assert float((pc - xg).abs().max()) <= float(xg.abs().max()) * 2.0 ** -21 and float(xg.abs().max()) > 0.1
+        v, vp = torch.empty(B, data.V, 3), torch.empty(B, data.V, 3)
+        lib.check(lib.lbs_verts_fwd_xs(C.byref(db.skin), ptr(tt['Xg']), ptr(tt['XgS']), Bp, ptr(tt['A']), data.nj, ptr(tr), None, data.V, B,
+                                       ptr(v), ptr(vp), None))
+        ids = torch.arange(3, data.V, 7, dtype=torch.int32)
+        vs = torch.empty(B, len(ids), 3)
+        lib.check(lib.lbs_verts_fwd_xs(C.byref(db.skin), ptr(tt['Xg']), ptr(tt['XgS']), Bp, ptr(tt['A']), data.nj, ptr(tr), ptr(ids), len(ids), B,
+                                       ptr(vs), None, None))
+        assert torch.equal(vs, v[:, ids.long()])
+        # float64 reference from the kernel's own inputs: Xg features, D, A, skinning weights
+        X = tt['Xg'].double().permute(1, 0, 2).reshape(Bp, -1)[:B]                       # [B][512]
+        vpr = (X @ torch.from_numpy(data.D).double()).reshape(B, data.V, 3) + torch.from_numpy(data.v_template).double()
+        A = tt['A'].double().reshape(B, data.nj, 3, 4)
+        Wd = torch.zeros(data.V, data.nj, dtype=torch.float64)
+        wi, wv = torch.from_numpy(data.w_idx).long(), torch.from_numpy(data.w_val).double()
+        Wd.scatter_add_(1, wi, wv)
+        T = torch.einsum('vj,bjrc->bvrc', Wd, A)
+        ref = torch.einsum('bvrc,bvc->bvr', T[..., :3], vpr) + T[..., 3] + tr.double()[:, None]
+        res[f16] = (float((v.double() - ref).abs().max()), float((vp.double() - vpr).abs().max()), float(ref.abs().max()))
+    (e16, p16, scale), (e32, p32, _) = res[True], res[False]
+    assert e16 < 4e-7 * max(1.0, scale) and p16 < 4e-7 * max(1.0, scale), res
+    assert e16 < 4 * e32 + 1e-7 and p16 < 4 * p32 + 1e-7, res
 
 
 @pytest.mark.parametrize('grouped', [False, True])

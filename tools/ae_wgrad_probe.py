@@ -16,7 +16,7 @@ ses = next(iter(infill._SESSIONS.values()))
 torch.cuda.synchronize()
 s = ses.stream.cuda_stream
 with torch.cuda.stream(ses.stream):
-    for mode, name in ((0, 'product'), (1, 'operands loaded once per wave'), (2, 'loads, no MFMAs'), (3, 'single register set (more waves)'), (0, 'product again')):
+    for mode, name in ((0, 'product'), (1, 'operands loaded once per wave'), (2, 'loads, no MFMAs'), (3, 'single register set (more waves)'), (4, 'no scheduling fences'), (0, 'product again')):
         for _ in range(3): lib.check(lib.ae_wgrad_probe(ses.h, mode, s))
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

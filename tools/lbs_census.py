@@ -8,7 +8,7 @@ from lemo_amd.body_model import BodyModelData, DeviceBody, alloc_pose_ws
 lib = _hip.get_lib(); dev = torch.device('cuda:0')
 data = BodyModelData(synthetic.make_synthetic_smplx(seed=0)); db = DeviceBody(data, dev)
 B = 119
-ws, tt, Bp = alloc_pose_ws(B, data.nj, dev)
+ws, tt, Bp = alloc_pose_ws(B, data.nj, dev, db.blend_f16)
 tt['Xg'].normal_(); tt['A'].normal_()
 PRE = os.environ.get('LBS_PRE', '1') == '1'          # B operand pre-split by the pose kernel (values do not matter for the timing)
 XGS = ptr(tt['XgS']) if PRE else None
