@@ -23,6 +23,8 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_s
 for i in 1 2; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_driver_style_$i.json 2>> $OUT/bench.err; done
 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_100.json 2>> $OUT/bench.err
 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --conv-variant 3 > $OUT/bench_100_variant3_bf16x3.json 2>> $OUT/bench.err
+LEMO_BLEND_F16=0 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_100_blend_bf16x3.json 2>> $OUT/bench.err
+timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_100_again.json 2>> $OUT/bench.err
 timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --active-vertices-only > $OUT/bench_active.json 2>> $OUT/bench.err
 timeout 400 python bench.py --workload prox --gpus 1 --steps 300 --warmup 100 > $OUT/bench_prox.json 2>> $OUT/bench.err
 # 3. kernel stats of the same command (rocprofv3 --kernel-trace --stats)
@@ -39,6 +41,13 @@ timeout 500 python tools/concurrent_clips.py 110 4 > $OUT/concurrent_clips.txt 2
 timeout 600 python tools/perframe_batched.py 6 100 > $OUT/perframe_batched.txt 2>&1
 timeout 400 python tools/race_hunt.py 1000 B > $OUT/race_hunt.txt 2>&1
 timeout 300 python tools/split_check.py > $OUT/split_check.txt 2>&1
+# 4b. infilling-AE step engine: per-kernel stats of 20 steps, k clips side by side on both paths, the weight-gradient probe
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/pa -o p -- python $R/tools/ae_prof.py engine graph > $R/$OUT/ae_prof.log 2>&1
+cd $R
+find $OUT/pa -name "*kernel_stats*" | head -1 | while read f; do cp "$f" $OUT/ae_engine_kernel_stats.csv; done
+rm -rf $OUT/pa
+timeout 600 python tools/ae_concurrent.py > $OUT/ae_concurrent.txt 2>&1
+timeout 300 python tools/ae_wgrad_probe.py > $OUT/ae_wgrad_probe.txt 2>&1
 # 5. the whole GPU suite with its printed measurements, smoke
 timeout 2400 python -m pytest tests -m gpu -q -s > $OUT/pytest_full.log 2>&1; grep -E "^FAILED|^ERROR" $OUT/pytest_full.log > $OUT/pytest_failures.txt; grep -E "passed|failed|MPJPE|it/s|iterations/s|max rel|vs float64|module-API|per-frame|3 frames|PROX|finetuned|clip pipeline|step [0-9]|gradient|s per clip|ms per clip|eager launches|vertices vs|max err|kink|marker residual|split conv" $OUT/pytest_full.log | grep -v "^\"void" > $OUT/pytest_gpu_measurements.txt; grep -v "^\"void" $OUT/pytest_full.log | tail -c 20000 > $OUT/pytest_tail.log; rm -f $OUT/pytest_full.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2 > $OUT/smoke.txt
@@ -47,6 +56,10 @@ import json
 d=json.load(open('$OUT/bench_driver_style.json')); r=d['roofline']
 print('value', d['value'], 'v100', d.get('value_100_steps'), 'conv us', r['kernel_ms']*1e3, 'frac', r['frac'], 'traffic', r['traffic'])
 for k in ('prox_window','perframe','ae_finetune','concurrent_clips','cpu_baseline'):
-    print(k, {kk: vv for kk, vv in d.get(k, {}).items() if kk in ('value','unit','error','one_clip_value','cores','bit_identical_to_solo')})
+    print(k, {kk: vv for kk, vv in d.get(k, {}).items() if kk in ('value','unit','error','one_clip_value','cores','bit_identical_to_solo','autograd_path_ms','side_by_side_ms_per_clip')})
+for f in ('bench_100','bench_100_again','bench_100_blend_bf16x3','bench_100_variant3_bf16x3','bench_prox'):
+    try:
+        e=json.load(open('$OUT/'+f+'.json')); print(f, e['value'], e['roofline'].get('hbm',{}).get('kernel_ms'))
+    except Exception as ex: print(f, 'ERR', ex)
 PY
 tail -3 $OUT/pytest_gpu_measurements.txt; cat $OUT/pytest_failures.txt; grep -E "side by side|rc=" $OUT/concurrent_clips.txt | cut -c1-200; tail -2 $OUT/race_hunt.txt; cat $OUT/smoke.txt | cut -c1-200
