@@ -390,8 +390,9 @@ int lemo_fit_forward(void* h, void* stream);
 /* after lemo_fit_forward: gradients of the total loss into g_transl / g_rot6d / g_other (priors' own
  * gradient terms are added inside the Adam kernel), no parameter update */
 int lemo_fit_backward(void* h, void* stream);
-/* n full iterations (forward, backward, Adam).  use_graph: the iteration is captured into hipGraphs of 20 / 5 / 1
- * iterations on first use (on `stream`, which must not be the legacy default stream) and replayed. */
+/* n full iterations (forward, backward, Adam).  use_graph: the call is replayed from hipGraphs -- a 1-iteration and a
+ * 5-iteration graph to get the device going, then 20-iteration graphs, then ONE graph for what is left (sizes 1 .. 20 are captured on
+ * first use, on `stream`, which must not be the legacy default stream, and kept). */
 int lemo_fit_step(void* h, int n, int use_graph, void* stream);
 /* record (without running anything) the graphs an n-iteration lemo_fit_step(use_graph = 1) on `stream` will replay,
  * so that the first such call does not pay for capture + instantiation */

@@ -234,16 +234,15 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 // ------------------------------------------------------------------------------------------------
 // fitting engine
 // ------------------------------------------------------------------------------------------------
-// a replay costs ~8 us of device idle time around the graph (tools/ubench/launch_ubench.hip) on top of its nodes:
-// up to FIT_UNROLL[0] iterations are captured into one graph; remainders run on the smaller graphs
-static const int FIT_LEVELS = 3;
-static const int FIT_UNROLL[FIT_LEVELS] = {20, 5, 1};   // iterations per graph, tried largest first (20: 372.4 vs 374.4 us
-                                                          // per iteration with 5 only, same box; 100-step fits = 5 replays)
+// a replay costs ~8 us of device idle time around the graph (tools/ubench/launch_ubench.hip) on top of its nodes, and every
+// graph re-launches the first VPoser layer: as few, as large graphs as the host can enqueue without starving the device.
+// Graphs of 1 .. FIT_MAXG iterations are captured on first use (lemo_fit_prepare) and kept.
+static const int FIT_MAXG = 20;     // iterations per graph, at most (20: 372.4 vs 374.4 us per iteration with 5 only, same box)
 
 struct FitEngine {
   lemo_fit_desc d;
-  hipGraphExec_t exec[FIT_LEVELS] = {nullptr, nullptr, nullptr};   // FIT_UNROLL[l] iterations each, captured on first use
-  int head = 5;     // replays of the 1-iteration graph that open a call (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
+  hipGraphExec_t exec[FIT_MAXG + 1] = {};      // exec[k] = k iterations
+  int head = 5;     // > 0: a call opens with a 1-iteration and a `head`-iteration graph (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
 };
 
 static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last);
@@ -262,28 +261,29 @@ static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphEx
   return ic;
 }
 
-// n iterations as replays of the 20 / 5 / 1-iteration graphs; launch = false only captures what is missing.
-// hipGraphLaunch hands a graph to the queue only after the host has written all of its nodes (measured: a 20-step call
-// that opens with the 621-node graph starts ~0.7 ms late, 9 % of the call; later replays are enqueued while the device is
-// busy and cost nothing).  A call therefore opens with a few replays of the 32-node graph, continues with the 156-node
-// one, and only then switches to the large graph -- the device starts within ~40 us and the host stays ahead.
+// n iterations as replays; launch = false only captures what is missing.
+// hipGraphLaunch hands a graph to the queue only after the host has written all of its nodes (measured: a 20-step call that
+// opens with the 621-node graph starts ~0.7 ms late, 9 % of the call; later replays are enqueued while the device is busy and
+// cost nothing).  A call therefore opens with the 32-node graph (the device starts within ~40 us), then a 5-iteration one
+// (enqueued in 0.17 ms while the first runs 0.33 ms), then 20-iteration graphs (0.7 ms of host time against 6.6 ms of device
+// time each) and ONE graph for what is left.  Round 3 first used only the 20 / 5 / 1 sizes -- [1 x 5, 5 x 3] for the driver's
+// 20-step call: 8 launches where [1, 5, 14] is 3, each launch ~13 us of gap + repeated first layer.
 static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
   // a hipGraphExec is not bound to the stream it was captured on: the graphs are kept when the caller changes streams
   // (round 2 destroyed and re-captured all three -- ~600 nodes -- per stream change, possibly under a replay still in flight)
-  int left = n;
-  int plan[FIT_LEVELS] = {0, 0, 0};                 // replays per level, in launch order: level 2 (1 it), 1 (5 it), 0 (20 it), then tails
-  int tail[FIT_LEVELS] = {0, 0, 0};
+  int open[2] = {0, 0}, left = n;
   if (e->head > 0) {
-    plan[2] = left < e->head ? left : e->head; left -= plan[2];
-    const int mid = left >= 15 + FIT_UNROLL[0] ? 3 : left / FIT_UNROLL[1];      // 3 x 5 before the first 20, or all fives
-    plan[1] = mid; left -= mid * FIT_UNROLL[1];
+    if (left > 0) { open[0] = 1; left -= 1; }
+    if (left > 0) { open[1] = left < e->head ? left : (e->head < FIT_MAXG ? e->head : FIT_MAXG); left -= open[1]; }
   }
-  for (int l = 0; l < FIT_LEVELS; ++l) { tail[l] = left / FIT_UNROLL[l]; left -= tail[l] * FIT_UNROLL[l]; }
-  for (int l = 0; l < FIT_LEVELS; ++l)
-    if ((plan[l] || tail[l]) && !e->exec[l]) CHK(capture_iterations(e, s, FIT_UNROLL[l], &e->exec[l]));
+  const int nfull = left / FIT_MAXG, rem = left - nfull * FIT_MAXG;
+  const int need[4] = {open[0], open[1], nfull ? FIT_MAXG : 0, rem};
+  for (int i = 0; i < 4; ++i)
+    if (need[i] && !e->exec[need[i]]) CHK(capture_iterations(e, s, need[i], &e->exec[need[i]]));
   if (!launch) return 0;
-  for (int l = FIT_LEVELS - 1; l >= 0; --l) for (int i = 0; i < plan[l]; ++i) CHK((int)hipGraphLaunch(e->exec[l], s));
-  for (int l = 0; l < FIT_LEVELS; ++l) for (int i = 0; i < tail[l]; ++i) CHK((int)hipGraphLaunch(e->exec[l], s));
+  for (int i = 0; i < 2; ++i) if (open[i]) CHK((int)hipGraphLaunch(e->exec[open[i]], s));
+  for (int i = 0; i < nfull; ++i) CHK((int)hipGraphLaunch(e->exec[FIT_MAXG], s));
+  if (rem) CHK((int)hipGraphLaunch(e->exec[rem], s));
   return 0;
 }
 
@@ -420,7 +420,7 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
 void lemo_fit_destroy(void* h) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return;
-  for (int l = 0; l < FIT_LEVELS; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
+  for (int l = 0; l <= FIT_MAXG; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
   delete e;
 }
 
