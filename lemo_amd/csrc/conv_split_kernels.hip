@@ -234,7 +234,11 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
   // requested TWO steps ahead through a ring of three register sets; activation fragments come from LDS
   // one step ahead (two sets; not across the phase barrier).  The sched_barriers keep hipcc from sinking
   // the loads next to their uses.
-  uint4 ra[3][NP], rb[2][2][NP];
+#ifndef CV3_RA
+#define CV3_RA 3
+#endif
+  constexpr int RA = CV3_RA;                                    // weight ring: requested RA - 1 steps ahead
+  uint4 ra[RA][NP], rb[2][2][NP];
 #define CV3_LOAD_A(SET, U)                                                                         \
   _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_)                                                \
     ra[SET][s_] = w3[(unsigned)((((NCC * kh + (U) / 9) * 9 + (U) % 9) * MT + ch) * NP + s_) * 64u + lane];
@@ -264,8 +268,9 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
   // the first two weight fragments are requested before anything else (nothing depends on them; issuing the staging
   // loads first instead shortens the prologue in isolation but measured 0.5 % slower inside the engine, and moving
   // the remainder patch's loads into the prologue 1.5 % slower: same-box A/B with tools/gpu_ab_bench.sh)
-  CV3_LOAD_A(0, 0)
-  CV3_LOAD_A(1, 1)
+#pragma unroll
+  for (int u0 = 0; u0 < RA - 1; ++u0)
+    if (u0 < NU) { CV3_LOAD_A(u0, u0) }
 
   // ---- remainder patch of this block: PPX px x 4 couts ---------------------------------------------
   const int rem0 = full_blocks * 128;
@@ -364,14 +369,14 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int u = cc * 9 + tap;
-      if (u + 2 < NU) { CV3_LOAD_A((u + 2) % 3, u + 2) }
+      if (u + RA - 1 < NU) { CV3_LOAD_A((u + RA - 1) % RA, u + RA - 1) }
       if (tap + 1 < 9) { CV3_LOAD_B((u + 1) & 1, u + 1) }
       if (u == 0) {
         split_patch_load<EPI, CIN, COUT, NP>(pt, in, wt, bias, aux, W, wmagic, Wp, HWp, P, rem0, has_patch ? tile : 0);
         pt.valid = pt.valid && has_patch;
       }
       __builtin_amdgcn_sched_barrier(0);
-      CV3_MFMA(u % 3, u & 1)
+      CV3_MFMA(u % RA, u & 1)
       if (u == 4) split_patch_finish<EPI, CIN>(pt, out, HWp);
       // NP 2, second phase: its maximum is published at tap 0 (the loads have had the first step to land) and
       // collected behind a workgroup barrier at tap 1, with this step's MFMAs already queued
