@@ -59,7 +59,7 @@ for k in ('prox_window','perframe','ae_finetune','concurrent_clips','cpu_baselin
     print(k, {kk: vv for kk, vv in d.get(k, {}).items() if kk in ('value','unit','error','one_clip_value','cores','bit_identical_to_solo','autograd_path_ms','side_by_side_ms_per_clip')})
 for f in ('bench_100','bench_100_again','bench_100_blend_bf16x3','bench_100_variant3_bf16x3','bench_prox'):
     try:
-        e=json.load(open('$OUT/'+f+'.json')); print(f, e['value'], e['roofline'].get('hbm',{}).get('kernel_ms'))
+        e=json.load(open('$OUT/'+f+'.json')); print(f, e['value'], e.get('roofline',{}).get('hbm',{}).get('kernel_ms'))
     except Exception as ex: print(f, 'ERR', ex)
 PY
 tail -3 $OUT/pytest_gpu_measurements.txt; cat $OUT/pytest_failures.txt; grep -E "side by side|rc=" $OUT/concurrent_clips.txt | cut -c1-200; tail -2 $OUT/race_hunt.txt; cat $OUT/smoke.txt | cut -c1-200
