@@ -29,6 +29,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see lemo_amd/__init__.py (only the side-by-side extras use > 1 stream)
+
 import numpy as np
 import torch
 import torch.distributed as dist
