@@ -553,6 +553,10 @@ class _EngineSession:
     def _s(self):
         return self.stream.cuda_stream if self.gpu else None
 
+    def _on(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.gpu else contextlib.nullcontext()
+
     def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True):
         """load the pretrained parameters and the clip, `steps` training steps, eval forward, parameters back out -- all on
         this session's stream; returns views of the session's output buffers (valid until its next run)"""
@@ -570,7 +574,8 @@ class _EngineSession:
             if self._ev is None:
                 self._ev = torch.cuda.Event()
             self._ev.record(self.stream)
-            self._keep = (flat0, x, moc)                 # read by the launches above: alive until the next run replaces them
+            for t in (flat0, x, moc):                    # read by the launches above on this session's stream
+                t.record_stream(self.stream)
             if join:
                 self.join()
         return self.flat, self.rec, self.z
@@ -579,6 +584,9 @@ class _EngineSession:
         if self.gpu:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
+
+AE_LANES = max(1, int(__import__('os').environ.get('LEMO_AE_LANES', '2')))
+"""finetune loops in flight at once in ``finetune_and_infill_many`` (see there)"""
 
 USE_ENGINE = __import__('os').environ.get('LEMO_AE_ENGINE', '1') != '0'
 """the finetune loop runs on the native step engine (round 3: 53 launches per step instead of ~150; csrc/ae_engine.hip).
@@ -647,14 +655,17 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
 def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor], train_masks: List[torch.Tensor], steps: int = 60,
                              lr: float = 3e-6, use_graph: Optional[bool] = None, engine: Optional[bool] = None):
     """:func:`finetune_and_infill` for several clips SIDE BY SIDE (the dataset-scale form, like
-    ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1): every clip's
-    60-step finetune runs on its own session -- own stream, own parameters, Adam state, workspace and captured graphs -- so
-    the k loops advance concurrently.  One training step is a chain of short launches (the deep layers are 27 x 17 and 14 x 9
-    pixel images: a handful of workgroups each) whose time is mostly latency; a second and third clip fill the idle device.
-    Each clip's result is bit-identical to its solo ``finetune_and_infill`` (same kernels, same order, no shared state;
-    tested).  Returns the list of ``(clip_img_rec, z)``; at most ``_MAX_SESSIONS`` clips per call; the model is left with the
-    LAST clip's finetuned weights."""
-    assert 1 <= len(clips) == len(train_masks) <= _MAX_SESSIONS
+    ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1): the clips' 60-step
+    finetunes run on ``AE_LANES`` sessions -- each its own stream, parameters, Adam state, workspace and captured graphs -- clip i
+    on lane i % AE_LANES, the clips of a lane one after the other.  One training step is a chain of short launches whose time is
+    mostly latency, so a second clip fills the idle device: 33 -> 24 ms per clip.  More than two loops truly in flight do NOT
+    help: with four hardware queues' worth of concurrency the step's chip-filling launches (weight gradients, the 210 x 135
+    layers) contend and a clip takes 33.6 ms again (``profiles/r03_hw_queues.txt``; with the runtime's default of 4 hardware
+    queues two of four streams shared a queue, which hid this).  Each clip's result is bit-identical to its solo
+    ``finetune_and_infill`` (same kernels, same order, no shared state; tested).  Returns the list of ``(clip_img_rec, z)``; the
+    model is left with the LAST clip's finetuned weights.  (``engine=False``: the round-2 path, one session per clip, at most
+    ``_MAX_SESSIONS`` clips.)"""
+    assert 1 <= len(clips) == len(train_masks)
     lib = model._lib_override or _hip.get_lib()
     if use_graph is None:
         use_graph = clips[0].is_cuda
@@ -662,20 +673,35 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
     engine = USE_ENGINE if engine is None else bool(engine)
     model.load_state_dict(weights)
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
-    results, sessions = [], []
     mocs = [tm.to(x.dtype) * (1.0 / tm.to(x.dtype).sum()) for x, tm in zip(clips, train_masks)]     # (on the current stream, before any fork)
+    if engine:
+        out, sessions, last_flat = [], {}, None
+        cur = torch.cuda.current_stream(clips[0].device) if clips[0].is_cuda else None
+        for i, (x, moc) in enumerate(zip(clips, mocs)):                      # enqueue: clip i's loop on lane i % AE_LANES
+            ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i % AE_LANES, engine=True)
+            flat, rec, z = ses.run(flat0, x, moc, steps, use_graph, join=False)     # the current stream waits for nobody yet
+            with ses._on():                                                 # the lane's next clip overwrites the session's buffers:
+                r, zz = rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()     # copies, made on the lane's stream
+                if i == len(clips) - 1:
+                    last_flat = flat.clone()
+            if cur is not None and ses.gpu:
+                for t in (r, zz) + ((last_flat,) if i == len(clips) - 1 else ()):
+                    t.record_stream(cur)                                    # read on the caller's stream after the join
+            out.append((r, zz))
+            sessions[id(ses)] = ses
+        for ses in sessions.values():
+            ses.join()
+        _store_params(model, last_flat)
+        return out
+    assert len(clips) <= _MAX_SESSIONS
+    results, sessions = [], []
     for i, (x, moc) in enumerate(zip(clips, mocs)):                          # enqueue: clip i's loop on session i's stream
-        ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i, engine=engine)
+        ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i, engine=False)
         results.append(ses.run(flat0, x, moc, steps, use_graph, join=False))   # the current stream waits for nobody yet
         sessions.append(ses)
     for ses in sessions:
         ses.join()
     out = []
-    if engine:
-        for flat, rec, z in results:
-            out.append((rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()))
-        _store_params(model, results[-1][0])
-        return out
     for x, flat in zip(clips, results):                                      # eval forwards, one after the other
         _store_params(model, flat)
         with torch.no_grad():

@@ -118,8 +118,9 @@ def test_finetune_session_carries_nothing_from_clip_to_clip(emu_lib):
 
 
 def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
-    """finetune_and_infill_many: clip i on session slot i (own parameters / Adam state / workspace) == clip i through
-    finetune_and_infill, bit for bit; and the session cache is an LRU of at most _MAX_SESSIONS entries"""
+    """finetune_and_infill_many: clip i on lane i % AE_LANES (a lane = a session: own parameters / Adam state / workspace; the
+    clips of a lane one after the other) == clip i through finetune_and_infill, bit for bit; and the session cache is an LRU of
+    at most _MAX_SESSIONS entries"""
     from lemo_amd import infill
     from lemo_amd.infill import AE, finetune_and_infill, finetune_and_infill_many
     w = _weights()
@@ -131,7 +132,7 @@ def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
     solo = [tuple(t.clone() for t in finetune_and_infill(ae, w, x, m, steps=2, lr=1e-3)) for x, m in zip(xs, ms)]
     infill._SESSIONS.clear()
     many = finetune_and_infill_many(AE(_lib=emu_lib), w, xs, ms, steps=2, lr=1e-3)
-    assert len(infill._SESSIONS) == 3
+    assert len(infill._SESSIONS) == min(3, infill.AE_LANES)             # clip i runs on lane i % AE_LANES
     for (ra, za), (rb, zb) in zip(solo, many):
         assert torch.equal(ra, rb) and torch.equal(za, zb)
     for t in range(infill._MAX_SESSIONS + 3):                          # other clip shapes: the cache stays bounded
