@@ -488,7 +488,7 @@ def main():
     ap.add_argument('--workload', choices=('amass', 'prox'), default='amass',
                     help="amass (default, the headline: BASELINE configs[1]/[2]) or prox (configs[4]'s per-GPU leg: one S3 window per GPU)")
     ap.add_argument('--no-extras', action='store_true', help='skip the non-headline objects (prox_window, perframe, ae_finetune)')
-    ap.add_argument('--concurrent-clips', type=int, default=3,
+    ap.add_argument('--concurrent-clips', type=int, default=4,
                     help='after the headline measurement (one clip per GPU), also time this many independent clips fitted side by '
                          'side on GPU 0 (reported as "concurrent_clips", never as "value"; 0 = off)')
     args = ap.parse_args()
