@@ -29,8 +29,6 @@ import os
 import sys
 import time
 
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')      # before the HIP runtime initialises: see lemo_amd/__init__.py (only the side-by-side extras use > 1 stream)
-
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -488,7 +486,7 @@ def main():
     ap.add_argument('--workload', choices=('amass', 'prox'), default='amass',
                     help="amass (default, the headline: BASELINE configs[1]/[2]) or prox (configs[4]'s per-GPU leg: one S3 window per GPU)")
     ap.add_argument('--no-extras', action='store_true', help='skip the non-headline objects (prox_window, perframe, ae_finetune)')
-    ap.add_argument('--concurrent-clips', type=int, default=4,
+    ap.add_argument('--concurrent-clips', type=int, default=3,
                     help='after the headline measurement (one clip per GPU), also time this many independent clips fitted side by '
                          'side on GPU 0 (reported as "concurrent_clips", never as "value"; 0 = off)')
     args = ap.parse_args()
