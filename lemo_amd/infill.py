@@ -518,13 +518,16 @@ class _EngineSession:
     Adam state, activations and gradients from, its stream, and the output buffers of the eval forward.  Kept across clips
     of the same shape like :class:`_FinetuneSession` (the captured graphs live inside the engine)."""
 
-    def __init__(self, lib, x_shape, lr, device):
+    def __init__(self, lib, x_shape, lr, device, slot: int = 0):
         self.lib, self.device = lib, torch.device(device)
         self.gpu = self.device.type == 'cuda' and not lib.is_emu
         H, W = int(x_shape[-2]), int(x_shape[-1])
         n = int(lib.ae_ws_floats(H, W))
         if n <= 0:
             raise _hip.LemoHipError(f'lemo_ae_ws_floats refuses a {H} x {W} clip image')
+        # (two lanes whose streams the runtime happens to put into one hardware queue run one after the other: 33 instead of 24 ms
+        # per clip, seen inside bench.py depending on how many streams the process had created before.  Giving the lanes different
+        # stream PRIORITIES to force them apart measured 58 ms per clip: not done.)
         self.stream = torch.cuda.Stream(self.device) if self.gpu else None
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
         h5, w5 = H, W
@@ -557,27 +560,38 @@ class _EngineSession:
         import contextlib
         return torch.cuda.stream(self.stream) if self.gpu else contextlib.nullcontext()
 
-    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True):
-        """load the pretrained parameters and the clip, `steps` training steps, eval forward, parameters back out -- all on
-        this session's stream; returns views of the session's output buffers (valid until its next run)"""
+    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True, own_stream=True):
+        """load the pretrained parameters and the clip, `steps` training steps, eval forward, parameters back out; returns views
+        of the session's output buffers (valid until its next run).  ``own_stream``: everything runs on this session's stream
+        (what a lane of ``finetune_and_infill_many`` needs); False: on the CALLER's current stream when that is not the legacy
+        default stream (which cannot be captured) -- one clip on its own then needs no hand-over between two hardware queues,
+        which measured 29.8 instead of 33.4 ms per clip (``profiles/r03_hw_queues.txt``; the graphs are not bound to a stream)."""
         lib = self.lib
         flat0, x, moc = flat0.contiguous().float(), x.reshape(4, *x.shape[-2:]).contiguous().float(), m_over_cnt.contiguous().float()
         assert flat0.numel() == self.flat.numel() and tuple(moc.shape) == tuple(self.rec.shape)
+        run_on, sh = self.stream, self._s()
         if self.gpu:
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            if not own_stream and cur != torch.cuda.default_stream(self.device):
+                run_on, sh = cur, cur.cuda_stream
+                if self._ev is not None:
+                    cur.wait_event(self._ev)               # the session's previous run (possibly on another stream)
+            else:
+                self.stream.wait_stream(cur)
             _hip.flush_deferred()
-        lib.check(lib.ae_load(self.h, ptr(flat0), ptr(x), ptr(moc), self._s()), 'ae_load')
-        lib.check(lib.ae_step(self.h, int(steps), 1 if (use_graph and self.gpu) else 0, self._s()), 'ae_step')
-        lib.check(lib.ae_forward(self.h, ptr(self.rec), ptr(self.z), self._s()), 'ae_forward')
-        lib.check(lib.ae_params(self.h, ptr(self.flat), self._s()), 'ae_params')
+        lib.check(lib.ae_load(self.h, ptr(flat0), ptr(x), ptr(moc), sh), 'ae_load')
+        lib.check(lib.ae_step(self.h, int(steps), 1 if (use_graph and self.gpu) else 0, sh), 'ae_step')
+        lib.check(lib.ae_forward(self.h, ptr(self.rec), ptr(self.z), sh), 'ae_forward')
+        lib.check(lib.ae_params(self.h, ptr(self.flat), sh), 'ae_params')
         if self.gpu:
             if self._ev is None:
                 self._ev = torch.cuda.Event()
-            self._ev.record(self.stream)
-            for t in (flat0, x, moc):                    # read by the launches above on this session's stream
-                t.record_stream(self.stream)
-            if join:
-                self.join()
+            self._ev.record(run_on)
+            if run_on is self.stream:
+                for t in (flat0, x, moc):                    # read by the launches above on this session's stream
+                    t.record_stream(self.stream)
+                if join:
+                    self.join()
         return self.flat, self.rec, self.z
 
     def join(self):
@@ -603,7 +617,7 @@ def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine:
     key = (str(device), tuple(shape), float(lr), id(lib), int(slot), bool(engine))
     ses = _SESSIONS.pop(key, None)
     if ses is None:
-        ses = _EngineSession(lib, tuple(shape), lr, device) if engine else _FinetuneSession(lib, n_param, tuple(shape), lr, device)
+        ses = _EngineSession(lib, tuple(shape), lr, device, slot) if engine else _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
     while len(_SESSIONS) > _MAX_SESSIONS:
         _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for its last launch and releases the graphs
@@ -642,7 +656,7 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     ses = _session(lib, flat0.numel(), clip_img_input.shape, lr, clip_img_input.device, engine=engine)
     if engine:
         _hip.check_device(lib, clip_img_input)
-        flat, rec, z = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
+        flat, rec, z = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph, own_stream=False)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
         _store_params(model, flat)
         return rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()
     flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)

@@ -18,6 +18,13 @@ rb, zb = finetune_and_infill(ae, w, xs[0], mask, steps=60, engine=False)
 pb = [p.detach().clone() for p in ae.parameters()]
 print('engine vs autograd path after 60 steps: max |d rec| %.3e (max |rec| %.3f), max |d z| %.3e, max |d param| %.3e (lr 3e-6: 60 steps move a parameter by <= 1.8e-4)' % (
     float((ra - rb).abs().max()), float(rb.abs().max()), float((za - zb).abs().max()), max(float((a - b).abs().max()) for a, b in zip(pa, pb))), flush=True)
+side = torch.cuda.Stream(dev)
+torch.cuda.synchronize()
+with torch.cuda.stream(side):
+    for eng in (True, False):
+        finetune_and_infill(ae, w, xs[0], mask, steps=60, engine=eng); torch.cuda.synchronize()
+        t0 = time.perf_counter(); finetune_and_infill(ae, w, xs[0], mask, steps=60, engine=eng); torch.cuda.synchronize()
+        print('one clip through finetune_and_infill, caller on its own stream, engine=%s: %.1f ms' % (eng, (time.perf_counter() - t0) * 1e3), flush=True)
 for engine in (True, False):
     print('engine:', engine, ' (autograd path: second stream for the weight gradients: %s)' % infill.WGRAD_SECOND_STREAM, flush=True)
     for use_graph in (True, False):
