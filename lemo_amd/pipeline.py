@@ -41,7 +41,20 @@ def load_infill_stats() -> Dict[str, np.ndarray]:
     return {k: d[k] for k in d.files}
 
 
+_CONST_CACHE: Dict[tuple, torch.Tensor] = {}
+"""small per-device constants (the statistics vector, the masked rows).  Uploading them per clip is not just a copy: a pageable
+host-to-device copy is ordered behind everything the current stream holds, so the host thread stood still until the previous
+clip's work had drained (62 of a clip's 66 ms were host time before round 3 cached them, tools/clip_pipeline_rate.py)."""
+
+
 def _stats_vector(stats: Dict[str, np.ndarray], device) -> torch.Tensor:
+    key = ('stats', id(stats), str(device))
+    if key not in _CONST_CACHE:
+        _CONST_CACHE[key] = _stats_vector_uncached(stats, device)
+    return _CONST_CACHE[key]
+
+
+def _stats_vector_uncached(stats: Dict[str, np.ndarray], device) -> torch.Tensor:
     v = np.concatenate([np.asarray(stats['Xmean_local'], np.float64).reshape(-1), np.asarray(stats['Xstd_local'], np.float64).reshape(-1),
                         [float(stats['Xmean_global_xy']), float(stats['Xstd_global_xy']), float(stats['Xmean_global_r']),
                          float(stats['Xstd_global_r'])]])
@@ -69,16 +82,24 @@ def amass_mask_input(clip_img: torch.Tensor):
     """clip_img [1,4,d,T] -> (clip_img_input [1,4,d+2,T+16], train_mask bool [d+2,T+16]).
     ``train_mask`` is the reference's ``res_map[:, upper_body_row][:, 0:-5]`` selection (:199-204): every padded row that
     is not a masked marker row, minus the last five (4 contact rows + the pad row)."""
+    # (no indexed assignment with a device index tensor here: `x[:, 0, rows, :] = 0` made the host wait for the device -- 48 ms per
+    # clip behind the previous clip's fit, tools/clip_pipeline_rate.py -- the row selections are cached boolean masks instead)
+    d, T = clip_img.shape[-2], clip_img.shape[-1]
+    key = ('amass_masks', d, T, str(clip_img.device))
+    if key not in _CONST_CACHE:
+        rows = torch.as_tensor(amass_mask_rows())
+        shown = torch.ones(d, dtype=torch.bool)
+        shown[rows] = False
+        shown[-4:] = False
+        keep = torch.ones(d + 2, dtype=torch.bool)
+        keep[rows + 1] = False
+        keep[-5:] = False
+        _CONST_CACHE[key] = (shown.to(clip_img.device), keep[:, None].expand(d + 2, T + 16).contiguous().to(clip_img.device))
+    shown, keep = _CONST_CACHE[key]
     x = clip_img.clone()
-    rows = torch.as_tensor(amass_mask_rows(), device=x.device)
-    x[:, 0, rows, :] = 0.
-    x[:, 0, -4:, :] = 0.
+    x[:, 0] = torch.where(shown[:, None], x[:, 0], torch.zeros((), dtype=x.dtype, device=x.device))
     x = F.pad(x, P2D, 'reflect')
-    H, W = x.shape[-2], x.shape[-1]
-    keep = torch.ones(H, dtype=torch.bool, device=x.device)
-    keep[rows + 1] = False
-    keep[-5:] = False
-    return x, keep[:, None].expand(H, W).contiguous()
+    return x, keep
 
 
 def decode_markers(clip_img_rec: torch.Tensor, clip_img: torch.Tensor, rot_0_pivot, stats: Optional[Dict[str, np.ndarray]] = None,
@@ -131,6 +152,59 @@ class AmassClipPipeline:
         fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
         return dict(p72=fit.params72(), contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in,
                     train_mask=mask)
+
+
+    def fit_clips(self, clips, steps: int = 100, finetune_steps: int = 60, use_graph: Optional[bool] = None):
+        """``fit_clip`` for a LIST of clips ``(clip_img, rot_0_pivot, init_params, gender)``, pipelined on the device: clip
+        i + 1's finetune (the caller's stream) runs while clip i's temporal fit is still replaying on its fitter's stream; nothing
+        in the loop makes the host wait for the device.  Three things make that possible: ``init_params`` goes up on a separate
+        upload stream (a pageable host-to-device copy on the caller's stream would wait for everything queued there), the
+        fitted parameters are read on a separate result stream (on the caller's stream that read would order the next finetune
+        behind this fit), and a fitter's next ``load_sequence`` waits for that read.  Returns the list of ``fit_clip`` dicts;
+        all of them are ordered on the caller's stream when the call returns.  Same kernels, same order per clip: results are
+        identical to ``fit_clip`` one by one (tested).  Measured (tools/clip_pipeline_rate.py, 60-step finetune + 100-step fit):
+        64.7 ms per clip one by one, 52.8 ms pipelined when the caller's stream and the fitter's stream sit in different hardware
+        queues (``GPU_MAX_HW_QUEUES=8``); with the runtime's default of 4 queues the two can land in one queue, and then nothing
+        overlaps (68 ms) -- DESIGN 9.11."""
+        dev = next(iter(self.fitters.values())).device
+        gpu = dev.type == 'cuda' and torch.cuda.is_available() and not next(iter(self.fitters.values())).lib.is_emu
+        if not gpu:
+            return [self.fit_clip(c, piv, init, gender=g, steps=steps, finetune_steps=finetune_steps, use_graph=use_graph)
+                    for c, piv, init, g in clips]
+        if getattr(self, '_up', None) is None:
+            self._up, self._res = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+            self._read_ev = {}
+        cur = torch.cuda.current_stream(dev)
+        outs, pinned = [], []
+        for clip_img, rot_0_pivot, init_params, gender in clips:
+            g = gender if isinstance(gender, str) else ('female' if int(gender) == 0 else 'male')
+            fit = self.fitters[g]
+            if isinstance(init_params, torch.Tensor) and init_params.is_cuda:
+                p_dev = init_params
+            else:
+                hp = torch.from_numpy(np.ascontiguousarray(np.asarray(init_params, np.float32))).pin_memory()
+                with torch.cuda.stream(self._up):
+                    p_dev = hp.to(dev, non_blocking=True)         # pinned + its own stream: the host does not wait for the device
+                    ev = torch.cuda.Event(); ev.record(self._up)
+                pinned.append(hp)                                 # alive until the copies have run (joined below)
+                cur.wait_event(ev)
+                p_dev.record_stream(cur)
+            x_in, mask = amass_mask_input(clip_img)
+            rec, _ = finetune_and_infill(self.ae, self.ae_weights, x_in, mask, steps=finetune_steps, use_graph=use_graph)
+            lbl, markers = decode_markers(rec[0, 0], clip_img[0], rot_0_pivot, self.stats, _lib=self.ae._lib_override)
+            if id(fit) in self._read_ev:
+                cur.wait_event(self._read_ev[id(fit)])            # the previous clip's parameters have been read out
+            fit.load_sequence(p_dev, markers, lbl)
+            fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
+            with torch.cuda.stream(self._res):
+                p72 = fit.params72()                              # waits for the fit on the RESULT stream only
+                ev = torch.cuda.Event(); ev.record(self._res)
+            p72.record_stream(cur)
+            self._read_ev[id(fit)] = ev
+            outs.append(dict(p72=p72, contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in, train_mask=mask))
+        cur.wait_stream(self._res)
+        self._up.synchronize()                                    # (the uploads finished long ago: releases `pinned` safely)
+        return outs
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -284,6 +284,40 @@ def test_amass_clip_pipeline_end_to_end_vs_oracle(dev):
     assert mpjpe < 1.2 and abs(lg - lo) < 2e-3 * abs(lo)          # measured 0.29 - 0.39 mm, |loss difference| 3e-4 of the loss
 
 
+def test_fit_clips_pipelined_equals_one_by_one(dev):
+    """AmassClipPipeline.fit_clips (clip i+1's finetune overlapping clip i's fit: upload / result streams, no host waits) returns
+    exactly what fit_clip returns clip by clip"""
+    from lemo_amd import pipeline as P
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.infill import AE
+    from lemo_amd.vposer import make_vposer_weights
+    A = load_assets()
+    g = np.load(os.path.join(GOLDEN, 'amass_clip.npz'))
+    model = synthetic.make_synthetic_smplx(seed=0)
+    fit = AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 119, dev)
+    pipe = P.AmassClipPipeline(fit, AE().to(dev), {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_ae_weights(7).items()})
+    clip = torch.from_numpy(g['clip_img']).to(dev)
+    piv = torch.from_numpy(g['rot_0_pivot']).to(dev)
+    items = []
+    for i in range(3):
+        init = synthetic.make_synthetic_sequence(i, B=119)['init_params'].copy()
+        init[:, 0:3] = g['markers_rec'].mean(1) - np.array([0, 0, 0.2 + 0.01 * i], np.float32)
+        items.append((clip * (1.0 + 0.01 * i), piv, init, 1))
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        solo = []
+        for c, p, init, gd in items:
+            o = pipe.fit_clip(c, p, init, gender=gd, steps=12, finetune_steps=10)
+            solo.append({k: v.clone() for k, v in o.items()})
+        many = pipe.fit_clips(items, steps=12, finetune_steps=10)
+        torch.cuda.synchronize()
+    for a, b in zip(solo, many):
+        for k in ('p72', 'markers_rec', 'contact_lbl_rec', 'clip_img_rec'):
+            assert torch.equal(a[k], b[k]), k
+    assert fit.nonfinite_step() == 0
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # PROX
 # ---------------------------------------------------------------------------------------------------------------------
