@@ -48,17 +48,13 @@ clip's work had drained (62 of a clip's 66 ms were host time before round 3 cach
 
 
 def _stats_vector(stats: Dict[str, np.ndarray], device) -> torch.Tensor:
-    key = ('stats', id(stats), str(device))
-    if key not in _CONST_CACHE:
-        _CONST_CACHE[key] = _stats_vector_uncached(stats, device)
-    return _CONST_CACHE[key]
-
-
-def _stats_vector_uncached(stats: Dict[str, np.ndarray], device) -> torch.Tensor:
     v = np.concatenate([np.asarray(stats['Xmean_local'], np.float64).reshape(-1), np.asarray(stats['Xstd_local'], np.float64).reshape(-1),
                         [float(stats['Xmean_global_xy']), float(stats['Xstd_global_xy']), float(stats['Xmean_global_r']),
                          float(stats['Xstd_global_r'])]])
-    return torch.from_numpy(v).to(device)
+    key = ('stats', v.tobytes(), str(device))                  # keyed by CONTENT: callers pass fresh dicts (load_infill_stats())
+    if key not in _CONST_CACHE:
+        _CONST_CACHE[key] = torch.from_numpy(v).to(device)
+    return _CONST_CACHE[key]
 
 
 def normalise_clip_image(img: torch.Tensor, stats: Dict[str, np.ndarray]) -> torch.Tensor:
