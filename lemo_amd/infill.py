@@ -518,7 +518,8 @@ class _EngineSession:
     Adam state, activations and gradients from, its stream, and the output buffers of the eval forward.  Kept across clips
     of the same shape like :class:`_FinetuneSession` (the captured graphs live inside the engine)."""
 
-    def __init__(self, lib, x_shape, lr, device, slot: int = 0):
+    def __init__(self, lib, x_shape, lr, device, slot: int = 0, beside=None):
+        # beside: the stream of the lane this one is to run next to (its own stream is then picked so that the two overlap)
         self.lib, self.device = lib, torch.device(device)
         self.gpu = self.device.type == 'cuda' and not lib.is_emu
         H, W = int(x_shape[-2]), int(x_shape[-1])
@@ -528,7 +529,7 @@ class _EngineSession:
         # (two lanes whose streams the runtime happens to put into one hardware queue run one after the other: 33 instead of 24 ms
         # per clip, seen inside bench.py depending on how many streams the process had created before.  Giving the lanes different
         # stream PRIORITIES to force them apart measured 58 ms per clip: not done.)
-        self.stream = torch.cuda.Stream(self.device) if self.gpu else None
+        self.stream = (torch.cuda.Stream(self.device) if beside is None else _hip.partner_stream(beside)) if self.gpu else None
         self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
         h5, w5 = H, W
         for _ in range(5):
@@ -617,7 +618,11 @@ def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine:
     key = (str(device), tuple(shape), float(lr), id(lib), int(slot), bool(engine))
     ses = _SESSIONS.pop(key, None)
     if ses is None:
-        ses = _EngineSession(lib, tuple(shape), lr, device, slot) if engine else _FinetuneSession(lib, n_param, tuple(shape), lr, device)
+        if engine:
+            other = _SESSIONS.get((str(device), tuple(shape), float(lr), id(lib), int(slot) ^ 1, True)) if AE_LANES == 2 else None
+            ses = _EngineSession(lib, tuple(shape), lr, device, slot, beside=getattr(other, 'stream', None))
+        else:
+            ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
     while len(_SESSIONS) > _MAX_SESSIONS:
         _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for its last launch and releases the graphs

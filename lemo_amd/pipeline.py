@@ -160,8 +160,7 @@ class AmassClipPipeline:
         all of them are ordered on the caller's stream when the call returns.  Same kernels, same order per clip: results are
         identical to ``fit_clip`` one by one (tested).  Measured (tools/clip_pipeline_rate.py, 60-step finetune + 100-step fit):
         64.7 ms per clip one by one, 52.8 ms pipelined when the caller's stream and the fitter's stream sit in different hardware
-        queues (``GPU_MAX_HW_QUEUES=8``); with the runtime's default of 4 queues the two can land in one queue, and then nothing
-        overlaps (68 ms) -- DESIGN 9.11."""
+        queues; ``_hip.partner_stream`` picks the fitter's stream accordingly (in one queue nothing overlaps: 67 ms) -- DESIGN 9.11."""
         dev = next(iter(self.fitters.values())).device
         gpu = dev.type == 'cuda' and torch.cuda.is_available() and not next(iter(self.fitters.values())).lib.is_emu
         if not gpu:
@@ -175,6 +174,11 @@ class AmassClipPipeline:
         for clip_img, rot_0_pivot, init_params, gender in clips:
             g = gender if isinstance(gender, str) else ('female' if int(gender) == 0 else 'male')
             fit = self.fitters[g]
+            if getattr(fit, '_own_for', None) != cur.cuda_stream:    # the fit must not share the caller's hardware queue
+                new = _hip.partner_stream(cur)
+                if fit._own is not None:
+                    new.wait_stream(fit._own)
+                fit._own, fit._own_for = new, cur.cuda_stream
             if isinstance(init_params, torch.Tensor) and init_params.is_cuda:
                 p_dev = init_params
             else:
