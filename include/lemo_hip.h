@@ -23,6 +23,9 @@ extern "C" {
 #define LEMO_ERR_STATE 10003
 
 int lemo_abi_version(void);
+/* bit 0: built with -fno-slp-vectorize -fno-vectorize (csrc/Makefile passes -DLEMO_NO_PACKED_FP32 together with them): no
+ * auto-vectorised packed fp32, the co-residency hazard of DESIGN 9.3.  lemo_amd._hip refuses a library without it. */
+int lemo_build_flags(void);
 
 /* ---- motion-smoothness encoder, models/AE_sep.py:11-30,77-99 (Enc(downsample=False)) ----------
  * Activations: CG8P layout act[C/8][(H+2)*(W+2)][8], zero 1-pixel border owned by the caller.
@@ -397,6 +400,21 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream);
 /* record (without running anything) the graphs an n-iteration lemo_fit_step(use_graph = 1) on `stream` will replay,
  * so that the first such call does not pay for capture + instantiation */
 int lemo_fit_prepare(void* h, int n, void* stream);
+/* Optimiser state of a fit = what torch.optim.Adam + the three parameter tensors hold between two iterations of
+ * opt_amass_temp.py:349-455 (opt_amass_perframe.py:312-355 for per_frame engines): the parameters, Adam's exp_avg /
+ * exp_avg_sq and the number of completed steps (which also selects the learning-rate level, :350-352).  All pointers are
+ * caller-owned DEVICE buffers shaped like the descriptor's ([B][3], [B][6], [B][56] each; step: int[1]).
+ * lemo_fit_load_state: engine <- st (and the NaN / Inf latch is cleared): the next lemo_fit_step continues from that state as
+ *   if the engine had produced it itself -- used to resume a fit and, in the parity tests, to run ONE step from a state the
+ *   reference's own loop went through (teacher forcing) instead of comparing free-running trajectories.
+ * lemo_fit_save_state: st <- engine.  One kernel launch each, asynchronous on `stream`, capturable. */
+typedef struct lemo_fit_state {
+  float *transl, *rot6d, *other;
+  float *adam_m[3], *adam_v[3];   /* transl, rot6d, other */
+  int* step;                      /* [1] completed Adam steps */
+} lemo_fit_state;
+int lemo_fit_load_state(void* h, const lemo_fit_state* st, void* stream);
+int lemo_fit_save_state(void* h, const lemo_fit_state* st, void* stream);
 
 /* ---- PROX sliding-window fitting iteration (the twin of the loop body above) ------------------------------------------
  * temp_prox/fitting_temp_slide.py: closure fitting_func :239-311 (VPoser decode, SMPL-X, loss, backward, erase of the
@@ -487,6 +505,18 @@ void lemo_prox_destroy(void* h);
 int lemo_prox_closure(void* h, void* stream);
 /* n iterations (closure + Adam); use_graph as lemo_fit_step */
 int lemo_prox_step(void* h, int n, int use_graph, void* stream);
+/* Optimiser state of a PROX window (fitting_temp_slide.py:196-204: optimizer.step(closure) x maxiters on the parameters
+ * fit_temp_loadprox_slide.py:511-519 collects): the nine optimised tensors in lemo_prox_desc's shapes, Adam's moments as
+ * [B][81] blocks in the same order (global_orient 3 | transl 3 | left_hand 12 | right_hand 12 | jaw 3 | leye 3 | reye 3 |
+ * expression 10 | pose_embedding 32) and the completed-step count.  Same contract as lemo_fit_load_state / save_state;
+ * window k + 1 of a recording is window k's saved parameters on the overlap with a FRESH Adam (data_parser_slide.py:326-331). */
+typedef struct lemo_prox_state {
+  float *global_orient, *transl, *left_hand_pose, *right_hand_pose, *jaw_pose, *leye_pose, *reye_pose, *expression, *pose_embedding;
+  float *adam_m, *adam_v;         /* [B][81] */
+  int* step;                      /* [1] */
+} lemo_prox_state;
+int lemo_prox_load_state(void* h, const lemo_prox_state* st, void* stream);
+int lemo_prox_save_state(void* h, const lemo_prox_state* st, void* stream);
 
 #ifdef __cplusplus
 }

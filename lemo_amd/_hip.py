@@ -147,6 +147,17 @@ class ProxDesc(C.Structure):
     ]
 
 
+class FitState(C.Structure):
+    """lemo_fit_state"""
+    _fields_ = [('transl', vp), ('rot6d', vp), ('other', vp), ('adam_m', vp * 3), ('adam_v', vp * 3), ('step', vp)]
+
+
+class ProxState(C.Structure):
+    """lemo_prox_state"""
+    _fields_ = [(n, vp) for n in ('global_orient', 'transl', 'left_hand_pose', 'right_hand_pose', 'jaw_pose', 'leye_pose', 'reye_pose',
+                                  'expression', 'pose_embedding', 'adam_m', 'adam_v', 'step')]
+
+
 def ptr(t: Optional[torch.Tensor]):
     """raw device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:
@@ -161,6 +172,7 @@ class LemoHipError(RuntimeError):
 
 _SIGS = {
     'lemo_abi_version': (C.c_int, []),
+    'lemo_build_flags': (C.c_int, []),
     'lemo_conv3x3_mfma': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_splitk': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_lds': (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
@@ -227,6 +239,10 @@ _SIGS = {
     'lemo_fit_backward': (C.c_int, [vp, vp]),
     'lemo_fit_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'lemo_fit_prepare': (C.c_int, [vp, C.c_int, vp]),
+    'lemo_fit_load_state': (C.c_int, [vp, C.POINTER(FitState), vp]),
+    'lemo_fit_save_state': (C.c_int, [vp, C.POINTER(FitState), vp]),
+    'lemo_prox_load_state': (C.c_int, [vp, C.POINTER(ProxState), vp]),
+    'lemo_prox_save_state': (C.c_int, [vp, C.POINTER(ProxState), vp]),
     'lemo_prox_create': (vp, [C.POINTER(ProxDesc)]),
     'lemo_prox_destroy': (None, [vp]),
     'lemo_prox_closure': (C.c_int, [vp, vp]),
@@ -249,6 +265,11 @@ class HipLib:
             fn = getattr(self._dll, name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name[len('lemo_'):], fn)
+        if not self.build_flags() & 1:
+            # auto-vectorised packed fp32 gave a wrong rotation entry in ~1 of 100 runs when another kernel shared the
+            # CU (root cause open; the flags remove every v_pk_*_f32).  A library built some other way is not the product.
+            raise LemoHipError(f'{path} was built without -fno-slp-vectorize -fno-vectorize (-DLEMO_NO_PACKED_FP32): rebuild it with '
+                               f'`make -C {_CSRC}`')
 
     def check(self, rc: int, what: str = ''):
         if rc != 0:

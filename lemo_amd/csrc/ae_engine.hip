@@ -438,11 +438,9 @@ struct AeAdamArgs {
   int n_w, n_all; float lr;
 };
 
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr, float bc1, float bc2s) {
-  const float mi = m + (g - m) * (1.f - 0.9f);                      // torch.optim.Adam defaults (adam_flat_kernel's arithmetic)
-  const float vi = v * 0.999f + (1.f - 0.999f) * g * g;
-  m = mi; v = vi;
-  return p - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + 1e-8f));
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, AdamCoef c) {
+  adam_update_torch(p, m, v, g, c);                                 // common.hpp: torch.optim.Adam's own evaluation order
+  return p;
 }
 
 __global__ void __launch_bounds__(256)
@@ -451,7 +449,7 @@ ae_adam_kernel(AeAdamArgs A) {
   // scatter into the backward pack
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= A.n_all) return;
-  const float bc1 = A.ctr[1], bc2s = A.ctr[2];
+  const AdamCoef ac{A.ctr[1], A.ctr[2]};                            // (-lr / (1 - b1^t), sqrt(1 - b2^t)) of this step
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int wb_idx = -1;
   if (idx < A.n_w) {
@@ -501,10 +499,10 @@ ae_adam_kernel(AeAdamArgs A) {
     }
   }
   float4 m = ld4(A.m + idx), v = ld4(A.v + idx), p = ld4(A.theta + idx);
-  p.x = adam_update(p.x, g.x, m.x, v.x, A.lr, bc1, bc2s);
-  p.y = adam_update(p.y, g.y, m.y, v.y, A.lr, bc1, bc2s);
-  p.z = adam_update(p.z, g.z, m.z, v.z, A.lr, bc1, bc2s);
-  p.w = adam_update(p.w, g.w, m.w, v.w, A.lr, bc1, bc2s);
+  p.x = adam_update(p.x, g.x, m.x, v.x, ac);
+  p.y = adam_update(p.y, g.y, m.y, v.y, ac);
+  p.z = adam_update(p.z, g.z, m.z, v.z, ac);
+  p.w = adam_update(p.w, g.w, m.w, v.w, ac);
   st4(A.m + idx, m); st4(A.v + idx, v); st4(A.theta + idx, p);
   if (wb_idx >= 0) { A.wb[wb_idx] = p.x; A.wb[wb_idx + 8] = p.y; A.wb[wb_idx + 16] = p.z; A.wb[wb_idx + 24] = p.w; }
 }
@@ -517,14 +515,15 @@ ae_adam_kernel(AeAdamArgs A) {
 // the bias corrections Adam reads later in the same step.
 __global__ void __launch_bounds__(256)
 ae_loss_grad_kernel(const float* __restrict__ rec, const float* __restrict__ x8, const float* __restrict__ moc,
-                    float* __restrict__ dpre, int H, int W, float* __restrict__ ctr) {
+                    float* __restrict__ dpre, int H, int W, float* __restrict__ ctr, double lr) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p == 0) {
     int* ci = reinterpret_cast<int*>(ctr);
     const int step = ci[0] + 1;
     ci[0] = step;
-    ctr[1] = (float)(1.0 - pow(0.9, (double)step));
-    ctr[2] = (float)sqrt(1.0 - pow(0.999, (double)step));
+    const AdamCoef ac = adam_coef_t(step, lr);
+    ctr[1] = ac.neg_step;
+    ctr[2] = ac.bc2s;
   }
   if (p >= H * W) return;
   const int y = p / W, x = p - y * W;
@@ -731,7 +730,7 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
   CHK_(ae_forward(e, s));
   const int H0 = e->H[0], W0 = e->W[0];
   hipLaunchKernelGGL(ae_loss_grad_kernel, dim3((H0 * W0 + 255) / 256), dim3(256), 0, s, (const float*)e->act[19], (const float*)e->x8,
-                     (const float*)e->moc, e->dp[19], H0, W0, e->ctr);
+                     (const float*)e->moc, e->dp[19], H0, W0, e->ctr, lr_decimal(e->lr));
   CHK_((int)hipGetLastError());
   // ---- decoder, last block first
   for (int b = 4; b >= 0; --b) {

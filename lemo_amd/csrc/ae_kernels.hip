@@ -361,22 +361,19 @@ int conv3x3_wgrad(const float* dy, const float* x, int H, int W, int cin, int co
 // graph of the training step can be replayed; the counter is advanced by adam_count_kernel AFTER this kernel.
 __global__ void __launch_bounds__(256)
 adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
-                 float lr, int step /*1-based*/, const int* __restrict__ step_dev) {
+                 double lr, int step /*1-based*/, const int* __restrict__ step_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (step_dev) step = step_dev[0] + 1;
-  const float bc1 = (float)(1.0 - pow(0.9, (double)step));
-  const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
-  const float gi = g[i];
-  const float mi = m[i] + (gi - m[i]) * (1.f - 0.9f);
-  const float vi = v[i] * 0.999f + (1.f - 0.999f) * gi * gi;
+  float pv = p[i], mi = m[i], vi = v[i];
+  adam_update_torch(pv, mi, vi, g[i], adam_coef_t(step, lr));       // common.hpp: torch.optim.Adam's own evaluation order
   m[i] = mi; v[i] = vi;
-  p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / bc2s + 1e-8f));
+  p[i] = pv;
 }
 __global__ void adam_count_kernel(int* ctr) { if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += 1; }
 int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int step, int* step_dev, hipStream_t s) {
   if (n <= 0 || (!step_dev && step < 1)) return LEMO_ERR_ARG;
-  hipLaunchKernelGGL(adam_flat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, g, m, v, n, lr, step, (const int*)step_dev);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, g, m, v, n, lr_decimal(lr), step, (const int*)step_dev);
   if (step_dev) hipLaunchKernelGGL(adam_count_kernel, dim3(1), dim3(64), 0, s, step_dev);
   return (int)hipGetLastError();
 }

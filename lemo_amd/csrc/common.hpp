@@ -99,6 +99,26 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+// ---- torch.optim.Adam (defaults), one element, OPERATION FOR OPERATION as torch's CPU kernels evaluate it -- probed bit for bit
+// against torch 2.10 (tests/test_adam_bits.py; rounds 1-3 used (1.f - 0.999f) for 1 - beta2, 1.3e-5 away from torch's 0.001f):
+//   exp_avg.lerp_(g, 1 - b1)                        m' = fma(g - m, 0.1f, m)
+//   exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)      v' = fma(0.001f * g, g, v * 0.999f)
+//   denom = sqrt(v') / sqrt(1 - b2^t) + eps         (the bias correction's square root in double, rounded once)
+//   p.addcdiv_(m', denom, value = -lr / (1 - b1^t))  p' = p + ((-step) * m') / denom  (step in double from the DECIMAL lr)
+struct AdamCoef { float neg_step, bc2s; };
+__host__ __device__ __forceinline__ AdamCoef adam_coef_t(int t /*1-based*/, double lr) {
+  AdamCoef c;
+  c.neg_step = (float)(-(lr / (1.0 - pow(0.9, (double)t))));
+  c.bc2s = (float)sqrt(1.0 - pow(0.999, (double)t));
+  return c;
+}
+__device__ __forceinline__ void adam_update_torch(float& p, float& m, float& v, float g, AdamCoef c) {
+  m = __builtin_fmaf(g - m, 0.1f, m);
+  v = __builtin_fmaf(0.001f * g, g, v * 0.999f);
+  const float denom = sqrtf(v) / c.bc2s + 1e-8f;
+  p = p + (c.neg_step * m) / denom;
+}
+
 // ---- tiny 3-vector algebra ------------------------------------------------------------------
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

@@ -4,7 +4,19 @@
 #include "common.hpp"
 #include "lemo_hip.h"
 
+#include <cmath>
+
 namespace lemo {
+
+// The reference writes its learning rates as decimal literals (0.01, 0.005, 0.1, 0.003, 3e-6: Python doubles) and torch divides
+// THAT double by the bias correction; the C ABI carries them as float.  The shortest decimal (<= 6 significant digits) that
+// rounds to the given float is that literal again; a float that is no short decimal is taken as it is.
+static inline double lr_decimal(float lr) {
+  if (!(lr > 0.f) || !std::isfinite(lr)) return (double)lr;
+  const double k = std::pow(10.0, 5.0 - std::floor(std::log10((double)lr)));
+  const double d = std::nearbyint((double)lr * k) / k;
+  return (float)d == lr ? d : (double)lr;
+}
 
 // ---------------- conv_kernels.hip ----------------
 int conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out,
@@ -133,9 +145,9 @@ struct FitTail {
   const float* weights;
   int* step_ctr;
   const int* step_cur;
-  float lr0, lr1;
+  double lr0, lr1;                  // decimal learning rates (lr_decimal of the descriptor's floats)
   int lr_switch;
-  float lr2;
+  double lr2;
   int lr_switch2;
   float* snap;
   int* nonfinite;
@@ -148,6 +160,19 @@ int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float*
               float* v1, float* other, const float* g_other, float* m2, float* v2, int B, const float* weights,
               int* step_ctr, const int* step_cur, float lr0, float lr1, int lr_switch, hipStream_t s, float lr2 = 0.f,
               int lr_switch2 = 0, float* snap = nullptr, int* nonfinite = nullptr, const float* losses = nullptr);
+
+// optimiser-state hand-over: flat device-to-device copies + step counter in one launch (lemo_*_load_state / save_state)
+static const int STATE_MAX_JOBS = 12;
+struct StateCopy {
+  const float* src[STATE_MAX_JOBS];
+  float* dst[STATE_MAX_JOBS];
+  int n[STATE_MAX_JOBS];
+  int njobs;
+  const int* step_src;
+  int* step_dst;
+  int* nonfinite;                  // [2] zeroed when non-null (load)
+};
+int state_copy(const StateCopy& a, hipStream_t s);
 
 // ---------------- marker_kernels.hip ----------------
 int reconstruct_global_body(const float* in, int T, int J, double rot0, float* out, hipStream_t s, const double* rot0_dev = nullptr);

@@ -12,7 +12,14 @@ using namespace lemo;
 
 extern "C" {
 
-int lemo_abi_version(void) { return 3; }
+int lemo_abi_version(void) { return 4; }
+int lemo_build_flags(void) {
+#ifdef LEMO_NO_PACKED_FP32
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int lemo_conv3x3_mfma(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W,
                       int cin, int cout, int epi, int variant, void* stream) {
@@ -296,7 +303,7 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
   a.transl = d.transl; a.rot6d = d.rot6d; a.other = d.other; a.g_transl = d.g_transl; a.g_rot6d = d.g_rot6d;
   a.m0 = d.adam_m[0]; a.v0 = d.adam_v[0]; a.m1 = d.adam_m[1]; a.v1 = d.adam_v[1]; a.m2 = d.adam_m[2]; a.v2 = d.adam_v[2];
   a.weights = d.weights; a.step_ctr = d.step_ctr; a.step_cur = d.step_cur;
-  a.lr0 = d.lr0; a.lr1 = d.lr1; a.lr_switch = d.lr_switch; a.lr2 = d.lr2; a.lr_switch2 = d.lr_switch2;
+  a.lr0 = lr_decimal(d.lr0); a.lr1 = lr_decimal(d.lr1); a.lr_switch = d.lr_switch; a.lr2 = lr_decimal(d.lr2); a.lr_switch2 = d.lr_switch2;
   a.snap = d.snap; a.nonfinite = d.nonfinite; a.losses = d.losses;
   a.B = d.B; a.do_dz = dz; a.do_adam = adam;
   a.Bn = d.per_frame ? 1 : d.B;       // per_frame: every row is a fit of its own (B > 1 = several clips' frames in lockstep)
@@ -453,5 +460,29 @@ int lemo_fit_prepare(void* h, int n, void* stream) {
   if (!e || n < 0) return LEMO_ERR_ARG;
   return fit_graphs(e, S(stream), n, false);
 }
+
+// engine <-> caller copies of the optimiser state (parameters, Adam moments, completed-step count): ONE launch
+static int fit_state_io(FitEngine* e, const lemo_fit_state* st, bool load, hipStream_t s) {
+  if (!e || !st || !st->transl || !st->rot6d || !st->other || !st->step) return LEMO_ERR_ARG;
+  const lemo_fit_desc& d = e->d;
+  if (!d.rot6d || !d.other || !d.step_ctr) return LEMO_ERR_STATE;
+  StateCopy a{};
+  float* eng[9] = {d.transl, d.rot6d, d.other, d.adam_m[0], d.adam_m[1], d.adam_m[2], d.adam_v[0], d.adam_v[1], d.adam_v[2]};
+  float* usr[9] = {st->transl, st->rot6d, st->other, st->adam_m[0], st->adam_m[1], st->adam_m[2], st->adam_v[0], st->adam_v[1], st->adam_v[2]};
+  const int width[3] = {3, 6, 56};
+  for (int i = 0; i < 9; ++i) {
+    if (!eng[i] || !usr[i]) return LEMO_ERR_ARG;
+    a.src[i] = load ? usr[i] : eng[i];
+    a.dst[i] = load ? eng[i] : usr[i];
+    a.n[i] = d.B * width[i % 3];
+  }
+  a.njobs = 9;
+  a.step_src = load ? st->step : d.step_ctr;
+  a.step_dst = load ? d.step_ctr : st->step;
+  a.nonfinite = load ? d.nonfinite : nullptr;
+  return state_copy(a, s);
+}
+int lemo_fit_load_state(void* h, const lemo_fit_state* st, void* stream) { return fit_state_io((FitEngine*)h, st, true, S(stream)); }
+int lemo_fit_save_state(void* h, const lemo_fit_state* st, void* stream) { return fit_state_io((FitEngine*)h, st, false, S(stream)); }
 
 }  // extern "C"

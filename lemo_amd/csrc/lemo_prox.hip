@@ -149,4 +149,28 @@ int lemo_prox_step(void* h, int n, int use_graph, void* stream) {
   return 0;
 }
 
+static int prox_state_io(ProxEngine* e, const lemo_prox_state* st, bool load, hipStream_t s) {
+  if (!e || !st || !st->adam_m || !st->adam_v || !st->step) return LEMO_ERR_ARG;
+  const lemo_prox_desc& d = e->d;
+  StateCopy a{};
+  float* eng[11] = {d.global_orient, d.transl, d.left_hand_pose, d.right_hand_pose, d.jaw_pose, d.leye_pose, d.reye_pose,
+                    d.expression, d.pose_embedding, d.adam_m, d.adam_v};
+  float* usr[11] = {st->global_orient, st->transl, st->left_hand_pose, st->right_hand_pose, st->jaw_pose, st->leye_pose,
+                    st->reye_pose, st->expression, st->pose_embedding, st->adam_m, st->adam_v};
+  const int width[11] = {3, 3, 12, 12, 3, 3, 3, 10, 32, 81, 81};
+  for (int i = 0; i < 11; ++i) {
+    if (!eng[i] || !usr[i]) return LEMO_ERR_ARG;
+    a.src[i] = load ? usr[i] : eng[i];
+    a.dst[i] = load ? eng[i] : usr[i];
+    a.n[i] = d.B * width[i];
+  }
+  a.njobs = 11;
+  a.step_src = load ? st->step : d.step_ctr;
+  a.step_dst = load ? d.step_ctr : st->step;
+  a.nonfinite = load ? d.nonfinite : nullptr;
+  return state_copy(a, s);
+}
+int lemo_prox_load_state(void* h, const lemo_prox_state* st, void* stream) { return prox_state_io((ProxEngine*)h, st, true, S(stream)); }
+int lemo_prox_save_state(void* h, const lemo_prox_state* st, void* stream) { return prox_state_io((ProxEngine*)h, st, false, S(stream)); }
+
 }  // extern "C"

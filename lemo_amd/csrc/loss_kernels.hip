@@ -271,28 +271,21 @@ struct AdamGroup { float* p; const float* g; float* m; float* v; int n; };
 __device__ __forceinline__ float adam_prior_grad(int col, float pv, const float* __restrict__ weights, int B) {
   return col < 32 ? weights[1] * 2.f * pv / ((float)B * 32.f) : weights[3] * 2.f * pv / ((float)B * 24.f);
 }
-// one element of torch.optim.Adam (shared by adam_kernel and fit_tail_kernel: the same arithmetic, bit for bit)
-// step-dependent scalars of one Adam update: step size lr / (1 - beta1^t) and sqrt(1 - beta2^t)
-struct AdamCoef { float lr_bc1, bc2s; };
-__device__ __forceinline__ AdamCoef adam_coef(int step, float lr0, float lr1, int lr_switch, float lr2, int lr_switch2) {
-  const float lr = (lr_switch2 > 0 && step > lr_switch2) ? lr2 : (step > lr_switch ? lr1 : lr0);
-  const double t1 = (double)(step + 1);
-  const float bc1 = (float)(1.0 - pow(0.9, t1));
-  AdamCoef c;
-  c.bc2s = (float)sqrt(1.0 - pow(0.999, t1));
-  c.lr_bc1 = lr / bc1;
-  return c;
+// step-dependent scalars of one Adam update (common.hpp adam_coef_t: torch's own evaluation order) at the loop's lr level:
+// lr = step > lr_switch ? lr1 : lr0 with step counted from 0 (opt_amass_temp.py:349-352; a third level for opt_amass_perframe.py)
+__device__ __forceinline__ AdamCoef adam_coef(int step, double lr0, double lr1, int lr_switch, double lr2, int lr_switch2) {
+  const double lr = (lr_switch2 > 0 && step > lr_switch2) ? lr2 : (step > lr_switch ? lr1 : lr0);
+  return adam_coef_t(step + 1, lr);
 }
+// one element of torch.optim.Adam (shared by adam_kernel and fit_tail_kernel: the same arithmetic, bit for bit)
 __device__ __forceinline__ void adam_update_one(float* p, float* mp, float* vp, float grad, AdamCoef c) {
-  const float m = *mp + (grad - *mp) * (1.f - 0.9f);               // lerp_
-  const float v = *vp * 0.999f + (1.f - 0.999f) * grad * grad;
-  *mp = m; *vp = v;
-  const float denom = sqrtf(v) / c.bc2s + 1e-8f;
-  *p = *p - c.lr_bc1 * (m / denom);
+  float pv = *p, m = *mp, v = *vp;
+  adam_update_torch(pv, m, v, grad, c);
+  *mp = m; *vp = v; *p = pv;
 }
 __global__ void __launch_bounds__(256)
 adam_kernel(AdamGroup g0, AdamGroup g1, AdamGroup g2, int B, const float* __restrict__ weights, int* __restrict__ step_ctr,
-            const int* __restrict__ step_cur, float lr0, float lr1, int lr_switch, float lr2, int lr_switch2,
+            const int* __restrict__ step_cur, double lr0, double lr1, int lr_switch, double lr2, int lr_switch2,
             float* __restrict__ snap, int* __restrict__ nonfinite, const float* __restrict__ losses) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   // 0-based index of this iteration, latched into step_cur at the start of the iteration (every thread
@@ -333,8 +326,8 @@ int adam_step(float* transl, const float* g_transl, float* m0, float* v0, float*
   AdamGroup a{transl, g_transl, m0, v0, B * 3}, b{rot6d, g_rot, m1, v1, B * 6}, c{other, g_other, m2, v2, B * 56};
   const int n = B * 65;
   if (nonfinite && !losses) return LEMO_ERR_ARG;
-  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr0, lr1, lr_switch,
-                     lr2, lr_switch2, snap, nonfinite, losses);
+  hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, B, weights, step_ctr, step_cur, lr_decimal(lr0),
+                     lr_decimal(lr1), lr_switch, lr_decimal(lr2), lr_switch2, snap, nonfinite, losses);
   return (int)hipGetLastError();
 }
 
@@ -395,7 +388,7 @@ fit_tail_kernel(FitTail a) {
   }
   // the two double-precision pow() of the bias corrections depend on the (scalar-loaded) step only: they run here, in the
   // shadow of the vector loads above
-  AdamCoef coef{0.f, 1.f};
+  AdamCoef coef{0.f, 1.f};        // (neg_step, bc2s)
   if (a.do_adam) coef = adam_coef(step, a.lr0, a.lr1, a.lr_switch, a.lr2, a.lr_switch2);
   LEMO_PIN(p_old); LEMO_PIN(m_old); LEMO_PIN(v_old); LEMO_PIN(g_in); LEMO_PIN(w_v); LEMO_PIN(w_h); LEMO_PIN(tot);
   LEMO_PIN(bias[0]); LEMO_PIN(bias[1]);
@@ -457,6 +450,35 @@ int fit_tail(const FitTail& a, hipStream_t s) {
   if (a.B <= 0 || (a.do_dz && (!a.dh1 || !a.g_other || !a.w1t)) || (a.h1 && (!a.w1 || !a.b1 || !a.other))) return LEMO_ERR_ARG;
   if (a.do_adam && (!a.step_ctr || !a.step_cur || (a.nonfinite && !a.losses))) return LEMO_ERR_ARG;
   hipLaunchKernelGGL(fit_tail_kernel, dim3(a.B), dim3(256), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimiser-state hand-over (lemo_fit_load_state / lemo_fit_save_state and the PROX twins): up to STATE_MAX_JOBS flat float
+// copies + the step counter in ONE launch, device to device, no host value involved (the call can be captured)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+state_copy_kernel(StateCopy a) {
+  const int j = blockIdx.y;
+  if (j < a.njobs) {
+    const float* src = a.src[j];
+    float* dst = a.dst[j];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[j]; i += gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+  if (blockIdx.x == 0 && j == 0 && threadIdx.x == 0) {
+    if (a.step_dst && a.step_src) *a.step_dst = *a.step_src;
+    if (a.nonfinite) { a.nonfinite[0] = 0; a.nonfinite[1] = 0; }       // a loaded state is a fresh run for the NaN / Inf latch
+  }
+}
+int state_copy(const StateCopy& a, hipStream_t s) {
+  if (a.njobs < 0 || a.njobs > STATE_MAX_JOBS) return LEMO_ERR_ARG;
+  int nmax = 1;
+  for (int j = 0; j < a.njobs; ++j) {
+    if (!a.src[j] || !a.dst[j] || a.n[j] < 0) return LEMO_ERR_ARG;
+    if (a.n[j] > nmax) nmax = a.n[j];
+  }
+  const int bx = (nmax + 255) / 256 < 64 ? (nmax + 255) / 256 : 64;
+  hipLaunchKernelGGL(state_copy_kernel, dim3(bx, a.njobs ? a.njobs : 1), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

@@ -373,7 +373,7 @@ struct ProxParams {
   float *m, *v;
 };
 __global__ void __launch_bounds__(256)
-prox_adam_kernel(ProxParams P, int B, int erase_n, float lr, int* __restrict__ step_ctr, const int* __restrict__ step_cur,
+prox_adam_kernel(ProxParams P, int B, int erase_n, double lr, int* __restrict__ step_ctr, const int* __restrict__ step_cur,
                  int* __restrict__ nonfinite, const float* __restrict__ losses) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int step = *step_cur;
@@ -398,14 +398,10 @@ prox_adam_kernel(ProxParams P, int B, int erase_n, float lr, int* __restrict__ s
   float grad = P.g[sgm][(size_t)b * dim + e] + P.gp[(size_t)b * PROX_NP + k];
   if (sgm == 1) grad += P.dtr_j[(size_t)b * 3 + e];
   if (b < erase_n) grad = 0.f;                             // "erase gradient for first 15 frames" (:282-289)
-  const double t1 = (double)(step + 1);
-  const float bc1 = (float)(1.0 - pow(0.9, t1));
-  const float bc2s = (float)sqrt(1.0 - pow(0.999, t1));
-  const float m = P.m[i] + (grad - P.m[i]) * (1.f - 0.9f);
-  const float v = P.v[i] * 0.999f + (1.f - 0.999f) * grad * grad;
+  float pv = *pp, m = P.m[i], v = P.v[i];
+  adam_update_torch(pv, m, v, grad, adam_coef_t(step + 1, lr));      // common.hpp: torch's own evaluation order
   P.m[i] = m; P.v[i] = v;
-  const float denom = sqrtf(v) / bc2s + 1e-8f;
-  *pp = *pp - (lr / bc1) * (m / denom);
+  *pp = pv;
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
@@ -451,7 +447,7 @@ int prox_adam(const lemo_prox_desc& d, hipStream_t s) {
   P.dtr_j = d.dtr_j; P.gp = d.gp; P.m = d.adam_m; P.v = d.adam_v;
   const int n = d.B * PROX_NP;
   const int erase_n = d.first_batch_flag ? 0 : (int)(d.B * 0.15);
-  hipLaunchKernelGGL(prox_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, d.B, erase_n, d.lr, d.step_ctr, d.step_cur, d.nonfinite, d.losses);
+  hipLaunchKernelGGL(prox_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, d.B, erase_n, lr_decimal(d.lr), d.step_ctr, d.step_cur, d.nonfinite, d.losses);
   return (int)hipGetLastError();
 }
 

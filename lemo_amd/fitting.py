@@ -223,6 +223,47 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         self._stepped = False
         self._after_write()
 
+    # -- optimiser state in / out (C ABI lemo_fit_load_state / lemo_fit_save_state) ---------------------------
+    STATE_KEYS = ('transl', 'rot6d', 'other', 'm_transl', 'm_rot6d', 'm_other', 'v_transl', 'v_rot6d', 'v_other')
+
+    def _state_struct(self, t: Dict[str, torch.Tensor], step: torch.Tensor) -> '_hip.FitState':
+        st = _hip.FitState()
+        st.transl, st.rot6d, st.other, st.step = ptr(t['transl']), ptr(t['rot6d']), ptr(t['other']), ptr(step)
+        for i, k in enumerate(('transl', 'rot6d', 'other')):
+            st.adam_m[i], st.adam_v[i] = ptr(t['m_' + k]), ptr(t['v_' + k])
+        return st
+
+    @torch.no_grad()
+    def save_state(self) -> Dict[str, torch.Tensor]:
+        """what ``optim.Adam`` + the three parameter tensors of ``opt_amass_temp.py:332-345`` hold between two iterations:
+        parameters, ``exp_avg`` (m_*), ``exp_avg_sq`` (v_*) and ``step`` = completed Adam steps (device tensors, copies)."""
+        B = self.B
+        t = {k: torch.empty(B, w, dtype=torch.float32, device=self.device)
+             for k, w in zip(self.STATE_KEYS, (3, 6, 56) * 3)}
+        step = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._before_run()
+        self.lib.check(self.lib.fit_save_state(self.handle, C.byref(self._state_struct(t, step)), self._s()), 'fit_save_state')
+        self._after_run()
+        t['step'] = step
+        return t
+
+    @torch.no_grad()
+    def load_state(self, state: Dict) -> None:
+        """continue from ``state`` (the dict :meth:`save_state` returns; numpy arrays or tensors, ``step`` an int or a
+        tensor): the next :meth:`step` is iteration ``step`` of the loop -- learning-rate level, bias corrections and all.
+        Sequence data (``target``, ``contact``, ``shape``) are not part of the optimiser state: :meth:`load_sequence` first."""
+        td = lambda a, w: (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32))
+                           ).to(self.device, torch.float32).reshape(self.B, w).contiguous()
+        t = {k: td(state[k], w) for k, w in zip(self.STATE_KEYS, (3, 6, 56) * 3)}
+        sv = state['step']
+        step = (sv.detach().to(self.device, torch.int32).reshape(1) if isinstance(sv, torch.Tensor)
+                else torch.full((1,), int(sv), dtype=torch.int32, device=self.device))
+        self._before_run()
+        self.lib.check(self.lib.fit_load_state(self.handle, C.byref(self._state_struct(t, step)), self._s()), 'fit_load_state')
+        self._stepped = False
+        self._after_run()
+        self._keep = (t, step)              # the copies read caller-side buffers asynchronously: keep them until the next call
+
     # -- execution ---------------------------------------------------------------------------
     def _s(self):
         if self.lib.is_emu:

@@ -477,6 +477,46 @@ class ProxWindowEngine(_hip.StreamOrdered):
         self.lib.check(self.lib.prox_step(self.handle, int(n), int(bool(use_graph) and not self.lib.is_emu), self._s()), 'prox_step')
         self._after_run()
 
+    # -- optimiser state in / out (C ABI lemo_prox_load_state / lemo_prox_save_state) ---------------------------
+    def _state_struct(self, t: Dict[str, torch.Tensor]):
+        from ._hip import ptr
+        st = _hip.ProxState()
+        for k, _ in ENGINE_PARAMS:
+            setattr(st, k, ptr(t[k]))
+        st.adam_m, st.adam_v, st.step = ptr(t['adam_m']), ptr(t['adam_v']), ptr(t['step'])
+        return st
+
+    @torch.no_grad()
+    def save_state(self) -> Dict[str, torch.Tensor]:
+        """the nine optimised tensors, Adam's ``exp_avg`` / ``exp_avg_sq`` as [B,81] blocks in ``ENGINE_PARAMS`` order and
+        ``step`` = completed ``optimizer.step(closure)`` calls (device tensors, copies)"""
+        import ctypes as C
+        t = {k: torch.empty(self.B, d, dtype=torch.float32, device=self.device) for k, d in ENGINE_PARAMS}
+        t['adam_m'], t['adam_v'] = (torch.empty(self.B, 81, dtype=torch.float32, device=self.device) for _ in range(2))
+        t['step'] = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._before_run()
+        self.lib.check(self.lib.prox_save_state(self.handle, C.byref(self._state_struct(t)), self._s()), 'prox_save_state')
+        self._after_run()
+        return t
+
+    @torch.no_grad()
+    def load_state(self, state: Dict) -> None:
+        """continue from ``state`` (see :meth:`save_state`; numpy or tensors; ``adam_m`` / ``adam_v`` / ``step`` default to a
+        fresh optimiser -- what a new window starts with, data_parser_slide.py:326-331 + fit_temp_loadprox_slide.py:511-519)"""
+        import ctypes as C
+        td = lambda a, w: (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, np.float32))
+                           ).to(self.device, torch.float32).reshape(self.B, w).contiguous()
+        t = {k: td(state[k], d) for k, d in ENGINE_PARAMS}
+        for k in ('adam_m', 'adam_v'):
+            t[k] = td(state[k], 81) if state.get(k) is not None else torch.zeros(self.B, 81, dtype=torch.float32, device=self.device)
+        sv = state.get('step', 0)
+        t['step'] = (sv.detach().to(self.device, torch.int32).reshape(1) if isinstance(sv, torch.Tensor)
+                     else torch.full((1,), int(sv), dtype=torch.int32, device=self.device))
+        self._before_run()
+        self.lib.check(self.lib.prox_load_state(self.handle, C.byref(self._state_struct(t)), self._s()), 'prox_load_state')
+        self._after_run()
+        self._keep = t
+
     def loss_dict(self) -> Dict[str, float]:
         self._before_read()
         v = self.ws['losses'].detach().cpu().numpy()

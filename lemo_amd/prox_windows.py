@@ -4,7 +4,8 @@ Reference: ``temp_prox/data_parser_slide.py:199-212`` (windows of ``batch_size``
 ``int(0.7 * batch_size)``; the frame lists of all windows are concatenated and consumed ``batch_size`` at a
 time), ``:106-126`` (``read_prox_pkl``), ``:329-331`` (a window initialises every frame from the newest result
 on disk: the current run's ``results/<frame>/000.pkl`` if it exists -- i.e. the overlap with the previous window
--- else the per-frame PROX fit), ``temp_prox/fit_temp_loadprox_slide.py:577-594`` (one protocol-2 pickle per
+-- else the per-frame PROX fit), ``temp_prox/fit_temp_loadprox_slide.py:495-499`` (a window's shape = the mean of its frames' loaded betas),
+``:577-594`` (one protocol-2 pickle per
 frame with ``camera_*``, the body-model parameters, ``pose_embedding`` and the decoded ``body_pose``, each with a
 leading axis of 1), ``fitting_temp_slide.py:282-289`` (gradients of the first ``int(0.15 B)`` frames are erased in
 every window but the first -- implemented in :class:`lemo_amd.prox.ProxTemporalFitter`).
@@ -105,6 +106,18 @@ def init_params_for_window(frame_names: Sequence[str], current_dir: str, prox_di
     return {k: np.stack([r[k] for r in rows]) for k in BODY_PARAM_KEYS}
 
 
+def window_start_params(init: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """what a window's fit starts from, given the stacked per-frame results (:func:`init_params_for_window`):
+    ``fit_temp_loadprox_slide.py:495-499`` -- ``betas`` is replaced by its MEAN over the window's frames, repeated for every
+    frame (the overlap carries the previous window's shape, the new frames the per-frame fits': one shape per window), and
+    ``body_model.reset_params(**prox_params_dict)`` copies every named parameter; ``pose_embedding`` is taken as it is
+    (:502-505).  float32 like the reference's numpy arrays (``np.mean`` of float32 rows in float32)."""
+    out = {k: np.asarray(v) for k, v in init.items()}
+    betas = np.asarray(init['betas'], np.float32)
+    out['betas'] = np.repeat(np.expand_dims(np.mean(betas, axis=0), axis=0), betas.shape[0], axis=0)
+    return out
+
+
 def run_recording(frame_names: Sequence[str], batch_size: int, current_dir: str, prox_dir: str, fit_window,
                   reference_chunking: bool = False) -> int:
     """drive ``fit_window(frame_names, init_params, first_window, n_frozen) -> (camera_params, body_params,
@@ -119,7 +132,7 @@ def run_recording(frame_names: Sequence[str], batch_size: int, current_dir: str,
         batches = [list(range(s, e)) for s, e in sliding_windows(len(frame_names), batch_size)]
     for w, ids in enumerate(batches):
         names = [frame_names[i] for i in ids]
-        init = init_params_for_window(names, current_dir, prox_dir)
+        init = window_start_params(init_params_for_window(names, current_dir, prox_dir))
         cam, body, emb, bp = fit_window(names, init, w == 0, frozen_prefix(batch_size, w == 0))
         for i, fn in enumerate(names):
             write_result_pkl(result_path(current_dir, fn), cam, body, emb, bp, i)

@@ -135,8 +135,9 @@ def fit_recordings_sharded(n_rec: int, fit_recording: Callable[[int], torch.Tens
     axis is therefore the RECORDING: recording r -> rank r mod world, its windows sequential on that rank
     (``fit_recording(r)`` runs :func:`lemo_amd.prox_windows.run_recording` or any equivalent and returns the per-frame result
     rows ``[n_frames_r, D]``), and ONE collective at the end hands every rank every recording's rows.  Recordings differ in
-    length: rows are padded with NaN to ``max_frames`` (default: the longest local recording, made common with one tiny
-    all-reduce -- pass it to skip that) and trimmed again after the gather.  ``n_rec`` must be a multiple of ``world``.
+    length: rows are zero-padded to ``max_frames`` (default: the longest local recording, made common with one tiny
+    all-reduce -- pass it to skip that), every block carries its frame count in one extra row, and the blocks are trimmed to it
+    after the gather (NaN / Inf rows of a diverged fit come back where they belong).  ``n_rec`` must be a multiple of ``world``.
     Returns the list of ``[n_frames_r, D]`` tensors in recording order."""
     assert n_rec % world == 0, 'pad the recording list to a multiple of the world size'
     mine = [fit_recording(r) for r in my_sequences(n_rec, rank, world)]
@@ -151,13 +152,15 @@ def fit_recordings_sharded(n_rec: int, fit_recording: Callable[[int], torch.Tens
     elif max_frames is not None:
         assert max_frames >= tmax
         tmax = int(max_frames)
-    pad = torch.full((len(mine), tmax, D), float('nan'), dtype=mine[0].dtype, device=mine[0].device)
+    # Lengths travel explicitly, in the same collective: row tmax of every padded block holds the recording's frame count
+    # (exact in float32 up to 2^24).  Round 3 recovered them from NaN padding, which dropped rows of a DIVERGED recording
+    # (genuine NaNs in column 0; the engines carry a non-finite latch because that happens) and misaligned its frames.
+    assert tmax < (1 << 24)
+    pad = torch.zeros((len(mine), tmax + 1, D), dtype=mine[0].dtype, device=mine[0].device)
     for i, m in enumerate(mine):
         pad[i, :m.shape[0]] = m
+        pad[i, tmax, 0] = float(m.shape[0])
     allp = gather_fitted_params(pad, group)                       # the path's one data collective
     allp = allp[torch.tensor(unshard_order(n_rec, world), device=allp.device)]
-    out = []
-    for r in range(n_rec):
-        valid = ~torch.isnan(allp[r, :, 0])
-        out.append(allp[r][valid])
-    return out
+    lens = allp[:, tmax, 0].round().to(torch.int64).tolist()
+    return [allp[r, :lens[r]] for r in range(n_rec)]

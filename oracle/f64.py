@@ -49,6 +49,29 @@ def amass_fit_oracle_f64(model, vposer_w, enc_w, ids, Xmean, Xstd, init_params, 
     return fit
 
 
+def prox_fit_oracle_f64(prob: dict, first_batch_flag: bool = False, cam: dict = None):
+    """``prox_oracle.ProxFitOracle`` on a ``__graft_entry__.prox_small_problem``-shaped dict with every floating-point tensor in
+    float64 (call its methods inside ``default_f64()``): the exact gradient / loss at a given fp32 state of a PROX window, the
+    yardstick for "how far is a correct fp32 implementation of this closure from the reference's fp32" (the
+    PROX gradient gates were constants).  ``grid_sample`` and the reductions run in float64 as well."""
+    from . import prox_oracle as PO
+    cam = cam or dict(fx=1060.53, fy=1060.38, cx=951.30, cy=536.77)
+    with default_f64():
+        so = O.SmplxOracle(prob['model'], extra_joint_ids=list(range(21)) if prob['V'] < 9930 else None)
+        _to_double(so)
+        vw = {k: torch.as_tensor(np.asarray(v)).double() for k, v in prob['vposer_w'].items()}
+        ew = {k: torch.as_tensor(np.asarray(v)).double() for k, v in prob['enc_w'].items()}
+        of = PO.ProxFitOracle(so, vw, ew, prob['joint_map'], prob['ids'], prob['fric_ids'], prob['Xmean'], prob['Xstd'], prob['weights'],
+                              cam, prob['R'], prob['t'], prob['sdf'], prob['grid_min'], prob['grid_max'], prob['params'],
+                              prob['gt_joints'], prob['joints_conf'], first_batch_flag=first_batch_flag, **prob['infill'])
+        _to_double(of)
+        of.joint_weights = of.joint_weights.double()
+        of.p = {k: v.detach().double().clone().requires_grad_(True) for k, v in of.p.items()}
+        of.pose_embedding = of.pose_embedding.detach().double().clone().requires_grad_(True)
+        of.opt = torch.optim.Adam(list(of.p.values()) + [of.pose_embedding], lr=0.005)
+    return of
+
+
 def perframe_iteration_f64(model, vposer_w, markers67_ids, p72_aa, target, weights=None, extra_joint_ids=None):
     """``pipeline_oracle.perframe_iteration`` (opt_amass_perframe.py:324-351, one evaluation + gradients) in float64, from
     the SAME float32 start point (the 6-D orientation is converted in float32 like the fit's)."""
@@ -226,23 +249,25 @@ class KinkProbe:
         return kinds
 
 
-def flip_sensitivity(fit: O.AmassFitOracle, tol_act: float = 3e-6, subsets: int = 2, seed: int = 0):
-    """COMPUTED kink exposure of the gradient.  ``KinkProbe`` shows that at BASELINE size hundreds of the
-    encoder's 21 M LeakyReLU units sit within any realistic error band of their kink in EVERY evaluation -- proximity alone
-    marks all frames.  What matters is how much the gradient can move when such units take the other branch.  This function
-    evaluates, in float64 at the oracle's current parameters, the objective's gradient (a) as it is and (b) with the slope
-    of EVERY unit whose pre-activation lies within ``tol_act`` x (layer maximum) of zero swapped (0.2 <-> 1; the value
-    changes by < tol_act x max), plus ``subsets`` random halves of that set (guards against cancellation), and returns
+def flip_sensitivity_of(loss_fn, params, tol_act: float = 3e-6, subsets: int = 2, seed: int = 0):
+    """COMPUTED kink exposure of a gradient that runs through the smoothness encoder.  ``KinkProbe`` shows that
+    at BASELINE size hundreds of the encoder's 21 M LeakyReLU units sit within any realistic error band of their kink in EVERY
+    evaluation -- proximity alone marks all frames.  What matters is how much the gradient can move when such units take the
+    other branch.  This function evaluates, in float64, ``d loss_fn() / d params`` (a) as it is and (b) with the slope of
+    EVERY unit whose pre-activation lies within ``tol_act`` x (layer maximum) of zero swapped (0.2 <-> 1; the value changes by
+    < tol_act x max), plus ``subsets`` random halves of that set (guards against cancellation), and returns, per parameter
+    tensor [B, d],
 
-        S[group][frame] = max over the variants of  max_entries |G_variant - G| / max|G_group|
+        S[frame] = max over the variants of  max_entries |G_variant - G| / max|G|
 
-    -- a per-frame, per-parameter-group bound on what rounding-sized differences of an fp32-accurate forward can do to the
-    gradient THROUGH THE ENCODER'S KINKS.  A frame's gradient error beyond ``rounding + 2 S`` is not explained by them.
-    (default tol_act 3e-6 = ~8 x the measured pre-activation error of the fp32-accurate convolutions, 4e-7 of the layer
-    maximum.)  Uses ``torch.autograd.grad``: the oracle's optimiser state and ``.grad`` fields are not touched."""
+    -- a per-frame bound on what rounding-sized differences of an fp32-accurate forward can do to the gradient THROUGH THE
+    ENCODER'S KINKS.  A frame's gradient error beyond ``rounding + 2 S`` is not explained by them.  (default tol_act 3e-6 = ~8 x
+    the measured pre-activation error of the fp32-accurate convolutions, 4e-7 of the layer maximum.)  ``loss_fn`` must reach
+    the encoder through ``lemo_oracle.enc_forward`` (both fit oracles do).  Uses ``torch.autograd.grad``: optimiser state and
+    ``.grad`` fields are not touched."""
     import torch.nn.functional as F
     orig = O.enc_forward
-    params = (fit.transl, fit.rot6d, fit.other)
+    params = tuple(params)
 
     def make_enc(mode, gen):
         def enc(w, x, return_all=False):
@@ -266,14 +291,21 @@ def flip_sensitivity(fit: O.AmassFitOracle, tol_act: float = 3e-6, subsets: int 
         O.enc_forward = make_enc(mode, gen)
         try:
             with default_f64():
-                total = fit.losses()[0]
-                return torch.autograd.grad(total, params)
+                return torch.autograd.grad(loss_fn(), params)
         finally:
             O.enc_forward = orig
     G0 = grads('none')
     variants = [grads('all')] + [grads('half', torch.Generator().manual_seed(seed + 1 + i)) for i in range(subsets)]
-    out = {}
-    for name, i in (('transl', 0), ('rot6d', 1), ('other', 2)):
+    out = []
+    for i in range(len(params)):
         n = G0[i].abs().max()
-        out[name] = torch.stack([(g[i] - G0[i]).abs().max(1).values / n for g in variants]).max(0).values
+        out.append(torch.stack([(g[i] - G0[i]).abs().max(1).values / n for g in variants]).max(0).values if float(n) > 0
+                   else torch.zeros(G0[i].shape[0], dtype=G0[i].dtype))
     return out
+
+
+def flip_sensitivity(fit: O.AmassFitOracle, tol_act: float = 3e-6, subsets: int = 2, seed: int = 0):
+    """:func:`flip_sensitivity_of` for the AMASS objective at the oracle's current parameters:
+    ``{'transl' | 'rot6d' | 'other': S[frame]}``"""
+    S = flip_sensitivity_of(lambda: fit.losses()[0], (fit.transl, fit.rot6d, fit.other), tol_act, subsets, seed)
+    return dict(zip(('transl', 'rot6d', 'other'), S))

@@ -244,6 +244,87 @@ def run_amass_loop_body(so: O.SmplxOracle, vposer_w, ids, Xmean, Xstd, init_para
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# Teacher-forcing fixtures: the reference's own LOOPS (optimizer construction, lr schedule, step) run as text with a
+# passive recorder in place of ``optim.Adam`` -- the recorder IS torch.optim.Adam (a subclass that copies the optimiser
+# state before and after the update of selected steps and changes nothing)
+# ------------------------------------------------------------------------------------------------------------------
+class AdamRecorder:
+    """``recorder.Adam(params, lr=...)`` is what the reference's ``optim.Adam(final_params, lr=init_lr)`` line gets.
+    For optimiser number ``o`` (in construction order) and its ``k``-th ``step()`` call (0-based) with ``(o, k)`` in
+    ``record_at``: ``records[(o, k)]`` = dict(before=state, after=state, lr=the group's lr at the call, grads=[...],
+    extra={name: float(ns[name])}); state = dict(params=[...], exp_avg=[...], exp_avg_sq=[...], step=completed steps)."""
+
+    def __init__(self, record_at, ns=None, extra_names=()):
+        self.record_at, self.ns, self.extra_names = set(record_at), ns, tuple(extra_names)
+        self.records, self.n_opt = {}, 0
+
+    @staticmethod
+    def _snap(opt):
+        ps = opt.param_groups[0]['params']
+        st = [opt.state.get(p, {}) for p in ps]
+        z = lambda p, s, k: (s[k].detach().numpy().copy() if k in s else np.zeros_like(p.detach().numpy()))
+        step = int(st[0]['step']) if st and 'step' in st[0] else 0
+        return dict(params=[p.detach().numpy().copy() for p in ps], exp_avg=[z(p, s, 'exp_avg') for p, s in zip(ps, st)],
+                    exp_avg_sq=[z(p, s, 'exp_avg_sq') for p, s in zip(ps, st)], step=step)
+
+    def Adam(self, params, **kw):
+        rec, o = self, self.n_opt
+        self.n_opt += 1
+
+        class _Adam(torch.optim.Adam):
+            _calls = 0
+
+            def step(self, closure=None):
+                k = self._calls
+                self._calls += 1
+                if (o, k) not in rec.record_at:
+                    return super().step(closure)
+                assert closure is None
+                r = dict(before=rec._snap(self), lr=float(self.param_groups[0]['lr']),
+                         grads=[p.grad.detach().numpy().copy() for p in self.param_groups[0]['params']],
+                         extra={n: float(rec.ns[n]) for n in rec.extra_names} if rec.ns is not None else {})
+                out = super().step()
+                r['after'] = rec._snap(self)
+                rec.records[(o, k)] = r
+                return out
+        return _Adam(params, **kw)
+
+
+AMASS_LOSS_VARS = ('loss_marker', 'loss_vposer', 'loss_shape', 'loss_hand', 'loss_contact_vel', 'loss_smooth', 'loss')
+
+
+def run_amass_loop_text(so: O.SmplxOracle, vposer_w, ids, Xmean, Xstd, init_params, markers_rec, contact_lbl, record_at,
+                        weights=None):
+    """exec opt_amass_temp.py:331-455 -- parameter init, ``optim.Adam(final_params, lr=init_lr)``, the WHOLE 100-step loop with
+    its own lr switch (:350-352), ``loss.backward``, ``optimizer.step()`` -- with an :class:`AdamRecorder` as ``optim``.
+    ``record_at``: iterable of step indices.  Returns (recorder.records keyed by step, final body_params_opt_t_72)."""
+    import torch.nn.functional as F
+    U = ref_utils()
+    B = init_params.shape[0]
+    w = dict(O.LOSS_WEIGHTS if weights is None else weights)
+    args = types.SimpleNamespace(weight_loss_rec_markers=w['rec_markers'], weight_loss_contact_vel=w['contact_vel'],
+                                 weight_loss_smooth=w['smooth'], weight_loss_vposer=w['vposer'],
+                                 weight_loss_shape=w['shape'], weight_loss_hand=w['hand'])
+    ns = dict(torch=torch, F=F, np=np, args=args, device=torch.device('cpu'),
+              convert_to_3D_rot=U.convert_to_3D_rot, convert_to_6D_all=U.convert_to_6D_all, gen_body_mesh_v1=U.gen_body_mesh_v1,
+              gen_body_joints_v1=U.gen_body_joints_v1,
+              smplx_model=RefSmplx(so, B), vposer_model=ref_vposer(vposer_w), smooth_encoder=ref_enc(),
+              infill_marker_ids=[int(i) for i in ids['markers67']], smooth_marker_ids=[int(i) for i in ids['markers81']],
+              left_heel_verts_id=np.asarray(ids['left_heel']), right_heel_verts_id=np.asarray(ids['right_heel']),
+              left_toe_verts_id=np.asarray(ids['left_toe']), right_toe_verts_id=np.asarray(ids['right_toe']),
+              Xmean_global_markers=torch.from_numpy(np.asarray(Xmean)).float(),
+              Xstd_global_markers=torch.from_numpy(np.asarray(Xstd)).float(),
+              markers_rec_t=torch.from_numpy(np.asarray(markers_rec, np.float32)),
+              contact_lbl_rec=torch.from_numpy(np.asarray(contact_lbl, np.float32)),
+              init_params=np.array(init_params, np.float32))
+    rec = AdamRecorder([(0, int(k)) for k in record_at], ns, AMASS_LOSS_VARS)
+    ns['optim'] = types.SimpleNamespace(Adam=rec.Adam)
+    exec_reference_lines(f'{REF}/opt_amass_temp.py', 331, 455, ns)
+    assert rec.n_opt == 1
+    return {k: r for (_, k), r in rec.records.items()}, ns['body_params_opt_t_72'].detach().numpy().copy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # PROX: the reference's own SMPLifyLoss / FittingMonitor closure / camera / priors / JointMapper / optimizer factory
 # ------------------------------------------------------------------------------------------------------------------
 def ref_prox_modules():
@@ -373,13 +454,28 @@ class RefProxWindow:
             return self.loss_dict
         self.loss.forward = _capture
 
-    def iterate(self, n=1):
-        """n x ``optimizer.step(closure)`` exactly like FittingMonitor.run_fitting (:196)"""
+    def iterate(self, n=1, record_at=None):
+        """n x ``optimizer.step(closure)`` exactly like FittingMonitor.run_fitting (:196).  ``record_at``: call indices
+        (counted from this object's construction) whose optimiser state before / after, gradients as the update saw them
+        (after the closure's first-15 % erase) and loss_dict are kept in ``self.records``"""
         out = []
         for _ in range(n):
+            k = self.n_calls = getattr(self, 'n_calls', -1) + 1
+            keep = record_at is not None and k in record_at
+            if keep:
+                before = AdamRecorder._snap(self.optimizer)
             self.optimizer.step(self.closure)
-            out.append({k: float(v) for k, v in self.loss_dict.items()})
+            out.append({k_: float(v) for k_, v in self.loss_dict.items()})
+            if keep:
+                self.records = getattr(self, 'records', {})
+                self.records[k] = dict(before=before, after=AdamRecorder._snap(self.optimizer), lr=float(self.optimizer.param_groups[0]['lr']),
+                                       grads=[p.grad.detach().numpy().copy() for p in self.optimizer.param_groups[0]['params']],
+                                       extra=dict(out[-1]))
         return out
+
+    def param_names(self):
+        """names of the optimised tensors in the optimiser's order (fit_temp_loadprox_slide.py:511-519)"""
+        return [n for n, p in self.body_model.named_parameters() if p.requires_grad] + ['pose_embedding']
 
     def grads(self):
         bm = self.body_model
@@ -425,7 +521,7 @@ def run_amass_decode_text(clip_img_rec, clip_img, rot_0_pivot):
 # ------------------------------------------------------------------------------------------------------------------
 # per-frame fit (BASELINE configs[0]): opt_amass_perframe.py:291-363 run as text
 # ------------------------------------------------------------------------------------------------------------------
-def run_perframe_text(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec, betas, steps=100):
+def run_perframe_text(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec, betas, steps=100, record_at=None):
     """exec the reference's per-frame loop.  ``total_steps = 100`` is a literal inside the text; ``steps`` < 100 is
     obtained by substituting that one literal (the lr switches at 60 / 80 are then simply never reached)."""
     import tempfile
@@ -439,13 +535,20 @@ def run_perframe_text(so: O.SmplxOracle, vposer_w, markers67_ids, markers_rec, b
     assert text.count('total_steps = 100') == 1
     text = text.replace('total_steps = 100', f'total_steps = {int(steps)}')
     with tempfile.TemporaryDirectory() as tmp:
+        if record_at is not None:           # [(frame, step), ...]: one optimiser per frame (:312), recorded passively
+            rec = AdamRecorder(record_at, None, ('loss_marker', 'loss_vposer', 'loss_shape', 'loss_hand', 'loss'))
+            optim = types.SimpleNamespace(Adam=rec.Adam)
         ns = dict(torch=torch, np=np, F=F, optim=optim, tqdm=lambda x: x, device=torch.device('cpu'), T=T, i=0, save_folder=tmp,
                   args=types.SimpleNamespace(weight_loss_rec_markers=1.0, weight_loss_vposer=0.02, weight_loss_shape=0.01,
                                              weight_loss_hand=0.01),
                   body_joints_rec=np.asarray(markers_rec, np.float64), beta_gt=torch.from_numpy(np.asarray(betas, np.float32)),
                   convert_to_6D_all=U.convert_to_6D_all, convert_to_3D_rot=U.convert_to_3D_rot, gen_body_mesh_v1=U.gen_body_mesh_v1,
                   smplx_model=RefSmplx(so, 1), vposer_model=ref_vposer(vposer_w), marker_ids=[int(v) for v in markers67_ids])
+        if record_at is not None:
+            rec.ns = ns
         exec(compile(text, f'{path}:291-364', 'exec'), ns)
+    if record_at is not None:
+        return ns['body_params_opt_cur_clip'], rec.records
     return ns['body_params_opt_cur_clip']
 
 

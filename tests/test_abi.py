@@ -23,7 +23,7 @@ def test_gfx950_library_exports_every_declared_symbol(hip_lib_built):
     dll = ctypes.CDLL(hip_lib_built)
     missing = [n for n in _declared() if not hasattr(dll, n)]
     assert not missing, missing
-    assert dll.lemo_abi_version() == 3
+    assert dll.lemo_abi_version() == 4
 
 
 def test_python_binding_covers_header():

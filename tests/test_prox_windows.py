@@ -146,3 +146,48 @@ def test_two_windows_chained_through_the_native_engine(emu_lib, tmp_path):
     assert not torch.equal(a1['transl'][1:], b1['transl'][1:]) and not torch.equal(a0['transl'], b0['transl'])
     assert np.array_equal(PW.read_prox_pkl(PW.result_path(cur, names[8]))['transl'], a1['transl'][1].numpy())   # overlap overwritten
     assert np.array_equal(PW.read_prox_pkl(PW.result_path(cur, names[3]))['transl'], a0['transl'][3].numpy())
+
+
+def test_window_two_starts_where_the_reference_started_it(tmp_path):
+    """tests/golden/teacher_prox.npz holds what the REFERENCE's window 2 started from: its own reader
+    (data_parser_slide.py:106-126, newest-result rule :326-331) over the pickles its own writer produced after window 1
+    (fit_temp_loadprox_slide.py:577-594), then its mean-betas initialisation (:495-499).  The product's writer / reader /
+    ``window_start_params`` on window 1's final state must give the same start, bit for bit."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_teacher import prox_recording, PROX_N, PROX_B
+    from lemo_amd.prox import ENGINE_PARAMS
+    T = np.load(os.path.join(GOLDEN, 'teacher_prox.npz'))
+    dims = dict(ENGINE_PARAMS)
+    for stage in ('S2', 'S3'):
+        base = prox_recording(stage)
+        P0 = base['params']
+        names = [f's001_frame_{i:05d}' for i in range(PROX_N)]
+        cur, prox = str(tmp_path / stage / 'cur'), str(tmp_path / stage / 'prox')
+        body0 = {k: np.asarray(P0[k], np.float32) for k in ('transl', 'global_orient', 'betas', 'left_hand_pose', 'right_hand_pose', 'jaw_pose',
+                                                           'leye_pose', 'reye_pose', 'expression')}
+        for i, fn in enumerate(names):
+            PW.write_result_pkl(PW.result_path(prox, fn), {}, body0, np.asarray(P0['pose_embedding'], np.float32), np.zeros((PROX_N, 63), np.float32), i)
+        (s0, e0), (s1, e1) = PW.sliding_windows(PROX_N, PROX_B)
+        # window 1 started from the per-frame fits with ITS mean betas ...
+        start0 = PW.window_start_params(PW.init_params_for_window(names[s0:e0], cur, prox))
+        assert np.array_equal(start0['betas'], T[f'{stage}_w0_betas']) and not np.array_equal(start0['betas'], body0['betas'][s0:e0])
+        # ... and ended in the fixture's last recorded state (after step 59): write it the way the product writes results
+        order = [str(n) for n in T[f'{stage}_w0_names']]
+        last = int(T['steps'][-1]) + 1
+        pf, o, fin = T[f'{stage}_w0_s{last}_p'], 0, {}
+        for n in order:
+            fin[n] = pf[:, o:o + dims[n]]
+            o += dims[n]
+        body = {k: fin[k] for k in order if k != 'pose_embedding'}
+        body['betas'] = T[f'{stage}_w0_betas']
+        for i, fn in enumerate(names[s0:e0]):
+            PW.write_result_pkl(PW.result_path(cur, fn), {}, body, fin['pose_embedding'], np.zeros((e0 - s0, 63), np.float32), i)
+        start1 = PW.window_start_params(PW.init_params_for_window(names[s1:e1], cur, prox))
+        assert np.array_equal(start1['betas'], T[f'{stage}_w1_betas'])
+        p1, o = T[f'{stage}_w1_s0_p'], 0
+        for n in [str(x) for x in T[f'{stage}_w1_names']]:
+            assert np.array_equal(start1[n], p1[:, o:o + dims[n]]), (stage, n)
+            o += dims[n]
+        assert np.array_equal(start1['transl'][:e0 - s1], fin['transl'][s1 - s0:])       # the overlap IS window 1's result

@@ -197,3 +197,18 @@ def test_two_rank_gloo_prox_recordings(tmp_path):
     for r in range(2):
         assert torch.equal(a[r], b[r]) and torch.equal(a[r], solo[r]), r
     assert not torch.equal(a[0][:15], a[1])
+
+
+def test_recording_rows_survive_nan(tmp_path):
+    """a diverged recording (NaN rows, column 0 included) keeps its length and its frame alignment through the
+    gather -- lengths travel explicitly, not as NaN padding"""
+    from lemo_amd.sharding import fit_recordings_sharded
+    a = torch.arange(5 * 3, dtype=torch.float32).reshape(5, 3)
+    b = torch.arange(8 * 3, dtype=torch.float32).reshape(8, 3) + 100
+    b[2:4] = float('nan')
+    b[7, 0] = float('inf')
+    out = fit_recordings_sharded(2, lambda r: (a, b)[r].clone(), 0, 1)
+    assert [tuple(o.shape) for o in out] == [(5, 3), (8, 3)]
+    assert torch.equal(out[0], a) and torch.equal(torch.nan_to_num(out[1], 7.0, 8.0), torch.nan_to_num(b, 7.0, 8.0))
+    out = fit_recordings_sharded(2, lambda r: (a, b)[r].clone(), 0, 1, max_frames=11)
+    assert [tuple(o.shape) for o in out] == [(5, 3), (8, 3)] and torch.equal(out[0], a)
