@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '4'))
+DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '5'))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -120,6 +120,24 @@ def _conv_layer(fit, l, bwd, src, dst, stream):
     lib.check(rc, 'conv layer')
 
 
+def _conv_pair(fit, l, bwd, src, mid, dst, stream):
+    """launch the fused pair the engine launches (conv variant 5): forward layers (l, l+1): act[l] -> act[l+1] (written) -> act[l+2];
+    backward-data layers (l, l-1): d(pre l+1) -> d(pre l-1) with act[l], act[l-1] as epilogue operands"""
+    from lemo_amd._hip import ptr
+    lib, H, W, e = fit.lib, fit.H, fit.W, fit.enc
+    if bwd:
+        pa, ia = e.split_pack(l, True, 5)
+        pb, ib = e.split_pack(l - 1, True, 5)
+        rc = lib.conv3x3_pair_f16(ptr(src), ptr(pa), ia, None, ptr(fit.act[l]), None, ptr(pb), ib, None, ptr(fit.act[l - 1]), ptr(dst), H, W, 1,
+                                  None, stream.cuda_stream)
+    else:
+        pa, ia = e.split_pack(l, False, 5)
+        pb, ib = e.split_pack(l + 1, False, 5)
+        rc = lib.conv3x3_pair_f16(ptr(src), ptr(pa), ia, ptr(e.b[l]), None, ptr(mid), ptr(pb), ib, ptr(e.b[l + 1]), None, ptr(dst), H, W, 0,
+                                  None, stream.cuda_stream)
+    lib.check(rc, 'conv pair')
+
+
 def _capture(fit, stream, body):
     lib = fit.lib
     g = C.c_void_p()
@@ -132,7 +150,7 @@ def _capture(fit, stream, body):
     return g
 
 
-def time_conv_chain(fit, stream, use_graph=True, reps=5, with_lbs=False):
+def time_conv_chain(fit, stream, use_graph=True, reps=5, with_lbs=False, pairs_only=False):
     """In-iteration duration of the dominant kernel: the iteration's own dependency chain of the fourteen 64->64 launches
     (7 forward layers act[3] -> ... -> act[10], then 7 backward-data layers through the two ping-pong gradient maps with
     the saved activations as epilogue operands) on the engine's own buffers -- every layer reads what the previous launch
@@ -152,6 +170,15 @@ def time_conv_chain(fit, stream, use_graph=True, reps=5, with_lbs=False):
         for _ in range(reps):
             if with_lbs:
                 lbs()
+            if pairs_only:
+                # conv variant 5: the six fused launches of the iteration, each reading what the previous one wrote
+                for l in (3, 5, 7):
+                    _conv_pair(fit, l, False, fit.act[l], fit.act[l + 1], fit.act[l + 2], stream)
+                cur = 0
+                for l in (9, 7, 5):
+                    _conv_pair(fit, l, True, fit.dact[cur], None, fit.dact[1 - cur], stream)
+                    cur = 1 - cur
+                continue
             for l in range(3, 10):
                 _conv_layer(fit, l, False, fit.act[l], fit.act[l + 1], stream)
             cur = 0
@@ -173,7 +200,7 @@ def time_conv_chain(fit, stream, use_graph=True, reps=5, with_lbs=False):
             best = min(best, e0.elapsed_time(e1))
     finally:
         fit.lib.graph_destroy(g)
-    return best / reps          # ms per repetition of the chain (14 conv launches [+ 1 lbs launch])
+    return best / reps          # ms per repetition of the chain (14 conv launches, or the 6 fused pairs [+ 1 lbs launch])
 
 
 def clock_ramp(fit, stream, ms, use_graph):
@@ -582,16 +609,26 @@ def main():
         value_100 = 100.0 / (time.perf_counter() - t1)
 
     b2b_ms, kern_flops = time_dominant_kernel(fit, stream, use_graph=use_graph)
-    chain_ms = time_conv_chain(fit, stream, use_graph=use_graph)                      # 14 launches per repetition
-    kern_ms = chain_ms / 14.0
+    pairs = fit.conv_variant >= 5
+    if pairs:
+        # conv variant 5: the dominant kernel is the fused PAIR (two 64 -> 64 layers per launch, 6 launches per iteration); its
+        # algorithmic work is two layers' (the halo recompute of the intermediate tile is overhead, not work)
+        chain_ms = time_conv_chain(fit, stream, use_graph=use_graph, pairs_only=True)     # 6 launches per repetition
+        kern_ms, kern_flops, n_chain = chain_ms / 6.0, 2.0 * kern_flops, 6
+    else:
+        chain_ms = time_conv_chain(fit, stream, use_graph=use_graph)                      # 14 launches per repetition
+        kern_ms, n_chain = chain_ms / 14.0, 14
     achieved = kern_flops / (kern_ms * 1e-3) / 1e12
     vs = time_vertex_stage(fit, stream, use_graph=use_graph)
-    lbs_in_chain_ms = (time_conv_chain(fit, stream, use_graph=use_graph, with_lbs=True) - chain_ms) if fit.full else None
+    lbs_in_chain_ms = (time_conv_chain(fit, stream, use_graph=use_graph, with_lbs=True, pairs_only=pairs) - chain_ms) if fit.full else None
     fit.dact[0].zero_(); fit.dact[1].zero_()          # the chain used the gradient maps as scratch (interiors are rewritten each step)
-    if fit.conv_variant == 4:
+    if fit.conv_variant >= 4:
         # every fp32-accurate multiply-accumulate is 3 fp16 MFMA products (two error-compensated fp16 pieces per operand, fp32
         # accumulate): the pipe that bounds the kernel is the 16-bit matrix pipe at 1/3 of its dense peak
-        peak, kname = PEAK_BF16_MATRIX_TFLOPS / 3.0, 'conv3x3_split_kernel<NP=2> (variant 4: two fp16 pieces per fp32 operand, 3 products on v_mfma_f32_32x32x16_f16)'
+        peak = PEAK_BF16_MATRIX_TFLOPS / 3.0
+        kname = ('conv3x3_pair_kernel (variant 5: TWO 64->64 layers per launch on 10x14 tiles, intermediate in LDS; two fp16 pieces per fp32 '
+                 'operand, 3 products on v_mfma_f32_32x32x16_f16)' if pairs else
+                 'conv3x3_split_kernel<NP=2> (variant 4: two fp16 pieces per fp32 operand, 3 products on v_mfma_f32_32x32x16_f16)')
         peak_note = ('algorithmic fp32 FLOP/s against f16 dense MFMA peak %.0f TF / 3 products per fp32-accurate MAC (variant 3, 6 bf16 '
                      'products: peak / 6; the fp32-MFMA kernel (--conv-variant 2): %.1f TF)' % (PEAK_BF16_MATRIX_TFLOPS, PEAK_FP32_MATRIX_TFLOPS))
     elif fit.conv_variant == 3:
@@ -603,6 +640,10 @@ def main():
     else:
         peak, kname = PEAK_FP32_MATRIX_TFLOPS, f'conv3x3_mfma (variant {fit.conv_variant}, v_mfma_f32_32x32x2_f32)'
         peak_note = 'fp32-input MFMA peak'
+    # algorithmic HBM bytes of the dominant launch: single layer = 8.4 MB in + 8.4 out + 0.3 weights; fused pair = in + out + the
+    # intermediate map (forward: written as the saved activation; backward: read as the lrelu' operand) + the second operand map of
+    # the backward epilogue (8.4 MB each) + 0.3 MB of weights: 25.5 MB forward, 33.9 MB backward, averaged over the 3 + 3 launches
+    alg_bytes = (3 * 25.5e6 + 3 * 33.9e6) / 6.0 if pairs else 17.1e6
     out = {
         'metric': 'fitting-iterations/sec (T=120 frames)', 'value': world * args.steps / dt,
         'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -613,7 +654,10 @@ def main():
                                'encoder 245x134, marker+contact+prior losses, Adam',
                    'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
                    'sequences': world, 'conv_variant': fit.conv_variant,
-                   'arithmetic': {4: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
+                   'arithmetic': {5: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
+                                     'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured error vs '
+                                     'float64 at the level of an fp32 convolution); consecutive 64->64 layers run as fused pairs (conv_pair_kernels.hip)',
+                                  4: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
                                      'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured '
                                      'error vs float64 at the level of an fp32 convolution, conv_split_kernels.hip)',
                                   3: 'fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
@@ -622,21 +666,26 @@ def main():
                    'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant >= 3
-                                                                         else 'lemo::conv3x3_mfma_v2_kernel<0'),
-                     'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; '
-                                     'algorithmic minimum 17.1e6)',
+                     'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_pair_kernel<0' if pairs else
+                                                                         ('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant >= 3
+                                                                          else 'lemo::conv3x3_mfma_v2_kernel<0')),
+                     'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; algorithmic '
+                                     'minimum %.1fe6)' % (alg_bytes / 1e6),
                      'peak_note': peak_note,
-                     'kernel': kname + ' 64->64ch 245x134, 14 of the 31 launches/iteration',
+                     'kernel': kname + (' 64->64->64ch 245x134, 6 of the 23 launches/iteration (12 of the 14 64->64 layers)' if pairs
+                                        else ' 64->64ch 245x134, 14 of the 31 launches/iteration'),
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops,
-                     'kernel_ms_source': 'HIP events around a captured replay of the iteration\'s own chain of the fourteen 64->64 '
-                                         'launches (7 fwd + 7 bwd-data, each reading what the previous one wrote, engine buffers), '
-                                         '/ 14: the in-iteration duration incl. the kernel boundary, comparable with the rocprofv3 '
+                     'kernel_ms_source': ('HIP events around a captured replay of the iteration\'s own chain of the six fused launches (3 forward '
+                                          'pairs act[3] -> act[9], 3 backward-data pairs through the gradient maps, each reading what the previous '
+                                          'one wrote, engine buffers), / 6' if pairs else
+                                          'HIP events around a captured replay of the iteration\'s own chain of the fourteen 64->64 '
+                                          'launches (7 fwd + 7 bwd-data, each reading what the previous one wrote, engine buffers), / 14') +
+                                         ': the in-iteration duration incl. the kernel boundary, comparable with the rocprofv3 '
                                          'average of the same kernel in profiles/ (kernel stats of this round)',
                      'kernel_ms_back_to_back': b2b_ms,
                      'memory_view': {
-                         'algorithmic_bytes_per_launch': 17.1e6, 'achieved_TBps': 17.1e6 / (kern_ms * 1e-3) / 1e12,
-                         'frac_of_hbm_peak': 17.1e6 / (kern_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         'algorithmic_bytes_per_launch': alg_bytes, 'achieved_TBps': alg_bytes / (kern_ms * 1e-3) / 1e12,
+                         'frac_of_hbm_peak': alg_bytes / (kern_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
                          'copy_layer_floor_ms': 0.00507,
                          'frac_of_copy_layer_floor': 0.00507 / kern_ms,
                          'note': 'since round 3 the layer is bound by data movement + launch boundary, not by the matrix pipe (DESIGN 9.2): '

@@ -68,6 +68,19 @@ int lemo_conv3x3_mfma_split_f16(const float* in, const void* w2, float winv, con
 /* census of either variant (pieces = 3: w = w3, winv ignored; pieces = 2: w = w2) */
 int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
                                     int H, int W, int cin, int cout, unsigned long long* dbg, void* stream);
+/* variant 5 ("pairs", the engines' default since round 4): TWO consecutive 64 -> 64 layers of the encoder in ONE launch, in the
+ * arithmetic of variant 4.  A workgroup owns a 10 x 14 output tile, stages the 14 x 18 input tile once, keeps the 12 x 16
+ * intermediate tile in LDS (zero outside the image = the second layer's padding) and never re-reads it from HBM:
+ *   epi 0 (forward, models/AE_sep.py:11-30): mid = lrelu(conv(in, A) + biasA), out = lrelu(conv(mid, B) + biasB); `mid` (all 64
+ *          channels, CG8P) is ALSO written -- the backward pass needs every layer's activation;
+ *   epi 1 (backward-data): mid = conv(in, A) * lrelu'(auxA), out = conv(mid, B) * lrelu'(auxB) with A / B the backward packs of the
+ *          LATER / EARLIER layer and auxA / auxB the saved activations at the mid / out positions; `mid` is not written.
+ * wA / wB: the variant-4 packs (pack_conv3x3_split_f16 / pack_conv3x3_bwd_split_f16), winvA / winvB their inverse host scales.
+ * dbg (epi 0 only, may be NULL): per wave {HW_ID, XCC_ID, start, end, after staging, after layer 1, after the mid planes} stamps. */
+int lemo_conv3x3_pair_supported(int H, int W, int c0, int c1, int c2);
+int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
+                          const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
+                          unsigned long long* dbg, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);
@@ -329,8 +342,9 @@ typedef struct lemo_fit_const {
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
-  int conv_variant;               /* 4: split-f16 (default) ; 0/1: lemo_conv3x3_mfma variants ; 2: lemo_conv3x3_mfma_lds ;
-                                   * 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
+  int conv_variant;               /* 5: fused layer pairs (lemo_conv3x3_pair_f16) where three consecutive channel counts allow,
+                                   * variant 4 for the remaining layers (default) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
+                                   * 2: lemo_conv3x3_mfma_lds ; 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;
   lemo_skin_const skin;

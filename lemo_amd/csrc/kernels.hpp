@@ -33,6 +33,12 @@ int conv3x3_mfma_split(const float* in, const void* w3, const float* wt, const f
                        int H, int W, int cin, int cout, int epi, hipStream_t s, unsigned long long* dbg = nullptr, int pieces = 3,
                        float winv = 1.f);
 int conv_split_init();
+// ---------------- conv_pair_kernels.hip ----------------
+// variant 5: TWO 64 -> 64 layers per launch on 10 x 14 tiles, intermediate in LDS (split-f16 arithmetic of variant 4)
+bool conv3x3_pair_supported(int H, int W, int c0, int c1, int c2);
+int conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid, const void* wB,
+                     float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi, hipStream_t s,
+                     unsigned long long* dbg = nullptr);
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);

@@ -2,6 +2,7 @@
 // sequence of one AMASS temporal-fitting iteration (opt_amass_temp.py:349-455), optionally captured
 // once into a hipGraph and replayed (the iteration is ~40 short kernels: launch-bound without it).
 #include "kernels.hpp"
+#include "enc_chain.hpp"
 
 #include <new>
 
@@ -51,6 +52,12 @@ int lemo_conv3x3_mfma_split_f16(const float* in, const void* w2, float winv, con
                                 float* out, int H, int W, int cin, int cout, int epi, void* stream) {
   if (!in || !w2 || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma_split(in, w2, wt, bias, aux, out, H, W, cin, cout, epi, S(stream), nullptr, 2, winv);
+}
+int lemo_conv3x3_pair_supported(int H, int W, int c0, int c1, int c2) { return conv3x3_pair_supported(H, W, c0, c1, c2) ? 1 : 0; }
+int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
+                          const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
+                          unsigned long long* dbg, void* stream) {
+  return conv3x3_pair_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
 }
 int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
                                     int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
@@ -310,24 +317,6 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
   return a;
 }
 
-// one MFMA layer of the smoothness encoder (forward: act[l] -> act[l+1]; backward-data: d(pre-act l+1) -> d(pre-act l) with
-// the saved activation act[l] as epilogue operand) on the kernel family conv_variant selects for its shape
-static int enc_layer(const lemo_fit_desc& d, int l, bool bwd, const float* src, float* dst, int H, int W, hipStream_t s) {
-  const int cin = bwd ? d.enc_ch[l + 1] : d.enc_ch[l], cout = bwd ? d.enc_ch[l] : d.enc_ch[l + 1];
-  const float* wt = bwd ? d.enc_wbwd[l] : d.enc_w[l];
-  const float* wt2 = bwd ? d.enc_wbwd2[l] : d.enc_w2[l];
-  const void* w3 = bwd ? d.enc_wbwd3[l] : d.enc_w3[l];
-  const float* bias = bwd ? nullptr : d.enc_b[l];
-  const float* aux = bwd ? d.act[l] : nullptr;
-  const int epi = bwd ? 1 : 0;
-  if (d.conv_variant >= 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
-    return conv3x3_mfma_split(src, w3, wt, bias, aux, dst, H, W, cin, cout, epi, s, nullptr, d.conv_variant == 4 ? 2 : 3,
-                              bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l]);
-  if (d.conv_variant >= 2 && 127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 <= 416)
-    return conv3x3_mfma_lds(src, wt, wt2, bias, aux, dst, H, W, cin, cout, epi, s);
-  return conv3x3_mfma(src, wt, bias, aux, dst, H, W, cin, cout, epi, d.conv_variant >= 2 ? 1 : d.conv_variant, s);
-}
-
 // compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
 // a run of iterations the previous iteration's tail launch has already produced it from the updated latent
 static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true) {
@@ -357,7 +346,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
   CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  for (int l = 1; l < 10; ++l) CHK(enc_layer(d, l, false, d.act[l], d.act[l + 1], H, W, s));
+  CHK(enc_chain_fwd(d, H, W, s));
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
   CHK(fit_losses(d.act[10], d.dact[0], H, W, d.enc_ch[10], coef2, d.loss_acc + 9, d.fit, d.verts, d.nrows, d.target, d.contact,
@@ -374,13 +363,8 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
   if (d.per_frame) goto vertex_stage;           // no encoder: d.fit.u_m81 is all -1, dx0 is never read
-  {
-  for (int l = 9; l >= 1; --l) {       // d(pre-act of layer l+1) -> d(pre-act of layer l)
-    CHK(enc_layer(d, l, true, d.dact[cur], d.dact[1 - cur], H, W, s));
-    cur = 1 - cur;
-  }
+  CHK(enc_chain_bwd(d, H, W, s, &cur));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
-  }
 vertex_stage:
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
     // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two

@@ -2,6 +2,7 @@
 // `optimizer.step(closure)` as a fixed sequence of kernel launches, captured once into hipGraphs and replayed.
 // The twin of the AMASS engine in lemo_hip.hip; kernels: prox_kernels.hip + the shared pose / LBS / encoder kernels.
 #include "kernels.hpp"
+#include "enc_chain.hpp"
 #include <new>
 
 namespace lemo {
@@ -22,21 +23,6 @@ struct ProxEngine {
   lemo_prox_desc d;
   hipGraphExec_t exec[PROX_LEVELS] = {nullptr, nullptr};
 };
-
-static int conv_layer(const lemo_prox_desc& d, int l, bool bwd, const float* x, const float* aux, float* out, int H, int W, hipStream_t s) {
-  const int cin = bwd ? d.enc_ch[l + 1] : d.enc_ch[l], cout = bwd ? d.enc_ch[l] : d.enc_ch[l + 1];
-  const float* wt = bwd ? d.enc_wbwd[l] : d.enc_w[l];
-  const float* wt2 = bwd ? d.enc_wbwd2[l] : d.enc_w2[l];
-  const void* w3 = bwd ? d.enc_wbwd3[l] : d.enc_w3[l];
-  const float* bias = bwd ? nullptr : d.enc_b[l];
-  const int epi = bwd ? 1 : 0;
-  if (d.conv_variant >= 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
-    return conv3x3_mfma_split(x, w3, wt, bias, aux, out, H, W, cin, cout, epi, s, nullptr, d.conv_variant == 4 ? 2 : 3,
-                              bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l]);
-  if (d.conv_variant >= 2 && 127 + 2 * (127 / W + 1) + 2 * (W + 2) + 3 <= 416)
-    return conv3x3_mfma_lds(x, wt, wt2, bias, aux, out, H, W, cin, cout, epi, s);
-  return conv3x3_mfma(x, wt, bias, aux, out, H, W, cin, cout, epi, 1, s);
-}
 
 // forward + backward of one iteration (fitting_func :239-311 without the erase, which the update applies)
 static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
@@ -59,13 +45,13 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   CHK(prox_frame(d, s));
   CHK(prox_dense(d, s));
   CHK(marker_c1(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  for (int l = 1; l < 10; ++l) CHK(conv_layer(d, l, false, d.act[l], nullptr, d.act[l + 1], H, W, s));
+  CHK(enc_chain_fwd(d, H, W, s));
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[8] * 2.0 / cnt);
   CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 32 * 32));
   // ---- backward
   int cur = 0;
-  for (int l = 9; l >= 1; --l) { CHK(conv_layer(d, l, true, d.dact[cur], d.act[l], d.dact[1 - cur], H, W, s)); cur = 1 - cur; }
+  CHK(enc_chain_bwd(d, H, W, s, &cur));
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
   CHK(prox_sparse(d, cnt, s));
   CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.V, d.dverts, B, d.Bp, d.dvp, d.dA, d.dtr_v, d.dX, s));

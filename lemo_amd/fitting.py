@@ -318,9 +318,17 @@ class AmassTemporalFitter(_hip.StreamOrdered):
 
     def grads_with_priors(self) -> Dict[str, torch.Tensor]:
         g = {k: v.clone() for k, v in self.grads().items()}
-        o, B, w = self.P['other'], self.B, self.weights
-        g['other'][:, :32] += w['vposer'] * 2.0 * o[:, :32] / (B * 32.0)
-        g['other'][:, 32:] += w['hand'] * 2.0 * o[:, 32:] / (B * 24.0)
+        o, w = self.P['other'], self.weights
+        Bn = 1 if self.per_frame else self.B                 # per_frame: every row is a fit of its own (FitTail.Bn)
+        # the tail kernel's own expression, operation for operation: (w * 2) * p / (Bn * d) with a TRUE division -- torch divides
+        # a device tensor by a Python scalar as a multiplication with the reciprocal (1 / 24 is not a power of two: last-bit
+        # differences from the kernel in the hand columns, seen by the bit-exact Adam check of the teacher-forced tests)
+        d32 = torch.full((), float(Bn) * 32.0, dtype=torch.float32, device=o.device)
+        d24 = torch.full((), float(Bn) * 24.0, dtype=torch.float32, device=o.device)
+        wv = torch.full((), float(np.float32(w['vposer']) * np.float32(2.0)), dtype=torch.float32, device=o.device)
+        wh = torch.full((), float(np.float32(w['hand']) * np.float32(2.0)), dtype=torch.float32, device=o.device)
+        g['other'][:, :32] += (wv * o[:, :32]) / d32
+        g['other'][:, 32:] += (wh * o[:, 32:]) / d24
         return g
 
     def params75(self) -> torch.Tensor:

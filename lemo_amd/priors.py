@@ -174,9 +174,11 @@ class EncWeights:
 # Encoder as autograd ops over the C ABI
 # ----------------------------------------------------------------------------------------------
 
-DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '4'))
-"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 4 = split-f16 kernel (two
-error-compensated fp16 pieces per fp32 operand, 3 products; the default since round 3), 3 = split-bf16 kernel (three
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '5'))
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 5 = the engines run consecutive 64 -> 64
+layers as fused PAIRS (one launch, intermediate in LDS; csrc/conv_pair_kernels.hip; the default since round 4) in the arithmetic
+of 4 = split-f16 kernel (two error-compensated fp16 pieces per fp32 operand, 3 products; layer by layer -- what the module /
+autograd path runs for 4 and 5 alike), 3 = split-bf16 kernel (three
 exact bf16 pieces, 6 products), LDS-tiled fp32-MFMA kernel (2) for shapes they do not take; 2 / 1 = fp32 MFMA only.
 The environment override exists for A/B runs of the parity suite."""
 

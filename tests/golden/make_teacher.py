@@ -80,7 +80,7 @@ def amass():
         out.update(_state_arrays(f's{k}', r['before']))
         out.update(_state_arrays(f's{k + 1}', r['after']))
         out[f'g{k}'] = _cat(r['grads'])
-        out[f'lr{k}'] = np.float32(r['lr'])
+        out[f'lr{k}'] = np.float64(r['lr'])
         out[f'loss{k}'] = np.asarray([r['extra'][n] for n in RH.AMASS_LOSS_VARS], np.float64)
         # float64 at the SAME fp32 state: exact gradient + computed kink exposure of every frame
         t0 = time.time()
@@ -136,7 +136,7 @@ def perframe():
         out.update(_state_arrays(f'f{f}s{k}', r['before']))
         out.update(_state_arrays(f'f{f}s{k + 1}', r['after']))
         out[f'f{f}g{k}'] = _cat(r['grads'])
-        out[f'f{f}lr{k}'] = np.float32(r['lr'])
+        out[f'f{f}lr{k}'] = np.float64(r['lr'])
         out[f'f{f}loss{k}'] = np.asarray([r['extra'][n] for n in ('loss_marker', 'loss_vposer', 'loss_shape', 'loss_hand', 'loss')], np.float64)
         with default_f64():
             tr, r6, ot = (torch.from_numpy(a).double().requires_grad_(True) for a in r['before']['params'])

@@ -326,7 +326,61 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert abs(fit.losses()['total'] - ref_total) < 2e-3 * ref_total
 
 
-@pytest.mark.parametrize('conv_variant', [4, 3, 2])
+def test_fused_pair_conv_full_size_vs_float64(dev):
+    """conv variant 5 (csrc/conv_pair_kernels.hip) at the encoder's own size (245 x 134, real runs/15217 weights of layers 3 / 4):
+    forward pair (intermediate AND output) and backward-data pair against torch float64 on the host; error of the size of an fp32
+    convolution's own rounding, and agreement with two single-layer launches of the same arithmetic (variant 4)"""
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import EncWeights, cg8p_alloc, from_cg8p, to_cg8p, enc_layer_keys
+    lib = _hip.get_lib()
+    A = load_assets()
+    enc = EncWeights(A['enc_w'], dev)
+    keys = enc_layer_keys()
+    H, W = 245, 134
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(64, H, W, generator=g) * 0.3
+    w1, b1 = torch.from_numpy(A['enc_w'][keys[3] + '.weight']), torch.from_numpy(A['enc_w'][keys[3] + '.bias'])
+    w2, b2 = torch.from_numpy(A['enc_w'][keys[4] + '.weight']), torch.from_numpy(A['enc_w'][keys[4] + '.bias'])
+    a1_64 = F.leaky_relu(F.conv2d(x[None].double(), w1.double(), b1.double(), padding=1), 0.2)
+    a2_64 = F.leaky_relu(F.conv2d(a1_64, w2.double(), b2.double(), padding=1), 0.2)[0]
+    a1_32 = F.leaky_relu(F.conv2d(x[None], w1, b1, padding=1), 0.2)
+    a2_32 = F.leaky_relu(F.conv2d(a1_32, w2, b2, padding=1), 0.2)[0]
+    s = torch.cuda.current_stream(dev).cuda_stream
+    xin, mid, out = to_cg8p(x).to(dev), cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    pa, ia = enc.split_pack(3, False, 5)
+    pb, ib = enc.split_pack(4, False, 5)
+    assert lib.conv3x3_pair_f16(ptr(xin), ptr(pa), ia, ptr(enc.b[3]), None, ptr(mid), ptr(pb), ib, ptr(enc.b[4]), None, ptr(out), H, W, 0, None, s) == 0
+    torch.cuda.synchronize()
+    e_mid, e_out = rel_err(from_cg8p(mid.cpu(), H, W).double(), a1_64[0]), rel_err(from_cg8p(out.cpu(), H, W).double(), a2_64)
+    f_mid, f_out = rel_err(a1_32[0].double(), a1_64[0]), rel_err(a2_32.double(), a2_64)
+    print(f'\nfused pair forward vs float64: mid {e_mid:.2e} out {e_out:.2e} (torch fp32 conv: {f_mid:.2e} / {f_out:.2e})')
+    assert e_mid < 2e-6 and e_out < 2e-6 and e_out < 3 * f_out + 2e-7
+    o = out.cpu().reshape(8, H + 2, W + 2, 8)
+    assert float(o[:, 0].abs().max()) == 0 and float(o[:, -1].abs().max()) == 0 and float(o[:, :, 0].abs().max()) == 0 and float(o[:, :, -1].abs().max()) == 0
+    s_mid, s_out = cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    assert lib.conv3x3_mfma_split_f16(ptr(xin), ptr(pa), ia, ptr(enc.w[3]), ptr(enc.b[3]), None, ptr(s_mid), H, W, 64, 64, 0, s) == 0
+    assert lib.conv3x3_mfma_split_f16(ptr(s_mid), ptr(pb), ib, ptr(enc.w[4]), ptr(enc.b[4]), None, ptr(s_out), H, W, 64, 64, 0, s) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), s_out.cpu()) < 1e-6 and rel_err(mid.cpu(), s_mid.cpu()) < 1e-6
+    # backward-data pair through layers (4, 3)
+    d2, a0 = torch.randn(64, H, W, generator=g) * 1e-6, torch.randn(64, H, W, generator=g)
+    # reference chain in float64 with the lrelu' branches taken from the SAME saved activations the kernel reads (a unit of the 2.1 M
+    # that sits within rounding of its kink would otherwise be a coin toss between the two sides)
+    a1_dev = from_cg8p(mid.cpu(), H, W)
+    dmid = F.conv_transpose2d(d2[None].double(), w2.double(), padding=1)[0] * torch.where(a1_dev > 0, 1.0, 0.2).double()
+    ref = F.conv_transpose2d(dmid[None], w1.double(), padding=1)[0] * torch.where(a0 > 0, 1.0, 0.2).double()
+    qa, ja = enc.split_pack(4, True, 5)
+    qb, jb = enc.split_pack(3, True, 5)
+    d0 = cg8p_alloc(64, H, W, dev)
+    assert lib.conv3x3_pair_f16(ptr(to_cg8p(d2).to(dev)), ptr(qa), ja, None, ptr(mid), None, ptr(qb), jb, None, ptr(to_cg8p(a0).to(dev)), ptr(d0), H, W, 1, None, s) == 0
+    torch.cuda.synchronize()
+    e_b = rel_err(from_cg8p(d0.cpu(), H, W).double(), ref)
+    print(f'fused pair backward-data vs float64: {e_b:.2e}')
+    assert e_b < 2e-6
+
+
+@pytest.mark.parametrize('conv_variant', [5, 4, 3, 2])
 def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""

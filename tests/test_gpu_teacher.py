@@ -47,7 +47,7 @@ def _cat_state(st):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('conv_variant', [4, 2])
+@pytest.mark.parametrize('conv_variant', [5, 2])
 def test_amass_loop_teacher_forced_full_size(dev, conv_variant):
     """BASELINE configs[1] (B = 119, V = 10475, all vertices forwarded): iterations 0, 1, 10, 30, 60, 61, 62, 99 of the
     reference's 100-step loop (opt_amass_temp.py:344-455; 60 -> 61 is its lr switch) from the reference's own optimiser state."""

@@ -18,6 +18,8 @@ BUDGETS = {
     'conv3x3_split_kernelILi1ELi64ELi64ELi2ELb0E': ('conv_split_kernels.hip', 256, 512),   # (NP = 2: split-f16, the default)
     'conv3x3_split_kernelILi0ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),   # (NP = 3: split-bf16)
     'conv3x3_split_kernelILi1ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),
+    'conv3x3_pair_kernelILi0ELb0E': ('conv_pair_kernels.hip', 256, 512),                # fused layer pairs (variant 5): forward / backward-data
+    'conv3x3_pair_kernelILi1ELb0E': ('conv_pair_kernels.hip', 256, 512),
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),
@@ -33,7 +35,7 @@ BUDGETS = {
 
 
 def _usage(fname):
-    out = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-fno-vectorize',    # the Makefile's flags
+    out = subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-slp-vectorize', '-fno-vectorize', '-DLEMO_NO_PACKED_FP32',    # the Makefile's flags
                           '-I' + os.path.join(ROOT, 'include'),
                           '-Wno-unused-function', '-Rpass-analysis=kernel-resource-usage', '-c', fname, '-o', os.devnull],
                          cwd=CSRC, capture_output=True, text=True, timeout=900)
