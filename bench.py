@@ -65,6 +65,23 @@ def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
                      seq=seq, markers=markers)
 
 
+def build_problem_emu(seq_id):
+    """--emu: the reduced seeded problem of __graft_entry__.small_problem (B = 14, V = 640) on liblemo_emu.so, sequence `seq_id`"""
+    import __graft_entry__ as ge
+    from lemo_amd import _hip, synthetic
+    from lemo_amd.fitting import AmassTemporalFitter
+    lib = _hip.HipLib(_hip.EMU_LIB_PATH, is_emu=True)
+    p = ge.small_problem()
+    B = p['B']
+    fit = AmassTemporalFitter(p['model'], p['vposer_w'], p['enc_w'], p['ids'], p['Xmean'], p['Xstd'], B, torch.device('cpu'), full_vertices=True, lib=lib)
+    seq = synthetic.make_synthetic_sequence(3 + seq_id, B=B)
+    fit.load_sequence(seq['target_params'], np.zeros((B, len(p['ids']['markers67']), 3), np.float32), seq['contact_lbl'])
+    fit.forward()
+    markers = fit.marker_vertices().detach().cpu().numpy().copy()
+    fit.load_sequence(seq['init_params'], markers, seq['contact_lbl'])
+    return fit, dict(seq=seq, markers=markers), B
+
+
 def conv_launcher(fit, stream):
     """closure that launches the engine's 64->64 conv (layer 10's shape, the engine's own buffers / scratch output)"""
     return lambda: _conv_layer(fit, 9, False, fit.act[9], fit.dact[1], stream)
@@ -207,7 +224,7 @@ def clock_ramp(fit, stream, ms, use_graph):
     """replay the real iteration for ~ms (the caller restores the initial fit state afterwards).  Returns the number
     of iterations run."""
     n = 0
-    if ms <= 0:
+    if ms <= 0 or stream is None:
         return n
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
@@ -446,6 +463,65 @@ def ae_probe(device):
             'workload': 'models/AE.py infilling autoencoder, [1,4,210,135] clip image, masked L1, Adam 3e-6 (opt_amass_temp.py:154-214)'}
 
 
+def timed_fit(fit, prob, stream, device, steps=100, warmup=10):
+    """iterations/s of a fresh fit over `steps` timed steps after `warmup` (graphs prepared before, result read inside the window)"""
+    fit.load_sequence(prob['seq']['init_params'], prob['markers'], prob['seq']['contact_lbl'])
+    with torch.cuda.stream(stream):
+        fit.prepare(steps); fit.prepare(warmup)
+        fit.step(warmup, use_graph=True)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        fit.step(steps, use_graph=True)
+        stream.synchronize()
+    _ = fit.params72()
+    torch.cuda.synchronize(device)
+    return steps / (time.perf_counter() - t1)
+
+
+def variant_probe(prob_seq_id, B, device, stream, variant, ramp_fit):
+    """the same clip on another kernel family of the encoder, same process, same box, clocks brought up by the headline engine first:
+    an A/B the line carries itself (VERDICT r03 #8)"""
+    f, p = build_problem(prob_seq_id, B, device, full_vertices=True, conv_variant=variant)
+    with torch.cuda.stream(stream):
+        ramp_fit.step(100, use_graph=True)
+    torch.cuda.synchronize(device)
+    best = max(timed_fit(f, p, stream, device) for _ in range(2))
+    assert f.nonfinite_step() == 0
+    return best
+
+
+def mpjpe_probe(fit, prob, stream, device, steps=100, budget_threads=16):
+    """BASELINE's 'MPJPE vs ref' (SURVEY 8(d)): the full 100-step fit on the GPU and on the CPU oracle (one SMPL-X forward per
+    iteration -- same arithmetic as the faithful two-forward loop, pinned equal in tests/test_oracle.py -- with the loop's own lr
+    switch) from identical inputs; mean over frames and the first 22 joints of ||J_gpu - J_oracle||_2 in mm."""
+    from oracle import lemo_oracle as O
+    fit.load_sequence(prob['seq']['init_params'], prob['markers'], prob['seq']['contact_lbl'])
+    with torch.cuda.stream(stream):
+        fit.step(steps, use_graph=True)
+        fit.forward()
+    torch.cuda.synchronize(device)
+    j_gpu = fit.posed_joints().cpu()
+    total_gpu = fit.losses()['total']
+    torch.set_num_threads(budget_threads)
+    so = O.SmplxOracle(prob['model'])
+    vw = {k: torch.from_numpy(v) for k, v in prob['vposer_w'].items()}
+    ew = {k: torch.from_numpy(v) for k, v in prob['enc_w'].items()}
+    ofit = O.AmassFitOracle(so, vw, ew, prob['ids'], prob['Xmean'], prob['Xstd'], prob['seq']['init_params'], prob['markers'],
+                            prob['seq']['contact_lbl'], faithful=False)
+    t0 = time.time()
+    first = ofit.step()
+    for _ in range(steps - 1):
+        last = ofit.step()
+    with torch.no_grad():
+        _, j_ref, _ = ofit._body(O.convert_to_3D_rot(ofit.params75()))
+    return {'value': O.mpjpe_mm(j_gpu, j_ref[:, :55]), 'unit': 'mm (mean over frames and the first 22 joints, GPU fit vs CPU oracle fit)',
+            'steps': steps, 'total_loss_start': first['total'], 'total_loss_oracle': last['total'], 'total_loss_gpu': total_gpu,
+            'oracle_seconds': time.time() - t0,
+            'note': 'free-running 100-step trajectories of a kinked objective under Adam: the per-step parity statements are the '
+                    'teacher-forced tests (tests/test_gpu_teacher.py); this is the metric BASELINE.json names'}
+
+
 def main_prox(args, world, rank, device):
     """--workload prox: BASELINE configs[4]'s per-GPU leg.  Recordings shard over ranks (windows of one recording are
     sequential: temp_prox/main_slide.py:257); every rank fits the current window of ITS recording -- B = 100, V = 10475,
@@ -453,35 +529,51 @@ def main_prox(args, world, rank, device):
     import __graft_entry__ as ge
     from lemo_amd.prox import ENGINE_PARAMS
     from lemo_amd.sharding import gather_fitted_params
-    prob = ge.prox_full_problem('S3')
+    import contextlib
+    gpu = not args.emu
+    lib = None
+    if gpu:
+        prob = ge.prox_full_problem('S3')
+    else:                                                      # --emu: the reduced seeded window on the host-emulated library
+        from lemo_amd import _hip
+        lib = _hip.HipLib(_hip.EMU_LIB_PATH, is_emu=True)
+        prob = ge.prox_small_problem(stage='S3')
     rng = np.random.default_rng(100 + rank)                    # rank r's own recording: perturbed initial fit and keypoints
     prob['params'] = {k: (np.asarray(v, np.float32) + (rng.standard_normal(np.shape(v)).astype(np.float32) * 0.01 if k != 'betas' else 0))
                       for k, v in prob['params'].items()}
-    eng, _ = ge.prox_engine_for(prob, device, first_batch_flag=False)
-    s = torch.cuda.Stream(device)
+    eng, _ = ge.prox_engine_for(prob, device, first_batch_flag=False, lib=lib)
+    s = torch.cuda.Stream(device) if gpu else None
+    on_stream = (lambda: torch.cuda.stream(s)) if gpu else contextlib.nullcontext
+    sync = (lambda: torch.cuda.synchronize(device)) if gpu else (lambda: None)
     rows = lambda: torch.cat([eng.P[k] for k, _ in ENGINE_PARAMS], dim=1)
+    n_warm = max(args.warmup, 100) if gpu else args.warmup
 
     def barrier():
         if world > 1:
             dist.barrier()
-    with torch.cuda.stream(s):
-        eng.step(max(args.warmup, 100), use_graph=True)          # graphs captured + clocks up
-    torch.cuda.synchronize(device)
+    with on_stream():
+        eng.step(n_warm, use_graph=gpu)                          # graphs captured + clocks up
+    sync()
     gather_fitted_params(rows()[None])
-    torch.cuda.synchronize(device)
+    sync()
     barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
-    with torch.cuda.stream(s):
-        eng.step(args.steps, use_graph=True)
-        s.synchronize()
+    with on_stream():
+        eng.step(args.steps, use_graph=gpu)
+        if gpu:
+            s.synchronize()
     local = rows()
     gathered = gather_fitted_params(local[None])
-    torch.cuda.synchronize(device)
+    sync()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    per_rank = None
     if world > 1:
+        allt = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(allt, tmax)
+        per_rank = [args.steps / float(t.item()) for t in allt]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     assert gathered.shape[0] == world and torch.equal(gathered[rank], local) and bool(torch.isfinite(gathered).all())
@@ -490,7 +582,7 @@ def main_prox(args, world, rank, device):
             assert not torch.equal(gathered[r], local), 'ranks fitted the same recording'
     assert eng.nonfinite_step() == 0
     out = {'metric': 'PROX fitting-iterations/sec (100-frame window, PROXD_temp_S3)', 'value': world * args.steps / dt,
-           'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': max(args.warmup, 100),
+           'unit': 'fitting-iterations/s', 'n_gpus': world, 'steps': args.steps, 'warmup': n_warm,
            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
            'data': 'synthetic',
            'config': {'workload': 'temp_prox/main_slide.py PROXD_temp_S3.yaml: one 100-frame sliding window per GPU (recordings shard '
@@ -498,6 +590,11 @@ def main_prox(args, world, rank, device):
                                   'infilling priors, native PROX engine', 'frames': 100, 'recordings': world,
                       'parallelism': f'recording-shard x{world} + 1 all_gather'},
            'total_loss': eng.loss_dict()['total_loss']}
+    if per_rank is not None:
+        out['per_rank_iterations_per_s'] = per_rank
+    if not gpu:
+        out['config'].update(workload='DRY RUN (--emu): reduced PROX window on the host-emulated kernel library -- control flow only, the '
+                                      'numbers mean nothing', frames=int(eng.B), backend=args.backend, emulated=True)
     if rank == 0:
         print(json.dumps(out), flush=True)
 
@@ -517,6 +614,11 @@ def main():
     ap.add_argument('--workload', choices=('amass', 'prox'), default='amass',
                     help="amass (default, the headline: BASELINE configs[1]/[2]) or prox (configs[4]'s per-GPU leg: one S3 window per GPU)")
     ap.add_argument('--no-extras', action='store_true', help='skip the non-headline objects (prox_window, perframe, ae_finetune)')
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default='nccl', help='torch.distributed backend (nccl = RCCL; gloo only with --emu)')
+    ap.add_argument('--emu', action='store_true',
+                    help='DRY RUN of the multi-rank control flow without GPUs (tests/test_sharding.py): a reduced problem on the host-emulated '
+                         'kernel library (liblemo_emu.so, CPU tensors), eager launches, no roofline / extras / CPU baseline -- the numbers '
+                         'mean nothing; the barriers, the max-over-ranks timing, the one all-gather and the shard self-checks are the real ones')
     ap.add_argument('--concurrent-clips', type=int, default=3,
                     help='after the headline measurement (one clip per GPU), also time this many independent clips fitted side by '
                          'side on GPU 0 (reported as "concurrent_clips", never as "value"; 0 = off)')
@@ -525,13 +627,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    if args.emu:
+        assert args.backend == 'gloo' or world == 1, '--emu runs on CPU tensors: use --backend gloo'
+        device = torch.device('cpu')
+        args.no_graph, args.no_cpu_baseline, args.no_extras, args.concurrent_clips, args.ramp_ms = True, True, True, 0, 0.0
+        torch.set_num_threads(2)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (no CPU fallback; --emu is a control-flow dry run, not a fallback)')
+        assert args.backend == 'nccl', 'GPU runs use RCCL (backend nccl)'
+        device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if args.emu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     if args.workload == 'prox':
         main_prox(args, world, rank, device)
@@ -540,37 +652,47 @@ def main():
         return
 
     from lemo_amd.sharding import gather_fitted_params
-    B = args.frames
-    fit, prob = build_problem(rank, B, device, full_vertices=not args.active_vertices_only, conv_variant=args.conv_variant)
-    stream = torch.cuda.Stream(device)
+    import contextlib
+    gpu = not args.emu
+    sync = (lambda: torch.cuda.synchronize(device)) if gpu else (lambda: None)
+    if gpu:
+        B = args.frames
+        fit, prob = build_problem(rank, B, device, full_vertices=not args.active_vertices_only, conv_variant=args.conv_variant)
+        stream = torch.cuda.Stream(device)
+        on_stream = lambda: torch.cuda.stream(stream)
+    else:
+        fit, prob, B = build_problem_emu(rank)
+        stream, on_stream = None, contextlib.nullcontext
     use_graph = not args.no_graph
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
+    with on_stream():
         if use_graph:                       # record + upload the graphs of all calls (nothing runs): capture is not a step
             fit.prepare(args.warmup)
             fit.prepare(args.steps)
             fit.prepare(20)
     ramp_iters = clock_ramp(fit, stream, args.ramp_ms, use_graph)
     gather_fitted_params(fit.params72()[None])           # result path once, untimed: its torch kernels load lazily
-    torch.cuda.synchronize(device)
+    sync()
     fit.load_sequence(prob['seq']['init_params'], prob['markers'], prob['seq']['contact_lbl'])   # back to iteration 0
-    stream.wait_stream(torch.cuda.current_stream(device))     # (the engine orders its launches behind load_sequence itself too)
-    with torch.cuda.stream(stream):
+    if gpu:
+        stream.wait_stream(torch.cuda.current_stream(device))     # (the engine orders its launches behind load_sequence itself too)
+    with on_stream():
         fit.step(args.warmup, use_graph=use_graph)
-    torch.cuda.synchronize(device)
+    sync()
     barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
+    with on_stream():
         fit.step(args.steps, use_graph=use_graph)
-        stream.synchronize()
+        if gpu:
+            stream.synchronize()
     local72 = fit.params72()
     gathered = gather_fitted_params(local72[None])                 # the path's one collective
-    torch.cuda.synchronize(device)
+    sync()
     barrier()
     dt_local = time.perf_counter() - t0
     tmax = torch.tensor([dt_local], dtype=torch.float64, device=device)
@@ -590,6 +712,20 @@ def main():
             assert not torch.equal(gathered[r], local72), f'rank {r} returned the same fit as rank {rank}: sequences not sharded'
     assert bool(torch.isfinite(gathered).all()) and fit.nonfinite_step() == 0
     losses = fit.losses()
+    if args.emu:
+        out = {'metric': 'fitting-iterations/sec (T=120 frames)', 'value': world * args.steps / dt, 'unit': 'fitting-iterations/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'DRY RUN (--emu): reduced problem on the host-emulated kernel library -- control flow only, the '
+                                      'numbers mean nothing', 'frames': B, 'sequences': world, 'parallelism': f'seq-shard x{world} + 1 all_gather',
+                          'backend': args.backend, 'emulated': True},
+               'final_total_loss': losses['total'], 'per_rank_iterations_per_s': per_rank,
+               'shard_self_checks': 'own block bit-identical, other ranks\' blocks differ, all finite'}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # a second, longer timed window of the same fit (world 1 only): the 20-step default window is 7 ms and the pool's boxes
     # differ by +-5 %; 100 steps is the reference's whole per-clip fit (opt_amass_temp.py:349)
@@ -608,6 +744,12 @@ def main():
         torch.cuda.synchronize(device)
         value_100 = 100.0 / (time.perf_counter() - t1)
 
+    stage_us = None
+    if world == 1 and use_graph and gpu:
+        with torch.cuda.stream(stream):
+            fit.step(40, use_graph=True)                    # clocks of the real kernel mix
+            stage_us = fit.stage_census(20)
+        torch.cuda.synchronize(device)
     b2b_ms, kern_flops = time_dominant_kernel(fit, stream, use_graph=use_graph)
     pairs = fit.conv_variant >= 5
     if pairs:
@@ -697,6 +839,11 @@ def main():
     }
     if value_100 is not None:
         out['value_100_steps'] = value_100
+    if stage_us is not None:
+        # where one iteration's time goes (lemo_fit_census: every stage replayed 20 x back to back from its own graph, us per
+        # iteration); 'forward_backward' is the whole chain measured the same way (no Adam update: + ~1 us in the tail launch)
+        out['stage_us'] = dict({k: round(v, 2) for k, v in stage_us.items()}, sum_of_stages=round(sum(v for k, v in stage_us.items() if k != 'forward_backward'), 2),
+                               ms_per_step_100=round(1e3 / value_100, 4) if value_100 else None)
     if vs is not None:
         vms_b2b, vbytes, vflops = vs
         vms = lbs_in_chain_ms if lbs_in_chain_ms and lbs_in_chain_ms > 0 else vms_b2b
@@ -717,6 +864,25 @@ def main():
             out['concurrent_clips'] = concurrent_probe(fit, prob, B, device, args.concurrent_clips, max(args.steps, 100), args.conv_variant)
         except Exception as e:       # noqa: BLE001
             out['concurrent_clips'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not args.no_extras and use_graph and not args.active_vertices_only:
+        # A/B rows the line carries itself: the same clip, same process, on the layer-by-layer split-f16 kernels (variant 4) and on
+        # the fp32-input MFMA kernels (variant 2); then BASELINE's second metric, MPJPE of the full fit against the oracle's
+        try:
+            ab = {}
+            if fit.conv_variant != 4:
+                ab['value_layer_by_layer_f16x2'] = variant_probe(rank, B, device, stream, 4, fit)
+            ab['value_fp32_mfma'] = variant_probe(rank, B, device, stream, 2, fit)
+            ab['value_headline_again'] = max(timed_fit(fit, prob, stream, device) for _ in range(2))
+            ab['note'] = ('fitting-iterations/s over 100 timed steps, same clip / process / box, interleaved: the encoder on conv variant 4 '
+                          '(one split-f16 launch per layer), on variant 2 (v_mfma_f32_32x32x2_f32, fp32 operands) and the headline engine once more')
+            out['variants'] = ab
+        except Exception as e:       # noqa: BLE001
+            out['variants'] = {'error': f'{type(e).__name__}: {e}'}
+        try:
+            out['mpjpe'] = mpjpe_probe(fit, prob, stream, device)
+            out['mpjpe_mm'] = out['mpjpe']['value']
+        except Exception as e:       # noqa: BLE001
+            out['mpjpe'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_extras and use_graph:
         # the other workloads of BASELINE.json on this GPU (never the headline value; a failure must not cost the line)
         del fit

@@ -414,6 +414,15 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream);
 /* record (without running anything) the graphs an n-iteration lemo_fit_step(use_graph = 1) on `stream` will replay,
  * so that the first such call does not pay for capture + instantiation */
 int lemo_fit_prepare(void* h, int n, void* stream);
+/* Diagnostics (bench.py's per-stage figures): average duration in ms of every stage of ONE iteration, each measured as `reps`
+ * back-to-back repetitions of the stage's own launches captured into a graph and replayed between two events (consecutive graph
+ * nodes, like inside the iteration): ms[0] VPoser decode + pose stage, [1] vertex stage (lbs_verts_fwd), [2] marker image + first
+ * layer + encoder forward, [3] losses, [4] encoder backward-data + first-layer adjoint, [5] vertex-stage backward (+ d(verts)),
+ * [6] pose / VPoser backward + tail (no update), [7] = LEMO_FIT_NSTAGE: the whole forward + backward the same way.  `stream` must be
+ * capturable (not the legacy default stream).  The call SYNCHRONISES (event timing) and leaves losses / gradients of a clean
+ * forward + backward of the current parameters behind; parameters and optimiser state are not touched. */
+#define LEMO_FIT_NSTAGE 7
+int lemo_fit_census(void* h, int reps, float* ms_out /* host [LEMO_FIT_NSTAGE + 1] */, void* stream);
 /* Optimiser state of a fit = what torch.optim.Adam + the three parameter tensors hold between two iterations of
  * opt_amass_temp.py:349-455 (opt_amass_perframe.py:312-355 for per_frame engines): the parameters, Adam's exp_avg /
  * exp_avg_sq and the number of completed steps (which also selects the learning-rate level, :350-352).  All pointers are

@@ -241,6 +241,7 @@ _SIGS = {
     'lemo_fit_backward': (C.c_int, [vp, vp]),
     'lemo_fit_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'lemo_fit_prepare': (C.c_int, [vp, C.c_int, vp]),
+    'lemo_fit_census': (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), vp]),
     'lemo_fit_load_state': (C.c_int, [vp, C.POINTER(FitState), vp]),
     'lemo_fit_save_state': (C.c_int, [vp, C.POINTER(FitState), vp]),
     'lemo_prox_load_state': (C.c_int, [vp, C.POINTER(ProxState), vp]),

@@ -88,11 +88,20 @@ __device__ __forceinline__ void pair_exchange(const f32x16 (&acc)[3], float4 (&v
 // K loop of one layer over one K half (2 k-chunks x 9 taps = 18 steps) for NT N-tiles: A = weights from L2 through the ring,
 // B = activation fragments from LDS planes at `bbase` (group stride GRP, piece stride PL, row pitch PITCH), one step ahead.
 // STAGE (layer 1 only): the second staging phase rides inside the first k-chunk (see the kernel body).
+// the first CP_RA - 1 weight fragments of a K loop: requested by the caller as early as it knows the layer (they come from L2,
+// ~700 cycles away: layer 2's are requested before the K-half exchange of layer 1, not at the top of its own loop)
+__device__ __forceinline__ void pair_preload_a(uint4 (&ra)[CP_RA][2], const uint4* __restrict__ w, int kh, int ch, int lane) {
+#pragma unroll
+  for (int u0 = 0; u0 < CP_RA - 1; ++u0)
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) ra[u0][s_] = w[(unsigned)((((2 * kh) * 9 + u0) * 2 + ch) * 2 + s_) * 64u + lane];
+}
+
 template <int NT, int GRP, int PL, int PITCH, typename MidFn, typename EndFn>
-__device__ __forceinline__ void pair_kloop(f32x16 (&acc)[3], const uint4* __restrict__ w, const unsigned char* bbase, const int (&li)[3],
-                                           int kh, int ch, int lane, MidFn&& mid_fn, EndFn&& end_fn) {
+__device__ __forceinline__ void pair_kloop(f32x16 (&acc)[3], uint4 (&ra)[CP_RA][2], const uint4* __restrict__ w, const unsigned char* bbase,
+                                           const int (&li)[3], int kh, int ch, int lane, MidFn&& mid_fn, EndFn&& end_fn) {
   const int h = lane >> 5;
-  uint4 ra[CP_RA][2], rb[2][3][2];
+  uint4 rb[2][3][2];
 #define CP_LOAD_A(SET, U)                                                                              \
   _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                     \
     ra[SET][s_] = w[(unsigned)((((2 * kh + (U) / 9) * 9 + (U) % 9) * 2 + ch) * 2 + s_) * 64u + lane];
@@ -105,8 +114,6 @@ __device__ __forceinline__ void pair_kloop(f32x16 (&acc)[3], const uint4* __rest
   _Pragma("unroll") for (int nt_ = 0; nt_ < NT; ++nt_)                                                 \
     acc[nt_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[SETA][SA]),         \
                                                       __builtin_bit_cast(f16x8, rb[SETB][nt_][SB]), acc[nt_], 0, 0, 0);
-#pragma unroll
-  for (int u0 = 0; u0 < CP_RA - 1; ++u0) { CP_LOAD_A(u0, u0) }
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
     CP_LOAD_B((cc * 9) & 1, cc * 9)
@@ -130,7 +137,7 @@ __device__ __forceinline__ void pair_kloop(f32x16 (&acc)[3], const uint4* __rest
 // second layer of the pair for a wave that carries NT (3 | 2) out N-tiles starting at tile T0
 template <int EPI, int NT>
 __device__ __forceinline__ void pair_layer2(const PairArgs& a, unsigned char* smem, float* smem_f, int y0, int x0, int T0, int ng2, int ch,
-                                            int kh, int lane, float smi) {
+                                            int kh, int lane, float smi, uint4 (&ra)[CP_RA][2]) {
   const int j = lane & 31, h = lane >> 5;
   const int Wp = a.W + 2, HWp = (a.H + 2) * Wp;
   int lo[3] = {0, 0, 0}, poff[3] = {0, 0, 0};
@@ -150,7 +157,7 @@ __device__ __forceinline__ void pair_layer2(const PairArgs& a, unsigned char* sm
   for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-  pair_kloop<NT, CP_GRP_MID, CP_PL_MID, CP_MIDW>(acc, a.wB, smem + CP_MID_OFF, lo, kh, ch, lane, [](int, int) {}, [](int) {});
+  pair_kloop<NT, CP_GRP_MID, CP_PL_MID, CP_MIDW>(acc, ra, a.wB, smem + CP_MID_OFF, lo, kh, ch, lane, [](int, int) {}, [](int) {});
   {
     const float f = smi * a.winvB;                          // back to the operands' own scale (exact: powers of two)
 #pragma unroll
@@ -198,7 +205,7 @@ __device__ __forceinline__ void pair_layer2(const PairArgs& a, unsigned char* sm
 template <int EPI, bool DBG>
 __global__ void __launch_bounds__(512)
 conv3x3_pair_kernel(PairArgs a) {
-  unsigned long long t_start = 0, t_pro = 0, t_l1 = 0, t_mid = 0;
+  unsigned long long t_start = 0, t_pro = 0, t_l1 = 0, t_mid = 0, t_ex = 0, t_mx = 0;
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
   LEMO_DYN_SMEM(smem_f);
   unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f);
@@ -216,6 +223,9 @@ conv3x3_pair_kernel(PairArgs a) {
   }
   const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
   const int y0 = ty * CP_TH, x0 = tx * CP_TW;
+
+  uint4 ra[CP_RA][2];
+  pair_preload_a(ra, a.wA, kh, ch, lane);                  // nothing depends on them: requested before anything else
 
   // ---- staging plan: phase f stages groups {2f, 2f+1, 4+2f, 4+2f+1} (the f-th k-chunk of both K halves) of the 14 x 18 input tile.
   // Pixels outside the image land on the zero border ring through CLAMPED coordinates (the ring is zero by the CG8P contract; a
@@ -277,7 +287,7 @@ conv3x3_pair_kernel(PairArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   pair_kloop<3, CP_GRP_IN, CP_PL_IN, CP_INW>(
-      acc, a.wA, smem, li, kh, ch, lane,
+      acc, ra, a.wA, smem, li, kh, ch, lane,
       [&](int cc, int tap) {
         if (cc != 0) return;
         // the second phase's maximum is published at tap 0 and collected behind a workgroup barrier at tap 1 (that step's MFMAs are
@@ -316,6 +326,7 @@ conv3x3_pair_kernel(PairArgs a) {
         }
       });
   if (DBG) t_l1 = __builtin_amdgcn_s_memtime();
+  pair_preload_a(ra, a.wB, kh, ch, lane);                  // layer 2's first weight fragments travel during the exchange / epilogue
   {
     const float f = sci[1] * a.winvA;
 #pragma unroll
@@ -358,13 +369,11 @@ conv3x3_pair_kernel(PairArgs a) {
     if (KHu) pair_exchange<3, 1>(acc, v, red + 1536, red);
     else pair_exchange<3, 0>(acc, v, red, red + 1536);
   }
+  if (DBG) t_ex = __builtin_amdgcn_s_memtime();
   float mloc = 0.f;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    const bool in_i = i < 4 ? inimg0 : inimg1, inner_i = i < 4 ? inner0 : inner1;
-    const int po = i < 4 ? mpoff0 : mpoff1;
-    const int q = KHu ? S3::keep_quad(1, i) : S3::keep_quad(0, i);
-    const int c0 = ch * 32 + q * 8 + 4 * h;
+    const bool in_i = i < 4 ? inimg0 : inimg1;
     float4 r = v[i];
     if (EPI == 1) {
       r.x *= lrelu_grad_from_out(eo[i].x); r.y *= lrelu_grad_from_out(eo[i].y);
@@ -373,8 +382,8 @@ conv3x3_pair_kernel(PairArgs a) {
       r.x = lrelu(r.x + eo[i].x); r.y = lrelu(r.y + eo[i].y); r.z = lrelu(r.z + eo[i].z); r.w = lrelu(r.w + eo[i].w);
     }
     if (!in_i) r = make_float4(0.f, 0.f, 0.f, 0.f);                    // zero padding of the second layer
-    if (EPI != 1 && inner_i) st4(a.mid + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), r);   // the saved activation
-    v[i] = r;
+    v[i] = r;          // (EPI 0: also the saved activation, written to HBM at the END of the kernel: a store issued here would be
+                       // waited for -- vmcnt(0) -- by the workgroup barriers below, an HBM round trip per barrier)
     mloc = absmax4(r, mloc);
   }
   mloc = wave_max(mloc);
@@ -387,6 +396,7 @@ conv3x3_pair_kernel(PairArgs a) {
     for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[16 + i]);
     f16_scale_for(mm, sm, smi);
   }
+  if (DBG) t_mx = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int q = KHu ? S3::keep_quad(1, i) : S3::keep_quad(0, i);
@@ -401,13 +411,21 @@ conv3x3_pair_kernel(PairArgs a) {
 
   // ---- layer 2 -------------------------------------------------------------------------------------------------------------------
   const int ng2 = __builtin_amdgcn_readfirstlane(ng ^ kh);
-  if (ng2) pair_layer2<EPI, 2>(a, smem, smem_f, y0, x0, 3, 1, ch, kh, lane, smi);
-  else pair_layer2<EPI, 3>(a, smem, smem_f, y0, x0, 0, 0, ch, kh, lane, smi);
+  if (ng2) pair_layer2<EPI, 2>(a, smem, smem_f, y0, x0, 3, 1, ch, kh, lane, smi, ra);
+  else pair_layer2<EPI, 3>(a, smem, smem_f, y0, x0, 0, 0, ch, kh, lane, smi, ra);
+  if (EPI != 1) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = KHu ? S3::keep_quad(1, i) : S3::keep_quad(0, i);
+      const int c0 = ch * 32 + q * 8 + 4 * h;
+      if (i < 4 ? inner0 : inner1) st4(a.mid + ((size_t)(c0 >> 3) * HWp + (i < 4 ? mpoff0 : mpoff1)) * 8 + (c0 & 7), v[i]);
+    }
+  }
   if (DBG && lane == 0) {
     unsigned long long* r = a.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
     r[0] = __builtin_amdgcn_s_getreg(63492);
-    r[1] = __builtin_amdgcn_s_getreg(63508);
-    r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = t_pro; r[5] = t_l1; r[6] = t_mid; r[7] = 0;
+    r[1] = t_ex;
+    r[2] = t_start; r[3] = __builtin_amdgcn_s_memtime(); r[4] = t_pro; r[5] = t_l1; r[6] = t_mid; r[7] = t_mx;
   }
 }
 

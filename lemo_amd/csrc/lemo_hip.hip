@@ -319,12 +319,14 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
 
 // compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
 // a run of iterations the previous iteration's tail launch has already produced it from the updated latent
-static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true) {
+// `stages` (diagnostics, lemo_fit_census): bit 0 VPoser + pose stage, 1 vertex stage, 2 marker image + encoder forward, 3 losses
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true, unsigned stages = ~0u) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   // VPoser MLP (3 MFMA GEMMs); its rotation head and the 6-D -> axis-angle conversion of the global
   // orientation are fused into the pose-stage kernel, which also zeroes the loss accumulators and
   // latches the step counter for this iteration.
+  if (stages & 1u) {
   if (compute_h1) CHK(fit_tail(fit_tail_args(d, false, false, true), s));
   CHK(gemm_nt16(d.vposer.w2, 512, d.h1, 512, 512, B, 512, d.h2, 512, d.vposer.b2, nullptr, 0, 1, s));
   CHK(gemm_nt16(d.vposer.w3, 512, d.h2, 512, 128, B, 512, d.vo, 128, d.vposer.b3, nullptr, 0, 2, s));
@@ -335,20 +337,26 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   in.nonfinite = d.nonfinite;
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
+  }
+  if (stages & 2u) {
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
     CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
   else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
+  }
   if (d.per_frame) {       // opt_amass_perframe.py:324-351: marker L1 + the three L2 priors, nothing temporal
     CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
     if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, 1.0, d.weights, d.losses, s));
     return 0;
   }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
+  if (stages & 4u) {
   CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
   CHK(enc_chain_fwd(d, H, W, s));
+  }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
+  if (stages & 8u)
   CHK(fit_losses(d.act[10], d.dact[0], H, W, d.enc_ch[10], coef2, d.loss_acc + 9, d.fit, d.verts, d.nrows, d.target, d.contact,
                  d.shape, d.other, B, d.loss_acc, s));
   if (finalize) CHK(loss_finalize(d.loss_acc, B, d.fit.n67, cnt, d.weights, d.losses, s));
@@ -357,15 +365,17 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
 
 // update = false: gradients only (lemo_fit_backward).  update = true: the tail launch also runs Adam and, with next_h1,
 // the first VPoser layer of the next iteration.
-static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false) {
+// `stages`: bit 4 encoder backward-data + first-layer adjoint, 5 vertex-stage backward, 6 pose / VPoser backward + tail
+static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false, unsigned stages = ~0u) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
-  if (d.per_frame) goto vertex_stage;           // no encoder: d.fit.u_m81 is all -1, dx0 is never read
+  if (d.per_frame || !(stages & 16u)) goto vertex_stage;           // per_frame: no encoder (d.fit.u_m81 is all -1, dx0 is never read)
   CHK(enc_chain_bwd(d, H, W, s, &cur));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
   CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
 vertex_stage:
+  if (!(stages & 32u)) goto pose_stage;
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
     // d(total)/d(verts) is computed inside the LBS backward (block per frame in both): one launch instead of two
     const FitFuse ff{d.fit, DvertsIn{d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, B, d.per_frame ? 1 : B}, d.loss_acc, cnt, d.losses};
@@ -374,6 +384,8 @@ vertex_stage:
     CHK(dverts_assemble(d.fit, d.verts, d.nrows, d.target, d.contact, d.dx0, d.canon, d.weights, d.loss_acc, cnt, d.losses, B, d.dverts, s, d.per_frame ? 1 : B));
     CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.nrows, d.dverts, B, d.Bp, d.dvp, d.dA, d.g_transl, d.dX, s));
   }
+pose_stage:
+  if (!(stages & 64u)) return 0;
   lemo_pose_grad_in gi{d.dA, nullptr, d.dX};
   lemo_pose_grad_out go{};
   go.d_lh = d.g_other + 32; go.d_rh = d.g_other + 44; go.hand_stride = 56;
@@ -443,6 +455,52 @@ int lemo_fit_prepare(void* h, int n, void* stream) {
   FitEngine* e = (FitEngine*)h;
   if (!e || n < 0) return LEMO_ERR_ARG;
   return fit_graphs(e, S(stream), n, false);
+}
+
+// Diagnostics: where an iteration's time goes, stage by stage.  Every stage (and the whole forward + backward) is captured `reps`
+// times back to back into its own graph and replayed between two events -- consecutive graph nodes, like inside the iteration.
+// Buffers are left in a consistent state by a clean forward + backward at the end.  SYNCHRONISES (events): not for the hot path.
+int lemo_fit_census(void* h, int reps, float* ms_out, void* stream) {
+  FitEngine* e = (FitEngine*)h;
+  hipStream_t s = S(stream);
+  if (!e || !ms_out || reps < 1 || !s) return LEMO_ERR_ARG;
+  const lemo_fit_desc& d = e->d;
+  CHK(fit_forward(d, s, true));
+  CHK(fit_backward(d, s));
+  hipEvent_t e0, e1;
+  CHK((int)hipEventCreate(&e0));
+  CHK((int)hipEventCreate(&e1));
+  int rc = 0;
+  for (int k = 0; k <= LEMO_FIT_NSTAGE && !rc; ++k) {           // k == LEMO_FIT_NSTAGE: the whole forward + backward (no update)
+    const unsigned mask = k == LEMO_FIT_NSTAGE ? ~0u : (1u << k);
+    hipGraph_t g = nullptr;
+    hipGraphExec_t x = nullptr;
+    rc = (int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int r = 0; r < reps && !rc; ++r) {
+      if (mask & 15u) rc = fit_forward(d, s, false, true, mask);
+      if (!rc && (mask & 112u)) rc = fit_backward(d, s, false, false, mask);
+    }
+    const int ec = (int)hipStreamEndCapture(s, &g);
+    if (!rc) rc = ec;
+    if (!rc) rc = (int)hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (!rc) {
+      rc = (int)hipGraphLaunch(x, s);                              // once untimed (upload, caches), once timed
+      if (!rc) rc = (int)hipEventRecord(e0, s);
+      if (!rc) rc = (int)hipGraphLaunch(x, s);
+      if (!rc) rc = (int)hipEventRecord(e1, s);
+      if (!rc) rc = (int)hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (!rc) rc = (int)hipEventElapsedTime(&ms, e0, e1);
+      ms_out[k] = ms / (float)reps;
+    }
+    if (x) (void)hipGraphExecDestroy(x);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!rc) rc = fit_forward(d, s, true);
+  if (!rc) rc = fit_backward(d, s);
+  return rc;
 }
 
 // engine <-> caller copies of the optimiser state (parameters, Adam moments, completed-step count): ONE launch

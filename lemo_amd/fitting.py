@@ -292,6 +292,20 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         self._stepped = self._stepped or n > 0
         self._after_run()
 
+    STAGES = ('vposer_pose_fwd', 'vertex_fwd', 'marker_encoder_fwd', 'losses', 'encoder_bwd', 'vertex_bwd', 'pose_vposer_bwd_tail')
+
+    def stage_census(self, reps: int = 20) -> Dict[str, float]:
+        """microseconds per iteration spent in each stage (``lemo_fit_census``: every stage replayed ``reps`` times back to back
+        from its own graph) + ``'forward_backward'`` = the whole chain measured the same way.  Diagnostics: synchronises."""
+        ms = (C.c_float * 8)()
+        self._before_run()
+        self.lib.check(self.lib.fit_census(self.handle, int(reps), ms, self._s()), 'fit_census')
+        self._stepped = False
+        self._after_run()
+        out = {k: float(ms[i]) * 1e3 for i, k in enumerate(self.STAGES)}
+        out['forward_backward'] = float(ms[7]) * 1e3
+        return out
+
     def nonfinite_step(self) -> int:
         """1-based index of the first iteration (since the last ``load_sequence`` / ``reset_optimizer``) whose total loss
         was NaN or Inf, 0 if none (synchronises).  From the following iteration on the engine skipped every update --

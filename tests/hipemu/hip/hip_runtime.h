@@ -88,6 +88,12 @@ static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hi
 static inline hipError_t hipGraphUpload(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
 namespace hipemu {
 

@@ -68,9 +68,12 @@ for it in range(3):
     lib.check(lib.conv3x3_pair_f16(ptr(x), ptr(pa), ia, ptr(enc.b[3]), None, ptr(bufs[0]), ptr(pb), ib, ptr(enc.b[4]), None, ptr(bufs[1]), H, W, 0, ptr(dbg), s))
     torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(nblk, 8, 8)
-t0, t1, tp, tl1, tmid = d[..., 2], d[..., 3], d[..., 4], d[..., 5], d[..., 6]
+t0, t1, tp, tl1, tmid, tex, tmx = d[..., 2], d[..., 3], d[..., 4], d[..., 5], d[..., 6], d[..., 1], d[..., 7]
 med = lambda a: int(np.median(a))
-print('%d workgroups; per-wave cycles median %d max %d; staging %d | layer 1 %d | exchange + epilogue 1 + mid planes %d | layer 2 + epilogue 2 %d' % (
-    nblk, med(t1 - t0), (t1 - t0).max(), med(tp - t0), med(tl1 - tp), med(tmid - tl1), med(t1 - tmid)))
+print('%d workgroups; per-wave cycles median %d max %d; staging %d | layer 1 %d | exchange %d + epilogue 1 / max barrier %d + mid planes %d | layer 2 + epilogue 2 %d' % (
+    nblk, med(t1 - t0), (t1 - t0).max(), med(tp - t0), med(tl1 - tp), med(tex - tl1), med(tmx - tex), med(tmid - tmx), med(t1 - tmid)))
+for w in range(8):
+    print('  wave %d: staging %d | L1 %d | exch %d | epi+max %d | planes %d | L2 %d' % (w, med(tp[:, w] - t0[:, w]), med(tl1[:, w] - tp[:, w]), med(tex[:, w] - tl1[:, w]),
+                                                                                  med(tmx[:, w] - tex[:, w]), med(tmid[:, w] - tmx[:, w]), med(t1[:, w] - tmid[:, w])))
 wg = (t1.max(1) - t0.min(1))
 print('per-workgroup lifetime median %d max %d cycles; launch span %d cycles' % (med(wg), wg.max(), t1.max() - t0.min()))
