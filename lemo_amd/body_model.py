@@ -219,7 +219,9 @@ class DeviceBody:
         own = dict(tt)                              # same immutable tensors + this caller's scratch (keeps both alive)
         nchunk = tt['jcsr_chunk'].shape[0]
         own['part'] = torch.zeros(frames, nchunk, self.data.nj * 12 + 4, dtype=torch.float32, device=self.device)
-        own['gemm_part'] = torch.zeros(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)   # 32 x 128 x 512 floats
+        # K-slab partials of the feature-gradient GEMM: rows n < frames are fully written by every launch and the reducer reads only
+        # those -- no zero-fill needed (17 MB memset per autograd backward otherwise); `part` above IS read sparsely
+        own['gemm_part'] = torch.empty(GEMM_SLABS * 128 * K_PAD, dtype=torch.float32, device=self.device)   # 32 x 128 x 512 floats
         mine.part, mine.part_frames = ptr(own['part']), frames
         mine.gemm_part, mine.gemm_slabs = ptr(own['gemm_part']), GEMM_SLABS
         return mine, own

@@ -575,10 +575,13 @@ class _EngineSession:
             cur = torch.cuda.current_stream(self.device)
             if not own_stream and cur != torch.cuda.default_stream(self.device):
                 run_on, sh = cur, cur.cuda_stream
-                if self._ev is not None:
-                    cur.wait_event(self._ev)               # the session's previous run (possibly on another stream)
             else:
                 self.stream.wait_stream(cur)
+            if self._ev is not None:
+                # ALWAYS order the stream about to be used after the session's previous run: a run on caller
+                # stream A followed by a lane / default-stream run used to wait for `cur` only, and ae_load / ae_step then
+                # overwrote the workspace and rec / z / flat that the previous run (or its output clones on A) still used
+                run_on.wait_event(self._ev)
             _hip.flush_deferred()
         lib.check(lib.ae_load(self.h, ptr(flat0), ptr(x), ptr(moc), sh), 'ae_load')
         lib.check(lib.ae_step(self.h, int(steps), 1 if (use_graph and self.gpu) else 0, sh), 'ae_step')

@@ -95,7 +95,7 @@ def amass_mask_input(clip_img: torch.Tensor):
     x = clip_img.clone()
     x[:, 0] = torch.where(shown[:, None], x[:, 0], torch.zeros((), dtype=x.dtype, device=x.device))
     x = F.pad(x, P2D, 'reflect')
-    return x, keep
+    return x, keep.clone()          # a fresh tensor per call (device-to-device copy, no host sync): callers may edit it in place
 
 
 def decode_markers(clip_img_rec: torch.Tensor, clip_img: torch.Tensor, rot_0_pivot, stats: Optional[Dict[str, np.ndarray]] = None,

@@ -169,3 +169,60 @@ def test_baseline_size_vs_float64(dev):
     _check(_run(dev, full, g['markers_rec'], None, 6), 'B=119 V=10475, all terms', flips=True)
     # the same with the contact term off: its threshold is not the only kink (see _check)
     _check(_run(dev, full, g['markers_rec'], dict(O.LOSS_WEIGHTS, contact_vel=0.0), 3), 'B=119 V=10475, contact term off', flips=True)
+
+
+@pytest.mark.timeout(1500)
+def test_gradient_error_statistics_over_seeds(dev):
+    """one sequence said "the GPU's worst frame is 3-8 x further from float64 than the reference's
+    fp32 CPU path" -- luck of which kink trips, or a property of the build?  Five sequences (seeds 0-4) x the encoder's kernel
+    families (5 fused pairs = default, 4 split-f16, 3 split-bf16, 2 fp32 MFMA): per seed the iteration-0 gradient of the GPU engine
+    and of the fp32 CPU oracle against the float64 oracle -- worst frame and median over frames of the per-frame maximum, per
+    parameter group.  Asserted: the median over seeds of (GPU worst / CPU worst) <= 2 for every family, and the GPU's median-frame
+    error <= 3 x the CPU's + 2e-6 on every seed (the arithmetic where nothing flipped).  The table is the evidence
+    (profiles/r04_gates.txt)."""
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.vposer import make_vposer_weights
+    from oracle import lemo_oracle as O
+    from oracle.f64 import amass_fit_oracle_f64, default_f64
+    torch.set_num_threads(32)
+    A = load_assets()
+    model, vw = synthetic.make_synthetic_smplx(seed=0), make_vposer_weights(2)
+    so = O.SmplxOracle(model)
+    vwt = {k: torch.from_numpy(v) for k, v in vw.items()}
+    ewt = {k: torch.from_numpy(v) for k, v in A['enc_w'].items()}
+    variants = (5, 4, 3, 2)
+    fits = {v: AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 119, dev, full_vertices=True, conv_variant=v) for v in variants}
+    rows, ratio = [], {v: [] for v in variants}
+    for seed in range(5):
+        seq = synthetic.make_synthetic_sequence(seed, B=119)
+        f0 = fits[variants[0]]
+        f0.load_sequence(seq['target_params'], np.zeros((119, 67, 3), np.float32), seq['contact_lbl'])
+        f0.forward(); torch.cuda.synchronize()
+        markers = f0.marker_vertices().cpu().numpy().copy()
+        o32 = O.AmassFitOracle(so, vwt, ewt, A['ids'], np.asarray(A['Xmean']).reshape(1, 1, -1), A['Xstd'], seq['init_params'], markers, seq['contact_lbl'], faithful=False)
+        o64 = amass_fit_oracle_f64(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], seq['init_params'], markers, seq['contact_lbl'])
+        t32 = o32.losses()[0]; t32.backward()
+        with default_f64():
+            t64 = o64.losses()[0]; t64.backward()
+        G64 = {k: getattr(o64, k).grad for k in ('transl', 'rot6d', 'other')}
+        cpu = {k: ((getattr(o32, k).grad.double() - G64[k]).abs() / G64[k].abs().max()).max(1).values for k in G64}
+        cpu_max, cpu_med = max(float(v.max()) for v in cpu.values()), max(float(v.median()) for v in cpu.values())
+        for v in variants:
+            fit = fits[v]
+            fit.load_sequence(seq['init_params'], markers, seq['contact_lbl'])
+            fit.forward(); fit.backward(); torch.cuda.synchronize()
+            g = fit.grads_with_priors()
+            gpu = {k: ((g[k].cpu().double() - G64[k]).abs() / G64[k].abs().max()).max(1).values for k in G64}
+            gmax, gmed = max(float(x.max()) for x in gpu.values()), max(float(x.median()) for x in gpu.values())
+            ltot = abs(fit.losses()['total'] - float(t64)) / float(t64)
+            rows.append((seed, v, gmax, gmed, cpu_max, cpu_med, ltot))
+            ratio[v].append(gmax / cpu_max)
+            assert gmed <= 3.0 * cpu_med + 2e-6, (seed, v, gmed, cpu_med)
+            assert ltot <= 1e-5, (seed, v, ltot)
+    print('\nseed variant | gradient vs float64: GPU worst frame / median frame | CPU-fp32 worst / median | GPU total loss rel')
+    for r in rows:
+        print('  %d    %d     | %.2e / %.2e | %.2e / %.2e | %.1e' % r)
+    for v in variants:
+        med = float(np.median(ratio[v]))
+        print(f'  variant {v}: GPU worst / CPU worst over the 5 seeds: ' + ' '.join(f'{x:.2f}' for x in ratio[v]) + f'  -> median {med:.2f}')
+        assert med <= 2.0, (v, ratio[v])
