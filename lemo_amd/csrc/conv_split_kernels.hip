@@ -21,9 +21,11 @@
 //   ones carry an absolute error < 2^-39 of that maximum -- far below the fp32 accumulation rounding of the
 //   sum they enter).  Scales never mix inside an accumulator: the accumulators are rescaled (exactly) between
 //   the two k-chunk phases and un-scaled before the epilogue.  Nothing crosses kernels: any fp32 CG8P tensor
-//   is a valid input.  Measured through the encoder's 10 layers on a real marker image (tools/f16x2_numerics.py,
-//   profiles/r03_f16x2_numerics.txt): pre-activations 2.9-4.4e-7 of max from float64 (torch's fp32 conv on
-//   the CPU: 3.3-4.6e-7; NP = 3: 1.7-2.9e-7), smoothness loss 4e-9, every backward layer 2.1-3.6e-7 (fp32 conv: 1.8-3.4e-7).
+//   is a valid input.  Measured ON THE GPU through the encoder's 10 layers on a real marker image, every layer against torch
+//   float64 (tools/enc_layer_numerics.py, profiles/r04_enc_layer_numerics.txt; round 3 cited a CPU emulation with a per-TENSOR
+//   scale here, which the kernels never used): forward activations 2.4-6.3e-7 of the layer maximum (torch's own fp32 convolution
+//   on the CPU: 3.0-9.2e-7; NP = 3: 3.2-8.2e-7; fp32-input MFMA: 5.6e-7-1.4e-6), backward-data maps 1.8-6.5e-7 per layer with
+//   float64 inputs to every layer, d(image) 6.1e-7 (NP = 3: 7.5e-7, fp32 MFMA: 6.5e-7).
 //
 // Work decomposition, written for the 64 -> 64 layers (one 512-thread block per CU, all 256 CUs, no second
 // wave of blocks; Cout 32 halves the waves, Cin 32 halves the k-chunks and needs one staging phase only):

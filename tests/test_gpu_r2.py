@@ -131,7 +131,11 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     print(f'marker residual mm: gpu {np.round(res_g, 2)} oracle f32 {np.round(res_o, 2)} oracle f64 {np.round(res_64, 2)}; '
           f'MPJPE mm gpu-vs-oracle f32 {np.round(mpjpe, 2)}, oracle f32-vs-f64 (rounding alone) {np.round(yard, 2)}')
     assert np.all(res_g <= 1.15 * np.maximum(res_o, res_64) + 0.5), (res_g, res_o, res_64)     # fits the markers as well as the reference's loop does
-    assert np.all(mpjpe <= 10.0 * yard + 10.0), (mpjpe, yard)
+    # (round 4) PARITY of this loop is asserted step by step in tests/test_gpu_teacher.py::test_perframe_loop_teacher_forced_full_size:
+    # from the reference's own optimiser state at steps 0, 1, 59, 60, 61, 79, 80, 81, 99 of both frames the next state is within
+    # 2.5e-5 x lr of the reference's (measured 6.6e-6).  The free-running distance printed above is what those per-step differences
+    # grow into when an L1 residual crosses zero on one side first; it is reported, not gated (the old gate, 10 x yardstick + 10 mm,
+    # measured 35-122 mm: decoration).
     ref10, last10 = PO.perframe_fit(O.SmplxOracle(model), {k: torch.from_numpy(v) for k, v in vw.items()}, A['ids']['markers67'], mr, betas, steps=10)
     got10 = pf.fit_clip(mr, betas, steps=10).cpu().numpy()
     d10 = np.abs(got10 - ref10)

@@ -104,7 +104,10 @@ def test_amass_loop_teacher_forced_full_size(dev, conv_variant):
         got = _cat_state(st)
         before = dict(p=T[f's{k}_p'], m=T[f's{k}_m'], v=T[f's{k}_v'])
         TC.check_adam_arithmetic(f'amass step {k}', before, g_eng.astype(np.float32), got, k, lr)
-        TC.check_next_state(f'amass[v{conv_variant}] step {k} (lr {lr:g})', got['p'], T[f's{k + 1}_p'], E, T[f's{k + 1}_v'], k, lr, REPORT)
+        reg, _ = TC.check_next_state(f'amass[v{conv_variant}] step {k} (lr {lr:g})', got['p'], T[f's{k + 1}_p'], E, T[f's{k + 1}_v'], k, lr, REPORT)
+        # besides the derived per-entry bound: a flat gate at 3 x the largest value measured over all recorded steps and both kernel
+        # families (1.7e-3 lr, profiles/r04_teacher.txt) -- what replaces "10 steps: max < 1e-2, mean < 1e-4" 
+        assert reg <= 5e-3, (k, reg)
     REPORT.append(f'amass[v{conv_variant}]: median-over-frames gradient error, worst step/group: {worst_med:.1e} of the group maximum')
     # body_params_opt_t_72 of the reference's LAST forward (opt_amass_temp.py:457) = state 99 through the 6-D -> aa conversion
     fit.load_state(_state(T, '', 99))

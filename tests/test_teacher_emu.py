@@ -170,7 +170,8 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
             before = dict(p=T[f'{tag}_s{k}_p'], m=T[f'{tag}_s{k}_m'], v=T[f'{tag}_s{k}_v'])
             assert got['step'] == k + 1
             TC.check_adam_arithmetic(f'{tag} step {k}', before, g_eng, got, k, lr)
-            TC.check_next_state(f'{tag} step {k}', got['p'], T[f'{tag}_s{k + 1}_p'], E, T[f'{tag}_s{k + 1}_v'], k, lr, report)
+            reg, _ = TC.check_next_state(f'{tag} step {k}', got['p'], T[f'{tag}_s{k + 1}_p'], E, T[f'{tag}_s{k + 1}_v'], k, lr, report)
+            assert reg <= 1.2e-2, (tag, k, reg)        # flat gate at 3 x the largest measured value (3.9e-3 lr, GPU, S3 window 2 step 2)
             if w > 0:                                  # frozen frames: parameters bit-identical to the loaded ones
                 assert np.array_equal(got['p'][:2], before['p'][:2])
         report.append(f'{tag}: worst gradient group error vs the reference fp32 {worst_g:.1e} of the group maximum')
@@ -226,7 +227,10 @@ def perframe_teacher_check(T, make_fitter, report, frames=(0, 1), steps=None, st
                        v=np.concatenate([s2['v_' + k_].cpu().numpy() for k_ in ('transl', 'rot6d', 'other')], 1))
             assert int(s2['step']) == k + 1
             TC.check_adam_arithmetic(f'perframe {tag} step {k}', dict(p=p, m=m, v=v), g_eng, got, k, lr)
-            TC.check_next_state(f'perframe {tag} step {k} (lr {lr:g})', got['p'], T[f'{tag}s{k + 1}_p'], E, T[f'{tag}s{k + 1}_v'], k, lr, report)
+            reg, nz = TC.check_next_state(f'perframe {tag} step {k} (lr {lr:g})', got['p'], T[f'{tag}s{k + 1}_p'], E, T[f'{tag}s{k + 1}_v'], k, lr, report)
+            # flat gate at 3 x the largest measured value (7.5e-6 lr on the emulator, 6.6e-6 on the GPU): this replaces stage 1's
+            # "MPJPE <= 10 x a chaos yardstick + 10 mm" (VERDICT r03 weak #3); no entry of this objective is noise-level
+            assert reg <= 2.5e-5 and nz == 0, (tag, k, reg, nz)
 
 
 @pytest.mark.timeout(1800)
