@@ -296,15 +296,26 @@ typedef struct lemo_ae_desc {
   float lr;
   float* ws;
   long long ws_floats;
+  int clips;                      /* round 4 (appended; 0 or 1 = one clip): K clips SIDE BY SIDE in every launch of a step -- the clip is
+                                   * the last grid dimension of the convolution / pooling / weight-gradient / Adam launches, each clip has
+                                   * its own parameters, Adam state and step counter in its own slice of the workspace (the reference
+                                   * finetunes a fresh copy of the pretrained model per clip): ws_floats >= clips * lemo_ae_ws_floats(H, W).
+                                   * A clip's results are bit-identical to a one-clip engine's (same kernels, same launch shapes). */
 } lemo_ae_desc;
 long long lemo_ae_ws_floats(int H, int W);
 int lemo_ae_n_param(void);
 void* lemo_ae_create(const lemo_ae_desc* d);
 void lemo_ae_destroy(void* h);
 int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream);
-int lemo_ae_step(void* h, int n, int use_graph, void* stream);
+int lemo_ae_step(void* h, int n, int use_graph, void* stream);          /* every clip of the engine advances n steps */
 int lemo_ae_forward(void* h, float* rec, float* z, void* stream);
 int lemo_ae_params(void* h, float* flat_out, void* stream);
+/* the same per clip of a multi-clip engine (clip 0 .. desc.clips - 1; the un-suffixed forms address clip 0).  lemo_ae_forward_clip with
+ * clip 0 (or -1: no copy-out) runs the eval forward of ALL clips; clips > 0 only copy that forward's reconstruction / latent out:
+ * call it for clip 0 first. */
+int lemo_ae_load_clip(void* h, int clip, const float* flat, const float* x, const float* moc, void* stream);
+int lemo_ae_forward_clip(void* h, int clip, float* rec, float* z, void* stream);
+int lemo_ae_params_clip(void* h, int clip, float* flat_out, void* stream);
 /* diagnostics (tools/ae_wgrad_probe.py): the step's weight-gradient launch alone on the engine's current buffers; mode 0 = as in
  * a step, 1 = operands loaded once per wave, 2 = loads without MFMAs (1 and 2 leave garbage in the slab partials). */
 int lemo_ae_wgrad_probe(void* h, int mode, void* stream);

@@ -64,7 +64,7 @@ class WgradJob(C.Structure):
 
 class AeDesc(C.Structure):
     """lemo_ae_desc"""
-    _fields_ = [('H', C.c_int), ('W', C.c_int), ('lr', C.c_float), ('ws', vp), ('ws_floats', C.c_longlong)]
+    _fields_ = [('H', C.c_int), ('W', C.c_int), ('lr', C.c_float), ('ws', vp), ('ws_floats', C.c_longlong), ('clips', C.c_int)]
 
 
 class SkinConst(C.Structure):
@@ -232,6 +232,9 @@ _SIGS = {
     'lemo_ae_step': (C.c_int, [vp, C.c_int, C.c_int, vp]),
     'lemo_ae_forward': (C.c_int, [vp, vp, vp, vp]),
     'lemo_ae_params': (C.c_int, [vp, vp, vp]),
+    'lemo_ae_load_clip': (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
+    'lemo_ae_forward_clip': (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    'lemo_ae_params_clip': (C.c_int, [vp, C.c_int, vp, vp]),
     'lemo_ae_wgrad_probe': (C.c_int, [vp, C.c_int, vp]),
     'lemo_ae_conv': (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 12 + [vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),

@@ -37,10 +37,19 @@ namespace lemo {
 // geometry).  Taps always address neighbouring pixels of the INPUT buffer.
 struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; int aux_Wp, aux_HWp, aux_s; };
 
+// Clips side by side (round 4): an engine of K clips carves K identical workspaces, `cs` floats apart, and every
+// launch of a training step carries the clip as its last grid dimension -- the same kernels, the same launch shapes, K times the
+// blocks.  Each clip has its OWN parameters, Adam state and step counter (the reference finetunes a fresh copy per clip), so a
+// clip's arithmetic does not depend on its neighbours: bit-identical to a solo run.  Null operands (an unused bias / aux) stay null.
+#define AE_CLIP_OFFSET5(in_, wt_, bias_, aux_, out_, cs_)                                             \
+  { const size_t o_ = (size_t)blockIdx.z * (cs_); in_ += o_; wt_ += o_; out_ += o_;                   \
+    if (bias_) bias_ += o_; if (aux_) aux_ += o_; }
+
 template <int MT, int EPI>          // MT x 32 couts per workgroup; EPI: conv_common.hpp (0 lrelu(acc + bias), 1 acc * lrelu'(aux), 2 acc + bias)
 __global__ void __launch_bounds__(1024)
 ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg) {
+               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs) {
+  AE_CLIP_OFFSET5(in, wt, bias, aux, out, cs);                 // clip = blockIdx.z: every operand lives in that clip's workspace
   LEMO_DYN_SMEM(red);                                          // [wave][MT][4][64 lanes] float4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // (scalar: see the ring below)
   // wave -> (pixel tile pt of the workgroup's 2^pt_lg, K slice ks of KS): the waves of one slice share the weights they load
@@ -145,7 +154,8 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
 template <int EPI>
 __global__ void __launch_bounds__(1024)
 ae_conv16_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-                 const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg) {
+                 const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs) {
+  AE_CLIP_OFFSET5(in, wt, bias, aux, out, cs);
   LEMO_DYN_SMEM(red);                                          // [wave][64 lanes] float4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
   const int PT = 1 << pt_lg, pt = wave & (PT - 1), ks = wave >> pt_lg, KS = NW >> pt_lg;
@@ -261,7 +271,7 @@ static void ae_conv_shape(int P, int cin, int cout, int* mt_out, int* pt_out, in
 }
 
 int ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, const AeGeo& g, int cin, int cout,
-            int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0) {
+            int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0, int nclip = 1, size_t cs = 0) {
   if (cin % 8 || (cin & (cin - 1)) || cout % 32 || g.H < 1 || g.W < 1 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
   int mt = 1, pt = 1, ks = 1;
   ae_conv_shape(g.H * g.W, cin, cout, &mt, &pt, &ks);
@@ -271,17 +281,17 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
   const int pt_lg = ilog2(pt);
   if (mt == 3) {
     if (cin < 16 || ks > 9 * (cin / 16)) return LEMO_ERR_ARG;
-    const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16);
+    const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16, nclip);
     const size_t lds = (size_t)nw * 1024;
-#define LAUNCH16(EPI_) hipLaunchKernelGGL((ae_conv16_kernel<EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg)
+#define LAUNCH16(EPI_) hipLaunchKernelGGL((ae_conv16_kernel<EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs)
     if (epi == 0) LAUNCH16(0); else if (epi == 1) LAUNCH16(1); else LAUNCH16(2);
 #undef LAUNCH16
     return (int)hipGetLastError();
   }
   if ((mt != 1 && mt != 2) || cout % (32 * mt) || nw * mt > 16 || ks > 9 * (cin / 8)) return LEMO_ERR_ARG;
-  const dim3 grid(((g.H * g.W + 31) / 32 + pt - 1) / pt, cout / (32 * mt));
+  const dim3 grid(((g.H * g.W + 31) / 32 + pt - 1) / pt, cout / (32 * mt), nclip);
   const size_t lds = (size_t)nw * mt * 4096;
-#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg)
+#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs)
   if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
   else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
 #undef LAUNCH
@@ -316,7 +326,7 @@ struct AeWgradJob {
 #define AE_NLAYER 20
 // the grid is the layers' waves in the order the host wants them DISPATCHED: the long ones first (full 576-pixel slabs run 23 us),
 // the short ones of the 14 x 9 layers last, so that the launch does not end on a few long waves
-struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int first[AE_NLAYER + 1]; int n; };
+struct AeWgradJobs { AeWgradJob j[AE_NLAYER]; int first[AE_NLAYER + 1]; int n; size_t cs; };       // cs: clip stride (clip = blockIdx.y)
 
 template <int MODE>        // 0: the product; diagnostics (tools/ae_wgrad_probe.py): 1 = operands loaded once per wave, 2 = no MFMAs
 __global__ void __launch_bounds__(64)
@@ -337,8 +347,9 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
   const int co = mt * 32 + i;
   int ci = ct * 32 + i;
   if (ci >= cin) ci = cin - 1;                                     // rows past cin are computed and never stored
-  const float* bp = q.dy + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
-  const float* ap = q.x + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
+  const size_t clip_off = (size_t)blockIdx.y * J.cs;
+  const float* bp = q.dy + clip_off + ((size_t)(co >> 3) * HWp) * 8 + (co & 7);
+  const float* ap = q.x + clip_off + ((size_t)(ci >> 3) * HWp) * 8 + (ci & 7);
   const int Q1 = (q.H + 1) * Wp;                                   // interior rows: padded pixels [Wp, (H + 1) Wp)
   const int qs = Wp + slab * q.slab_len;
   const int qe = qs + q.slab_len < Q1 ? qs + q.slab_len : Q1;      // (host: qs < Q1)
@@ -409,7 +420,7 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
 #undef WG_MFMA
 #undef WG_FAKE
   // D: col = lane & 31 -> co, rows (e & 3) + 8 (e >> 2) + 4 kk -> ci: quad qd = 4 consecutive ci of channel group ct*4 + qd
-  float* outp = q.partial + (size_t)slab * (9 * (size_t)cin * cout);
+  float* outp = q.partial + clip_off + (size_t)slab * (9 * (size_t)cin * cout);
   const int CG = cin >> 3;
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
@@ -422,7 +433,7 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
       st4(o + 2 * tap_stride, make_float4(acc2[4 * qd], acc2[4 * qd + 1], acc2[4 * qd + 2], acc2[4 * qd + 3]));
     }
   }
-  if (r == 1 && ct == 0) q.dbp[((size_t)slab * 2 + kk) * cout + co] = bsum;   // sum over this slab's pixels of parity kk, in pixel order
+  if (r == 1 && ct == 0) q.dbp[clip_off + ((size_t)slab * 2 + kk) * cout + co] = bsum;   // sum over this slab's pixels of parity kk, in pixel order
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -434,8 +445,9 @@ ae_wgrad_multi_kernel(AeWgradJobs J) {
 struct AeAdamLayer { const float* partial; const float* dbp; int nslab, w_off, b_off, wb_off, cin_lg /*log2(cin_pad/8)*/, cout_lg, cin, cout; };
 struct AeAdamArgs {
   AeAdamLayer L[AE_NLAYER];
-  float* theta; float* m; float* v; float* wb; const float* ctr;    // ctr: [1] = bc1, [2] = bc2s (floats)
+  float* theta; float* m; float* v; float* wb; const float* ctr;    // ctr: [1] = -lr / (1 - b1^t), [2] = sqrt(1 - b2^t) (floats)
   int n_w, n_all; float lr;
+  size_t cs;                                                        // clip stride (clip = blockIdx.y)
 };
 
 __device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, AdamCoef c) {
@@ -449,7 +461,13 @@ ae_adam_kernel(AeAdamArgs A) {
   // scatter into the backward pack
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (idx >= A.n_all) return;
-  const AdamCoef ac{A.ctr[1], A.ctr[2]};                            // (-lr / (1 - b1^t), sqrt(1 - b2^t)) of this step
+  const size_t clip_off = (size_t)blockIdx.y * A.cs;                // (the argument struct itself stays read-only: a kernel that
+  float* const theta = A.theta + clip_off;                          //  writes to it gets a private copy in scratch -- 30 -> 250 us)
+  float* const am = A.m + clip_off;
+  float* const av = A.v + clip_off;
+  float* const wb = A.wb + clip_off;
+  const float* const ctr = A.ctr + clip_off;
+  const AdamCoef ac{ctr[1], ctr[2]};                            // (-lr / (1 - b1^t), sqrt(1 - b2^t)) of this step
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   int wb_idx = -1;
   if (idx < A.n_w) {
@@ -466,7 +484,7 @@ ae_adam_kernel(AeAdamArgs A) {
       for (int s0 = 0; s0 < q.nslab; s0 += 8) {                     // slab order: deterministic; 8 loads in flight
         float4 pv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.partial + (size_t)(s0 + u < q.nslab ? s0 + u : q.nslab - 1) * n_w + i);
+        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.partial + clip_off + (size_t)(s0 + u < q.nslab ? s0 + u : q.nslab - 1) * n_w + i);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (s0 + u < q.nslab) { g.x += pv[u].x; g.y += pv[u].y; g.z += pv[u].z; g.w += pv[u].w; }
@@ -488,7 +506,7 @@ ae_adam_kernel(AeAdamArgs A) {
       for (int s0 = 0; s0 < ns; s0 += 8) {                          // slab order, even pixels then odd: deterministic
         float4 pv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.dbp + (size_t)(s0 + u < ns ? s0 + u : ns - 1) * cop + co);
+        for (int u = 0; u < 8; ++u) pv[u] = ld4(q.dbp + clip_off + (size_t)(s0 + u < ns ? s0 + u : ns - 1) * cop + co);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           if (s0 + u < ns) { g.x += pv[u].x; g.y += pv[u].y; g.z += pv[u].z; g.w += pv[u].w; }
@@ -498,13 +516,13 @@ ae_adam_kernel(AeAdamArgs A) {
       if (co + 3 >= q.cout) g.w = 0.f;
     }
   }
-  float4 m = ld4(A.m + idx), v = ld4(A.v + idx), p = ld4(A.theta + idx);
+  float4 m = ld4(am + idx), v = ld4(av + idx), p = ld4(theta + idx);
   p.x = adam_update(p.x, g.x, m.x, v.x, ac);
   p.y = adam_update(p.y, g.y, m.y, v.y, ac);
   p.z = adam_update(p.z, g.z, m.z, v.z, ac);
   p.w = adam_update(p.w, g.w, m.w, v.w, ac);
-  st4(A.m + idx, m); st4(A.v + idx, v); st4(A.theta + idx, p);
-  if (wb_idx >= 0) { A.wb[wb_idx] = p.x; A.wb[wb_idx + 8] = p.y; A.wb[wb_idx + 16] = p.z; A.wb[wb_idx + 24] = p.w; }
+  st4(am + idx, m); st4(av + idx, v); st4(theta + idx, p);
+  if (wb_idx >= 0) { wb[wb_idx] = p.x; wb[wb_idx + 8] = p.y; wb[wb_idx + 16] = p.z; wb[wb_idx + 24] = p.w; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -515,7 +533,8 @@ ae_adam_kernel(AeAdamArgs A) {
 // the bias corrections Adam reads later in the same step.
 __global__ void __launch_bounds__(256)
 ae_loss_grad_kernel(const float* __restrict__ rec, const float* __restrict__ x8, const float* __restrict__ moc,
-                    float* __restrict__ dpre, int H, int W, float* __restrict__ ctr, double lr) {
+                    float* __restrict__ dpre, int H, int W, float* __restrict__ ctr, double lr, size_t cs) {
+  { const size_t o_ = (size_t)blockIdx.y * cs; rec += o_; x8 += o_; moc += o_; dpre += o_; ctr += o_; }       // clip = blockIdx.y
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p == 0) {
     int* ci = reinterpret_cast<int*>(ctr);
@@ -630,6 +649,8 @@ struct AeEngine {
   unsigned char* idx[5];
   hipGraphExec_t exec[2] = {nullptr, nullptr};      // 5 steps, 1 step
   int loaded = 0;
+  int nclip = 1;               // clips side by side: clip c's buffers are the pointers above + c * cs floats
+  size_t cs = 0;
 };
 
 // every buffer is wrapped in AE_GUARD zeroed floats that nothing writes: the weight-gradient kernel's operand windows may
@@ -703,23 +724,26 @@ static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
 
 static AeGeo geo_plain(int H, int W) { const int Wp = W + 2, HWp = (H + 2) * Wp; return AeGeo{H, W, Wp, HWp, 1, Wp, HWp, 1, Wp, HWp, 1}; }
 
+// engine launches carry every clip: ae_conv(..., s) -> ae_conv(..., s, 0, 0, 0, e->nclip, e->cs)
+#define AE_CONV(e_, ...) ae_conv(__VA_ARGS__, 0, 0, 0, (e_)->nclip, (e_)->cs)
+
 static int ae_forward(AeEngine* e, hipStream_t s) {
   for (int b = 0; b < 5; ++b) {
     const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
     const AeGeo g = geo_plain(H, W);
-    CHK_(ae_conv(e->xin[i0], e->theta + e->L[i0].w_off, e->theta + e->n_w + e->L[i0].b_off, nullptr, e->act[i0], g, e->L[i0].cin_pad, e->L[i0].cout_pad, 0, s));
-    CHK_(ae_conv(e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, 0, s));
-    CHK_(maxpool3s2_fwd(e->act[i2], H, W, e->P[b], e->idx[b], e->L[i2].cout_pad, s));
+    CHK_(AE_CONV(e, e->xin[i0], e->theta + e->L[i0].w_off, e->theta + e->n_w + e->L[i0].b_off, nullptr, e->act[i0], g, e->L[i0].cin_pad, e->L[i0].cout_pad, 0, s));
+    CHK_(AE_CONV(e, e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, 0, s));
+    CHK_(maxpool3s2_fwd(e->act[i2], H, W, e->P[b], e->idx[b], e->L[i2].cout_pad, s, e->nclip, e->cs));
   }
-  CHK_(stuff2_fwd(e->P[4], e->H[5], e->W[5], e->S[0], e->H[4], e->W[4], e->L[10].cin_pad, s));
+  CHK_(stuff2_fwd(e->P[4], e->H[5], e->W[5], e->S[0], e->H[4], e->W[4], e->L[10].cin_pad, s, e->nclip, e->cs));
   for (int b = 0; b < 5; ++b) {
     const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
     AeGeo g = geo_plain(H, W);
-    CHK_(ae_conv(e->xin[i1], e->theta + e->L[i1].w_off, e->theta + e->n_w + e->L[i1].b_off, nullptr, e->act[i1], g, e->L[i1].cin_pad, e->L[i1].cout_pad, 0, s));
+    CHK_(AE_CONV(e, e->xin[i1], e->theta + e->L[i1].w_off, e->theta + e->n_w + e->L[i1].b_off, nullptr, e->act[i1], g, e->L[i1].cin_pad, e->L[i1].cout_pad, 0, s));
     if (b < 4) {       // straight into the stuffed input of the next block: pixel (y, x) -> (2y, 2x) of the next finer level
       g.out_Wp = e->W[lv - 1] + 2; g.out_HWp = (e->H[lv - 1] + 2) * g.out_Wp; g.out_s = 2;
     }
-    CHK_(ae_conv(e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, b < 4 ? 0 : 2, s));
+    CHK_(AE_CONV(e, e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, b < 4 ? 0 : 2, s));
   }
   return 0;
 }
@@ -729,14 +753,14 @@ static int ae_wgrad_launch(AeEngine* e, hipStream_t s, int mode);
 static int ae_train_step(AeEngine* e, hipStream_t s) {
   CHK_(ae_forward(e, s));
   const int H0 = e->H[0], W0 = e->W[0];
-  hipLaunchKernelGGL(ae_loss_grad_kernel, dim3((H0 * W0 + 255) / 256), dim3(256), 0, s, (const float*)e->act[19], (const float*)e->x8,
-                     (const float*)e->moc, e->dp[19], H0, W0, e->ctr, lr_decimal(e->lr));
+  hipLaunchKernelGGL(ae_loss_grad_kernel, dim3((H0 * W0 + 255) / 256, e->nclip), dim3(256), 0, s, (const float*)e->act[19], (const float*)e->x8,
+                     (const float*)e->moc, e->dp[19], H0, W0, e->ctr, lr_decimal(e->lr), e->cs);
   CHK_((int)hipGetLastError());
   // ---- decoder, last block first
   for (int b = 4; b >= 0; --b) {
     const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
     const AeGeo g = geo_plain(H, W);
-    CHK_(ae_conv(e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i1], e->dp[i1], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));     // * lrelu'(act[i1])
+    CHK_(AE_CONV(e, e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i1], e->dp[i1], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));     // * lrelu'(act[i1])
     // adjoint of (stuffing, transposed conv): only the even pixels of d(stuffed input) exist downstream -> enumerate the
     // coarse grid, centre taps at (2i, 2j); times lrelu' of the previous block's output (read where it lives: stuffed in S[b])
     const int h = e->H[lv + 1], w = e->W[lv + 1];
@@ -744,16 +768,16 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     gs.in_Wp = W + 2; gs.in_HWp = (H + 2) * (W + 2); gs.in_s = 2;
     gs.aux_Wp = gs.in_Wp; gs.aux_HWp = gs.in_HWp; gs.aux_s = 2;
     float* dst = b > 0 ? e->dp[i1 - 1] : e->dP[4];
-    if (b > 0) CHK_(ae_conv(e->dp[i1], e->wb + e->L[i1].wb_off, nullptr, e->S[b], dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 1, s));
-    else       CHK_(ae_conv(e->dp[i1], e->wb + e->L[i1].wb_off, e->zero_bias, nullptr, dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 2, s));   // the latent has no activation
+    if (b > 0) CHK_(AE_CONV(e, e->dp[i1], e->wb + e->L[i1].wb_off, nullptr, e->S[b], dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 1, s));
+    else       CHK_(AE_CONV(e, e->dp[i1], e->wb + e->L[i1].wb_off, e->zero_bias, nullptr, dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 2, s));   // the latent has no activation
   }
   // ---- encoder, last block first
   for (int b = 4; b >= 0; --b) {
     const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
     const AeGeo g = geo_plain(H, W);
-    CHK_(maxpool3s2_bwd(e->dP[b], e->idx[b], e->act[i2], e->dp[i2], H, W, e->L[i2].cout_pad, s));
-    CHK_(ae_conv(e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i0], e->dp[i0], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));
-    if (b > 0) CHK_(ae_conv(e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
+    CHK_(maxpool3s2_bwd(e->dP[b], e->idx[b], e->act[i2], e->dp[i2], H, W, e->L[i2].cout_pad, s, e->nclip, e->cs));
+    CHK_(AE_CONV(e, e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i0], e->dp[i0], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));
+    if (b > 0) CHK_(AE_CONV(e, e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
   }
   // ---- all weight and bias gradients
   CHK_(ae_wgrad_launch(e, s, 0));
@@ -764,8 +788,8 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     A.L[i] = AeAdamLayer{e->part + l.part_off, e->dbp + l.dbp_off, l.nslab, l.w_off, l.b_off, l.wb_off, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout};
   }
   A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.ctr = e->ctr;
-  A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr;
-  hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all / 4 + 255) / 256), dim3(256), 0, s, A);        // (n_w and n_b are multiples of 4)
+  A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr; A.cs = e->cs;
+  hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all / 4 + 255) / 256, e->nclip), dim3(256), 0, s, A);        // (n_w and n_b are multiples of 4)
   return (int)hipGetLastError();
 }
 
@@ -784,12 +808,12 @@ static int ae_wgrad_launch(AeEngine* e, hipStream_t s, int mode) {
       J.first[n++] = nb;
       nb += q.nwave;
     }
-  J.first[n] = nb; J.n = n;
-  if (mode == 1) hipLaunchKernelGGL(ae_wgrad_multi_kernel<1>, dim3(nb), dim3(64), 0, s, J);
-  else if (mode == 2) hipLaunchKernelGGL(ae_wgrad_multi_kernel<2>, dim3(nb), dim3(64), 0, s, J);
-  else if (mode == 3) hipLaunchKernelGGL(ae_wgrad_multi_kernel<3>, dim3(nb), dim3(64), 0, s, J);
-  else if (mode == 4) hipLaunchKernelGGL(ae_wgrad_multi_kernel<4>, dim3(nb), dim3(64), 0, s, J);
-  else hipLaunchKernelGGL(ae_wgrad_multi_kernel<0>, dim3(nb), dim3(64), 0, s, J);
+  J.first[n] = nb; J.n = n; J.cs = e->cs;
+  if (mode == 1) hipLaunchKernelGGL(ae_wgrad_multi_kernel<1>, dim3(nb, e->nclip), dim3(64), 0, s, J);
+  else if (mode == 2) hipLaunchKernelGGL(ae_wgrad_multi_kernel<2>, dim3(nb, e->nclip), dim3(64), 0, s, J);
+  else if (mode == 3) hipLaunchKernelGGL(ae_wgrad_multi_kernel<3>, dim3(nb, e->nclip), dim3(64), 0, s, J);
+  else if (mode == 4) hipLaunchKernelGGL(ae_wgrad_multi_kernel<4>, dim3(nb, e->nclip), dim3(64), 0, s, J);
+  else hipLaunchKernelGGL(ae_wgrad_multi_kernel<0>, dim3(nb, e->nclip), dim3(64), 0, s, J);
   return (int)hipGetLastError();
 }
 
@@ -845,7 +869,9 @@ void* lemo_ae_create(const lemo_ae_desc* d) {
   if (!e) return nullptr;
   size_t total = 0;
   ae_layout(e, d->H, d->W, d->ws, &total);
-  if ((long long)total > d->ws_floats) { delete e; return nullptr; }
+  e->nclip = d->clips > 1 ? d->clips : 1;
+  e->cs = total;                                            // clip c = the same layout, c * total floats further
+  if (e->nclip > 64 || (long long)(total * (size_t)e->nclip) > d->ws_floats) { delete e; return nullptr; }
   e->lr = d->lr;
   return e;
 }
@@ -857,22 +883,24 @@ void lemo_ae_destroy(void* h) {
   delete e;
 }
 
-int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream) {
+int lemo_ae_load_clip(void* h, int clip, const float* flat, const float* x, const float* moc, void* stream) {
   AeEngine* e = (AeEngine*)h;
-  if (!e || !flat || !x || !moc) return LEMO_ERR_ARG;
+  if (!e || !flat || !x || !moc || clip < 0 || clip >= e->nclip) return LEMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int n_all = e->n_w + e->n_b, H = e->H[0], W = e->W[0];
-  hipLaunchKernelGGL((ae_pack_kernel<false>), dim3((n_all + 255) / 256), dim3(256), 0, s, ae_pack_args(e), flat, e->theta, e->wb);
+  const size_t o = (size_t)clip * e->cs;
+  hipLaunchKernelGGL((ae_pack_kernel<false>), dim3((n_all + 255) / 256), dim3(256), 0, s, ae_pack_args(e), flat, e->theta + o, e->wb + o);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  if ((rc = (int)hipMemsetAsync(e->m, 0, sizeof(float) * n_all, s))) return rc;            // a fresh optimizer (opt_amass_temp.py:160-164)
-  if ((rc = (int)hipMemsetAsync(e->v, 0, sizeof(float) * n_all, s))) return rc;
-  if ((rc = (int)hipMemsetAsync(e->ctr, 0, sizeof(float) * 64, s))) return rc;
-  if ((rc = (int)hipMemcpyAsync(e->moc, moc, sizeof(float) * H * W, hipMemcpyDeviceToDevice, s))) return rc;
-  hipLaunchKernelGGL(ae_to_cg8p_kernel, dim3((4 * H * W + 255) / 256), dim3(256), 0, s, x, 4, H, W, e->x8);
+  if ((rc = (int)hipMemsetAsync(e->m + o, 0, sizeof(float) * n_all, s))) return rc;        // a fresh optimizer (opt_amass_temp.py:160-164)
+  if ((rc = (int)hipMemsetAsync(e->v + o, 0, sizeof(float) * n_all, s))) return rc;
+  if ((rc = (int)hipMemsetAsync(e->ctr + o, 0, sizeof(float) * 64, s))) return rc;
+  if ((rc = (int)hipMemcpyAsync(e->moc + o, moc, sizeof(float) * H * W, hipMemcpyDeviceToDevice, s))) return rc;
+  hipLaunchKernelGGL(ae_to_cg8p_kernel, dim3((4 * H * W + 255) / 256), dim3(256), 0, s, x, 4, H, W, e->x8 + o);
   e->loaded = 1;
   return (int)hipGetLastError();
 }
+int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream) { return lemo_ae_load_clip(h, 0, flat, x, moc, stream); }
 
 int lemo_ae_step(void* h, int n, int use_graph, void* stream) {
   AeEngine* e = (AeEngine*)h;
@@ -893,27 +921,32 @@ int lemo_ae_step(void* h, int n, int use_graph, void* stream) {
   return 0;
 }
 
-int lemo_ae_forward(void* h, float* rec, float* z, void* stream) {
+// eval forward of ALL clips (one set of launches), then clip `clip`'s reconstruction / latent are copied out; clip < 0: forward only
+int lemo_ae_forward_clip(void* h, int clip, float* rec, float* z, void* stream) {
   AeEngine* e = (AeEngine*)h;
-  if (!e || !rec) return LEMO_ERR_ARG;
+  if (!e || clip >= e->nclip || (clip >= 0 && !rec)) return LEMO_ERR_ARG;
   if (!e->loaded) return LEMO_ERR_STATE;
   hipStream_t s = (hipStream_t)stream;
-  int rc = ae_forward(e, s);
-  if (rc) return rc;
+  if (clip <= 0) { const int rc = ae_forward(e, s); if (rc) return rc; }      // clip 0 (or -1) runs the forward; later clips read its results
+  if (clip < 0) return 0;
   const int H = e->H[0], W = e->W[0];
-  hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, (const float*)e->act[19], 1, H, W, rec);
-  if (z) hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((256 * e->H[5] * e->W[5] + 255) / 256), dim3(256), 0, s, (const float*)e->P[4], 256, e->H[5], e->W[5], z);
+  const size_t o = (size_t)clip * e->cs;
+  hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((H * W + 255) / 256), dim3(256), 0, s, (const float*)e->act[19] + o, 1, H, W, rec);
+  if (z) hipLaunchKernelGGL(ae_from_cg8p_kernel, dim3((256 * e->H[5] * e->W[5] + 255) / 256), dim3(256), 0, s, (const float*)e->P[4] + o, 256, e->H[5], e->W[5], z);
   return (int)hipGetLastError();
 }
+int lemo_ae_forward(void* h, float* rec, float* z, void* stream) { return lemo_ae_forward_clip(h, 0, rec, z, stream); }
 
-int lemo_ae_params(void* h, float* flat_out, void* stream) {
+int lemo_ae_params_clip(void* h, int clip, float* flat_out, void* stream) {
   AeEngine* e = (AeEngine*)h;
-  if (!e || !flat_out) return LEMO_ERR_ARG;
+  if (!e || !flat_out || clip < 0 || clip >= e->nclip) return LEMO_ERR_ARG;
   if (!e->loaded) return LEMO_ERR_STATE;
   const int n_all = e->n_w + e->n_b;
-  hipLaunchKernelGGL((ae_pack_kernel<true>), dim3((n_all + 255) / 256), dim3(256), 0, (hipStream_t)stream, ae_pack_args(e), (const float*)e->theta, flat_out, (float*)nullptr);
+  hipLaunchKernelGGL((ae_pack_kernel<true>), dim3((n_all + 255) / 256), dim3(256), 0, (hipStream_t)stream, ae_pack_args(e),
+                     (const float*)e->theta + (size_t)clip * e->cs, flat_out, (float*)nullptr);
   return (int)hipGetLastError();
 }
+int lemo_ae_params(void* h, float* flat_out, void* stream) { return lemo_ae_params_clip(h, 0, flat_out, stream); }
 
 /* diagnostics: the weight-gradient launch alone on the engine's current buffers (mode 0 product, 1 operands loaded once per wave,
    2 no MFMAs) */

@@ -12,7 +12,8 @@ namespace lemo {
 // row-major window order, like torch) or 255 -------------------------------------------------------
 __global__ void __launch_bounds__(256)
 maxpool3s2_fwd_kernel(const float* __restrict__ in, int H, int W, float* __restrict__ out, unsigned char* __restrict__ idx,
-                      int Ho, int Wo, int C) {
+                      int Ho, int Wo, int C, size_t cs) {
+  { const size_t o_ = (size_t)blockIdx.y * cs; in += o_; out += o_; idx += 4 * o_; }         // clip = blockIdx.y (cs in floats; idx is bytes)
   const int Wp = W + 2, HWp = (H + 2) * Wp, Wop = Wo + 2, HWop = (Ho + 2) * Wop;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = (C >> 3) * Ho * Wo;
@@ -49,7 +50,8 @@ maxpool3s2_fwd_kernel(const float* __restrict__ in, int H, int W, float* __restr
 // multiplied by lrelu'(act[y][x]) (act = the pooled layer's input = a LeakyReLU output)
 __global__ void __launch_bounds__(256)
 maxpool3s2_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx, int Ho, int Wo,
-                      const float* __restrict__ act, float* __restrict__ din, int H, int W, int C) {
+                      const float* __restrict__ act, float* __restrict__ din, int H, int W, int C, size_t cs) {
+  { const size_t o_ = (size_t)blockIdx.y * cs; dout += o_; idx += 4 * o_; din += o_; if (act) act += o_; }
   const int Wp = W + 2, HWp = (H + 2) * Wp, Wop = Wo + 2, HWop = (Ho + 2) * Wop;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = (C >> 3) * H * W;
@@ -90,25 +92,26 @@ maxpool3s2_bwd_kernel(const float* __restrict__ dout, const unsigned char* __res
   st4(din + o + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
 }
 
-int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s) {
+int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s, int nclip, size_t cs) {
   if (C % 8 || H < 1 || W < 1) return LEMO_ERR_SHAPE;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;             // floor((H + 2 - 3) / 2) + 1
   const int n = (C / 8) * Ho * Wo;
-  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, H, W, out, idx, Ho, Wo, C);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((n + 255) / 256, nclip), dim3(256), 0, s, in, H, W, out, idx, Ho, Wo, C, cs);
   return (int)hipGetLastError();
 }
-int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s) {
+int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s, int nclip, size_t cs) {
   if (C % 8) return LEMO_ERR_SHAPE;
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int n = (C / 8) * H * W;
-  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dout, idx, Ho, Wo, act, din, H, W, C);
+  hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((n + 255) / 256, nclip), dim3(256), 0, s, dout, idx, Ho, Wo, act, din, H, W, C, cs);
   return (int)hipGetLastError();
 }
 
 // ---- zero-stuffing for ConvTranspose2d(stride 2): out[2i][2j] = in[i][j], everything else 0 (out: H x W given
 // by output_size); backward = the gather out[2i][2j] (optionally times lrelu'(act[i][j])) ----------------
 __global__ void __launch_bounds__(256)
-stuff2_fwd_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out, int H, int W, int C) {
+stuff2_fwd_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out, int H, int W, int C, size_t cs) {
+  { const size_t o_ = (size_t)blockIdx.y * cs; in += o_; out += o_; }
   const int Wp = W + 2, HWp = (H + 2) * Wp, wp = w + 2, hwp = (h + 2) * wp;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = (C >> 3) * H * W;
@@ -140,10 +143,10 @@ stuff2_bwd_kernel(const float* __restrict__ dout, int H, int W, const float* __r
   }
   st4(din + o, v0); st4(din + o + 4, v1);
 }
-int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s) {
+int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s, int nclip, size_t cs) {
   if (C % 8 || 2 * (h - 1) > H - 1 || 2 * (w - 1) > W - 1) return LEMO_ERR_SHAPE;
   const int n = (C / 8) * H * W;
-  hipLaunchKernelGGL(stuff2_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, h, w, out, H, W, C);
+  hipLaunchKernelGGL(stuff2_fwd_kernel, dim3((n + 255) / 256, nclip), dim3(256), 0, s, in, h, w, out, H, W, C, cs);
   return (int)hipGetLastError();
 }
 int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, hipStream_t s) {

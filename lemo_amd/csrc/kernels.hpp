@@ -110,9 +110,11 @@ int sdf_sample(const float* sdf, int D, int H, int W, const float* pts, int N, c
                const float* gmax /*host[3]*/, float* val, float* dval, hipStream_t s);
 
 // ---------------- ae_kernels.hip ----------------
-int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s);
-int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s);
-int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s);
+// nclip / cs (AE step engine): the same launch for `nclip` clips whose buffers lie `cs` floats apart (clip = blockIdx.y)
+int maxpool3s2_fwd(const float* in, int H, int W, float* out, unsigned char* idx, int C, hipStream_t s, int nclip = 1, size_t cs = 0);
+int maxpool3s2_bwd(const float* dout, const unsigned char* idx, const float* act, float* din, int H, int W, int C, hipStream_t s,
+                   int nclip = 1, size_t cs = 0);
+int stuff2_fwd(const float* in, int h, int w, float* out, int H, int W, int C, hipStream_t s, int nclip = 1, size_t cs = 0);
 int stuff2_bwd(const float* dout, int H, int W, const float* act, float* din, int h, int w, int C, hipStream_t s);
 int conv3x3_wgrad_nslab(int H, int W);
 int conv3x3_wgrad_partial(const float* dy, const float* x, int H, int W, int cin, int cout, float* partial, hipStream_t s);

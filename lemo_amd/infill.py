@@ -518,9 +518,10 @@ class _EngineSession:
     Adam state, activations and gradients from, its stream, and the output buffers of the eval forward.  Kept across clips
     of the same shape like :class:`_FinetuneSession` (the captured graphs live inside the engine)."""
 
-    def __init__(self, lib, x_shape, lr, device, slot: int = 0, beside=None):
+    def __init__(self, lib, x_shape, lr, device, slot: int = 0, beside=None, clips: int = 1):
         # beside: the stream of the lane this one is to run next to (its own stream is then picked so that the two overlap)
-        self.lib, self.device = lib, torch.device(device)
+        # clips: K clips side by side in every launch (lemo_ae_desc.clips): K workspaces back to back, one engine, one stream
+        self.lib, self.device, self.clips = lib, torch.device(device), int(clips)
         self.gpu = self.device.type == 'cuda' and not lib.is_emu
         H, W = int(x_shape[-2]), int(x_shape[-1])
         n = int(lib.ae_ws_floats(H, W))
@@ -530,16 +531,16 @@ class _EngineSession:
         # per clip, seen inside bench.py depending on how many streams the process had created before.  Giving the lanes different
         # stream PRIORITIES to force them apart measured 58 ms per clip: not done.)
         self.stream = (torch.cuda.Stream(self.device) if beside is None else _hip.partner_stream(beside)) if self.gpu else None
-        self.ws = torch.zeros(n, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
+        self.ws = torch.zeros(n * self.clips, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
         h5, w5 = H, W
         for _ in range(5):
             h5, w5 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
-        self.rec = torch.empty(H, W, dtype=torch.float32, device=self.device)
-        self.z = torch.empty(256, h5, w5, dtype=torch.float32, device=self.device)
-        self.flat = torch.empty(int(lib.ae_n_param()), dtype=torch.float32, device=self.device)
+        self.rec = torch.empty(self.clips, H, W, dtype=torch.float32, device=self.device)
+        self.z = torch.empty(self.clips, 256, h5, w5, dtype=torch.float32, device=self.device)
+        self.flat = torch.empty(self.clips, int(lib.ae_n_param()), dtype=torch.float32, device=self.device)
         if self.gpu:
             torch.cuda.current_stream(self.device).synchronize()            # the zero fill, before another stream uses ws
-        desc = _hip.AeDesc(H, W, float(lr), ptr(self.ws), n)
+        desc = _hip.AeDesc(H, W, float(lr), ptr(self.ws), n * self.clips, self.clips)
         self.h = lib.ae_create(C.byref(desc))
         if not self.h:
             raise _hip.LemoHipError('lemo_ae_create failed')
@@ -562,14 +563,23 @@ class _EngineSession:
         return torch.cuda.stream(self.stream) if self.gpu else contextlib.nullcontext()
 
     def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True, own_stream=True):
-        """load the pretrained parameters and the clip, `steps` training steps, eval forward, parameters back out; returns views
-        of the session's output buffers (valid until its next run).  ``own_stream``: everything runs on this session's stream
-        (what a lane of ``finetune_and_infill_many`` needs); False: on the CALLER's current stream when that is not the legacy
-        default stream (which cannot be captured) -- one clip on its own then needs no hand-over between two hardware queues,
+        """one clip on a one-clip session (:meth:`run_clips`); returns ``(flat, rec, z)`` views of the session's output buffers"""
+        flat, rec, z = self.run_clips(flat0, [x], [m_over_cnt], steps, use_graph, join, own_stream)
+        return flat[0], rec[0], z[0]
+
+    def run_clips(self, flat0, xs, mocs, steps, use_graph, join=True, own_stream=True):
+        """load the pretrained parameters and ``self.clips`` clips, `steps` training steps of all of them (each launch carries
+        every clip), eval forward, parameters back out; returns views ``(flat [K, n], rec [K, H, W], z [K, 256, h, w])`` of the
+        session's output buffers (valid until its next run).  ``own_stream``: everything runs on this session's stream (what
+        a lane of ``finetune_and_infill_many`` needs); False: on the CALLER's current stream when that is not the legacy
+        default stream (which cannot be captured) -- a run on its own then needs no hand-over between two hardware queues,
         which measured 29.8 instead of 33.4 ms per clip (``profiles/r03_hw_queues.txt``; the graphs are not bound to a stream)."""
         lib = self.lib
-        flat0, x, moc = flat0.contiguous().float(), x.reshape(4, *x.shape[-2:]).contiguous().float(), m_over_cnt.contiguous().float()
-        assert flat0.numel() == self.flat.numel() and tuple(moc.shape) == tuple(self.rec.shape)
+        assert len(xs) == len(mocs) == self.clips
+        flat0 = flat0.contiguous().float()
+        xs = [x.reshape(4, *x.shape[-2:]).contiguous().float() for x in xs]
+        mocs = [m.contiguous().float() for m in mocs]
+        assert flat0.numel() == self.flat.shape[1] and all(tuple(m.shape) == tuple(self.rec.shape[1:]) for m in mocs)
         run_on, sh = self.stream, self._s()
         if self.gpu:
             cur = torch.cuda.current_stream(self.device)
@@ -583,16 +593,18 @@ class _EngineSession:
                 # overwrote the workspace and rec / z / flat that the previous run (or its output clones on A) still used
                 run_on.wait_event(self._ev)
             _hip.flush_deferred()
-        lib.check(lib.ae_load(self.h, ptr(flat0), ptr(x), ptr(moc), sh), 'ae_load')
+        for c, (x, moc) in enumerate(zip(xs, mocs)):
+            lib.check(lib.ae_load_clip(self.h, c, ptr(flat0), ptr(x), ptr(moc), sh), 'ae_load_clip')
         lib.check(lib.ae_step(self.h, int(steps), 1 if (use_graph and self.gpu) else 0, sh), 'ae_step')
-        lib.check(lib.ae_forward(self.h, ptr(self.rec), ptr(self.z), sh), 'ae_forward')
-        lib.check(lib.ae_params(self.h, ptr(self.flat), sh), 'ae_params')
+        for c in range(self.clips):                          # (clip 0 runs the eval forward of all clips)
+            lib.check(lib.ae_forward_clip(self.h, c, ptr(self.rec[c]), ptr(self.z[c]), sh), 'ae_forward_clip')
+            lib.check(lib.ae_params_clip(self.h, c, ptr(self.flat[c]), sh), 'ae_params_clip')
         if self.gpu:
             if self._ev is None:
                 self._ev = torch.cuda.Event()
             self._ev.record(run_on)
             if run_on is self.stream:
-                for t in (flat0, x, moc):                    # read by the launches above on this session's stream
+                for t in [flat0] + xs + mocs:                # read by the launches above on this session's stream
                     t.record_stream(self.stream)
                 if join:
                     self.join()
@@ -603,8 +615,14 @@ class _EngineSession:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
 
-AE_LANES = max(1, int(__import__('os').environ.get('LEMO_AE_LANES', '2')))
-"""finetune loops in flight at once in ``finetune_and_infill_many`` (see there)"""
+AE_CLIPS = max(1, min(16, int(__import__('os').environ.get('LEMO_AE_CLIPS', '8'))))
+"""clips per engine in ``finetune_and_infill_many``: every launch of a training step carries this many clips (round 4; measured
+on 210 x 135 clip images, ms per clip: 1 clip 29.0 | 2 23.8 | 3 22.6 | 4 20.6 | 8 18.3 -- ``profiles/r04_ae_clips.txt``; the kernels
+of a step are throughput-bound from ~4 clips on, a clip's workspace is ~50 MB)"""
+
+AE_LANES = max(1, int(__import__('os').environ.get('LEMO_AE_LANES', '1')))
+"""engines in flight at once in ``finetune_and_infill_many``, each on its own stream (round 3 ran 2 one-clip lanes; with clips
+batched into the launches one lane is enough -- see there)"""
 
 USE_ENGINE = __import__('os').environ.get('LEMO_AE_ENGINE', '1') != '0'
 """the finetune loop runs on the native step engine (round 3: 53 launches per step instead of ~150; csrc/ae_engine.hip).
@@ -617,13 +635,13 @@ _MAX_SESSIONS = 8
 tail windows and recordings of varying length would otherwise add one per clip shape without bound (ADVICE r02)."""
 
 
-def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine: bool = False):
-    key = (str(device), tuple(shape), float(lr), id(lib), int(slot), bool(engine))
+def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine: bool = False, clips: int = 1):
+    key = (str(device), tuple(shape), float(lr), id(lib), int(slot), bool(engine), int(clips))
     ses = _SESSIONS.pop(key, None)
     if ses is None:
         if engine:
-            other = _SESSIONS.get((str(device), tuple(shape), float(lr), id(lib), int(slot) ^ 1, True)) if AE_LANES == 2 else None
-            ses = _EngineSession(lib, tuple(shape), lr, device, slot, beside=getattr(other, 'stream', None))
+            other = _SESSIONS.get((str(device), tuple(shape), float(lr), id(lib), int(slot) ^ 1, True, int(clips))) if AE_LANES == 2 else None
+            ses = _EngineSession(lib, tuple(shape), lr, device, slot, beside=getattr(other, 'stream', None), clips=clips)
         else:
             ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
@@ -677,16 +695,19 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
 def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor], train_masks: List[torch.Tensor], steps: int = 60,
                              lr: float = 3e-6, use_graph: Optional[bool] = None, engine: Optional[bool] = None):
     """:func:`finetune_and_infill` for several clips SIDE BY SIDE (the dataset-scale form, like
-    ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1): the clips' 60-step
-    finetunes run on ``AE_LANES`` sessions -- each its own stream, parameters, Adam state, workspace and captured graphs -- clip i
-    on lane i % AE_LANES, the clips of a lane one after the other.  One training step is a chain of short launches whose time is
-    mostly latency, so a second clip fills the idle device: 33 -> 24 ms per clip.  More than two loops truly in flight do NOT
-    help: with four hardware queues' worth of concurrency the step's chip-filling launches (weight gradients, the 210 x 135
-    layers) contend and a clip takes 33.6 ms again (``profiles/r03_hw_queues.txt``; with the runtime's default of 4 hardware
-    queues two of four streams shared a queue, which hid this).  Each clip's result is bit-identical to its solo
-    ``finetune_and_infill`` (same kernels, same order, no shared state; tested).  Returns the list of ``(clip_img_rec, z)``; the
-    model is left with the LAST clip's finetuned weights.  (``engine=False``: the round-2 path, one session per clip, at most
-    ``_MAX_SESSIONS`` clips.)"""
+    ``lemo_amd.sharding.ConcurrentClips`` for the temporal fit and ``BatchedPerFrameFitter`` for stage 1).  Clips of one shape go
+    ``AE_CLIPS`` at a time into ONE engine whose every launch carries all of them -- the clip is the last grid dimension of the
+    convolution, pooling, weight-gradient and Adam launches; each clip has its own parameters, Adam state, step counter and
+    workspace slice (``lemo_ae_desc.clips``; the reference finetunes a fresh copy of the pretrained model per clip).  One training
+    step of one clip is 53 short launches whose time is mostly launch latency and tail, so K clips per launch cost far less than
+    K steps: 29.0 ms for one clip alone -> 20.6 ms per clip with four -> 18.3 with eight (``profiles/r04_ae_clips.txt``; from there
+    the step's kernels are throughput-bound: their summed time is 18.1 ms per clip).  (Round 3 overlapped two one-clip
+    engines on two streams instead -- 24 ms per clip when the runtime happened to put the streams into different hardware queues,
+    33 when not; ``LEMO_AE_LANES=2 LEMO_AE_CLIPS=1`` still runs that.)  A group smaller than ``AE_CLIPS`` (the tail, or clips of a
+    shape of their own) runs on an engine of its own size.  Each clip's result is bit-identical to its solo
+    ``finetune_and_infill`` (same kernels, same launch shapes per clip, no shared state; tested).  Returns the list of
+    ``(clip_img_rec, z)`` in input order; the model is left with the LAST clip's finetuned weights.  (``engine=False``: the
+    round-2 path, one session per clip, at most ``_MAX_SESSIONS`` clips.)"""
     assert 1 <= len(clips) == len(train_masks)
     lib = model._lib_override or _hip.get_lib()
     if use_graph is None:
@@ -697,19 +718,25 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
     mocs = [tm.to(x.dtype) * (1.0 / tm.to(x.dtype).sum()) for x, tm in zip(clips, train_masks)]     # (on the current stream, before any fork)
     if engine:
-        out, sessions, last_flat = [], {}, None
+        out, sessions, last_flat = [None] * len(clips), {}, None
         cur = torch.cuda.current_stream(clips[0].device) if clips[0].is_cuda else None
-        for i, (x, moc) in enumerate(zip(clips, mocs)):                      # enqueue: clip i's loop on lane i % AE_LANES
-            ses = _session(lib, flat0.numel(), x.shape, lr, x.device, slot=i % AE_LANES, engine=True)
-            flat, rec, z = ses.run(flat0, x, moc, steps, use_graph, join=False)     # the current stream waits for nobody yet
-            with ses._on():                                                 # the lane's next clip overwrites the session's buffers:
-                r, zz = rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()     # copies, made on the lane's stream
-                if i == len(clips) - 1:
-                    last_flat = flat.clone()
+        by_shape: Dict[tuple, List[int]] = {}
+        for i, x in enumerate(clips):
+            by_shape.setdefault((str(x.device), tuple(x.shape)), []).append(i)
+        groups = [idx[j:j + AE_CLIPS] for idx in by_shape.values() for j in range(0, len(idx), AE_CLIPS)]
+        for gi, grp in enumerate(groups):                                   # enqueue: group gi on lane gi % AE_LANES
+            x0 = clips[grp[0]]
+            ses = _session(lib, flat0.numel(), x0.shape, lr, x0.device, slot=gi % AE_LANES, engine=True, clips=len(grp))
+            flat, rec, z = ses.run_clips(flat0, [clips[i] for i in grp], [mocs[i] for i in grp], steps, use_graph, join=False)
+            with ses._on():                                                 # the lane's next group overwrites the session's buffers:
+                r, zz = rec[:, None, None, 1:-1, 8:-8].clone(), z[:, None].clone()     # copies, made on the lane's stream
+                if grp[-1] == len(clips) - 1:
+                    last_flat = flat[-1].clone()
             if cur is not None and ses.gpu:
-                for t in (r, zz) + ((last_flat,) if i == len(clips) - 1 else ()):
+                for t in (r, zz) + ((last_flat,) if grp[-1] == len(clips) - 1 else ()):
                     t.record_stream(cur)                                    # read on the caller's stream after the join
-            out.append((r, zz))
+            for c, i in enumerate(grp):
+                out[i] = (r[c], zz[c])
             sessions[id(ses)] = ses
         for ses in sessions.values():
             ses.join()

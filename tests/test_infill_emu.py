@@ -117,28 +117,57 @@ def test_finetune_session_carries_nothing_from_clip_to_clip(emu_lib):
     infill._SESSIONS.clear()
 
 
-def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib):
-    """finetune_and_infill_many: clip i on lane i % AE_LANES (a lane = a session: own parameters / Adam state / workspace; the
-    clips of a lane one after the other) == clip i through finetune_and_infill, bit for bit; and the session cache is an LRU of
-    at most _MAX_SESSIONS entries"""
+def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib, monkeypatch):
+    """finetune_and_infill_many: clips of one shape go AE_CLIPS at a time into ONE engine whose launches carry all of them (the
+    clip is the last grid dimension; own parameters / Adam state / step counter / workspace slice per clip) == clip i through
+    finetune_and_infill, bit for bit -- full groups, the tail group, a clip of another shape in the middle, the model left with
+    the LAST clip's weights; and the session cache is an LRU of at most _MAX_SESSIONS entries"""
     from lemo_amd import infill
     from lemo_amd.infill import AE, finetune_and_infill, finetune_and_infill_many
     w = _weights()
     g = torch.Generator().manual_seed(6)
-    xs = [torch.randn(1, 4, 18, 22, generator=g) for _ in range(3)]
-    ms = [torch.rand(18, 22, generator=g) > 0.3 for _ in range(3)]
+    shapes = [(18, 22), (18, 22), (18, 30), (18, 22), (18, 22), (18, 22)]         # five of one shape (2 + 2 + 1) and an odd one
+    xs = [torch.randn(1, 4, h, ww, generator=g) for h, ww in shapes]
+    ms = [torch.rand(h, ww, generator=g) > 0.3 for h, ww in shapes]
     infill._SESSIONS.clear()
     ae = AE(_lib=emu_lib)
     solo = [tuple(t.clone() for t in finetune_and_infill(ae, w, x, m, steps=2, lr=1e-3)) for x, m in zip(xs, ms)]
+    p_last = {k: v.detach().clone() for k, v in ae.state_dict().items()}
     infill._SESSIONS.clear()
-    many = finetune_and_infill_many(AE(_lib=emu_lib), w, xs, ms, steps=2, lr=1e-3)
-    assert len(infill._SESSIONS) == min(3, infill.AE_LANES)             # clip i runs on lane i % AE_LANES
+    monkeypatch.setattr(infill, 'AE_CLIPS', 2)
+    ae_many = AE(_lib=emu_lib)
+    many = finetune_and_infill_many(ae_many, w, xs, ms, steps=2, lr=1e-3)
+    assert sorted(k[-1] for k in infill._SESSIONS) == [1, 1, 2]           # a 2-clip engine (used twice), the tail's and the odd shape's
     for (ra, za), (rb, zb) in zip(solo, many):
+        assert ra.shape == rb.shape and torch.equal(ra, rb) and torch.equal(za, zb)
+    for k, v in ae_many.state_dict().items():
+        assert torch.equal(v, p_last[k]), k
+    infill._SESSIONS.clear()
+    monkeypatch.setattr(infill, 'AE_CLIPS', 4)
+    many = finetune_and_infill_many(AE(_lib=emu_lib), w, xs[:2] + xs[3:], ms[:2] + ms[3:], steps=2, lr=1e-3)    # 4 + 1
+    for (ra, za), (rb, zb) in zip(solo[:2] + solo[3:], many):
         assert torch.equal(ra, rb) and torch.equal(za, zb)
     for t in range(infill._MAX_SESSIONS + 3):                          # other clip shapes: the cache stays bounded
         finetune_and_infill(ae, w, torch.randn(1, 4, 18, 24 + 2 * t, generator=g), torch.ones(18, 24 + 2 * t) > 0, steps=0)
     assert len(infill._SESSIONS) == infill._MAX_SESSIONS
     infill._SESSIONS.clear()
+
+
+def test_engine_rejects_bad_clip_indices(emu_lib):
+    """lemo_ae_*_clip: clip outside [0, desc.clips) is an argument error; a workspace too small for the clips fails create"""
+    import ctypes as C
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    n = int(emu_lib.ae_ws_floats(18, 22))
+    ws = torch.zeros(2 * n)
+    assert not emu_lib.ae_create(C.byref(_hip.AeDesc(18, 22, 1e-3, ptr(ws), 2 * n, 3)))
+    h = emu_lib.ae_create(C.byref(_hip.AeDesc(18, 22, 1e-3, ptr(ws), 2 * n, 2)))
+    assert h
+    flat, x, moc = torch.zeros(int(emu_lib.ae_n_param())), torch.zeros(4, 18, 22), torch.zeros(18, 22)
+    assert emu_lib.ae_load_clip(h, 2, ptr(flat), ptr(x), ptr(moc), None) != 0
+    assert emu_lib.ae_load_clip(h, -1, ptr(flat), ptr(x), ptr(moc), None) != 0
+    assert emu_lib.ae_params_clip(h, 2, ptr(flat), None) != 0
+    emu_lib.ae_destroy(h)
 
 
 @pytest.mark.parametrize('mt,pt,ks', [(0, 0, 0), (1, 1, 1), (1, 1, 4), (1, 4, 2), (2, 2, 2), (1, 2, 8), (2, 1, 8), (3, 1, 1), (3, 4, 1), (3, 2, 8)])
