@@ -378,26 +378,6 @@ def check_device(lib: HipLib, t: torch.Tensor):
         raise LemoHipError('lemo_amd compute entry points need tensors on a HIP device (no CPU fallback)')
 
 
-def partner_stream(ref) -> 'torch.cuda.Stream':
-    """A stream for work that should run BESIDE what `ref` runs (another clip's loop, the fit next to the finetune).  The HIP
-    runtime deals a process's streams onto 4 hardware queues, and two streams in one queue are serialised -- whether a
-    side-by-side path overlapped at all used to depend on how many streams the process had created before.  torch hands out its
-    pool streams in order (``stream_id = 3 + 32 i``); measured with the pipelined clip loop (profiles/r03_hw_queues.txt): a
-    partner whose pool index differs from `ref`'s by 1 or 2 (mod 4) overlaps (53.3 ms per clip), by 0 or 3 does not (67 ms).
-    Draws pool streams until the difference is 1 or 2; for a `ref` that is not a pool stream (the default stream, an external
-    one) any pool stream is returned.  An empirical rule about this runtime, used only to PICK among equivalent streams."""
-    dev = ref.device
-    pool_index = lambda s: (int(s.stream_id) >> 5) if int(s.stream_id) & 31 == 3 else None
-    r = pool_index(ref)
-    s = torch.cuda.Stream(dev)
-    for _ in range(8):
-        i = pool_index(s)
-        if r is None or i is None or (i - r) % 4 in (1, 2):
-            break
-        s = torch.cuda.Stream(dev)
-    return s
-
-
 class StreamOrdered:
     """Ordering between an engine's host-side state writes (torch ops on whatever stream is current) and its launches
     (possibly on another, non-blocking stream), owned by the engine: each side records an event that the other side's

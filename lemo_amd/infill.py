@@ -518,8 +518,7 @@ class _EngineSession:
     Adam state, activations and gradients from, its stream, and the output buffers of the eval forward.  Kept across clips
     of the same shape like :class:`_FinetuneSession` (the captured graphs live inside the engine)."""
 
-    def __init__(self, lib, x_shape, lr, device, slot: int = 0, beside=None, clips: int = 1):
-        # beside: the stream of the lane this one is to run next to (its own stream is then picked so that the two overlap)
+    def __init__(self, lib, x_shape, lr, device, clips: int = 1):
         # clips: K clips side by side in every launch (lemo_ae_desc.clips): K workspaces back to back, one engine, one stream
         self.lib, self.device, self.clips = lib, torch.device(device), int(clips)
         self.gpu = self.device.type == 'cuda' and not lib.is_emu
@@ -527,10 +526,7 @@ class _EngineSession:
         n = int(lib.ae_ws_floats(H, W))
         if n <= 0:
             raise _hip.LemoHipError(f'lemo_ae_ws_floats refuses a {H} x {W} clip image')
-        # (two lanes whose streams the runtime happens to put into one hardware queue run one after the other: 33 instead of 24 ms
-        # per clip, seen inside bench.py depending on how many streams the process had created before.  Giving the lanes different
-        # stream PRIORITIES to force them apart measured 58 ms per clip: not done.)
-        self.stream = (torch.cuda.Stream(self.device) if beside is None else _hip.partner_stream(beside)) if self.gpu else None
+        self.stream = torch.cuda.Stream(self.device) if self.gpu else None       # used when the caller sits on the legacy default stream
         self.ws = torch.zeros(n * self.clips, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
         h5, w5 = H, W
         for _ in range(5):
@@ -562,18 +558,18 @@ class _EngineSession:
         import contextlib
         return torch.cuda.stream(self.stream) if self.gpu else contextlib.nullcontext()
 
-    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True, own_stream=True):
+    def run(self, flat0, x, m_over_cnt, steps, use_graph, join=True, own_stream=False):
         """one clip on a one-clip session (:meth:`run_clips`); returns ``(flat, rec, z)`` views of the session's output buffers"""
         flat, rec, z = self.run_clips(flat0, [x], [m_over_cnt], steps, use_graph, join, own_stream)
         return flat[0], rec[0], z[0]
 
-    def run_clips(self, flat0, xs, mocs, steps, use_graph, join=True, own_stream=True):
+    def run_clips(self, flat0, xs, mocs, steps, use_graph, join=True, own_stream=False):
         """load the pretrained parameters and ``self.clips`` clips, `steps` training steps of all of them (each launch carries
         every clip), eval forward, parameters back out; returns views ``(flat [K, n], rec [K, H, W], z [K, 256, h, w])`` of the
-        session's output buffers (valid until its next run).  ``own_stream``: everything runs on this session's stream (what
-        a lane of ``finetune_and_infill_many`` needs); False: on the CALLER's current stream when that is not the legacy
-        default stream (which cannot be captured) -- a run on its own then needs no hand-over between two hardware queues,
-        which measured 29.8 instead of 33.4 ms per clip (``profiles/r03_hw_queues.txt``; the graphs are not bound to a stream)."""
+        session's output buffers (valid until its next run).  Everything runs on the CALLER's current stream when that is not the
+        legacy default stream (which cannot be captured) -- no hand-over between two hardware queues, which measured 29.8 instead
+        of 33.4 ms per clip (``profiles/r03_hw_queues.txt``; the graphs are not bound to a stream); ``own_stream=True`` (or a caller
+        on the default stream): on this session's stream, the caller's stream joined afterwards unless ``join=False``."""
         lib = self.lib
         assert len(xs) == len(mocs) == self.clips
         flat0 = flat0.contiguous().float()
@@ -620,10 +616,6 @@ AE_CLIPS = max(1, min(16, int(__import__('os').environ.get('LEMO_AE_CLIPS', '8')
 on 210 x 135 clip images, ms per clip: 1 clip 29.0 | 2 23.8 | 3 22.6 | 4 20.6 | 8 18.3 -- ``profiles/r04_ae_clips.txt``; the kernels
 of a step are throughput-bound from ~4 clips on, a clip's workspace is ~50 MB)"""
 
-AE_LANES = max(1, int(__import__('os').environ.get('LEMO_AE_LANES', '1')))
-"""engines in flight at once in ``finetune_and_infill_many``, each on its own stream (round 3 ran 2 one-clip lanes; with clips
-batched into the launches one lane is enough -- see there)"""
-
 USE_ENGINE = __import__('os').environ.get('LEMO_AE_ENGINE', '1') != '0'
 """the finetune loop runs on the native step engine (round 3: 53 launches per step instead of ~150; csrc/ae_engine.hip).
 ``LEMO_AE_ENGINE=0`` (or ``engine=False``) keeps the round-2 path -- the autograd function + flat Adam under a captured graph
@@ -640,8 +632,7 @@ def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine:
     ses = _SESSIONS.pop(key, None)
     if ses is None:
         if engine:
-            other = _SESSIONS.get((str(device), tuple(shape), float(lr), id(lib), int(slot) ^ 1, True, int(clips))) if AE_LANES == 2 else None
-            ses = _EngineSession(lib, tuple(shape), lr, device, slot, beside=getattr(other, 'stream', None), clips=clips)
+            ses = _EngineSession(lib, tuple(shape), lr, device, clips=clips)
         else:
             ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
@@ -682,7 +673,7 @@ def finetune_and_infill(model: AE, weights: dict, clip_img_input: torch.Tensor, 
     ses = _session(lib, flat0.numel(), clip_img_input.shape, lr, clip_img_input.device, engine=engine)
     if engine:
         _hip.check_device(lib, clip_img_input)
-        flat, rec, z = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph, own_stream=False)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
+        flat, rec, z = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)   # d(loss)/d(rec) = sign(rec - x) * m / cnt
         _store_params(model, flat)
         return rec[None, None, 1:-1, 8:-8].clone(), z[None].clone()
     flat = ses.run(flat0, clip_img_input, m * (1.0 / cnt), steps, use_graph)
@@ -703,7 +694,8 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
     K steps: 29.0 ms for one clip alone -> 20.6 ms per clip with four -> 18.3 with eight (``profiles/r04_ae_clips.txt``; from there
     the step's kernels are throughput-bound: their summed time is 18.1 ms per clip).  (Round 3 overlapped two one-clip
     engines on two streams instead -- 24 ms per clip when the runtime happened to put the streams into different hardware queues,
-    33 when not; ``LEMO_AE_LANES=2 LEMO_AE_CLIPS=1`` still runs that.)  A group smaller than ``AE_CLIPS`` (the tail, or clips of a
+    33 when not; gone.)  Everything is enqueued on the caller's stream (the session's own stream when the caller sits on the legacy
+    default stream, which cannot be captured).  A group smaller than ``AE_CLIPS`` (the tail, or clips of a
     shape of their own) runs on an engine of its own size.  Each clip's result is bit-identical to its solo
     ``finetune_and_infill`` (same kernels, same launch shapes per clip, no shared state; tested).  Returns the list of
     ``(clip_img_rec, z)`` in input order; the model is left with the LAST clip's finetuned weights.  (``engine=False``: the
@@ -718,28 +710,21 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
     flat0 = flatten_params([p.detach() for p in model.ordered_parameters()])
     mocs = [tm.to(x.dtype) * (1.0 / tm.to(x.dtype).sum()) for x, tm in zip(clips, train_masks)]     # (on the current stream, before any fork)
     if engine:
-        out, sessions, last_flat = [None] * len(clips), {}, None
-        cur = torch.cuda.current_stream(clips[0].device) if clips[0].is_cuda else None
+        out, last_flat = [None] * len(clips), None
         by_shape: Dict[tuple, List[int]] = {}
         for i, x in enumerate(clips):
             by_shape.setdefault((str(x.device), tuple(x.shape)), []).append(i)
         groups = [idx[j:j + AE_CLIPS] for idx in by_shape.values() for j in range(0, len(idx), AE_CLIPS)]
-        for gi, grp in enumerate(groups):                                   # enqueue: group gi on lane gi % AE_LANES
+        for grp in groups:
             x0 = clips[grp[0]]
-            ses = _session(lib, flat0.numel(), x0.shape, lr, x0.device, slot=gi % AE_LANES, engine=True, clips=len(grp))
-            flat, rec, z = ses.run_clips(flat0, [clips[i] for i in grp], [mocs[i] for i in grp], steps, use_graph, join=False)
-            with ses._on():                                                 # the lane's next group overwrites the session's buffers:
-                r, zz = rec[:, None, None, 1:-1, 8:-8].clone(), z[:, None].clone()     # copies, made on the lane's stream
-                if grp[-1] == len(clips) - 1:
-                    last_flat = flat[-1].clone()
-            if cur is not None and ses.gpu:
-                for t in (r, zz) + ((last_flat,) if grp[-1] == len(clips) - 1 else ()):
-                    t.record_stream(cur)                                    # read on the caller's stream after the join
+            ses = _session(lib, flat0.numel(), x0.shape, lr, x0.device, engine=True, clips=len(grp))
+            flat, rec, z = ses.run_clips(flat0, [clips[i] for i in grp], [mocs[i] for i in grp], steps, use_graph)
+            # the session's next run overwrites its buffers: copies (ordered after the run: same stream, or joined)
+            r, zz = rec[:, None, None, 1:-1, 8:-8].clone(), z[:, None].clone()
+            if grp[-1] == len(clips) - 1:
+                last_flat = flat[-1].clone()
             for c, i in enumerate(grp):
                 out[i] = (r[c], zz[c])
-            sessions[id(ses)] = ses
-        for ses in sessions.values():
-            ses.join()
         _store_params(model, last_flat)
         return out
     assert len(clips) <= _MAX_SESSIONS

@@ -151,59 +151,65 @@ class AmassClipPipeline:
 
 
     def fit_clips(self, clips, steps: int = 100, finetune_steps: int = 60, use_graph: Optional[bool] = None):
-        """``fit_clip`` for a LIST of clips ``(clip_img, rot_0_pivot, init_params, gender)``, pipelined on the device: clip
-        i + 1's finetune (the caller's stream) runs while clip i's temporal fit is still replaying on its fitter's stream; nothing
-        in the loop makes the host wait for the device.  Three things make that possible: ``init_params`` goes up on a separate
-        upload stream (a pageable host-to-device copy on the caller's stream would wait for everything queued there), the
-        fitted parameters are read on a separate result stream (on the caller's stream that read would order the next finetune
-        behind this fit), and a fitter's next ``load_sequence`` waits for that read.  Returns the list of ``fit_clip`` dicts;
-        all of them are ordered on the caller's stream when the call returns.  Same kernels, same order per clip: results are
-        identical to ``fit_clip`` one by one (tested).  Measured (tools/clip_pipeline_rate.py, 60-step finetune + 100-step fit):
-        64.7 ms per clip one by one, 52.8 ms pipelined when the caller's stream and the fitter's stream sit in different hardware
-        queues; ``_hip.partner_stream`` picks the fitter's stream accordingly (in one queue nothing overlaps: 67 ms) -- DESIGN 9.11."""
+        """``fit_clip`` for a LIST of clips ``(clip_img, rot_0_pivot, init_params, gender)`` at dataset rate.  The clips go through
+        the infilling AE ``infill.AE_CLIPS`` at a time (``finetune_and_infill_many``: every launch of a finetune step carries the
+        whole group -- 18.3 instead of 29 ms per clip, on the caller's stream, no second hardware queue needed); each clip of the
+        group is then decoded and fitted on its fitter's own stream, so the next group's finetune is enqueued while those fits
+        replay.  Nothing in the loop makes the host wait for the device: ``init_params`` goes up on a separate upload stream (a
+        pageable host-to-device copy on the caller's stream would wait for everything queued there), the fitted parameters are read
+        on a separate result stream, and a fitter's next ``load_sequence`` waits for that read.  Whether the fits and the next
+        finetune actually overlap is up to the runtime's hardware queues (round 3 steered that with an empirical rule about torch's
+        stream pool; deleted): one after the other they cost 18.3 + 30 ms per clip, which is the rate this path promises.  Returns
+        the list of ``fit_clip`` dicts, ordered on the caller's stream when the call returns.  Same kernels, same order per clip:
+        results are identical to ``fit_clip`` one by one (tested)."""
+        from . import infill
+        from .infill import finetune_and_infill_many
         dev = next(iter(self.fitters.values())).device
         gpu = dev.type == 'cuda' and torch.cuda.is_available() and not next(iter(self.fitters.values())).lib.is_emu
-        if not gpu:
-            return [self.fit_clip(c, piv, init, gender=g, steps=steps, finetune_steps=finetune_steps, use_graph=use_graph)
-                    for c, piv, init, g in clips]
-        if getattr(self, '_up', None) is None:
+        if gpu and getattr(self, '_up', None) is None:
             self._up, self._res = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
             self._read_ev = {}
-        cur = torch.cuda.current_stream(dev)
+        cur = torch.cuda.current_stream(dev) if gpu else None
         outs, pinned = [], []
-        for clip_img, rot_0_pivot, init_params, gender in clips:
-            g = gender if isinstance(gender, str) else ('female' if int(gender) == 0 else 'male')
-            fit = self.fitters[g]
-            if getattr(fit, '_own_for', None) != cur.cuda_stream:    # the fit must not share the caller's hardware queue
-                new = _hip.partner_stream(cur)
-                if fit._own is not None:
-                    new.wait_stream(fit._own)
-                fit._own, fit._own_for = new, cur.cuda_stream
-            if isinstance(init_params, torch.Tensor) and init_params.is_cuda:
-                p_dev = init_params
-            else:
-                hp = torch.from_numpy(np.ascontiguousarray(np.asarray(init_params, np.float32))).pin_memory()
-                with torch.cuda.stream(self._up):
-                    p_dev = hp.to(dev, non_blocking=True)         # pinned + its own stream: the host does not wait for the device
-                    ev = torch.cuda.Event(); ev.record(self._up)
-                pinned.append(hp)                                 # alive until the copies have run (joined below)
-                cur.wait_event(ev)
-                p_dev.record_stream(cur)
-            x_in, mask = amass_mask_input(clip_img)
-            rec, _ = finetune_and_infill(self.ae, self.ae_weights, x_in, mask, steps=finetune_steps, use_graph=use_graph)
-            lbl, markers = decode_markers(rec[0, 0], clip_img[0], rot_0_pivot, self.stats, _lib=self.ae._lib_override)
-            if id(fit) in self._read_ev:
-                cur.wait_event(self._read_ev[id(fit)])            # the previous clip's parameters have been read out
-            fit.load_sequence(p_dev, markers, lbl)
-            fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
-            with torch.cuda.stream(self._res):
-                p72 = fit.params72()                              # waits for the fit on the RESULT stream only
-                ev = torch.cuda.Event(); ev.record(self._res)
-            p72.record_stream(cur)
-            self._read_ev[id(fit)] = ev
-            outs.append(dict(p72=p72, contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in, train_mask=mask))
-        cur.wait_stream(self._res)
-        self._up.synchronize()                                    # (the uploads finished long ago: releases `pinned` safely)
+        clips = list(clips)
+        for g0 in range(0, len(clips), infill.AE_CLIPS):
+            group = clips[g0:g0 + infill.AE_CLIPS]
+            masked = [amass_mask_input(c[0]) for c in group]
+            recs = finetune_and_infill_many(self.ae, self.ae_weights, [m[0] for m in masked], [m[1] for m in masked], steps=finetune_steps,
+                                            use_graph=use_graph)
+            for (clip_img, rot_0_pivot, init_params, gender), (x_in, mask), (rec, _) in zip(group, masked, recs):
+                g = gender if isinstance(gender, str) else ('female' if int(gender) == 0 else 'male')
+                fit = self.fitters[g]
+                lbl, markers = decode_markers(rec[0, 0], clip_img[0], rot_0_pivot, self.stats, _lib=self.ae._lib_override)
+                if not gpu:
+                    fit.load_sequence(init_params, markers, lbl)
+                    fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
+                    outs.append(dict(p72=fit.params72(), contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in,
+                                     train_mask=mask))
+                    continue
+                if isinstance(init_params, torch.Tensor) and init_params.is_cuda:
+                    p_dev = init_params
+                else:
+                    hp = torch.from_numpy(np.ascontiguousarray(np.asarray(init_params, np.float32))).pin_memory()
+                    with torch.cuda.stream(self._up):
+                        p_dev = hp.to(dev, non_blocking=True)     # pinned + its own stream: the host does not wait for the device
+                        ev = torch.cuda.Event(); ev.record(self._up)
+                    pinned.append(hp)                             # alive until the copies have run (joined below)
+                    cur.wait_event(ev)
+                    p_dev.record_stream(cur)
+                if id(fit) in self._read_ev:
+                    cur.wait_event(self._read_ev[id(fit)])        # the previous clip's parameters have been read out
+                fit.load_sequence(p_dev, markers, lbl)
+                fit.step_async(steps, use_graph=True if use_graph is None else bool(use_graph))
+                with torch.cuda.stream(self._res):
+                    p72 = fit.params72()                          # waits for the fit on the RESULT stream only
+                    ev = torch.cuda.Event(); ev.record(self._res)
+                p72.record_stream(cur)
+                self._read_ev[id(fit)] = ev
+                outs.append(dict(p72=p72, contact_lbl_rec=lbl, markers_rec=markers, clip_img_rec=rec, clip_img_input=x_in, train_mask=mask))
+        if gpu:
+            cur.wait_stream(self._res)
+            self._up.synchronize()                                # (the uploads finished long ago: releases `pinned` safely)
         return outs
 
 

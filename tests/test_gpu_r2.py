@@ -171,7 +171,6 @@ def test_finetune_many_clips_side_by_side_bit_identical(dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter(); finetune_and_infill(ae, ae_w, xs[0], ms[0], steps=60); torch.cuda.synchronize()
     t_solo = (time.perf_counter() - t0) * 1e3
-    assert infill.AE_LANES == 1
     many = finetune_and_infill_many(ae, ae_w, xs, ms, steps=60)             # captures the engines' graphs
     torch.cuda.synchronize()
     for (ra, za), (rb, zb) in zip(solo, many):
@@ -299,8 +298,8 @@ def test_amass_clip_pipeline_end_to_end_vs_oracle(dev):
 
 
 def test_fit_clips_pipelined_equals_one_by_one(dev):
-    """AmassClipPipeline.fit_clips (clip i+1's finetune overlapping clip i's fit: upload / result streams, no host waits) returns
-    exactly what fit_clip returns clip by clip"""
+    """AmassClipPipeline.fit_clips (the clips' finetunes carried together by the launches of one AE engine, then each clip's fit on
+    the fitter's stream: upload / result streams, no host waits) returns exactly what fit_clip returns clip by clip"""
     from lemo_amd import pipeline as P
     from lemo_amd.fitting import AmassTemporalFitter
     from lemo_amd.infill import AE

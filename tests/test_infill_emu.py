@@ -260,3 +260,39 @@ def test_engine_refuses_bad_use(emu_lib):
     assert emu_lib.ae_step(h, 1, 0, None) == 10003 and emu_lib.ae_forward(h, ptr(rec), None, None) == 10003
     assert emu_lib.ae_load(h, None, None, None, None) == 10002 and emu_lib.ae_step(h, -1, 0, None) == 10002
     emu_lib.ae_destroy(h)
+
+
+def test_clip_pipeline_many_equals_one_by_one(emu_lib, monkeypatch):
+    """AmassClipPipeline.fit_clips (clips grouped AE_CLIPS at a time through one AE engine, then decoded and fitted one by one)
+    == fit_clip clip by clip, bit for bit, on the host-emulated kernels: 3 clips with AE_CLIPS = 2 (a full group and the tail)"""
+    import __graft_entry__ as ge
+    from lemo_amd import infill, pipeline as P, synthetic
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.infill import AE
+    p = ge.small_problem()
+    B = p['B']
+    fit = AmassTemporalFitter(p['model'], p['vposer_w'], p['enc_w'], p['ids'], p['Xmean'], p['Xstd'], B, torch.device('cpu'), full_vertices=True, lib=emu_lib)
+    pipe = P.AmassClipPipeline(fit, AE(_lib=emu_lib), _weights())
+    real_decode = P.decode_markers                    # (the reduced problem fits 5 markers: keep the first 5 of the decoded 67)
+
+    def decode5(*a, **k):
+        lbl, mk = real_decode(*a, **k)
+        return lbl, mk[:, :5].contiguous()
+    monkeypatch.setattr(P, 'decode_markers', decode5)
+    g = torch.Generator().manual_seed(12)
+    items = []
+    for i in range(3):
+        clip = torch.randn(1, 4, 208, B, generator=g) * 0.5
+        init = synthetic.make_synthetic_sequence(20 + i, B=B)['init_params']
+        items.append((clip, torch.tensor([0.3 * i], dtype=torch.float64), init, 1))
+    infill._SESSIONS.clear()
+    solo = []
+    for c, piv, init, gd in items:
+        o = pipe.fit_clip(c, piv, init, gender=gd, steps=2, finetune_steps=2, use_graph=False)
+        solo.append({k: v.clone() for k, v in o.items()})
+    monkeypatch.setattr(infill, 'AE_CLIPS', 2)
+    many = pipe.fit_clips(items, steps=2, finetune_steps=2, use_graph=False)
+    for a, b in zip(solo, many):
+        for k in ('p72', 'markers_rec', 'contact_lbl_rec', 'clip_img_rec'):
+            assert torch.equal(a[k], b[k]), k
+    infill._SESSIONS.clear()

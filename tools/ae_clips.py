@@ -1,4 +1,4 @@
-"""K clips per engine launch (lemo_ae_desc.clips) x lanes: ms per clip of the 60-step infilling-AE finetune on 210 x 135 clip images
+"""K clips per engine launch (lemo_ae_desc.clips): ms per clip of the 60-step infilling-AE finetune on 210 x 135 clip images
 through lemo_amd.infill.finetune_and_infill_many, each configuration's results checked bit for bit against the solo runs
 (diagnostic, GPU box only).  Usage: python tools/ae_clips.py [n_clips]"""
 import os, sys, time
@@ -23,10 +23,10 @@ with torch.cuda.stream(side):
         finetune_and_infill(ae, w, x, m, steps=60)
     torch.cuda.synchronize()
     print(f'{n} clips one after the other through finetune_and_infill: {(time.perf_counter() - t0) * 1e3 / n:6.2f} ms per clip', flush=True)
-    for lanes, clips in ((2, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (2, 2), (2, 4)):
-        if clips * lanes > n:
+    for clips in (1, 2, 3, 4, 6, 8, 12, 16):
+        if clips > n:
             continue
-        infill.AE_LANES, infill.AE_CLIPS = lanes, clips
+        infill.AE_CLIPS = clips
         infill._SESSIONS.clear()
         many = finetune_and_infill_many(ae, w, xs, masks, steps=60); torch.cuda.synchronize()
         same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(solo, many))
@@ -35,4 +35,4 @@ with torch.cuda.stream(side):
             t0 = time.perf_counter()
             finetune_and_infill_many(ae, w, xs, masks, steps=60); torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) * 1e3)
-        print(f'lanes {lanes} x clips per engine {clips}: {best / n:6.2f} ms per clip ({n} clips, best of 3); bit-identical to solo: {same}', flush=True)
+        print(f'clips per engine {clips}: {best / n:6.2f} ms per clip ({n} clips, best of 3); bit-identical to solo: {same}', flush=True)

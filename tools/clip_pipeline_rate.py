@@ -1,7 +1,7 @@
 """End-to-end per-clip rate of the AMASS stage-2 pipeline (opt_amass_temp.py:159-458: mask -> 60-step AE finetune -> decode -> 100-step
 temporal fit) through lemo_amd.pipeline.AmassClipPipeline, N clips back to back on one GPU without a host synchronisation between
-them -- fit_clip in a loop (host-bound before round 3 cached its per-clip uploads) and fit_clips (clip i+1's finetune on the caller's
-stream overlaps clip i's fit on the fitter's stream).
+them -- fit_clip in a loop (host-bound before round 3 cached its per-clip uploads) and fit_clips (infill.AE_CLIPS clips per finetune
+launch on the caller's stream, then their fits on the fitter's stream while the next group's finetune is enqueued).
 Diagnostic, GPU box only.  Usage: python tools/clip_pipeline_rate.py [n_clips=8]"""
 import os, sys, time
 import numpy as np
@@ -13,7 +13,7 @@ from lemo_amd.fitting import AmassTemporalFitter
 from lemo_amd.infill import AE
 from lemo_amd.vposer import make_vposer_weights
 dev = torch.device('cuda:0')
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 A = load_assets()
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'amass_clip.npz'))
 model = synthetic.make_synthetic_smplx(seed=0)
@@ -40,7 +40,7 @@ with torch.cuda.stream(side):
         print(f'{label}: {n} clips in {dt * 1e3:.1f} ms = {dt / n * 1e3:.1f} ms per clip ({n / dt:.1f} clips/s); host time {th / n * 1e3:.1f} ms per clip', flush=True)
     for label, use in (('fit_clips, one fitter', pipes[0]),):
         items = [(clip, piv, init, 1)] * n
-        use.fit_clips(items[:2], steps=100); torch.cuda.synchronize()
+        use.fit_clips(items, steps=100); torch.cuda.synchronize()        # (engines of the group sizes created, graphs captured)
         t0 = time.perf_counter()
         outs = use.fit_clips(items, steps=100)
         th = time.perf_counter() - t0

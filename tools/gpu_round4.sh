@@ -41,6 +41,8 @@ timeout 300 python tools/pair_check.py > $OUT/pair_check.txt 2>&1
 timeout 600 python tools/enc_layer_numerics.py > $OUT/enc_layer_numerics.txt 2>&1
 timeout 500 python tools/concurrent_clips.py 110 4 > $OUT/concurrent_clips.txt 2>&1; echo "rc=$?" >> $OUT/concurrent_clips.txt
 timeout 400 python tools/race_hunt.py 1000 B > $OUT/race_hunt.txt 2>&1
+timeout 300 python tools/ae_clips.py 16 > $OUT/ae_clips.txt 2>&1
+timeout 300 python tools/clip_pipeline_rate.py 16 > $OUT/clip_pipeline_rate.txt 2>&1
 # 5. the whole GPU suite with its printed measurements, smoke
 timeout 2400 python -m pytest tests -m gpu -q -s > $OUT/pytest_full.log 2>&1; grep -E "^FAILED|^ERROR" $OUT/pytest_full.log > $OUT/pytest_failures.txt
 grep -v "^\"void" $OUT/pytest_full.log | grep -E "passed|failed|MPJPE|it/s|iterations/s|max rel|vs float64|module-API|per-frame|3 frames|PROX|finetuned|clip pipeline|gradient|s per clip|ms per clip|eager launches|vertices vs|max err|kink|marker residual|split conv|fused pair|free-running" > $OUT/pytest_gpu_measurements.txt
