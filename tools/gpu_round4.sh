@@ -3,7 +3,7 @@
 #   gpurun --timeout 3000 -- 'bash tools/gpu_round4.sh r04final'     then     python tools/copy_evidence.py r04final r04
 TAG=${1:-r04final}; OUT=gpurun_out/$TAG; mkdir -p $OUT/pmc; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit" | head -4 > $OUT/gpu.txt
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|gfx" | tail -6 > $OUT/gpu.txt
 nproc >> $OUT/gpu.txt; lscpu | grep -E "Model name|^CPU\(s\)|Core|Socket" >> $OUT/gpu.txt
 # 1. PMC passes (separate runs, kernel-trace only) -> roofline.traffic of THIS code state
 cd /tmp
