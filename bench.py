@@ -616,6 +616,9 @@ def main():
     ap.add_argument('--active-vertices-only', action='store_true',
                     help='forward only the 253 vertices the losses read (NOT the headline config)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--model', choices=('iid', 'coherent'), default='iid',
+                    help='synthetic SMPL-X-shaped model: skinning joints i.i.d. per vertex (the worst case, rounds 1-3) or with the index '
+                         'locality of the licensed model (lemo_amd.synthetic._coherent_skinning)')
     ap.add_argument('--conv-variant', type=int, default=DEFAULT_CONV_VARIANT)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ramp-ms', type=float, default=250.0, help='untimed replay of the iteration before the warm-up steps (0 = off)')
@@ -631,6 +634,9 @@ def main():
                     help='after the headline measurement (one clip per GPU), also time this many independent clips fitted side by '
                          'side on GPU 0 (reported as "concurrent_clips", never as "value"; 0 = off)')
     args = ap.parse_args()
+    if args.model == 'coherent':
+        from lemo_amd import synthetic as _syn
+        _syn.DEFAULT_COHERENT = True
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -803,6 +809,8 @@ def main():
                                '(the T=120 clip), SMPL-X-shaped synthetic model V=10475, VPoser decode, smoothness '
                                'encoder 245x134, marker+contact+prior losses, Adam',
                    'frames': B, 'vertices_per_frame': 10475 if not args.active_vertices_only else int(fit.n),
+                   'synthetic_model': args.model + (' (skinning joints i.i.d. per vertex: every 512-vertex chunk touches all 55 joints -- the worst case)'
+                                                     if args.model == 'iid' else ' (index locality of the licensed model: a 512-vertex chunk touches 4-17 joints)'),
                    'sequences': world, 'conv_variant': fit.conv_variant,
                    'arithmetic': {5: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
                                      'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured error vs '
@@ -891,6 +899,32 @@ def main():
             out['mpjpe_mm'] = out['mpjpe']['value']
         except Exception as e:       # noqa: BLE001
             out['mpjpe'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not args.no_extras and use_graph and not args.active_vertices_only and args.model == 'iid':
+        # the same two workloads on the synthetic model with the licensed model's index locality (the i.i.d.-joint model
+        # of the headline is the worst case for the skinning gather and the chunked all-vertex LBS backward)
+        try:
+            from lemo_amd import synthetic as _syn
+            _syn.DEFAULT_COHERENT = True
+            try:
+                fc, pc = build_problem(rank, B, device, full_vertices=True, conv_variant=fit.conv_variant)
+                with torch.cuda.stream(stream):
+                    fit.step(100, use_graph=True)
+                torch.cuda.synchronize(device)
+                v_co = max(timed_fit(fc, pc, stream, device) for _ in range(2))
+                assert fc.nonfinite_step() == 0
+                del fc, pc
+                p_co = prox_probe(device)[1]['value']
+            finally:
+                _syn.DEFAULT_COHERENT = False
+            out['coherent_model'] = {
+                'value': v_co, 'prox_window_value': p_co, 'unit': 'fitting-iterations/s',
+                'note': 'lemo_amd.synthetic.make_synthetic_smplx(coherent=True): consecutive vertex indices share their dominant joint in runs '
+                        'of 20-400 vertices, a vertex is skinned to its part\'s joint and up to three tree neighbours (a 512-vertex chunk '
+                        'touches 4-17 joints instead of all 55); same shapes and non-zero bounds as the headline\'s i.i.d. model.  The AMASS '
+                        'iteration does not care (its skinning gather is LDS-issue bound either way); the PROX window (all-vertex LBS backward in '
+                        '512-vertex chunks, SDF sampling) does'}
+        except Exception as e:       # noqa: BLE001
+            out['coherent_model'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_extras and use_graph:
         # the other workloads of BASELINE.json on this GPU (never the headline value; a failure must not cost the line)
         del fit

@@ -105,11 +105,13 @@ def test_smplx_module_golden(dev):
         assert rel_err(p[k].grad.cpu(), g['g_' + k]) < 1e-4, k
 
 
-def test_smplx_module_full_size_vs_oracle(dev):
-    """V=10475, B=119: every vertex and joint against the oracle (<= 1e-4 rel)."""
+@pytest.mark.parametrize('coherent', [False, True])
+def test_smplx_module_full_size_vs_oracle(dev, coherent):
+    """V=10475, B=119: every vertex and joint against the oracle (<= 1e-4 rel), on the i.i.d.-joint synthetic model and on the one
+    with the licensed model's index locality (1 .. 4 skinning joints per vertex, lemo_amd.synthetic._coherent_skinning)."""
     from lemo_amd.body_model import create
     from oracle import lemo_oracle as O
-    m = synthetic.make_synthetic_smplx(seed=0)
+    m = synthetic.make_synthetic_smplx(seed=0, coherent=coherent)
     seq = synthetic.make_synthetic_sequence(1, B=119)
     p = torch.from_numpy(seq['init_params'])
     gen = torch.Generator().manual_seed(0)
@@ -548,12 +550,13 @@ def test_mpjpe_after_full_fit(full_problem, dev):
     assert mpjpe < 2.0, mpjpe
 
 
-@pytest.mark.parametrize('stage,first', [('S3', False), ('S2', True)])
-def test_prox_iteration_vs_oracle(dev, stage, first):
-    """PROX twin (a11/a12/a14): 14 loss_dict entries, gradients, first-window erase, 3 Adam steps."""
+@pytest.mark.parametrize('stage,first,coherent', [('S3', False, False), ('S2', True, False), ('S3', False, True)])
+def test_prox_iteration_vs_oracle(dev, stage, first, coherent):
+    """PROX twin (a11/a12/a14): 14 loss_dict entries, gradients, first-window erase, 3 Adam steps (the third case: on the synthetic
+    model with the licensed model's index locality -- chunks of the all-vertex LBS backward that touch few joints)."""
     import __graft_entry__ as ge
     from lemo_amd.prox import LOSS_KEYS
-    prob = ge.prox_small_problem(stage=stage)
+    prob = ge.prox_small_problem(stage=stage, coherent=coherent)
     of = ge.prox_oracle_for(prob, first_batch_flag=first)
     old = of.closure()
     fit, bm = ge.prox_fitter_for(prob, dev, first_batch_flag=first)

@@ -178,13 +178,14 @@ def test_smplx_module_forward_backward_vs_golden(emu_lib):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('full', [True, False])
-def test_fit_iteration_vs_oracle(emu_lib, full):
+@pytest.mark.parametrize('full,coherent', [(True, False), (False, False), (True, True)])
+def test_fit_iteration_vs_oracle(emu_lib, full, coherent):
     """whole AMASS iteration through the native engine (C-ABI lemo_fit_*): six loss scalars, total,
-    gradients, and parameters after 3 Adam steps -- full-vertex and active-vertex forward."""
+    gradients, and parameters after 3 Adam steps -- full-vertex and active-vertex forward; on the i.i.d.-joint synthetic model
+    and on the one with the licensed model's index locality (vertices with 1 .. 4 skinning joints, ELL rows padded with weight 0)."""
     import __graft_entry__ as ge
     from lemo_amd.fitting import AmassTemporalFitter
-    prob = ge.small_problem()
+    prob = ge.small_problem(coherent=coherent)
     ofit, markers = ge.oracle_for(prob)
     total, parts, _, verts = ofit.losses()
     total.backward()

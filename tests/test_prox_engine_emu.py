@@ -8,11 +8,11 @@ from conftest import rel_err
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize('stage,first', [('S3', False), ('S2', True)])
-def test_prox_engine_iteration_vs_oracle(emu_lib, stage, first):
+@pytest.mark.parametrize('stage,first,coherent', [('S3', False, False), ('S2', True, False), ('S3', False, True)])
+def test_prox_engine_iteration_vs_oracle(emu_lib, stage, first, coherent):
     import __graft_entry__ as ge
     from lemo_amd.prox import ENGINE_PARAMS, LOSS_KEYS
-    prob = ge.prox_small_problem(stage=stage)
+    prob = ge.prox_small_problem(stage=stage, coherent=coherent)     # coherent: the synthetic model with the licensed model's index locality
     of = ge.prox_oracle_for(prob, first_batch_flag=first)
     old = of.closure()
     eng, bm = ge.prox_engine_for(prob, torch.device('cpu'), first_batch_flag=first, lib=emu_lib)
