@@ -86,6 +86,39 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// 16 values per lane -> lane L ends with the sum over its 16-lane row of value (L & 15): each butterfly level keeps the half of the
+// values selected by one bit of the lane index (17 DPP moves instead of 64 for 16 separate row sums); fixed order.
+__device__ __forceinline__ float row16_transposed_sum(const float (&a)[16], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float w8[8], x4[4], y2[2];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const float keep = b0 ? a[2 * m + 1] : a[2 * m], send = b0 ? a[2 * m] : a[2 * m + 1];
+    w8[m] = keep + dpp_move<0xB1>(send);                              // lane ^ 1
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float keep = b1 ? w8[2 * m + 1] : w8[2 * m], send = b1 ? w8[2 * m] : w8[2 * m + 1];
+    x4[m] = keep + dpp_move<0x4E>(send);                              // lane ^ 2
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const float keep = b2 ? x4[2 * m + 1] : x4[2 * m], send = b2 ? x4[2 * m] : x4[2 * m + 1];
+    const float dn = dpp_move<0x124>(send), up = dpp_move<0x12C>(send);   // row_ror 4 / 12: from lane - 4 / lane + 4
+    y2[m] = keep + (b2 ? dn : up);                                    // lane ^ 4
+  }
+  const float keep = b3 ? y2[1] : y2[0], send = b3 ? y2[0] : y2[1];
+  return keep + dpp_move<0x128>(send);                                // row_ror 8: lane ^ 8
+}
+// ... and over the whole wave: every lane L ends with the sum over all 64 lanes of value (L & 15) (two cross-row exchanges through
+// the LDS crossbar on top of the row butterfly; all 64 lanes must be active)
+__device__ __forceinline__ float wave_transposed_sum16(const float (&a)[16], int lane) {
+  float t = row16_transposed_sum(a, lane);
+  t += __shfl_xor(t, 16);
+  t += __shfl_xor(t, 32);
+  return t;
+}
+
 // Deterministic block sum (fixed tree order).  `red` must hold blockDim.x/64 floats.  All threads
 // must call; result valid in every thread.
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -915,7 +915,7 @@ lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
 __global__ void __launch_bounds__(256)
 lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj, const float* __restrict__ v_posed,
                      int vp_rows, const float* __restrict__ dverts, float* __restrict__ dvp) {
-  __shared__ float As[64 * 12];
+  __shared__ __attribute__((aligned(16))) float As[64 * 12];
   __shared__ float gs[LBS_DENSE_CHUNK * 3], vs[LBS_DENSE_CHUNK * 3];
   __shared__ float red[3 * 4];
   const int b = blockIdx.y, ch = blockIdx.x, t = threadIdx.x;
@@ -997,9 +997,10 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     for (int k = 0; k < KWF; ++k) {
       const float w = wk[r][k];
       const float* Aj = As + wj[r][k];
-      T[0] = fmaf(w, Aj[0], T[0]); T[1] = fmaf(w, Aj[1], T[1]); T[2] = fmaf(w, Aj[2], T[2]);
-      T[3] = fmaf(w, Aj[4], T[3]); T[4] = fmaf(w, Aj[5], T[4]); T[5] = fmaf(w, Aj[6], T[5]);
-      T[6] = fmaf(w, Aj[8], T[6]); T[7] = fmaf(w, Aj[9], T[7]); T[8] = fmaf(w, Aj[10], T[8]);
+      const float4 a0 = ld4(Aj), a1 = ld4(Aj + 4), a2 = ld4(Aj + 8);   // three 16-byte LDS reads per joint (48-byte rows)
+      T[0] = fmaf(w, a0.x, T[0]); T[1] = fmaf(w, a0.y, T[1]); T[2] = fmaf(w, a0.z, T[2]);
+      T[3] = fmaf(w, a1.x, T[3]); T[4] = fmaf(w, a1.y, T[4]); T[5] = fmaf(w, a1.z, T[5]);
+      T[6] = fmaf(w, a2.x, T[6]); T[7] = fmaf(w, a2.y, T[7]); T[8] = fmaf(w, a2.z, T[8]);
     }
     for (int k = KWF; k < c.KW; ++k) {                         // models with more than 4 weights per vertex
       const float w = wv[k];
@@ -1026,9 +1027,9 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
       if (lane < 12) part[j * 12 + lane] = 0.f;
       continue;
     }
-    float acc[12];
+    float acc[16];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (int q = q0 + lane; q < q1; q += 64) {
       const int l = (staged ? cus[q - e0] : u.jc_u[q]) - s0;
       const float w = staged ? cws[q - e0] : u.jc_w[q];
@@ -1040,12 +1041,11 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
         acc[4 * r + 2] = fmaf(gv, vz, acc[4 * r + 2]); acc[4 * r + 3] += gv;
       }
     }
-#pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = wave_sum(acc[e]);
-    if (lane == 0) {
-#pragma unroll
-      for (int e = 0; e < 12; ++e) part[j * 12 + e] = acc[e];
-    }
+    // the twelve sums over the wave in one transposed butterfly (lane e ends with entry e) and ONE store by twelve lanes: twelve
+    // separate wave sums + twelve stores by lane 0 were ~170 of the ~220 vector instructions a joint costs, and the kernel is bound
+    // by exactly those (round 4: 4 instruction-issue cycles each; frames per workgroup, occupancy and table staging made no difference)
+    const float tot = wave_transposed_sum16(acc, lane);
+    if (lane < 12) part[j * 12 + lane] = tot;
   }
 }
 __global__ void __launch_bounds__(256)
