@@ -125,6 +125,9 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         if int(conv_variant) >= 2 and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
             conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124)
         self.conv_variant = d.conv_variant = int(conv_variant)
+        if not self.per_frame:
+            from .priors import warn_if_wide_image
+            warn_if_wide_image(self.lib, H, W, self.conv_variant)
         d.vposer, d.body, d.skin, d.uset, d.fit = self.vposer_struct, self.dev.body, self.dev.skin, uset, fit
         d.fwd_ids = ptr(I['fwd_ids'])
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c

@@ -324,3 +324,19 @@ class Enc(nn.Module):
         """mean((z[...,1:]-z[...,:-1])**2) for x [1,1,d,T] without materialising z in NCHW."""
         lib = self._lib_override or _hip.get_lib()
         return _SmoothPriorLoss.apply(x[0, 0], self.packed(x.device), lib)
+
+
+def warn_if_wide_image(lib, H: int, W: int, conv_variant: int) -> bool:
+    """The single-layer split kernels stage a 1-D tile of 128 pixels with its two halo rows and hold images up to W = 134 -- the
+    T = 120 clip (and the 100-frame PROX window) they were built for.  Longer clips still fit correctly, but five of the encoder's
+    fourteen 3x3 launches fall back to the fp32-input kernels (3.9 x the encoder time for 1.9 x the pixels at 238
+    frames).  Warn once per shape so that the slowdown is not silent; returns True when the fallback applies."""
+    import warnings
+    H, W = int(H), int(W)
+    too_wide = 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 > 408          # conv_split_kernels.hip: CV3_NPX staged pixels
+    if conv_variant >= 3 and H * W >= 128 and too_wide and not lib.conv3x3_split_supported(H, W, 64, 64):
+        warnings.warn(f'lemo_amd: smoothness image {H} x {W} is wider than the split-f16 single-layer kernels take (W <= 134, i.e. clips of '
+                      f'up to 120 frames); the 32-channel layers and the unpaired 64 -> 64 layers run on the slower fp32-input kernels',
+                      RuntimeWarning, stacklevel=3)
+        return True
+    return False

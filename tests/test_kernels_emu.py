@@ -568,3 +568,17 @@ def _splitk_case(lib, g, M, N, K, S, grouped):
         outs.append(Cm)
     assert torch.equal(outs[0], outs[1])
     assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_wide_clip_warns_about_the_slower_encoder_path(emu_lib):
+    """clips longer than 120 frames: the image is wider than the split-f16 single-layer kernels stage (W <= 134); the engine still
+    fits them (fp32-input fallback for five launches) but says so once at construction; the reference's clip length does not warn"""
+    import warnings
+    from lemo_amd.priors import warn_if_wide_image
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert warn_if_wide_image(emu_lib, 245, 134, 5) is False            # T = 120
+        assert warn_if_wide_image(emu_lib, 245, 115, 5) is False            # the 100-frame PROX window
+        assert warn_if_wide_image(emu_lib, 245, 253, 2) is False            # fp32 variants have no such limit
+    with pytest.warns(RuntimeWarning, match='wider than'):
+        assert warn_if_wide_image(emu_lib, 245, 253, 5) is True
