@@ -122,8 +122,10 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         d.B, d.Bp, d.V, d.nrows, d.full_vertices = B, Bp, data.V, self.nrows, int(self.full)
         if conv_variant is None:
             conv_variant = DEFAULT_CONV_VARIANT
-        if int(conv_variant) >= 2 and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
-            conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124)
+        if int(conv_variant) in (2, 3, 4) and 127 + 2 * (127 // self.W + 1) + 2 * (self.W + 2) + 3 > 416:
+            conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124); the single-layer split kernels W <= 134
+        # (variant 5 stays: the fused pairs take any width -- 12 of the 14 64 -> 64 layers; the engine sends the other launches to the
+        # fp32-input kernel layer by layer, lemo_amd/csrc/enc_chain.hpp::enc_layer.  Round 4: all 18 launches used to fall back.)
         self.conv_variant = d.conv_variant = int(conv_variant)
         if not self.per_frame:
             from .priors import warn_if_wide_image

@@ -328,9 +328,9 @@ class Enc(nn.Module):
 
 def warn_if_wide_image(lib, H: int, W: int, conv_variant: int) -> bool:
     """The single-layer split kernels stage a 1-D tile of 128 pixels with its two halo rows and hold images up to W = 134 -- the
-    T = 120 clip (and the 100-frame PROX window) they were built for.  Longer clips still fit correctly, but five of the encoder's
-    fourteen 3x3 launches fall back to the fp32-input kernels (3.9 x the encoder time for 1.9 x the pixels at 238
-    frames).  Warn once per shape so that the slowdown is not silent; returns True when the fallback applies."""
+    T = 120 clip (and the 100-frame PROX window) they were built for.  Longer clips fit correctly and keep the fused 64 -> 64 pairs
+    (any width), but the five encoder launches that are not pairs fall back to the fp32-input kernel (1563 it/s at
+    238 frames where linear scaling from 119 would give ~1700).  Warn so that the slowdown is not silent; True when it applies."""
     import warnings
     H, W = int(H), int(W)
     too_wide = 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 > 408          # conv_split_kernels.hip: CV3_NPX staged pixels

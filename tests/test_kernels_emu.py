@@ -570,6 +570,41 @@ def _splitk_case(lib, g, M, N, K, S, grouped):
     assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
+@pytest.mark.timeout(1800)
+def test_wide_clip_keeps_the_fused_pairs_and_matches_the_oracle(emu_lib):
+    """B = 130 (W = 145 > 134): the single-layer split kernels do not take the image, the fused pairs do -- the engine keeps conv
+    variant 5 (pairs fused, the other encoder launches on the fp32-input kernel layer by layer) and the iteration still matches the
+    oracle: losses, gradients, one Adam step"""
+    import warnings
+    import __graft_entry__ as ge
+    from lemo_amd.fitting import AmassTemporalFitter
+    prob = ge.small_problem(B=130)
+    ofit, markers = ge.oracle_for(prob)
+    total, parts, _, verts = ofit.losses()
+    total.backward()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
+                                  prob['B'], 'cpu', full_vertices=True, lib=emu_lib, conv_variant=5)
+    assert fit.conv_variant == 5 and any('wider than' in str(x.message) for x in w)
+    assert not emu_lib.conv3x3_split_supported(fit.H, fit.W, 64, 64) and emu_lib.conv3x3_pair_supported(fit.H, fit.W, 64, 64, 64)
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    fit.forward()
+    fit.backward()
+    L = fit.losses()
+    for k in ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth'):
+        assert abs(L[k] - float(parts[k])) <= 1e-5 * abs(float(parts[k])), (k, L[k], float(parts[k]))
+    g = fit.grads_with_priors()
+    for k, ref in (('transl', ofit.transl.grad), ('rot6d', ofit.rot6d.grad), ('other', ofit.other.grad)):
+        assert rel_err(g[k], ref) < 2e-4, k
+    fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
+    ofit.opt.zero_grad()
+    ofit.step()
+    fit.step(1, use_graph=False)
+    dp = (fit.params75() - ofit.params75()).abs()                   # lr 1e-2: a few entries with rounding-sized gradients among 9750
+    assert float(dp.max()) < 2e-5 and float(dp.mean()) < 2e-8, (float(dp.max()), float(dp.mean()))
+
+
 def test_wide_clip_warns_about_the_slower_encoder_path(emu_lib):
     """clips longer than 120 frames: the image is wider than the split-f16 single-layer kernels stage (W <= 134); the engine still
     fits them (fp32-input fallback for five launches) but says so once at construction; the reference's clip length does not warn"""
