@@ -638,6 +638,22 @@ def main():
         from lemo_amd import synthetic as _syn
         _syn.DEFAULT_COHERENT = True
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain ``python bench.py --gpus N`` (the way a driver runs --gpus 1; the reference itself is one process looping over clips,
+        # opt_amass_temp.py:251): become the launcher -- one rank per GPU under torch.distributed.run, same argv, and pass its exit
+        # code on.  The ranks print the ONE JSON line (rank 0) to this process's stdout.
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(('127.0.0.1', 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '2' if args.emu else '8')
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

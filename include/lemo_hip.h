@@ -312,7 +312,9 @@ int lemo_ae_forward(void* h, float* rec, float* z, void* stream);
 int lemo_ae_params(void* h, float* flat_out, void* stream);
 /* the same per clip of a multi-clip engine (clip 0 .. desc.clips - 1; the un-suffixed forms address clip 0).  lemo_ae_forward_clip with
  * clip 0 (or -1: no copy-out) runs the eval forward of ALL clips; clips > 0 only copy that forward's reconstruction / latent out:
- * call it for clip 0 first. */
+ * call it for clip 0 first.  State rules (LEMO_ERR_STATE otherwise): lemo_ae_step / lemo_ae_forward* need EVERY clip of the engine loaded
+ * since creation (a step advances all of them; an unloaded clip would train from a zeroed workspace); lemo_ae_forward_clip(clip > 0) needs
+ * an eval forward (clip 0 or -1) AFTER the last step / load; lemo_ae_params_clip needs that clip loaded. */
 int lemo_ae_load_clip(void* h, int clip, const float* flat, const float* x, const float* moc, void* stream);
 int lemo_ae_forward_clip(void* h, int clip, float* rec, float* z, void* stream);
 int lemo_ae_params_clip(void* h, int clip, float* flat_out, void* stream);

@@ -648,7 +648,8 @@ struct AeEngine {
   float *P[5], *dP[5], *S[5];
   unsigned char* idx[5];
   hipGraphExec_t exec[2] = {nullptr, nullptr};      // 5 steps, 1 step
-  int loaded = 0;
+  unsigned long long loaded = 0;   // bit c: clip c has been loaded (every clip must be before a step / forward: ADVICE r04)
+  int forward_valid = 0;           // an eval forward of all clips ran after the last step / load (what forward_clip(c > 0) copies from)
   int nclip = 1;               // clips side by side: clip c's buffers are the pointers above + c * cs floats
   size_t cs = 0;
 };
@@ -897,16 +898,21 @@ int lemo_ae_load_clip(void* h, int clip, const float* flat, const float* x, cons
   if ((rc = (int)hipMemsetAsync(e->ctr + o, 0, sizeof(float) * 64, s))) return rc;
   if ((rc = (int)hipMemcpyAsync(e->moc + o, moc, sizeof(float) * H * W, hipMemcpyDeviceToDevice, s))) return rc;
   hipLaunchKernelGGL(ae_to_cg8p_kernel, dim3((4 * H * W + 255) / 256), dim3(256), 0, s, x, 4, H, W, e->x8 + o);
-  e->loaded = 1;
+  e->loaded |= 1ull << clip;
+  e->forward_valid = 0;
   return (int)hipGetLastError();
+}
+static bool ae_all_loaded(const AeEngine* e) {
+  return e->loaded == (e->nclip >= 64 ? ~0ull : (1ull << e->nclip) - 1ull);
 }
 int lemo_ae_load(void* h, const float* flat, const float* x, const float* moc, void* stream) { return lemo_ae_load_clip(h, 0, flat, x, moc, stream); }
 
 int lemo_ae_step(void* h, int n, int use_graph, void* stream) {
   AeEngine* e = (AeEngine*)h;
   if (!e || n < 0) return LEMO_ERR_ARG;
-  if (!e->loaded) return LEMO_ERR_STATE;
+  if (!ae_all_loaded(e)) return LEMO_ERR_STATE;            // a step advances EVERY clip: one that was never loaded would train from stale parameters
   hipStream_t s = (hipStream_t)stream;
+  if (n > 0) e->forward_valid = 0;
   if (!use_graph) {
     for (int i = 0; i < n; ++i) { const int rc = ae_train_step(e, s); if (rc) return rc; }
     return 0;
@@ -925,9 +931,10 @@ int lemo_ae_step(void* h, int n, int use_graph, void* stream) {
 int lemo_ae_forward_clip(void* h, int clip, float* rec, float* z, void* stream) {
   AeEngine* e = (AeEngine*)h;
   if (!e || clip >= e->nclip || (clip >= 0 && !rec)) return LEMO_ERR_ARG;
-  if (!e->loaded) return LEMO_ERR_STATE;
+  if (!ae_all_loaded(e)) return LEMO_ERR_STATE;
   hipStream_t s = (hipStream_t)stream;
-  if (clip <= 0) { const int rc = ae_forward(e, s); if (rc) return rc; }      // clip 0 (or -1) runs the forward; later clips read its results
+  if (clip <= 0) { const int rc = ae_forward(e, s); if (rc) return rc; e->forward_valid = 1; }      // clip 0 (or -1) runs the forward; later clips read its results
+  else if (!e->forward_valid) return LEMO_ERR_STATE;       // no eval forward since the last step / load: nothing valid to copy out
   if (clip < 0) return 0;
   const int H = e->H[0], W = e->W[0];
   const size_t o = (size_t)clip * e->cs;
@@ -940,7 +947,7 @@ int lemo_ae_forward(void* h, float* rec, float* z, void* stream) { return lemo_a
 int lemo_ae_params_clip(void* h, int clip, float* flat_out, void* stream) {
   AeEngine* e = (AeEngine*)h;
   if (!e || !flat_out || clip < 0 || clip >= e->nclip) return LEMO_ERR_ARG;
-  if (!e->loaded) return LEMO_ERR_STATE;
+  if (!(e->loaded >> clip & 1ull)) return LEMO_ERR_STATE;
   const int n_all = e->n_w + e->n_b;
   hipLaunchKernelGGL((ae_pack_kernel<true>), dim3((n_all + 255) / 256), dim3(256), 0, (hipStream_t)stream, ae_pack_args(e),
                      (const float*)e->theta + (size_t)clip * e->cs, flat_out, (float*)nullptr);
@@ -953,7 +960,7 @@ int lemo_ae_params(void* h, float* flat_out, void* stream) { return lemo_ae_para
 int lemo_ae_wgrad_probe(void* h, int mode, void* stream) {
   AeEngine* e = (AeEngine*)h;
   if (!e || mode < 0 || mode > 4) return LEMO_ERR_ARG;
-  if (!e->loaded) return LEMO_ERR_STATE;
+  if (!ae_all_loaded(e)) return LEMO_ERR_STATE;
   return ae_wgrad_launch(e, (hipStream_t)stream, mode);
 }
 

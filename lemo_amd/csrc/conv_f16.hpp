@@ -44,6 +44,19 @@ __device__ __forceinline__ void f16_scale_for(float m, float& scale, float& inv)
   scale = __builtin_bit_cast(float, (unsigned)bs << 23);
   inv = __builtin_bit_cast(float, (unsigned)(254 - bs) << 23);
 }
+// scale of a LATER staging phase of the same accumulation: the accumulators are rescaled by scale / prev when the phase changes, so the
+// ratio is bounded (2^40: sums of <= 2^39 stay finite) -- a phase that is all zero, or > 2^40 below the previous one, takes prev * 2^40
+// instead of 2^126 (its operands are then carried to an absolute 2^-64 of the previous phase's: far below that phase's own rounding).
+// Without the bound an input whose channels 16-31 / 48-63 vanish on a tile turned every output of that tile into Inf * 0.
+__device__ __forceinline__ void f16_scale_after(float m, float prev_scale, float& scale, float& inv) {
+  const int biased = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu);
+  const int bp = (int)((__builtin_bit_cast(unsigned, prev_scale) >> 23) & 0xffu);
+  int bs = 268 - biased;
+  bs = bs > bp + 40 ? bp + 40 : bs;
+  bs = bs < 1 ? 1 : (bs > 253 ? 253 : bs);
+  scale = __builtin_bit_cast(float, (unsigned)bs << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(254 - bs) << 23);
+}
 __device__ __forceinline__ float absmax4(float4 v, float m) {
   return fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
 }

@@ -319,7 +319,7 @@ conv3x3_pair_kernel(PairArgs a) {
           float mm = 0.f;
 #pragma unroll
           for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[8 + i]);
-          f16_scale_for(mm, sc[1], sci[1]);
+          f16_scale_after(mm, sc[0], sc[1], sci[1]);
         }
 #pragma unroll
         for (int k = 0; k < CP_NSLOT; ++k) {

@@ -357,7 +357,7 @@ __device__ __forceinline__ void split_layer(const float* __restrict__ in, const 
           float mm = 0.f;
 #pragma unroll
           for (int i = 0; i < NW; ++i) mm = fmaxf(mm, wmax[16 + i]);
-          f16_scale_for(mm, sc[1], sci[1]);
+          f16_scale_after(mm, sc[0], sc[1], sci[1]);
         }
       }
       // second-phase staging spread over taps 2..8 (slot k at tap 2 + 7k/NB): its VALU ops and LDS writes

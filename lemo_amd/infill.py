@@ -528,6 +528,7 @@ class _EngineSession:
             raise _hip.LemoHipError(f'lemo_ae_ws_floats refuses a {H} x {W} clip image')
         self.stream = torch.cuda.Stream(self.device) if self.gpu else None       # used when the caller sits on the legacy default stream
         self.ws = torch.zeros(n * self.clips, dtype=torch.float32, device=self.device)       # zero borders = the convolutions' padding
+        self.ws_bytes = 4 * n * self.clips
         h5, w5 = H, W
         for _ in range(5):
             h5, w5 = (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1
@@ -625,6 +626,19 @@ _SESSIONS: Dict[tuple, object] = {}
 _MAX_SESSIONS = 8
 """sessions kept alive at once (LRU): each pins a workspace (or ~45 workspace buffers), a stream and instantiated graphs; PROX
 tail windows and recordings of varying length would otherwise add one per clip shape without bound (ADVICE r02)."""
+_MAX_SESSION_BYTES = 4 << 30
+"""... and the bytes their workspaces may pin together (ADVICE r04: an engine session holds clips x ~160 MB at 210 x 135; counting
+sessions alone let eight 8-clip engines of different shapes hold 10 GB).  The most recent session always stays."""
+
+
+def _engine_clips(n: int) -> int:
+    """engine size for a group of n clips: the next power of two (1, 2, 4, 8, 16).  A tail group runs on an engine of that size
+    with its last clip repeated in the spare slots (outputs ignored) -- at most five engine sizes (and captured graph sets) per clip
+    shape instead of one per distinct tail length."""
+    k = 1
+    while k < n:
+        k *= 2
+    return k
 
 
 def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine: bool = False, clips: int = 1):
@@ -636,7 +650,8 @@ def _session(lib, n_param: int, shape, lr: float, device, slot: int = 0, engine:
         else:
             ses = _FinetuneSession(lib, n_param, tuple(shape), lr, device)
     _SESSIONS[key] = ses                                   # most recently used last
-    while len(_SESSIONS) > _MAX_SESSIONS:
+    pinned = lambda: sum(int(getattr(v, 'ws_bytes', 0)) for v in _SESSIONS.values())
+    while len(_SESSIONS) > 1 and (len(_SESSIONS) > _MAX_SESSIONS or pinned() > _MAX_SESSION_BYTES):
         _SESSIONS.pop(next(iter(_SESSIONS)))               # its destructor waits for its last launch and releases the graphs
     return ses
 
@@ -696,7 +711,7 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
     engines on two streams instead -- 24 ms per clip when the runtime happened to put the streams into different hardware queues,
     33 when not; gone.)  Everything is enqueued on the caller's stream (the session's own stream when the caller sits on the legacy
     default stream, which cannot be captured).  A group smaller than ``AE_CLIPS`` (the tail, or clips of a
-    shape of their own) runs on an engine of its own size.  Each clip's result is bit-identical to its solo
+    shape of their own) runs on an engine of the next power-of-two size with its last clip repeated (:func:`_engine_clips`).  Each clip's result is bit-identical to its solo
     ``finetune_and_infill`` (same kernels, same launch shapes per clip, no shared state; tested).  Returns the list of
     ``(clip_img_rec, z)`` in input order; the model is left with the LAST clip's finetuned weights.  (``engine=False``: the
     round-2 path, one session per clip, at most ``_MAX_SESSIONS`` clips.)"""
@@ -717,12 +732,14 @@ def finetune_and_infill_many(model: AE, weights: dict, clips: List[torch.Tensor]
         groups = [idx[j:j + AE_CLIPS] for idx in by_shape.values() for j in range(0, len(idx), AE_CLIPS)]
         for grp in groups:
             x0 = clips[grp[0]]
-            ses = _session(lib, flat0.numel(), x0.shape, lr, x0.device, engine=True, clips=len(grp))
-            flat, rec, z = ses.run_clips(flat0, [clips[i] for i in grp], [mocs[i] for i in grp], steps, use_graph)
+            k = _engine_clips(len(grp))
+            run = list(grp) + [grp[-1]] * (k - len(grp))          # spare slots repeat the last clip; their outputs are dropped
+            ses = _session(lib, flat0.numel(), x0.shape, lr, x0.device, engine=True, clips=k)
+            flat, rec, z = ses.run_clips(flat0, [clips[i] for i in run], [mocs[i] for i in run], steps, use_graph)
             # the session's next run overwrites its buffers: copies (ordered after the run: same stream, or joined)
             r, zz = rec[:, None, None, 1:-1, 8:-8].clone(), z[:, None].clone()
             if grp[-1] == len(clips) - 1:
-                last_flat = flat[-1].clone()
+                last_flat = flat[len(grp) - 1].clone()
             for c, i in enumerate(grp):
                 out[i] = (r[c], zz[c])
         _store_params(model, last_flat)

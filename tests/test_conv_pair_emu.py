@@ -100,6 +100,43 @@ def test_pair_range_homogeneity_and_zero_input(emu_lib):
     assert rel_err(from_cg8p(oz, H, W), refz) < 2e-6
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('case', ['second_phase_zero', 'second_phase_tiny', 'first_phase_zero'])
+def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case):
+    """the kernels stage channels {0-15, 32-47} and {16-31, 48-63} in two phases with their own power-of-two
+    scales and rescale the accumulators by the ratio in between.  A second phase that is exactly zero (scale clamped to 2^126) or
+    2^90 below the first made that ratio overflow: all-NaN tiles with rc == 0.  The later phase's scale is now bounded by the
+    earlier one's (conv_f16.hpp::f16_scale_after); every output stays finite and fp32-accurate."""
+    H, W = 16, 20
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(64, H, W, generator=g)
+    second = torch.zeros(64, dtype=torch.bool)
+    second[16:32] = True
+    second[48:64] = True
+    if case == 'second_phase_zero':
+        x[second] = 0.0
+    elif case == 'second_phase_tiny':
+        x[second] *= 2.0 ** -95
+    else:
+        x[~second] = 0.0
+    w1, w2 = torch.randn(64, 64, 3, 3, generator=g) * 0.06, torch.randn(64, 64, 3, 3, generator=g) * 0.06
+    b1, b2 = torch.randn(64, generator=g) * 0.3, torch.randn(64, generator=g) * 0.3
+    p1, i1, _, _ = _packs(w1)
+    p2, i2, _, _ = _packs(w2)
+    a1 = F.leaky_relu(F.conv2d(x[None].double(), w1.double(), b1.double(), padding=1), 0.2)
+    a2 = F.leaky_relu(F.conv2d(a1, w2.double(), b2.double(), padding=1), 0.2)[0]
+    xin, mid, out = to_cg8p(x), cg8p_alloc(64, H, W, 'cpu'), cg8p_alloc(64, H, W, 'cpu')
+    assert emu_lib.conv3x3_pair_f16(ptr(xin), ptr(p1), i1, ptr(b1), None, ptr(mid), ptr(p2), i2, ptr(b2), None, ptr(out), H, W, 0, None, None) == 0
+    assert bool(torch.isfinite(mid).all()) and bool(torch.isfinite(out).all())
+    assert rel_err(from_cg8p(mid, H, W).double(), a1[0]) < 2e-6 and rel_err(from_cg8p(out, H, W).double(), a2) < 2e-6
+    if emu_lib.conv3x3_split_supported(H, W, 64, 64):          # the single-layer kernel the pair's staging was taken from
+        from lemo_amd.priors import pack_conv3x3
+        wt1 = torch.from_numpy(pack_conv3x3(w1.numpy()))
+        s_mid = cg8p_alloc(64, H, W, 'cpu')
+        assert emu_lib.conv3x3_mfma_split_f16(ptr(xin), ptr(p1), i1, ptr(wt1), ptr(b1), None, ptr(s_mid), H, W, 64, 64, 0, None) == 0
+        assert bool(torch.isfinite(s_mid).all()) and rel_err(from_cg8p(s_mid, H, W).double(), a1[0]) < 2e-6
+
+
 def test_pair_rejects_bad_arguments(emu_lib):
     x = cg8p_alloc(64, 12, 20, 'cpu')
     w = torch.zeros(4 * 9 * 2 * 2 * 64 * 8, dtype=torch.int16)
