@@ -316,12 +316,27 @@ class SmplxOracle:
 # --------------------------------------------------------------------------------------------
 
 
-def vposer_decode(w: Dict[str, torch.Tensor], Z: torch.Tensor, output_type: str = 'aa'):
-    """``w`` holds bodyprior_dec_{fc1,fc2,out}.{weight,bias}; dropout is identity in eval()."""
+def vposer_decode(w: Dict[str, torch.Tensor], Z: torch.Tensor, output_type: str = 'aa', branches=None, hidden=None, perturb=None):
+    """``w`` holds bodyprior_dec_{fc1,fc2,out}.{weight,bias}; dropout is identity in eval().
+
+    Test devices (not reference behaviour): ``branches`` = two bool tensors [B,512], True where a hidden unit takes the slope-1 branch
+    of its LeakyReLU whatever its sign (``AmassFitOracle.decisions``); ``hidden`` = a list that receives the two hidden activations;
+    ``perturb(x6d, abs_sum)`` = replaces the out layer's result (abs_sum = sum_i |w_ji h_i| + |b_j|, the scale of an fp32 dot product's
+    rounding error): how tests measure the CONDITIONING of the Gram-Schmidt decode that follows (tests/kink_attribution.py)."""
     assert output_type in ('matrot', 'aa')
-    x = F.leaky_relu(F.linear(Z, w['bodyprior_dec_fc1.weight'], w['bodyprior_dec_fc1.bias']), 0.2)
-    x = F.leaky_relu(F.linear(x, w['bodyprior_dec_fc2.weight'], w['bodyprior_dec_fc2.bias']), 0.2)
+    x = Z
+    for i, name in enumerate(('bodyprior_dec_fc1', 'bodyprior_dec_fc2')):
+        pre = F.linear(x, w[name + '.weight'], w[name + '.bias'])
+        if branches is None:
+            x = F.leaky_relu(pre, 0.2)
+        else:
+            x = pre * torch.where(branches[i], torch.ones((), dtype=pre.dtype), torch.full((), 0.2, dtype=pre.dtype))
+        if hidden is not None:
+            hidden.append(x.detach())
+    h2 = x
     x = F.linear(x, w['bodyprior_dec_out.weight'], w['bodyprior_dec_out.bias'])
+    if perturb is not None:
+        x = perturb(x, F.linear(h2.detach().abs(), w['bodyprior_dec_out.weight'].abs(), w['bodyprior_dec_out.bias'].abs()))
     nj = x.shape[1] // 6
     x = rot6d_to_matrix(x).view([-1, 1, nj, 9])
     if output_type == 'aa':
@@ -349,13 +364,20 @@ def make_vposer_weights(seed: int = 2, latentD: int = 32, num_neurons: int = 512
 # --------------------------------------------------------------------------------------------
 
 
-def enc_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, return_all: bool = False):
-    """models/AE_sep.py:91-99 with ``downsample=False`` (no pooling, :24-27)."""
+def enc_forward(w: Dict[str, torch.Tensor], x: torch.Tensor, return_all: bool = False, branches=None):
+    """models/AE_sep.py:91-99 with ``downsample=False`` (no pooling, :24-27).
+
+    ``branches`` (test device, not reference behaviour): ten bool tensors, True where a unit is to take the slope-1 branch of its
+    LeakyReLU whatever the sign of its pre-activation -- ``AmassFitOracle.decisions`` explains the use."""
     acts = []
     for blk in range(1, 6):
         for idx in (0, 2):
-            x = F.leaky_relu(F.conv2d(x, w[f'enc_blc{blk}.main.{idx}.weight'],
-                                      w[f'enc_blc{blk}.main.{idx}.bias'], stride=1, padding=1), 0.2)
+            pre = F.conv2d(x, w[f'enc_blc{blk}.main.{idx}.weight'], w[f'enc_blc{blk}.main.{idx}.bias'], stride=1, padding=1)
+            if branches is None:
+                x = F.leaky_relu(pre, 0.2)
+            else:
+                b = branches[len(acts)].reshape(pre.shape)
+                x = pre * torch.where(b, torch.ones((), dtype=pre.dtype), torch.full((), 0.2, dtype=pre.dtype))
             acts.append(x)
     return (x, acts) if return_all else x
 
@@ -422,11 +444,22 @@ class AmassFitOracle:
         self.opt = torch.optim.Adam([self.transl, self.rot6d, self.other], lr=0.01)
         self.step_idx = 0
         self.last_p72 = None
+        # Test device (NOT reference behaviour; None = the reference's arithmetic): the objective is piecewise smooth -- 21 M LeakyReLU
+        # units, 24 k L1 residuals, thresholded contact speeds -- and two correct implementations that round differently can sit on
+        # different pieces.  ``decisions`` pins the piece: dict(lrelu=[10 bool tensors: unit on its slope-1 branch],
+        # l1_sign=[B,67,3] in {-1,0,1}, contact=[4 bool tensors over the labelled (frame, vertex) speeds: inside the mean]).  With
+        # another implementation's decisions loaded, this oracle in float64 returns the EXACT gradient of the piece that implementation
+        # was on: what remains between the two is arithmetic, not luck (tests/kink_attribution.py).  Optional key vposer=[2 bool
+        # tensors [B,512]]: the decoder's own 2 x 512 LeakyReLU units per frame (vposer_smpl.py:107-121) -- the fourth kink family.
+        self.decisions = None
 
     # -- forward pieces -------------------------------------------------------------------
     def _body(self, p72):
         B = p72.shape[0]
-        body_pose = vposer_decode(self.vposer_w, p72[:, 16:48], 'aa').view(B, -1)
+        dec = getattr(self, 'decisions', None)
+        self.last_hidden = []
+        body_pose = vposer_decode(self.vposer_w, p72[:, 16:48], 'aa', branches=None if dec is None else dec.get('vposer'),
+                                  hidden=self.last_hidden, perturb=getattr(self, 'perturb6d', None)).view(B, -1)
         return self.smplx.forward(betas=p72[:, 6:16], global_orient=p72[:, 3:6], body_pose=body_pose,
                                   left_hand_pose=p72[:, 48:60], right_hand_pose=p72[:, 60:],
                                   transl=p72[:, 0:3])
@@ -455,11 +488,15 @@ class AmassFitOracle:
         img = img.permute(0, 2, 1).unsqueeze(1)                         # [1,1,243,B]
         img_v = img[:, :, :, 1:] - img[:, :, :, 0:-1]
         img_v = F.pad(img_v, (8, 8, 1, 1), 'reflect')                   # [1,1,245,B-1+16]
-        z = enc_forward(self.enc_w, img_v)
+        dec = self.decisions
+        z = enc_forward(self.enc_w, img_v) if dec is None else enc_forward(self.enc_w, img_v, branches=dec['lrelu'])
         z_v = z[:, :, :, 1:] - z[:, :, :, 0:-1]
         loss_smooth = torch.mean(z_v ** 2)
 
-        loss_marker = F.l1_loss(markers_opt, self.markers_rec)
+        if dec is None:
+            loss_marker = F.l1_loss(markers_opt, self.markers_rec)
+        else:
+            loss_marker = torch.mean((markers_opt - self.markers_rec) * dec['l1_sign'].to(markers_opt.dtype))
         loss_vposer = torch.mean(p72[:, 16:48] ** 2)
         loss_shape = torch.mean(p72[:, 6:16] ** 2)
         loss_hand = torch.mean(p72[:, 48:] ** 2)
@@ -471,7 +508,10 @@ class AmassFitOracle:
                 lbl = self.contact[:, k]
                 s = torch.norm(vel[:, self.ids[name], :][lbl[0:-1] == 1], dim=-1)
                 part = torch.tensor(0.0)
-                if (s - 0.1).gt(0).sum().item() >= 1:
+                if dec is not None:
+                    if bool(dec['contact'][k].any()):
+                        part = s[dec['contact'][k]].abs().mean()
+                elif (s - 0.1).gt(0).sum().item() >= 1:
                     part = s[s > 0.1].abs().mean()
                 loss_contact = loss_contact + part
         total = (self.w['rec_markers'] * loss_marker + self.w['vposer'] * loss_vposer +

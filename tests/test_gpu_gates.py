@@ -192,7 +192,8 @@ def test_gradient_error_statistics_over_seeds(dev):
     ewt = {k: torch.from_numpy(v) for k, v in A['enc_w'].items()}
     variants = (5, 4, 3, 2)
     fits = {v: AmassTemporalFitter(model, vw, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 119, dev, full_vertices=True, conv_variant=v) for v in variants}
-    rows, ratio = [], {v: [] for v in variants}
+    rows, ratio, cond = [], {v: [] for v in variants}, []
+    import kink_attribution as KA
     for seed in range(5):
         seq = synthetic.make_synthetic_sequence(seed, B=119)
         f0 = fits[variants[0]]
@@ -219,6 +220,20 @@ def test_gradient_error_statistics_over_seeds(dev):
             ratio[v].append(gmax / cpu_max)
             assert gmed <= 3.0 * cpu_med + 2e-6, (seed, v, gmed, cpu_med)
             assert ltot <= 1e-5, (seed, v, ltot)
+        # Round 5: the same seed CONDITIONED on the engine's own kink decisions (tests/kink_attribution.py) -- the
+        # float64 oracle pinned to the piece of the objective the engine was on, the conditioning of the 6-D decode computed per frame.
+        # Every frame of every seed inside ROUND + C_R R[frame]; the engine's median frame <= 1.5 x the fp32 CPU path's; the worst
+        # unconditioned frame attributed (which decisions differ from float64's, what each family explains).
+        fit = fits[variants[0]]
+        fit.load_sequence(seq['init_params'], markers, seq['contact_lbl'])
+        out = KA.analyse(fit, o32, o64, label=f'seed {seed}')
+        KA.check(out, f'seed {seed}')
+        cond.append((seed, float(out['unc_gpu'].max()), float(out['cond_gpu'].max()), float((out['cond_gpu'] / (KA.ROUND + KA.C_R * out['R'])).max()),
+                     float(out['cond_gpu'].median()), float(out['cond_cpu'].max()), float(out['cond_cpu'].median()), float(out['R'].max()), out['n_diff']))
+    print('\nseed | GPU worst frame: unconditioned -> conditioned on its own decisions (x its computed bound) | conditioned median: GPU / CPU-fp32 | '
+          'CPU-fp32 conditioned worst | max R | decisions differing from float64')
+    for r in cond:
+        print('  %d  | %.2e -> %.2e (%.2f) | %.2e / %.2e | %.2e | %.1e | %s' % (r[0], r[1], r[2], r[3], r[4], r[6], r[5], r[7], r[8]))
     print('\nseed variant | gradient vs float64: GPU worst frame / median frame | CPU-fp32 worst / median | GPU total loss rel')
     for r in rows:
         print('  %d    %d     | %.2e / %.2e | %.2e / %.2e | %.1e' % r)
