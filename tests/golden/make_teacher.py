@@ -152,15 +152,24 @@ def perframe():
 
 # ----------------------------------------------------------------------------------------------------------------------
 PROX_N, PROX_B = 23, 14            # windows (0, 14) and (9, 23); frozen prefix of the second window int(0.15 * 14) = 2 frames
+# Round 5 (VERDICT r04 missing #2 / next #4): the same two chained windows at the BASELINE shape -- B = 100 frames per window (stride 70:
+# windows (0, 100) and (70, 170)), V = 10475, the real marker / friction id tables, the S2 / S3 YAML weights; 64^3 SDF so that the
+# reference's per-frame `repeat` of the grid stays at 105 MB.  Frozen prefix of the second window int(0.15 * 100) = 15 frames.
+PROX_FULL_N, PROX_FULL_B, PROX_FULL_D = 170, 100, 64
+PROX_FULL_STEPS = (0, 1, 30, 59)
+PROX_SIZES = dict(small=dict(N=PROX_N, B=PROX_B, steps=PROX_STEPS, file='teacher_prox.npz'),
+                  full=dict(N=PROX_FULL_N, B=PROX_FULL_B, steps=PROX_FULL_STEPS, file='teacher_prox_full.npz'))
 
 
-def prox_recording(stage):
-    """the seeded 23-frame recording both sides fit (``__graft_entry__.prox_small_problem(real_markers=True)``), with betas that
-    DIFFER from frame to frame so that the reference's per-window mean (fit_temp_loadprox_slide.py:497-498) is visible"""
+def prox_recording(stage, size='small'):
+    """the seeded recording both sides fit -- 23 frames of ``__graft_entry__.prox_small_problem(real_markers=True)`` or 170 frames of
+    ``prox_full_problem(D=64)`` -- with betas that DIFFER from frame to frame so that the reference's per-window mean
+    (fit_temp_loadprox_slide.py:497-498) is visible"""
     import __graft_entry__ as ge
-    base = ge.prox_small_problem(B=PROX_N, stage=stage, real_markers=True)
+    N = PROX_SIZES[size]['N']
+    base = ge.prox_small_problem(B=N, stage=stage, real_markers=True) if size == 'small' else ge.prox_full_problem(stage, B=N, D=PROX_FULL_D)
     rng = np.random.default_rng(17)
-    base['params'] = dict(base['params'], betas=(base['params']['betas'] + rng.standard_normal((PROX_N, 10)) * 0.05).astype(np.float32))
+    base['params'] = dict(base['params'], betas=(base['params']['betas'] + rng.standard_normal((N, 10)) * 0.05).astype(np.float32))
     return base
 
 
@@ -174,7 +183,7 @@ def prox_window_problem(base, s, e, params):
     return prob
 
 
-def prox():
+def prox(size='small'):
     """Two CHAINED windows through the reference's own objects: window 1 (first_batch_flag) -> the reference's pickle writer
     (fit_temp_loadprox_slide.py:577-594) -> the reference's reader (data_parser_slide.py:106-126) with its newest-result rule
     (:326-331) -> the reference's window initialisation (fit_temp_loadprox_slide.py:495-499: mean betas, reset_params) ->
@@ -182,12 +191,13 @@ def prox():
     import ref_harness as RH
     from lemo_amd import prox_windows as PW
     from oracle.f64 import prox_fit_oracle_f64, default_f64, flip_sensitivity_of
+    PROX_N, PROX_B, PROX_STEPS = (PROX_SIZES[size][k] for k in ('N', 'B', 'steps'))
     out = dict(steps=np.asarray(PROX_STEPS, np.int32), n_frames=np.int32(PROX_N), batch=np.int32(PROX_B))
     names = [f's001_frame_{i:05d}' for i in range(PROX_N)]
     wins = PW.sliding_windows(PROX_N, PROX_B)
-    assert wins == [(0, 14), (9, 23)]
+    assert wins == ([(0, 14), (9, 23)] if size == 'small' else [(0, 100), (70, 170)])
     for stage in ('S2', 'S3'):
-        base = prox_recording(stage)
+        base = prox_recording(stage, size)
         P0 = base['params']
         with tempfile.TemporaryDirectory() as tmp:
             cur, prox_dir = os.path.join(tmp, 'cur'), os.path.join(tmp, 'prox')
@@ -210,8 +220,10 @@ def prox():
                 RH.exec_reference_lines(f'{RH.REF}/temp_prox/fit_temp_loadprox_slide.py', 495, 498, ns)
                 start = {k: np.asarray(v, np.float32) for k, v in ns['prox_params_dict'].items()}
                 prob = prox_window_problem(base, s, e, start)
+                t0 = time.time()
                 rw = RH.RefProxWindow(prob, first_batch_flag=(w == 0))
                 rw.iterate(max(PROX_STEPS) + 1, record_at=set(PROX_STEPS))
+                print(f'  {stage} window {w}: reference closure x {max(PROX_STEPS) + 1} in {time.time() - t0:.0f} s', flush=True)
                 tag = f'{stage}_w{w}'
                 out[f'{tag}_names'] = np.asarray(rw.param_names())
                 out[f'{tag}_betas'] = start['betas']
@@ -244,8 +256,8 @@ def prox():
             final = [RH.reference_read_prox_pkl(PW.result_path(cur, fn)) for fn in names]
             for k in ('transl', 'global_orient', 'pose_embedding', 'betas'):
                 out[f'{stage}_final_{k}'] = np.stack([r[k] for r in final])
-    np.savez_compressed(os.path.join(HERE, 'teacher_prox.npz'), **out)
-    print('teacher_prox.npz', os.path.getsize(os.path.join(HERE, 'teacher_prox.npz')))
+    np.savez_compressed(os.path.join(HERE, PROX_SIZES[size]['file']), **out)
+    print(PROX_SIZES[size]['file'], os.path.getsize(os.path.join(HERE, PROX_SIZES[size]['file'])))
 
 
 def RH_LOSS_KEYS():
@@ -257,4 +269,4 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['amass', 'perframe', 'prox']
     for w in what:
         print(f'== {w}')
-        {'amass': amass, 'perframe': perframe, 'prox': prox}[w]()
+        {'amass': amass, 'perframe': perframe, 'prox': prox, 'prox_full': lambda: prox('full')}[w]()

@@ -110,14 +110,18 @@ def prox_state_from_fixture(T, tag, k, names):
     return st
 
 
-def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t: t.numpy()):
-    """the two CHAINED windows of tests/golden/teacher_prox.npz through an engine factory ``make_engine(prob, first)``"""
+def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t: t.numpy(), size='small', flat_gate=1.2e-2):
+    """the two CHAINED windows of tests/golden/teacher_prox.npz (``size='full'``: teacher_prox_full.npz, B = 100 / V = 10475 windows of a
+    170-frame recording) through an engine factory ``make_engine(prob, first)``"""
     import sys
     sys.path.insert(0, GOLDEN)
-    from make_teacher import prox_recording, prox_window_problem, PROX_N, PROX_B
+    from make_teacher import prox_recording, prox_window_problem, PROX_SIZES
     from lemo_amd import prox_windows as PW
     from oracle.prox_oracle import LOSS_KEYS
-    base = prox_recording(stage)
+    PROX_N, PROX_B = PROX_SIZES[size]['N'], PROX_SIZES[size]['B']
+    assert int(T['n_frames']) == PROX_N and int(T['batch']) == PROX_B
+    frozen = int(0.15 * PROX_B)
+    base = prox_recording(stage, size)
     wins = PW.sliding_windows(PROX_N, PROX_B)
     steps = [int(k) for k in T['steps']] if steps is None else steps
     lr = 0.005
@@ -130,7 +134,7 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
         start['betas'] = T[f'{tag}_betas']
         prob = prox_window_problem(base, s, e, start)
         eng = make_engine(prob, w == 0)
-        assert PW.frozen_prefix(PROX_B, w == 0) == (0 if w == 0 else 2)
+        assert PW.frozen_prefix(PROX_B, w == 0) == (0 if w == 0 else frozen)
         worst_g = 0.0
         for k in steps:
             eng.load_state(prox_state_from_fixture(T, tag, k, names))
@@ -165,15 +169,15 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
                 worst_g = max(worst_g, float(err.max()) / max(scale, 1e-30))
                 o += d
             if w > 0:
-                assert not g_eng[:2].any() and not g_ref[:2].any()
+                assert not g_eng[:frozen].any() and not g_ref[:frozen].any()
             got = _prox_engine_states(eng, names, to_np)
             before = dict(p=T[f'{tag}_s{k}_p'], m=T[f'{tag}_s{k}_m'], v=T[f'{tag}_s{k}_v'])
             assert got['step'] == k + 1
             TC.check_adam_arithmetic(f'{tag} step {k}', before, g_eng, got, k, lr)
             reg, _ = TC.check_next_state(f'{tag} step {k}', got['p'], T[f'{tag}_s{k + 1}_p'], E, T[f'{tag}_s{k + 1}_v'], k, lr, report)
-            assert reg <= 1.2e-2, (tag, k, reg)        # flat gate at 3 x the largest measured value (3.9e-3 lr, GPU, S3 window 2 step 2)
+            assert reg <= flat_gate, (tag, k, reg)     # flat gate at 3 x the largest measured value (3.9e-3 lr, GPU, S3 window 2 step 2)
             if w > 0:                                  # frozen frames: parameters bit-identical to the loaded ones
-                assert np.array_equal(got['p'][:2], before['p'][:2])
+                assert np.array_equal(got['p'][:frozen], before['p'][:frozen])
         report.append(f'{tag}: worst gradient group error vs the reference fp32 {worst_g:.1e} of the group maximum')
 
 
