@@ -59,6 +59,11 @@ int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const fl
                           unsigned long long* dbg, void* stream) {
   return conv3x3_pair_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
 }
+int lemo_conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
+                           const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
+                           unsigned long long* dbg, void* stream) {
+  return conv3x3_pair4_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
+}
 int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
                                     int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
   if (!in || !w || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;

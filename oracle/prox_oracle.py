@@ -50,6 +50,13 @@ def joint_weights_for(B: int, w: dict) -> torch.Tensor:
     return jw
 
 
+THRESHOLDS = dict(fric_sdf=0.01, fric_vt=0.0001, fric_vn=0.0, infill_res=0.0, contact=0.1)
+"""the selection constants of fitting_temp_slide.py:699-739 (friction: sdf < 0.01, |v_t| > 1e-4, v.n < 0) and :944-992 (infill residual > 0,
+contact speed > 0.1).  ``ProxFitOracle.thresholds`` (None = these) lets tests/golden/make_teacher.py measure, in float64, how far each
+loss_dict entry JUMPS when an element sits within fp32 rounding of its threshold (a thresholded mean changes by (x - mean) / n when one
+element changes sides): the slack the teacher tests add to the 1e-5 loss gate for exactly those entries."""
+
+
 class ProxFitOracle:
     def __init__(self, smplx: O.SmplxOracle, vposer_w, enc_w, joint_map, ids: Dict[str, np.ndarray], fric_ids,
                  Xmean, Xstd, weights: dict, cam: dict, R, t, sdf, grid_min, grid_max, params: Dict[str, np.ndarray],
@@ -152,17 +159,18 @@ class ProxFitOracle:
         vf = vw[:, self.fric_ids, :]
         vel = vf[1:] - vf[:-1]
         sdf_f = body_sdf[0:-1, :, self.fric_ids, :, :].squeeze()
-        sel = torch.where(sdf_f < 0.01)
+        thr = getattr(self, 'thresholds', None) or THRESHOLDS       # (test device: the reference's constants unless a test shifts them)
+        sel = torch.where(sdf_f < thr['fric_sdf'])
         if len(sel[0]) > 0:
             n = torch.tensor([0.0, 0.0, 1.0]).repeat(len(sel[0]), 1)
             vc = vel[sel]
             vdn = torch.sum(vc * n, dim=-1)
             vt = vc - vdn.repeat(3, 1).permute(1, 0) * n
             goal_t = torch.norm(vt, dim=-1)
-            if (goal_t - 0.0001).gt(0).sum().item() >= 1:
-                fric_t = goal_t[goal_t > 0.0001].abs().mean() * w['friction_tangent_weight']
-            if vdn.lt(0).sum().item() >= 1:
-                fric_n = vdn[vdn < 0].abs().mean() * w['friction_normal_weight']
+            if (goal_t - thr['fric_vt']).gt(0).sum().item() >= 1:
+                fric_t = goal_t[goal_t > thr['fric_vt']].abs().mean() * w['friction_tangent_weight']
+            if vdn.lt(thr['fric_vn']).sum().item() >= 1:
+                fric_n = vdn[vdn < thr['fric_vn']].abs().mean() * w['friction_normal_weight']
         # ---- infill terms (S3) :944-992
         infill, infill_contact = zero, zero
         if self.body_markers_rec is not None and self.marker_mask.shape[0] * self.marker_mask.shape[1] > self.marker_mask.sum():
@@ -170,14 +178,14 @@ class ProxFitOracle:
             mw = self.marker_mask.repeat_interleave(3).reshape([self.marker_mask.shape[0], -1, 3])
             T = self.body_markers_rec.shape[0]
             diff = (self.body_markers_rec - markers[0:T]).abs() * (1 - mw[0:T])
-            diff = diff[diff > 0]
+            diff = diff[diff > thr['infill_res']]
             infill = w['motion_infill_rec_weight'] * torch.mean(diff)
             vel30 = (vw[1:] - vw[:-1]) * 30
             tot = zero
             for k, name in enumerate(('left_heel', 'right_heel', 'left_toe', 'right_toe')):
                 s = torch.norm(vel30[:, self.ids[name], :][self.contact_lbl_rec[:, k] == 1], dim=-1)
-                if (s - 0.1).gt(0).sum().item() >= 1:
-                    tot = tot + s[s > 0.1].abs().mean()
+                if (s - thr['contact']).gt(0).sum().item() >= 1:
+                    tot = tot + s[s > thr['contact']].abs().mean()
             infill_contact = w['motion_infill_contact_weight'] * tot
         # ---- smoothness prior :997-1031
         ms = vw[:, self.ids['markers81'], :]

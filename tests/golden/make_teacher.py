@@ -183,6 +183,33 @@ def prox_window_problem(base, s, e, params):
     return prob
 
 
+PROX_THRESHOLD_SHIFTS = (('fric_sdf', (-2e-6, 2e-6)), ('fric_vt', (-5e-7, 5e-7)), ('fric_vn', (-5e-7, 5e-7)), ('infill_res', (1e-6,)),
+                         ('contact', (-2e-5, 2e-5)))
+"""how far fp32 rounding can move each thresholded quantity of the PROX closure (world-frame vertices of a few metres: ulp 2.4e-7; the trilinear
+SDF sample adds a few of them; frame differences two; the contact speed is 30 x a difference; the infill residual's threshold is 0, below which
+the masked-out zeros sit -- shifted upwards only)"""
+
+
+def prox_loss_jumps(of):
+    """per loss_dict entry: how far it moves, in float64 at the oracle's current state, when each selection threshold of the closure is
+    shifted by the rounding of the quantity it tests (a thresholded mean jumps by (x - mean) / n when one element changes sides) -- the
+    slack a 1e-5 loss gate needs for exactly the entries that have such a threshold, computed per state instead of guessed"""
+    from oracle.prox_oracle import LOSS_KEYS, THRESHOLDS
+    from oracle.f64 import default_f64
+    with default_f64(), torch.no_grad():
+        base = {k: float(v) for k, v in of.loss_dict().items()}
+        J = np.zeros(len(LOSS_KEYS))
+        for name, shifts in PROX_THRESHOLD_SHIFTS:
+            j = np.zeros(len(LOSS_KEYS))
+            for d in shifts:
+                of.thresholds = dict(THRESHOLDS, **{name: THRESHOLDS[name] + d})
+                ld = of.loss_dict()
+                j = np.maximum(j, [abs(float(ld[k]) - base[k]) for k in LOSS_KEYS])
+            J += j
+        of.thresholds = None
+    return J
+
+
 def prox(size='small'):
     """Two CHAINED windows through the reference's own objects: window 1 (first_batch_flag) -> the reference's pickle writer
     (fit_temp_loadprox_slide.py:577-594) -> the reference's reader (data_parser_slide.py:106-126) with its newest-result rule
@@ -243,6 +270,8 @@ def prox(size='small'):
                     out[f'{tag}_g64_{k}'] = np.concatenate([(of.pose_embedding if n == 'pose_embedding' else of.p[n]).grad.numpy()
                                                            for n in rw.param_names()], axis=1)
                     out[f'{tag}_loss64_{k}'] = np.float64(float(ld['total_loss'].detach()))
+                    if size == 'full':
+                        out[f'{tag}_lossjump{k}'] = prox_loss_jumps(of)
                     # computed exposure of every frame's gradient to the encoder's kinks (the smoothness prior carries weight 1e8 here)
                     plist = [of.pose_embedding if n == 'pose_embedding' else of.p[n] for n in rw.param_names()]
                     S = flip_sensitivity_of(lambda: of.loss_dict()['total_loss'], plist, subsets=1)

@@ -546,6 +546,7 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 // only ever applied to wave-uniform values in the kernels
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0u; }
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }
 
 // ---- math -----------------------------------------------------------------------------------

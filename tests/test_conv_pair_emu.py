@@ -24,9 +24,12 @@ def _border_is_zero(buf, H, W):
 
 
 @pytest.mark.timeout(1800)
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
 @pytest.mark.parametrize('H,W', [(10, 14), (7, 9), (23, 31), (36, 57)])
-def test_pair_forward_and_backward_vs_float64(emu_lib, H, W):
-    """one tile exactly / less than one tile / ragged edges in both directions / several tiles per XCD run"""
+def test_pair_forward_and_backward_vs_float64(emu_lib, H, W, kernel):
+    """one tile exactly / less than one tile / ragged edges in both directions / several tiles per XCD run -- for the 8-wave kernel on
+    10 x 14 tiles (variant 5) and the 4-wave kernel on 5 x 14 tiles (variant 6, csrc/conv_pair4_kernels.hip)"""
+    pair = getattr(emu_lib, kernel)
     g = torch.Generator().manual_seed(H * 100 + W)
     x = torch.randn(64, H, W, generator=g)
     w1, w2 = torch.randn(64, 64, 3, 3, generator=g) * 0.06, torch.randn(64, 64, 3, 3, generator=g) * 0.06
@@ -38,7 +41,7 @@ def test_pair_forward_and_backward_vs_float64(emu_lib, H, W):
     a1_32 = F.leaky_relu(F.conv2d(x[None], w1, b1, padding=1), 0.2)
     a2_32 = F.leaky_relu(F.conv2d(a1_32, w2, b2, padding=1), 0.2)[0]
     xin, mid, out = to_cg8p(x), cg8p_alloc(64, H, W, 'cpu'), cg8p_alloc(64, H, W, 'cpu')
-    assert emu_lib.conv3x3_pair_f16(ptr(xin), ptr(p1), i1, ptr(b1), None, ptr(mid), ptr(p2), i2, ptr(b2), None, ptr(out), H, W, 0, None, None) == 0
+    assert pair(ptr(xin), ptr(p1), i1, ptr(b1), None, ptr(mid), ptr(p2), i2, ptr(b2), None, ptr(out), H, W, 0, None, None) == 0
     e_mid, e_out = rel_err(from_cg8p(mid, H, W).double(), a1_64[0]), rel_err(from_cg8p(out, H, W).double(), a2_64)
     f_mid, f_out = rel_err(a1_32[0].double(), a1_64[0]), rel_err(a2_32.double(), a2_64)
     assert e_mid < 2e-6 and e_mid < 4 * f_mid, (e_mid, f_mid)
@@ -64,13 +67,14 @@ def test_pair_forward_and_backward_vs_float64(emu_lib, H, W):
     # torch's own chain uses lrelu'(pre1); the kernel takes the sign from the saved activation a1 = lrelu(pre1): same sign
     ref_d0 = xr.grad * torch.where(a0 > 0, 1.0, 0.2).double()
     d2b, a1b, a0b, d0b = to_cg8p(d2), to_cg8p(a1), to_cg8p(a0), cg8p_alloc(64, H, W, 'cpu')
-    assert emu_lib.conv3x3_pair_f16(ptr(d2b), ptr(pb2), ib2, None, ptr(a1b), None, ptr(pb1), ib1, None, ptr(a0b), ptr(d0b), H, W, 1, None, None) == 0
+    assert pair(ptr(d2b), ptr(pb2), ib2, None, ptr(a1b), None, ptr(pb1), ib1, None, ptr(a0b), ptr(d0b), H, W, 1, None, None) == 0
     assert rel_err(from_cg8p(d0b, H, W).double(), ref_d0) < 2e-6
     assert _border_is_zero(d0b, H, W)
 
 
 @pytest.mark.timeout(900)
-def test_pair_range_homogeneity_and_zero_input(emu_lib):
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
+def test_pair_range_homogeneity_and_zero_input(emu_lib, kernel):
     """per-workgroup power-of-two scales: magnitudes falling by 8 orders across the image keep fp32-sized errors row by row, the
     result is exactly homogeneous under power-of-two scalings (zero bias), and an all-zero input gives lrelu(conv(lrelu(b1)) + b2)"""
     H, W = 36, 29
@@ -84,7 +88,7 @@ def test_pair_range_homogeneity_and_zero_input(emu_lib):
 
     def run(xx, ba, bb):
         mid, out = cg8p_alloc(64, H, W, 'cpu'), cg8p_alloc(64, H, W, 'cpu')
-        assert emu_lib.conv3x3_pair_f16(ptr(to_cg8p(xx)), ptr(p1), i1, ptr(ba), None, ptr(mid), ptr(p2), i2, ptr(bb), None, ptr(out), H, W, 0, None, None) == 0
+        assert getattr(emu_lib, kernel)(ptr(to_cg8p(xx)), ptr(p1), i1, ptr(ba), None, ptr(mid), ptr(p2), i2, ptr(bb), None, ptr(out), H, W, 0, None, None) == 0
         return mid, out
     mid, out = run(x, zb, zb)
     got = from_cg8p(out, H, W).double()
@@ -101,8 +105,9 @@ def test_pair_range_homogeneity_and_zero_input(emu_lib):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
 @pytest.mark.parametrize('case', ['second_phase_zero', 'second_phase_tiny', 'first_phase_zero'])
-def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case):
+def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case, kernel):
     """the kernels stage channels {0-15, 32-47} and {16-31, 48-63} in two phases with their own power-of-two
     scales and rescale the accumulators by the ratio in between.  A second phase that is exactly zero (scale clamped to 2^126) or
     2^90 below the first made that ratio overflow: all-NaN tiles with rc == 0.  The later phase's scale is now bounded by the
@@ -111,8 +116,11 @@ def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case):
     g = torch.Generator().manual_seed(77)
     x = torch.randn(64, H, W, generator=g)
     second = torch.zeros(64, dtype=torch.bool)
-    second[16:32] = True
-    second[48:64] = True
+    if kernel == 'conv3x3_pair4_f16':
+        second[32:64] = True                # the 4-wave kernel stages channel groups 0-3, then 4-7
+    else:
+        second[16:32] = True
+        second[48:64] = True
     if case == 'second_phase_zero':
         x[second] = 0.0
     elif case == 'second_phase_tiny':
@@ -126,7 +134,7 @@ def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case):
     a1 = F.leaky_relu(F.conv2d(x[None].double(), w1.double(), b1.double(), padding=1), 0.2)
     a2 = F.leaky_relu(F.conv2d(a1, w2.double(), b2.double(), padding=1), 0.2)[0]
     xin, mid, out = to_cg8p(x), cg8p_alloc(64, H, W, 'cpu'), cg8p_alloc(64, H, W, 'cpu')
-    assert emu_lib.conv3x3_pair_f16(ptr(xin), ptr(p1), i1, ptr(b1), None, ptr(mid), ptr(p2), i2, ptr(b2), None, ptr(out), H, W, 0, None, None) == 0
+    assert getattr(emu_lib, kernel)(ptr(xin), ptr(p1), i1, ptr(b1), None, ptr(mid), ptr(p2), i2, ptr(b2), None, ptr(out), H, W, 0, None, None) == 0
     assert bool(torch.isfinite(mid).all()) and bool(torch.isfinite(out).all())
     assert rel_err(from_cg8p(mid, H, W).double(), a1[0]) < 2e-6 and rel_err(from_cg8p(out, H, W).double(), a2) < 2e-6
     if emu_lib.conv3x3_split_supported(H, W, 64, 64):          # the single-layer kernel the pair's staging was taken from

@@ -141,8 +141,16 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
             eng.step(1, use_graph=False)
             L = eng.loss_dict()
             ref = dict(zip(LOSS_KEYS, T[f'{tag}_loss{k}']))
+            # 1e-5 on every loss_dict entry; the entries that are MEANS OVER A THRESHOLDED SELECTION (friction, infill, contact speed:
+            # fitting_temp_slide.py:699-739, 944-992) additionally get the jump float64 computes at this state when an element within fp32
+            # rounding of its threshold changes sides (make_teacher.prox_loss_jumps; both implementations may flip: factor 2) -- at
+            # B = 100 / V = 10475 tens of thousands of elements are selected and one of them sits that close in some state
+            jump = dict(zip(LOSS_KEYS, T[f'{tag}_lossjump{k}'])) if f'{tag}_lossjump{k}' in T else {}
+            jump['total_loss'] = sum(v for kk, v in jump.items() if kk != 'total_loss')
             for key, r in ref.items():
-                assert abs(L[key] - r) <= 1e-5 * abs(r) + 1e-12, (tag, k, key, L[key], r)
+                assert abs(L[key] - r) <= 1e-5 * abs(r) + 2.0 * jump.get(key, 0.0) + 1e-12, (tag, k, key, L[key], r, jump.get(key, 0.0))
+                if jump.get(key, 0.0) > 1e-5 * abs(r):
+                    report.append(f'{tag} step {k}: {key} carries a threshold jump of {jump[key] / max(abs(r), 1e-30):.1e} of its value (engine vs reference {abs(L[key] - r) / max(abs(r), 1e-30):.1e})')
             g = eng.grads(erase=True)
             g_eng = np.concatenate([to_np(g[n]) for n in names], axis=1)
             g_ref = T[f'{tag}_g{k}']
