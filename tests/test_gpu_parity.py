@@ -328,8 +328,10 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert abs(fit.losses()['total'] - ref_total) < 2e-3 * ref_total
 
 
-def test_fused_pair_conv_full_size_vs_float64(dev):
-    """conv variant 5 (csrc/conv_pair_kernels.hip) at the encoder's own size (245 x 134, real runs/15217 weights of layers 3 / 4):
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
+def test_fused_pair_conv_full_size_vs_float64(dev, kernel):
+    """conv variant 5 (csrc/conv_pair_kernels.hip) and variant 6 (four-wave workgroups, csrc/conv_pair4_kernels.hip: same arithmetic and
+    summation order, so the same bits -- run ten times: its two co-resident workgroups per CU are where a race would show) at the encoder's own size (245 x 134, real runs/15217 weights of layers 3 / 4):
     forward pair (intermediate AND output) and backward-data pair against torch float64 on the host; error of the size of an fp32
     convolution's own rounding, and agreement with two single-layer launches of the same arithmetic (variant 4)"""
     from lemo_amd import _hip
@@ -352,8 +354,17 @@ def test_fused_pair_conv_full_size_vs_float64(dev):
     xin, mid, out = to_cg8p(x).to(dev), cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
     pa, ia = enc.split_pack(3, False, 5)
     pb, ib = enc.split_pack(4, False, 5)
-    assert lib.conv3x3_pair_f16(ptr(xin), ptr(pa), ia, ptr(enc.b[3]), None, ptr(mid), ptr(pb), ib, ptr(enc.b[4]), None, ptr(out), H, W, 0, None, s) == 0
+    pair = getattr(lib, kernel)
+    assert pair(ptr(xin), ptr(pa), ia, ptr(enc.b[3]), None, ptr(mid), ptr(pb), ib, ptr(enc.b[4]), None, ptr(out), H, W, 0, None, s) == 0
     torch.cuda.synchronize()
+    if kernel == 'conv3x3_pair4_f16':
+        m5, o5 = cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+        assert lib.conv3x3_pair_f16(ptr(xin), ptr(pa), ia, ptr(enc.b[3]), None, ptr(m5), ptr(pb), ib, ptr(enc.b[4]), None, ptr(o5), H, W, 0, None, s) == 0
+        for _ in range(10):
+            m6, o6 = cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+            assert pair(ptr(xin), ptr(pa), ia, ptr(enc.b[3]), None, ptr(m6), ptr(pb), ib, ptr(enc.b[4]), None, ptr(o6), H, W, 0, None, s) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(m6, m5) and torch.equal(o6, o5)
     e_mid, e_out = rel_err(from_cg8p(mid.cpu(), H, W).double(), a1_64[0]), rel_err(from_cg8p(out.cpu(), H, W).double(), a2_64)
     f_mid, f_out = rel_err(a1_32[0].double(), a1_64[0]), rel_err(a2_32.double(), a2_64)
     print(f'\nfused pair forward vs float64: mid {e_mid:.2e} out {e_out:.2e} (torch fp32 conv: {f_mid:.2e} / {f_out:.2e})')
@@ -375,14 +386,14 @@ def test_fused_pair_conv_full_size_vs_float64(dev):
     qa, ja = enc.split_pack(4, True, 5)
     qb, jb = enc.split_pack(3, True, 5)
     d0 = cg8p_alloc(64, H, W, dev)
-    assert lib.conv3x3_pair_f16(ptr(to_cg8p(d2).to(dev)), ptr(qa), ja, None, ptr(mid), None, ptr(qb), jb, None, ptr(to_cg8p(a0).to(dev)), ptr(d0), H, W, 1, None, s) == 0
+    assert pair(ptr(to_cg8p(d2).to(dev)), ptr(qa), ja, None, ptr(mid), None, ptr(qb), jb, None, ptr(to_cg8p(a0).to(dev)), ptr(d0), H, W, 1, None, s) == 0
     torch.cuda.synchronize()
     e_b = rel_err(from_cg8p(d0.cpu(), H, W).double(), ref)
     print(f'fused pair backward-data vs float64: {e_b:.2e}')
     assert e_b < 2e-6
 
 
-@pytest.mark.parametrize('conv_variant', [5, 4, 3, 2])
+@pytest.mark.parametrize('conv_variant', [5, 6, 4, 3, 2])
 def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""

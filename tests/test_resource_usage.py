@@ -20,6 +20,8 @@ BUDGETS = {
     'conv3x3_split_kernelILi1ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),
     'conv3x3_pair_kernelILi0ELb0E': ('conv_pair_kernels.hip', 256, 512),                # fused layer pairs (variant 5): forward / backward-data
     'conv3x3_pair_kernelILi1ELb0E': ('conv_pair_kernels.hip', 256, 512),
+    'conv3x3_pair4_kernelILi0ELb0E': ('conv_pair4_kernels.hip', 256, 256),              # variant 6: four waves, TWO workgroups per CU -> 2 waves per SIMD
+    'conv3x3_pair4_kernelILi1ELb0E': ('conv_pair4_kernels.hip', 256, 256),
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),

@@ -93,13 +93,4 @@ half = np.arange(nblk) >= (nblk + 1) // 2
 for nm, m in (('first half of the grid', ~half), ('second half', half)):
     print('   %s: layer 1 median %d | layer 2 %d | lifetime %d' % (nm, med((tl1 - tp)[m]), med((tl2 - tmid)[m]), med((t1 - t0)[m])))
 wg = t1.max(1) - t0.min(1)
-print('per-workgroup lifetime median %d max %d cycles; launch span %d cycles (first start to last end)' % (med(wg), wg.max(), t1.max() - t0.min()))
-# HW_ID (s_getreg 63492 = HW_REG_HW_ID, offset 0 size 32): [3:0] wave, [5:4] simd, [11:8] cu, [12] sh, [15:13] se; XCC id is a separate register:
-# co-residency is read off the time axis instead -- how many workgroups overlap the lifetime of each
-st, en = t0.min(1), t1.max(1)
-cu = ((hw[:, 0] >> 8) & 0xF) | (((hw[:, 0] >> 12) & 0x1) << 4) | (((hw[:, 0] >> 13) & 0x7) << 5)
-print('distinct (se, sh, cu) ids seen: %d (x 8 XCDs; the id does not carry the XCD)' % len(set(cu.tolist())))
-order = np.argsort(st)
-late = np.sort(st)[256:] if nblk > 256 else np.array([])
-print('start times: first 256 workgroups within %d cycles; the other %d start %s after the first' % (
-    int(np.sort(st)[min(255, nblk - 1)] - st.min()), max(nblk - 256, 0), ('%d .. %d cycles' % (int(late.min() - st.min()), int(late.max() - st.min()))) if late.size else '-'))
+print('per-workgroup lifetime median %d max %d cycles (s_memtime is per XCD: spans across workgroups are not comparable)' % (med(wg), wg.max()))
