@@ -225,10 +225,16 @@ def test_split_f16_conv_error_is_fp32_sized(dev):
     assert float((got[-1, -62:] - refdx[-1, -62:]).abs().max() / refdx.abs().max()) < 2e-6      # the remainder patches
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4])
+DX0_GATE = 7e-6          # 3 x the largest measured value (round 5: 1.2e-6 .. 2.2e-6 across the seven families; was a silent 1e-4)
+
+
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6])
 def test_encoder_full_size_golden(dev, variant):
     """10-layer MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad.  Variants 0-2 run
-    every layer on the fp32 MFMA; 3 / 4 run the nine MFMA layers (forward and backward-data) on the split-bf16 / split-f16 kernel."""
+    every layer on the fp32 MFMA; 3 / 4 run the nine MFMA layers (forward and backward-data) on the split-bf16 / split-f16 kernel;
+    5 / 6 run the SHIPPED chain (csrc/enc_chain.hpp): fused pairs (3,4) (5,6) (7,8) forward and (9,8) (7,6) (5,4) backward on the 8-wave /
+    4-wave pair kernel, the other launches layer by layer on the split-f16 kernel (the default chain had no
+    standalone z / loss / dx0 golden run)."""
     from lemo_amd import _hip
     from lemo_amd._hip import ptr
     from lemo_amd.priors import ENC_CHANNELS, EncWeights, cg8p_alloc, from_cg8p, _conv_layer
@@ -243,8 +249,15 @@ def test_encoder_full_size_golden(dev, variant):
     act = [None] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
     s = torch.cuda.current_stream(dev).cuda_stream
     lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, 32, s))
+    pair = {5: lib.conv3x3_pair_f16, 6: lib.conv3x3_pair4_f16}.get(variant)
+    P = (lambda l, bwd: enc.split_pack(l, bwd, variant)) if pair else None
     for l in range(1, 10):
-        if variant >= 2:
+        if pair and l in (3, 5, 7):
+            (pa, ia), (pb, ib) = P(l, False), P(l + 1, False)
+            lib.check(pair(ptr(act[l]), ptr(pa), ia, ptr(enc.b[l]), None, ptr(act[l + 1]), ptr(pb), ib, ptr(enc.b[l + 1]), None, ptr(act[l + 2]), H, W, 0, None, s))
+        elif pair and l in (4, 6, 8):
+            continue
+        elif variant >= 2:
             _conv_layer(lib, enc, l, False, act[l], act[l + 1], None, H, W, variant, s)
         else:
             lib.check(lib.conv3x3_mfma(ptr(act[l]), ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(act[l + 1]), H, W,
@@ -261,7 +274,12 @@ def test_encoder_full_size_golden(dev, variant):
     cur = [d0, d1]
     ci = 0
     for l in range(9, 0, -1):
-        if variant >= 2:
+        if pair and l in (9, 7, 5):
+            (pa, ia), (pb, ib) = P(l, True), P(l - 1, True)
+            lib.check(pair(ptr(cur[ci]), ptr(pa), ia, None, ptr(act[l]), None, ptr(pb), ib, None, ptr(act[l - 1]), ptr(cur[1 - ci]), H, W, 1, None, s))
+        elif pair and l in (8, 6, 4):
+            continue
+        elif variant >= 2:
             _conv_layer(lib, enc, l, True, cur[ci], cur[1 - ci], act[l], H, W, variant, s)
         else:
             lib.check(lib.conv3x3_mfma(ptr(cur[ci]), ptr(enc.wbwd[l]), None, ptr(act[l]), ptr(cur[1 - ci]), H, W,
@@ -269,7 +287,11 @@ def test_encoder_full_size_golden(dev, variant):
         ci = 1 - ci
     dx0 = torch.zeros(H * W, device=dev)
     lib.check(lib.conv3x3_c1_bwd(ptr(cur[ci]), ptr(enc.w[0]), ptr(dx0), H, W, 32, s))
-    assert rel_err(dx0.view(H, W).cpu(), g['gx'][0, 0]) < 1e-4
+    e_dx0 = rel_err(dx0.view(H, W).cpu(), g['gx'][0, 0])
+    print(f'\nencoder chain variant {variant}: d loss / d image vs the reference-generated golden: {e_dx0:.2e} of max; loss rel '
+          f'{abs(loss - float(g["loss_smooth"])) / float(g["loss_smooth"]):.1e}')
+    # measured 1.2e-6 (split-f16 families, pairs included) .. 2.2e-6 (fp32-input MFMA) of the largest entry: gate at 3 x the largest
+    assert e_dx0 < DX0_GATE, (variant, e_dx0)
 
 
 def test_fit_small_vs_oracle_eager_and_graph(dev):

@@ -557,7 +557,32 @@ def test_prox_engine_baseline_size(dev, stage):
     errs = {n: rel_err(gr[n].cpu(), of.pose_embedding.grad if n == 'pose_embedding' else of.p[n].grad) for n, _ in ENGINE_PARAMS}
     print(f'\nPROX engine {stage} at B=100 / V=10475 / 256^3: 14 losses <= 1e-5; gradient max-rel errors: '
           + ', '.join(f'{k} {v:.1e}' for k, v in errs.items()))
-    assert max(errs.values()) < 3e-3
+    # Round 5: the flat 3e-3 is replaced by the bound the teacher tests use, COMPUTED in float64 at this state
+    # (oracle/f64.py): per frame and parameter group  |engine - oracle32| <= scale (2e-5 + 4 S[frame]) + 2 |oracle32 - float64|[frame],
+    # S = how far the frame's gradient moves when every LeakyReLU unit of the smoothness encoder within 3e-6 x layer-max of its kink
+    # takes the other branch (the prior carries weight 1e8 here).  The reference-RUN counterpart at this shape is
+    # tests/test_gpu_teacher.py::test_prox_chained_windows_teacher_forced_baseline_size.
+    from oracle.f64 import prox_fit_oracle_f64, default_f64, flip_sensitivity_of
+    o64 = prox_fit_oracle_f64(prob, first_batch_flag=False)
+    with default_f64():
+        o64.closure()
+    names = [n for n, _ in ENGINE_PARAMS]
+    p64 = lambda n: o64.pose_embedding if n == 'pose_embedding' else o64.p[n]
+    S = flip_sensitivity_of(lambda: o64.loss_dict()['total_loss'], [p64(n) for n in names], subsets=1)
+    worst = 0.0
+    for gi, n in enumerate(names):
+        gx = p64(n).grad
+        g32 = (of.pose_embedding if n == 'pose_embedding' else of.p[n]).grad.double()
+        scale = float(gx.abs().max())
+        if scale == 0.0:
+            continue
+        bound = scale * (2e-5 + 4.0 * S[gi]) + 2.0 * (g32 - gx).abs().max(1).values
+        err = (gr[n].cpu().double() - g32).abs().max(1).values
+        bad = (err > bound).nonzero().flatten().tolist()
+        assert not bad, (stage, n, bad, [float(err[i]) / scale for i in bad], [float(bound[i]) / scale for i in bad])
+        worst = max(worst, float((err / bound.clamp_min(1e-300)).max()))
+    print(f'PROX engine {stage}: every frame of every gradient group inside its computed bound (worst {worst:.2f} of it; exposure S max '
+          f'{max(float(x.max()) for x in S):.1e})')
     assert float(gr['pose_embedding'][:15].abs().max()) == 0.0
     # graph replay == eager, bit for bit, over 12 iterations (3 single-iteration replays + the 10-iteration graph)
     e1, _ = ge.prox_engine_for(prob, dev, first_batch_flag=False)
