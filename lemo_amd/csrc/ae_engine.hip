@@ -22,6 +22,7 @@
 #include "conv_common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -40,7 +41,7 @@ struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; in
 // Clips side by side (round 4): an engine of K clips carves K identical workspaces, `cs` floats apart, and every
 // launch of a training step carries the clip as its last grid dimension -- the same kernels, the same launch shapes, K times the
 // blocks.  Each clip has its OWN parameters, Adam state and step counter (the reference finetunes a fresh copy per clip), so a
-// clip's arithmetic does not depend on its neighbours: bit-identical to a solo run.  Null operands (an unused bias / aux) stay null.
+// clip's arithmetic does not depend on its neighbours (only on HOW MANY ride along: ae_conv_shape picks the launch shape for the clips in flight).  Null operands (an unused bias / aux) stay null.
 #define AE_CLIP_OFFSET5(in_, wt_, bias_, aux_, out_, cs_)                                             \
   { const size_t o_ = (size_t)blockIdx.z * (cs_); in_ += o_; wt_ += o_; out_ += o_;                   \
     if (bias_) bias_ += o_; if (aux_) aux_ += o_; }
@@ -248,13 +249,19 @@ static int ae_conv_init() {
 // workgroups (they share their weight loads).  KS: four waves per workgroup (one per pipe) -- with the 8-deep operand ring a
 // wave keeps its pipe busy on its own, and every further slice only adds to the LDS reduction (8 or 16 waves measured 10-25 %
 // slower) -- unless a wave's chain would exceed ~36 steps' worth of MFMAs, which is what the deep 256-channel layers need.
-static void ae_conv_shape(int P, int cin, int cout, int* mt_out, int* pt_out, int* ks_out) {
+// nclip (round 5): the launch carries nclip clips (blockIdx.z), so the tiles that share the CUs are nclip x a clip's -- the shape is
+// chosen for what is actually in flight (a small layer of ONE clip needs 16 x 16 tiles and K slices to reach enough CUs; eight clips
+// of it do not).  A clip's results then depend on the engine's clip count through the summation order of the K slices: bit-identical
+// for equal nclip (and between the slots of one engine), equal to a solo run to rounding (tests/test_infill_emu.py, test_gpu_r2.py).
+static void ae_conv_shape(int P, int cin, int cout, int nclip, int* mt_out, int* pt_out, int* ks_out) {
+  static const bool solo_shapes = getenv("LEMO_AE_SHAPE_SOLO") && atoi(getenv("LEMO_AE_SHAPE_SOLO")) != 0;      // A/B knob: round 4's rule
+  if (solo_shapes || nclip < 1) nclip = 1;
   double best = -1;
   for (int mt = 3; mt >= 1; --mt) {
     const int px = mt == 3 ? 16 : 32, co = mt == 3 ? 16 : 32 * mt;
     if (cout % co || (mt == 3 && cin < 16)) continue;
     const int nit = mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8);
-    const long tiles = (long)((P + px - 1) / px) * (cout / co);
+    const long tiles = (long)((P + px - 1) / px) * (cout / co) * nclip;
     int pt = 1;
     while (pt < 4 && tiles / (2 * pt) >= 200) pt *= 2;
     const int max_nw = mt == 2 ? 8 : 16;
@@ -274,7 +281,7 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
             int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0, int nclip = 1, size_t cs = 0) {
   if (cin % 8 || (cin & (cin - 1)) || cout % 32 || g.H < 1 || g.W < 1 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
   int mt = 1, pt = 1, ks = 1;
-  ae_conv_shape(g.H * g.W, cin, cout, &mt, &pt, &ks);
+  ae_conv_shape(g.H * g.W, cin, cout, nclip, &mt, &pt, &ks);
   if (force_mt) { mt = force_mt; pt = force_pt; ks = force_ks; }
   const int lg = ilog2(cin / 8), nw = pt * ks;
   if (pt < 1 || (pt & (pt - 1)) || ks < 1 || nw > 16) return LEMO_ERR_ARG;

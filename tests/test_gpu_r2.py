@@ -149,10 +149,10 @@ def test_perframe_fit_full_size_vs_oracle(dev):
     assert np.abs(got2 - ref2).max() < 5e-5
 
 
-def test_finetune_many_clips_side_by_side_bit_identical(dev):
+def test_finetune_many_clips_side_by_side(dev):
     """ten clips' 60-step AE finetunes through finetune_and_infill_many -- AE_CLIPS (8) clips carried by every launch of one
-    engine on one stream, the tail of two on an engine of its own size -- == each clip through finetune_and_infill on its own,
-    bit for bit; the aggregate time per clip of a full group is the per-clip cost a dataset-scale run pays (VERDICT r03 #6:
+    engine on one stream, the tail of two on a 2-clip engine -- == each clip through finetune_and_infill on its own to rounding
+    (bit for bit for equal grouping); the aggregate time per clip of a full group is the per-clip cost a dataset-scale run pays (VERDICT r03 #6:
     <= 20 ms per clip on ONE stream; measured 18.3, one clip alone 29.0)"""
     import time
     from lemo_amd import infill
@@ -173,10 +173,17 @@ def test_finetune_many_clips_side_by_side_bit_identical(dev):
     t_solo = (time.perf_counter() - t0) * 1e3
     many = finetune_and_infill_many(ae, ae_w, xs, ms, steps=60)             # captures the engines' graphs
     torch.cuda.synchronize()
+    # Round 5: launch shapes follow the clips in flight (ae_conv_shape), so a clip in the 8-clip engine sums its K slices in another
+    # order than alone -- after the reference's 60 steps: the same optimisation to the tolerance the engine-vs-autograd test uses
+    # (two summation splits of one arithmetic: reconstruction 1e-6, parameters 5e-6 where the finetune moves them by 2e-4); bit for
+    # bit between two runs of the same grouping
     for (ra, za), (rb, zb) in zip(solo, many):
+        assert float((ra - rb).abs().max()) < 1e-6 * max(1.0, float(ra.abs().max())) and float((za - zb).abs().max()) < 2e-6 * max(1.0, float(za.abs().max()))
+    assert max(float((a - b.detach()).abs().max()) for a, b in zip(p_last, ae.ordered_parameters())) < 5e-6     # the model is left with the LAST clip's weights
+    again = finetune_and_infill_many(ae, ae_w, xs, ms, steps=60)
+    torch.cuda.synchronize()
+    for (ra, za), (rb, zb) in zip(many, again):
         assert torch.equal(ra, rb) and torch.equal(za, zb)
-    for a, b in zip(p_last, ae.ordered_parameters()):                       # the model is left with the LAST clip's weights
-        assert torch.equal(a, b)
     k = infill.AE_CLIPS
     t_many = 1e30
     for _ in range(3):

@@ -120,8 +120,8 @@ def test_finetune_session_carries_nothing_from_clip_to_clip(emu_lib):
 def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib, monkeypatch):
     """finetune_and_infill_many: clips of one shape go AE_CLIPS at a time into ONE engine whose launches carry all of them (the
     clip is the last grid dimension; own parameters / Adam state / step counter / workspace slice per clip) == clip i through
-    finetune_and_infill, bit for bit -- full groups, the tail group, a clip of another shape in the middle, the model left with
-    the LAST clip's weights; and the session cache is an LRU of at most _MAX_SESSIONS entries"""
+    finetune_and_infill to rounding (bit for bit for equal grouping) -- full groups, the tail group, a clip of another shape in the
+    middle, the model left with the LAST clip's weights; and the session cache is an LRU of at most _MAX_SESSIONS entries"""
     from lemo_amd import infill
     from lemo_amd.infill import AE, finetune_and_infill, finetune_and_infill_many
     w = _weights()
@@ -138,15 +138,30 @@ def test_finetune_many_clips_equals_solo_and_sessions_are_bounded(emu_lib, monke
     ae_many = AE(_lib=emu_lib)
     many = finetune_and_infill_many(ae_many, w, xs, ms, steps=2, lr=1e-3)
     assert sorted(k[-1] for k in infill._SESSIONS) == [1, 1, 2]           # a 2-clip engine (used twice), the tail's and the odd shape's
+    # Round 5: the convolutions' launch shapes are chosen for the clips IN FLIGHT (csrc/ae_engine.hip::ae_conv_shape), so a clip in a
+    # K-clip engine sums its K slices in another order than alone: equal to the solo run to rounding, bit-identical between two runs of
+    # the same grouping and between the slots of one engine (the padded tail repeats its last clip: same bits in both slots)
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7
     for (ra, za), (rb, zb) in zip(solo, many):
-        assert ra.shape == rb.shape and torch.equal(ra, rb) and torch.equal(za, zb)
+        assert ra.shape == rb.shape and close(ra, rb) and close(za, zb)
     for k, v in ae_many.state_dict().items():
-        assert torch.equal(v, p_last[k]), k
+        assert close(v, p_last[k]), k
+    again = finetune_and_infill_many(AE(_lib=emu_lib), w, xs, ms, steps=2, lr=1e-3)
+    for (ra, za), (rb, zb) in zip(many, again):
+        assert torch.equal(ra, rb) and torch.equal(za, zb)
     infill._SESSIONS.clear()
     monkeypatch.setattr(infill, 'AE_CLIPS', 4)
     many = finetune_and_infill_many(AE(_lib=emu_lib), w, xs[:2] + xs[3:], ms[:2] + ms[3:], steps=2, lr=1e-3)    # 4 + 1
     for (ra, za), (rb, zb) in zip(solo[:2] + solo[3:], many):
-        assert torch.equal(ra, rb) and torch.equal(za, zb)
+        assert close(ra, rb) and close(za, zb)
+    # engine sizes are powers of two: three clips run as 2 + 1, seven on an 8-clip engine with the last one repeated (slot dropped)
+    assert infill._engine_groups(3) == [(2, 2), (1, 1)] and infill._engine_groups(7) == [(7, 8)] and infill._engine_groups(5) == [(4, 4), (1, 1)]
+    monkeypatch.setattr(infill, 'AE_CLIPS', 8)
+    idx7 = [0, 1, 3, 4, 5, 0, 1]
+    many7 = finetune_and_infill_many(AE(_lib=emu_lib), w, [xs[i] for i in idx7], [ms[i] for i in idx7], steps=2, lr=1e-3)
+    for i, (rb, zb) in zip(idx7, many7):
+        assert close(solo[i][0], rb) and close(solo[i][1], zb)
+    assert torch.equal(many7[0][0], many7[5][0]) and torch.equal(many7[1][1], many7[6][1])      # the same clip in two slots of one engine: same bits
     for t in range(infill._MAX_SESSIONS + 3):                          # other clip shapes: the cache stays bounded
         finetune_and_infill(ae, w, torch.randn(1, 4, 18, 24 + 2 * t, generator=g), torch.ones(18, 24 + 2 * t) > 0, steps=0)
     assert len(infill._SESSIONS) == infill._MAX_SESSIONS
@@ -292,7 +307,14 @@ def test_clip_pipeline_many_equals_one_by_one(emu_lib, monkeypatch):
         solo.append({k: v.clone() for k, v in o.items()})
     monkeypatch.setattr(infill, 'AE_CLIPS', 2)
     many = pipe.fit_clips(items, steps=2, finetune_steps=2, use_graph=False)
+    # (round 5: the AE's launch shapes follow the clips in flight -- a clip finetuned in a 2-clip engine equals its solo run to rounding,
+    # and so does everything downstream of its reconstruction; the contact labels are a threshold of it)
     for a, b in zip(solo, many):
+        for k in ('p72', 'markers_rec', 'clip_img_rec'):
+            assert float((a[k] - b[k]).abs().max()) <= 1e-4 * float(a[k].abs().max()) + 1e-6, k
+        assert float((a['contact_lbl_rec'] != b['contact_lbl_rec']).float().mean()) <= 0.01
+    many2 = pipe.fit_clips(items, steps=2, finetune_steps=2, use_graph=False)
+    for a, b in zip(many, many2):
         for k in ('p72', 'markers_rec', 'contact_lbl_rec', 'clip_img_rec'):
             assert torch.equal(a[k], b[k]), k
     infill._SESSIONS.clear()

@@ -30,9 +30,10 @@ with torch.cuda.stream(side):
         infill._SESSIONS.clear()
         many = finetune_and_infill_many(ae, w, xs, masks, steps=60); torch.cuda.synchronize()
         same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(solo, many))
+        worst = max(float((a[0] - b[0]).abs().max()) for a, b in zip(solo, many))
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
             finetune_and_infill_many(ae, w, xs, masks, steps=60); torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) * 1e3)
-        print(f'clips per engine {clips}: {best / n:6.2f} ms per clip ({n} clips, best of 3); bit-identical to solo: {same}', flush=True)
+        print(f'clips per engine {clips}: {best / n:6.2f} ms per clip ({n} clips, best of 3); bit-identical to solo: {same} (max |rec - solo| {worst:.1e})', flush=True)
