@@ -359,12 +359,24 @@ typedef struct lemo_fit_const {
                                    * published canon matrix is R^T R0 so that it acts on camera-frame vertices directly */
 } lemo_fit_const;
 
+/* conv variant 7 (round 5) = variant 5 + the encoder's head and tail as ONE launch each (csrc/conv_head_kernels.hip):
+ *   lemo_enc_head: canonicalised marker image (opt_amass_temp.py:366-392) -> layer 0 (1 -> 32, fp32 FMAs, bit-identical to lemo_conv3x3_c1 on the
+ *     published x0) -> layer 1 (32 -> 32, split-f16 MFMA; w1pack / w1inv = pack_conv3x3_split_f16 of its weights) -- writes x0 (padded image),
+ *     canon [12], act1 and act2 (CG8P, 32 channels each); replaces the marker_c1 launch + one single-layer launch;
+ *   lemo_enc_tail: d(pre-act 2) (CG8P, 32 channels) -> layer 1 backward-data x lrelu'(act1) (w1bpack = pack_conv3x3_bwd_split_f16) -> layer 0
+ *     adjoint (w0 [32][9]) -> dx0 [H * W]; replaces one single-layer launch + lemo_conv3x3_c1_bwd; d(pre-act 1) stays in LDS. */
+int lemo_enc_head(const lemo_fit_const* fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B, const float* w0,
+                  const float* b0, const void* w1pack, float w1inv, const float* b1, float* x0, float* canon, float* act1, float* act2,
+                  void* stream);
+int lemo_enc_tail(const float* din, const void* w1bpack, float w1binv, const float* act1, const float* w0, float* dx0, int H, int W,
+                  void* stream);
+
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
   int conv_variant;               /* 5: fused layer pairs (lemo_conv3x3_pair_f16) where three consecutive channel counts allow,
                                    * variant 4 for the remaining layers (default) ; 6: the same pairs through lemo_conv3x3_pair4_f16 (four-wave
-                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
+                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
                                    * 2: lemo_conv3x3_mfma_lds ; 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;

@@ -192,6 +192,8 @@ _SIGS = {
     'lemo_conv3x3_pair_supported': (C.c_int, [C.c_int] * 5),
     'lemo_conv3x3_pair_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_pair4_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    'lemo_enc_head': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp]),
+    'lemo_enc_tail': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, vp]),
     'lemo_conv3x3_mfma_split_census2': (C.c_int, [vp, vp, C.c_float, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_mfma_lds_census': (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_c1': (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -7,6 +7,11 @@ namespace lemo {
 
 #define ENC_CHK(e) do { int _e = (e); if (_e) return _e; } while (0)
 
+// conv variant 7 = variant 5 + the fused head / tail (conv_head_kernels.hip): layers 0 and 1 ride with the marker image / the image gradient
+template <class D> static inline bool enc_fused_head(const D& d) {
+  return d.conv_variant == 7 && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
+}
+
 // one layer (forward: act[l] -> act[l+1]; backward-data: d(pre-act l+1) -> d(pre-act l) with the saved activation act[l] as
 // epilogue operand) on the kernel family conv_variant selects for its shape
 template <class D>
@@ -30,12 +35,12 @@ static inline int enc_layer(const D& d, int l, bool bwd, const float* src, float
 // run as ONE launch (64 -> 64 -> 64: layers (3,4), (5,6), (7,8); 6 launches instead of 9), the intermediate activation is still
 // written (the backward pass reads every act[l])
 template <class D>
-static inline int enc_chain_fwd(const D& d, int H, int W, hipStream_t s) {
-  int l = 1;
+static inline int enc_chain_fwd(const D& d, int H, int W, hipStream_t s, int l_first = 1) {
+  int l = l_first;                 // (2 when enc_head produced act[2] already: conv variant 7)
   while (l < 10) {
     if (d.conv_variant >= 5 && l + 1 < 10 && d.enc_w3[l] && d.enc_w3[l + 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1], d.enc_ch[l + 2])) {
-      ENC_CHK((d.conv_variant >= 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.act[l], d.enc_w3[l], d.enc_w3_inv[l], d.enc_b[l], nullptr, d.act[l + 1],
+      ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.act[l], d.enc_w3[l], d.enc_w3_inv[l], d.enc_b[l], nullptr, d.act[l + 1],
                                                                            d.enc_w3[l + 1], d.enc_w3_inv[l + 1], d.enc_b[l + 1], nullptr, d.act[l + 2],
                                                                            H, W, 0, s, nullptr));
       l += 2;
@@ -50,12 +55,12 @@ static inline int enc_chain_fwd(const D& d, int H, int W, hipStream_t s) {
 // layers 9..1 backward-data: d(pre-act 10) in dact[0] -> d(pre-act 1) in dact[*cur_out] through the two ping-pong maps.
 // conv_variant >= 5: pairs (9,8), (7,6), (5,4) in one launch each -- the intermediate gradient map never leaves the CU
 template <class D>
-static inline int enc_chain_bwd(const D& d, int H, int W, hipStream_t s, int* cur_out) {
-  int cur = 0, l = 9;
-  while (l >= 1) {
-    if (d.conv_variant >= 5 && l - 1 >= 1 && d.enc_wbwd3[l] && d.enc_wbwd3[l - 1] &&
+static inline int enc_chain_bwd(const D& d, int H, int W, hipStream_t s, int* cur_out, int l_last = 1) {
+  int cur = 0, l = 9;              // (l_last = 2: enc_tail takes d(pre-act 2) from here: conv variant 7)
+  while (l >= l_last) {
+    if (d.conv_variant >= 5 && l - 1 >= l_last && d.enc_wbwd3[l] && d.enc_wbwd3[l - 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l], d.enc_ch[l - 1])) {
-      ENC_CHK((d.conv_variant >= 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd3_inv[l], nullptr, d.act[l], nullptr,
+      ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd3_inv[l], nullptr, d.act[l], nullptr,
                                                                            d.enc_wbwd3[l - 1], d.enc_wbwd3_inv[l - 1], nullptr, d.act[l - 1],
                                                                            d.dact[1 - cur], H, W, 1, s, nullptr));
       l -= 2;

@@ -131,6 +131,12 @@ int adam_flat(float* p, const float* g, float* m, float* v, int n, float lr, int
 // ---------------- loss_kernels.hip ----------------
 int marker_c1(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
               const float* w, const float* bias, float* x0, float* canon, float* out, int cout, hipStream_t s);
+// ---------------- conv_head_kernels.hip (conv variant 7: variant 5 + these) ----------------
+// marker image + layer 0 (1 -> 32, fp32 FMAs) + layer 1 (32 -> 32, split-f16 MFMA) in one launch / its adjoint in one launch
+int enc_head(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B, const float* w0,
+             const float* b0, const void* w1pack, float w1inv, const float* b1, float* x0, float* canon, float* act1, float* act2,
+             hipStream_t s);
+int enc_tail(const float* din, const void* w1bpack, float w1binv, const float* act1, const float* w0, float* dx0, int H, int W, hipStream_t s);
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);
 // acc (f64[16], zeroed at the start of the iteration): [0] marker L1 sum, [1..4] contact sums, [5..8] contact

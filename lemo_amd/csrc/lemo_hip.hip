@@ -64,6 +64,16 @@ int lemo_conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const f
                            unsigned long long* dbg, void* stream) {
   return conv3x3_pair4_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
 }
+int lemo_enc_head(const lemo_fit_const* fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B, const float* w0,
+                  const float* b0, const void* w1pack, float w1inv, const float* b1, float* x0, float* canon, float* act1, float* act2,
+                  void* stream) {
+  if (!fc) return LEMO_ERR_ARG;
+  return enc_head(*fc, verts, nrows, Jtr, nj, transl, B, w0, b0, w1pack, w1inv, b1, x0, canon, act1, act2, S(stream));
+}
+int lemo_enc_tail(const float* din, const void* w1bpack, float w1binv, const float* act1, const float* w0, float* dx0, int H, int W,
+                  void* stream) {
+  return enc_tail(din, w1bpack, w1binv, act1, w0, dx0, H, W, S(stream));
+}
 int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
                                     int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
   if (!in || !w || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
@@ -356,8 +366,12 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
   if (stages & 4u) {
-  CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  CHK(enc_chain_fwd(d, H, W, s));
+  if (enc_fused_head(d))
+    CHK(enc_head(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.enc_w3[1], d.enc_w3_inv[1], d.enc_b[1], d.x0, d.canon,
+                 d.act[1], d.act[2], s));
+  else
+    CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
+  CHK(enc_chain_fwd(d, H, W, s, enc_fused_head(d) ? 2 : 1));
   }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);
@@ -377,8 +391,9 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
   if (d.per_frame || !(stages & 16u)) goto vertex_stage;           // per_frame: no encoder (d.fit.u_m81 is all -1, dx0 is never read)
-  CHK(enc_chain_bwd(d, H, W, s, &cur));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
-  CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_fused_head(d) ? 2 : 1));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
+  if (enc_fused_head(d)) CHK(enc_tail(d.dact[cur], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s));
+  else CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
 vertex_stage:
   if (!(stages & 32u)) goto pose_stage;
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {

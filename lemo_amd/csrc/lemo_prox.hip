@@ -44,15 +44,20 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   // ---- loss: per-frame terms, dense SDF term, smoothness prior through the encoder
   CHK(prox_frame(d, s));
   CHK(prox_dense(d, s));
-  CHK(marker_c1(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  CHK(enc_chain_fwd(d, H, W, s));
+  if (enc_fused_head(d))
+    CHK(enc_head(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.enc_w3[1], d.enc_w3_inv[1], d.enc_b[1], d.x0, d.canon,
+                 d.act[1], d.act[2], s));
+  else
+    CHK(marker_c1(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
+  CHK(enc_chain_fwd(d, H, W, s, enc_fused_head(d) ? 2 : 1));
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[8] * 2.0 / cnt);
   CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 32 * 32));
   // ---- backward
   int cur = 0;
-  CHK(enc_chain_bwd(d, H, W, s, &cur));
-  CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_fused_head(d) ? 2 : 1));
+  if (enc_fused_head(d)) CHK(enc_tail(d.dact[cur], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s));
+  else CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
   CHK(prox_sparse(d, cnt, s));
   CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.V, d.dverts, B, d.Bp, d.dvp, d.dA, d.dtr_v, d.dX, s));
   lemo_pose_grad_in gi{d.dA, d.dJtr, d.dX, d.dfp_add};

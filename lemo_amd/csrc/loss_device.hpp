@@ -6,6 +6,51 @@
 
 namespace lemo {
 
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// canon[0..8] = R0 (row-major, columns x,y,z axes), canon[9..11] = marker 0 of frame 0
+__device__ __forceinline__ void canonical_frame(const float* verts, int nrows, const int* row81, const float* Jtr,
+                                                int nj, const float* transl, float* canon, const float* cam2world = nullptr) {
+  // joints[0, 1:3] (posed joints + transl), opt_amass_temp.py:368-375
+  float j1[3], j2[3];
+  for (int k = 0; k < 3; ++k) {
+    const float tr = transl ? transl[k] : 0.f;
+    j1[k] = Jtr[3 * 1 + k] + tr;
+    j2[k] = Jtr[3 * 2 + k] + tr;
+  }
+  if (cam2world) {                 // PROX: the frame is built in world coordinates (fitting_temp_slide.py:1001-1010)
+    float w1[3], w2[3];
+    for (int i = 0; i < 3; ++i) {
+      w1[i] = cam2world[3 * i] * j1[0] + cam2world[3 * i + 1] * j1[1] + cam2world[3 * i + 2] * j1[2] + cam2world[9 + i];
+      w2[i] = cam2world[3 * i] * j2[0] + cam2world[3 * i + 1] * j2[1] + cam2world[3 * i + 2] * j2[2] + cam2world[9 + i];
+    }
+    for (int i = 0; i < 3; ++i) { j1[i] = w1[i]; j2[i] = w2[i]; }
+  }
+  (void)nj;
+  float xx = j2[0] - j1[0], xy = j2[1] - j1[1];
+  const float nx = sqrtf(xx * xx + xy * xy);
+  xx /= nx; xy /= nx;
+  // y = cross(z, x) = (-x.y, x.x, 0), normalised
+  float yx = -xy, yy = xx;
+  const float ny = sqrtf(yx * yx + yy * yy);
+  yx /= ny; yy /= ny;
+  canon[0] = xx; canon[1] = yx; canon[2] = 0.f;
+  canon[3] = xy; canon[4] = yy; canon[5] = 0.f;
+  canon[6] = 0.f; canon[7] = 0.f; canon[8] = 1.f;
+  if (cam2world) {                 // world marker differences are R (v - v0): fold R into the matrix, canon' = R^T R0
+    float m[9];
+    for (int k = 0; k < 3; ++k)
+      for (int c = 0; c < 3; ++c)
+        m[3 * k + c] = cam2world[k] * canon[c] + cam2world[3 + k] * canon[3 + c] + cam2world[6 + k] * canon[6 + c];
+    for (int e = 0; e < 9; ++e) canon[e] = m[e];
+  }
+  const float* m0 = verts + (size_t)row81[0] * 3;       // frame 0, marker 0
+  (void)nrows;
+  canon[9] = m0[0]; canon[10] = m0[1]; canon[11] = m0[2];
+}
+
+
+
 // ---- latent smoothness loss (opt_amass_temp.py:390-391) + its gradient, fused ------------------
 //   loss = mean_{c,y,x<W-1} (z[c,y,x+1]-z[c,y,x])^2
 //   dpre[c,y,x] = coef * 2 * ((z[x]-z[x-1])[x>=1] - (z[x+1]-z[x])[x<=W-2]) * lrelu'(z[c,y,x])

@@ -571,10 +571,11 @@ def _splitk_case(lib, g, M, N, K, S, grouped):
 
 
 @pytest.mark.timeout(1800)
-def test_wide_clip_keeps_the_fused_pairs_and_matches_the_oracle(emu_lib):
+@pytest.mark.parametrize('variant', [5, 7])
+def test_wide_clip_keeps_the_fused_pairs_and_matches_the_oracle(emu_lib, variant):
     """B = 130 (W = 145 > 134): the single-layer split kernels do not take the image, the fused pairs do -- the engine keeps conv
-    variant 5 (pairs fused, the other encoder launches on the fp32-input kernel layer by layer) and the iteration still matches the
-    oracle: losses, gradients, one Adam step"""
+    variant 5 / 7 (pairs fused -- 7: head and tail fused as well, any width -- the other encoder launches on the fp32-input kernel layer
+    by layer) and the iteration still matches the oracle: losses, gradients, one Adam step"""
     import warnings
     import __graft_entry__ as ge
     from lemo_amd.fitting import AmassTemporalFitter
@@ -585,8 +586,8 @@ def test_wide_clip_keeps_the_fused_pairs_and_matches_the_oracle(emu_lib):
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
         fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'],
-                                  prob['B'], 'cpu', full_vertices=True, lib=emu_lib, conv_variant=5)
-    assert fit.conv_variant == 5 and any('wider than' in str(x.message) for x in w)
+                                  prob['B'], 'cpu', full_vertices=True, lib=emu_lib, conv_variant=variant)
+    assert fit.conv_variant == variant and any('wider than' in str(x.message) for x in w)
     assert not emu_lib.conv3x3_split_supported(fit.H, fit.W, 64, 64) and emu_lib.conv3x3_pair_supported(fit.H, fit.W, 64, 64, 64)
     fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
     fit.forward()

@@ -22,6 +22,8 @@ BUDGETS = {
     'conv3x3_pair_kernelILi1ELb0E': ('conv_pair_kernels.hip', 256, 512),
     'conv3x3_pair4_kernelILi0ELb0E': ('conv_pair4_kernels.hip', 256, 256),              # variant 6: four waves, TWO workgroups per CU -> 2 waves per SIMD
     'conv3x3_pair4_kernelILi1ELb0E': ('conv_pair4_kernels.hip', 256, 256),
+    'enc_head_kernel': ('conv_head_kernels.hip', 128, 512),                              # variant 7: fused head / tail of the encoder
+    'enc_tail_kernel': ('conv_head_kernels.hip', 128, 512),
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),
