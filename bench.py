@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 MFMA (guide: ~2.5 PF; AMD's 5 PF headline is 2:1 sparse)
 PEAK_HBM_TBS = 8.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PMC_FILE = os.path.join('profiles', 'r04_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
+PMC_FILE = os.path.join('profiles', 'r05_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
 
 
 def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
