@@ -87,6 +87,19 @@ def frame_errors(g_impl, G64):
     return per.max(0).values, per.argmax(0)
 
 
+def frames_in_reach(l: int, x: int, B: int):
+    """frames whose gradient a LeakyReLU unit of encoder layer l (1-based) at image column x can reach: layers l+1 .. 10 spread it by
+    10 - l columns (+1: the temporal difference of z), image column c is velocity column c - 8 (reflect-padded by 8) = frames j, j + 1"""
+    nd = B - 1
+    fr = set()
+    for cc in range(max(0, x - (11 - l)), min(nd + 15, x + (11 - l)) + 1):
+        j = cc - 8
+        j = -j if j < 0 else (2 * (nd - 1) - j if j > nd - 1 else j)
+        j = min(max(j, 0), nd - 1)
+        fr.update((j, j + 1))
+    return sorted(fr)
+
+
 def diff_decisions(dec, dec64, o64, verts64, acts64):
     """where two sets of decisions differ: list of (family, detail, frames in reach, distance of float64's value from the kink)"""
     out = []
@@ -96,15 +109,8 @@ def diff_decisions(dec, dec64, o64, verts64, acts64):
         d = (a != b).nonzero()
         m = float(acts64[l - 1].abs().max())
         for _, c, y, x in d.tolist():
-            cols = range(max(0, x - (11 - l)), min(nd + 15, x + (11 - l)) + 1)       # layers l+1 .. 10 spread a unit by 10 - l columns (+1: z_v)
-            fr = set()
-            for cc in cols:
-                j = cc - 8
-                j = -j if j < 0 else (2 * (nd - 1) - j if j > nd - 1 else j)
-                j = min(max(j, 0), nd - 1)
-                fr.update((j, j + 1))
             val = float(acts64[l - 1][c, y, x])
-            out.append((f'lrelu{l}', (c, y, x), sorted(fr), abs(val if val > 0 else val / 0.2) / m))
+            out.append((f'lrelu{l}', (c, y, x), frames_in_reach(l, x, B), abs(val if val > 0 else val / 0.2) / m))
     if 'vposer' in dec and 'vposer' in dec64:
         for l, (a, b) in enumerate(zip(dec['vposer'], dec64['vposer']), start=1):
             for t, u in (a != b).nonzero().tolist():

@@ -531,6 +531,7 @@ def test_compat_lbs_function(dev):
 
 def test_active_vertex_forward_is_identical(full_problem, dev):
     """forwarding only the 253 vertices the losses read gives the same losses and gradients."""
+    from lemo_amd.priors import from_cg8p
     g, seq = full_problem['g'], full_problem['seq']
     res = []
     for full in (True, False):
@@ -538,13 +539,29 @@ def test_active_vertex_forward_is_identical(full_problem, dev):
         fit.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
         fit.forward(); fit.backward()
         torch.cuda.synchronize()
-        res.append((fit.losses(), {k: v.clone() for k, v in fit.grads().items()}))
+        acts = [from_cg8p(fit.act[l], fit.H, fit.W).cpu() for l in range(1, 11)]
+        res.append((fit.losses(), {k: v.clone() for k, v in fit.grads().items()}, acts))
     for k in res[0][0]:
         assert abs(res[0][0][k] - res[1][0][k]) <= 1e-6 * abs(res[0][0][k]) + 1e-12, k
+    # The two forwards differ in the last bits (blend GEMM of 10475 vs 253 rows), so a LeakyReLU unit of the encoder's 21 M that sits within
+    # rounding of its kink can take different branches in the two runs (round 5: with conv variant 7 one unit of layer 7 does on this clip
+    # -- the very unit float64 disagrees with the engine about, profiles/r05_gates.txt seed 0, frame 35, 5.6e-4).  The frames such a unit
+    # reaches are excluded -- after checking that the unit IS at its kink -- and every other frame must agree to 5e-5 (the orientation
+    # gradient is a sum over all vertices with cancellation and carries the last-bit differences at ~2e-5 of its max).
+    import kink_attribution as KA
+    B = res[0][1]['transl'].shape[0]
+    skip = set()
+    for l, (a, b) in enumerate(zip(res[0][2], res[1][2]), start=1):
+        m = float(a.abs().max())
+        for c, y, x in ((a > 0) != (b > 0)).nonzero().tolist():
+            assert abs(float(a[c, y, x])) <= 1e-5 * m and abs(float(b[c, y, x])) <= 1e-5 * m, (l, c, y, x, float(a[c, y, x]), float(b[c, y, x]))
+            skip.update(KA.frames_in_reach(l, x, B))
+    assert len(skip) <= B // 3, sorted(skip)
+    keep = torch.tensor([f not in skip for f in range(B)])
+    print(f'\nactive vs all-vertex forward: {len(skip)} frames within reach of a unit at its kink excluded')
     for k in res[0][1]:
-        # the two forwards differ in the last bits (split-bf16 vs fp32-MFMA blend GEMM); the orientation gradient is a
-        # sum over all vertices with cancellation and carries that at ~2e-5 of its max
-        assert rel_err(res[1][1][k], res[0][1][k]) < 5e-5, k
+        ref = res[0][1][k]
+        assert float((res[1][1][k][keep] - ref[keep]).abs().max() / ref.abs().max()) < 5e-5, k
 
 
 def test_translation_invariance_property(full_problem, dev):

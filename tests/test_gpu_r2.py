@@ -306,7 +306,7 @@ def test_amass_clip_pipeline_end_to_end_vs_oracle(dev):
 
 def test_fit_clips_pipelined_equals_one_by_one(dev):
     """AmassClipPipeline.fit_clips (the clips' finetunes carried together by the launches of one AE engine, then each clip's fit on
-    the fitter's stream: upload / result streams, no host waits) returns exactly what fit_clip returns clip by clip"""
+    the fitter's stream: upload / result streams, no host waits) returns what fit_clip returns clip by clip (to the AE grouping's rounding)"""
     from lemo_amd import pipeline as P
     from lemo_amd.fitting import AmassTemporalFitter
     from lemo_amd.infill import AE
@@ -331,8 +331,20 @@ def test_fit_clips_pipelined_equals_one_by_one(dev):
             o = pipe.fit_clip(c, p, init, gender=gd, steps=12, finetune_steps=10)
             solo.append({k: v.clone() for k, v in o.items()})
         many = pipe.fit_clips(items, steps=12, finetune_steps=10)
+        many = [{k: v.clone() for k, v in o.items()} for o in many]
+        again = pipe.fit_clips(items, steps=12, finetune_steps=10)
         torch.cuda.synchronize()
+    # Round 5: the AE's convolution launch shapes follow the clips in flight (three clips = a 2-clip and a 1-clip engine), so a clip's
+    # reconstruction equals its solo run to rounding (5e-7 after 60 steps, tools/ae_clips.py) and so does what is decoded from it; the
+    # twelve fit steps that follow start from targets that differ in the last bits (early Adam steps divide by sqrt(v) ~ 0: single
+    # entries may move by a fraction of lr).  Bit for bit: two runs of the same grouping.
     for a, b in zip(solo, many):
+        for k in ('markers_rec', 'clip_img_rec'):
+            assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(a[k].abs().max()), k
+        assert float((a['contact_lbl_rec'] != b['contact_lbl_rec']).float().mean()) <= 0.01
+        d = (a['p72'] - b['p72']).abs()
+        assert float(d.median()) <= 1e-5 and float(d.max()) <= 5e-3, (float(d.median()), float(d.max()))
+    for a, b in zip(many, again):
         for k in ('p72', 'markers_rec', 'contact_lbl_rec', 'clip_img_rec'):
             assert torch.equal(a[k], b[k]), k
     assert fit.nonfinite_step() == 0
