@@ -65,21 +65,22 @@ template <int NT> struct PairSplit {
   static constexpr int give_quad(int KH, int i) { return i < 4 ? i : (i - 4) + 2 * (1 - KH); }
 };
 
-// hand the "give" quads to the partner wave through LDS; after a workgroup barrier AT KERNEL SCOPE (one call site for all waves: the
-// NT-specialised code paths used to carry their own __syncthreads(), which only works because s_barrier counts waves -- ADVICE r04)
-// add the partner's to the "keep" quads in the fixed order kh 0 + kh 1
+// hand the "give" quads to the partner wave through LDS, add the partner's to the "keep" quads in the fixed order kh 0 + kh 1
+// (The __syncthreads() below is reached through differently specialised inlined copies of this function -- NT 3 | 2, KH 0 | 1 -- i.e. the
+// waves of a workgroup meet at different s_barrier instructions.  gfx9's s_barrier counts waves, not call sites, and the host emulator
+// does the same; ADVICE r04 asked for ONE call site at kernel scope.  Round 5 built that (exchange split into give / keep around a
+// barrier in the kernel body, layer 2 split into two halves) and measured it: bit-identical results, but +1.0 us per pair on the same
+// box, interleaved (fwd 25.6 vs 24.5, bwd 23.7 vs 22.8 us) and SQ_LDS_BANK_CONFLICT 5.2e5 -> 1.09e6 per launch (profiles/r05_pmc_summary.txt
+// of commit 1121d81 vs r04) -- the merged control flow costs the layer-2 epilogue its schedule.  Reverted; the form below stays.)
 template <int NT, int KH>
-__device__ __forceinline__ void pair_give(const f32x16 (&acc)[3], float* red_mine) {
+__device__ __forceinline__ void pair_exchange(const f32x16 (&acc)[3], float4 (&v)[6], float* red_mine, const float* red_theirs) {
   typedef PairSplit<NT> S;
 #pragma unroll
   for (int i = 0; i < S::NQ; ++i) {
     const int t = S::give_tile(KH, i), q = S::give_quad(KH, i);
     st4(red_mine + i * 256, make_float4(acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]));
   }
-}
-template <int NT, int KH>
-__device__ __forceinline__ void pair_keep(const f32x16 (&acc)[3], float4 (&v)[6], const float* red_theirs) {
-  typedef PairSplit<NT> S;
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < S::NQ; ++i) {
     const int t = S::keep_tile(KH, i), q = S::keep_quad(KH, i);
@@ -149,17 +150,10 @@ __device__ __forceinline__ void pair_kloop(f32x16 (&acc)[3], uint4 (&ra)[CP_RA][
 #undef CP_MFMA1
 }
 
-// second layer of the pair for a wave that carries NT (3 | 2) out N-tiles starting at tile T0, in two halves around the K-half exchange
-// barrier (which sits at kernel scope).  L2State: what the second half needs from the first.
-struct L2State {
-  f32x16 acc[3];
-  float4 eo[6];
-  int poA, poB;
-  bool okA, okB;
-};
+// second layer of the pair for a wave that carries NT (3 | 2) out N-tiles starting at tile T0
 template <int EPI, int NT>
-__device__ __forceinline__ void pair_layer2_kloop(const PairArgs& a, unsigned char* smem, float* smem_f, int y0, int x0, int T0, int ng2, int ch,
-                                                  int kh, int lane, float smi, uint4 (&ra)[CP_RA][2], L2State& st) {
+__device__ __forceinline__ void pair_layer2(const PairArgs& a, unsigned char* smem, float* smem_f, int y0, int x0, int T0, int ng2, int ch,
+                                            int kh, int lane, float smi, uint4 (&ra)[CP_RA][2]) {
   const int j = lane & 31, h = lane >> 5;
   const int Wp = a.W + 2, HWp = (a.H + 2) * Wp;
   int lo[3] = {0, 0, 0}, poff[3] = {0, 0, 0};
@@ -174,61 +168,53 @@ __device__ __forceinline__ void pair_layer2_kloop(const PairArgs& a, unsigned ch
     const int yc = y < a.H ? y : a.H - 1, xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1);
     poff[nt] = (yc + 1) * Wp + (xc + 1);
   }
+  f32x16 acc[3];
 #pragma unroll
   for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st.acc[nt][r] = 0.f;
-  pair_kloop<NT, CP_GRP_MID, CP_PL_MID, CP_MIDP>(st.acc, ra, a.wB, smem + CP_MID_OFF, lo, kh, ch, lane, [](int, int) {}, [](int) {});
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  pair_kloop<NT, CP_GRP_MID, CP_PL_MID, CP_MIDP>(acc, ra, a.wB, smem + CP_MID_OFF, lo, kh, ch, lane, [](int, int) {}, [](int) {});
   {
     const float f = smi * a.winvB;                          // back to the operands' own scale (exact: powers of two)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st.acc[nt][r] *= f;
+      for (int r = 0; r < 16; ++r) acc[nt][r] *= f;
   }
   typedef PairSplit<NT> S;
   // geometry of the quads this K half finishes: quads 0..3 belong to tile KH, quads 4..5 (NT 3 only) to tile 2
   const int KHu = __builtin_amdgcn_readfirstlane(kh);
-  st.poA = KHu ? poff[1] : poff[0]; st.poB = poff[2];
-  st.okA = KHu ? ok[1] : ok[0]; st.okB = ok[2];
+  const int poA = KHu ? poff[1] : poff[0], poB = poff[2];
+  const bool okA = KHu ? ok[1] : ok[0], okB = ok[2];
   // epilogue operands: requested before the exchange barrier (their round trip hides behind it)
+  float4 eo[6];
 #pragma unroll
   for (int i = 0; i < S::NQ; ++i) {
     const int q = KHu ? S::keep_quad(1, i) : S::keep_quad(0, i);
     const int c0 = ch * 32 + q * 8 + 4 * h;
-    const int po = i < 4 ? st.poA : st.poB;
-    st.eo[i] = EPI == 1 ? ld4(a.auxB + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7)) : ld4(a.biasB + c0);
+    const int po = i < 4 ? poA : poB;
+    eo[i] = EPI == 1 ? ld4(a.auxB + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7)) : ld4(a.biasB + c0);
   }
   float* red = smem_f + ((ng2 * 2 + ch) * 2) * 1536 + lane * 4;      // [slot (ng2, ch)][writer kh][6 quads][64 lanes][4]: input planes are dead
-  // (no barrier needed before these writes: the scratch aliases the INPUT planes, dead since layer 1, and two workgroup barriers
-  // lie between layer 1's exchange reads and here)
-  if (KHu) pair_give<NT, 1>(st.acc, red + 1536);
-  else pair_give<NT, 0>(st.acc, red);
-}
-template <int EPI, int NT>
-__device__ __forceinline__ void pair_layer2_finish(const PairArgs& a, float* smem_f, int ng2, int ch, int kh, int lane, const L2State& st) {
-  typedef PairSplit<NT> S;
-  const int h = lane >> 5;
-  const int Wp = a.W + 2, HWp = (a.H + 2) * Wp;
-  const int KHu = __builtin_amdgcn_readfirstlane(kh);
-  const float* red = smem_f + ((ng2 * 2 + ch) * 2) * 1536 + lane * 4;
   float4 v[6];
-  if (KHu) pair_keep<NT, 1>(st.acc, v, red);
-  else pair_keep<NT, 0>(st.acc, v, red + 1536);
+  // (no barrier needed before the exchange: its scratch aliases the INPUT planes, dead since layer 1, and two workgroup barriers
+  // lie between layer 1's exchange reads and these writes)
+  if (KHu) pair_exchange<NT, 1>(acc, v, red + 1536, red);
+  else pair_exchange<NT, 0>(acc, v, red, red + 1536);
 #pragma unroll
   for (int i = 0; i < S::NQ; ++i) {
     const int q = KHu ? S::keep_quad(1, i) : S::keep_quad(0, i);
     const int c0 = ch * 32 + q * 8 + 4 * h;
-    const int po = i < 4 ? st.poA : st.poB;
-    const bool stv = i < 4 ? st.okA : st.okB;
+    const int po = i < 4 ? poA : poB;
+    const bool st = i < 4 ? okA : okB;
     float4 r = v[i];
     if (EPI == 1) {
-      r.x *= lrelu_grad_from_out(st.eo[i].x); r.y *= lrelu_grad_from_out(st.eo[i].y);
-      r.z *= lrelu_grad_from_out(st.eo[i].z); r.w *= lrelu_grad_from_out(st.eo[i].w);
+      r.x *= lrelu_grad_from_out(eo[i].x); r.y *= lrelu_grad_from_out(eo[i].y);
+      r.z *= lrelu_grad_from_out(eo[i].z); r.w *= lrelu_grad_from_out(eo[i].w);
     } else {
-      r.x = lrelu(r.x + st.eo[i].x); r.y = lrelu(r.y + st.eo[i].y); r.z = lrelu(r.z + st.eo[i].z); r.w = lrelu(r.w + st.eo[i].w);
+      r.x = lrelu(r.x + eo[i].x); r.y = lrelu(r.y + eo[i].y); r.z = lrelu(r.z + eo[i].z); r.w = lrelu(r.w + eo[i].w);
     }
-    if (stv) st4(a.out + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), r);
+    if (st) st4(a.out + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), r);
   }
 }
 
@@ -401,11 +387,8 @@ conv3x3_pair_kernel(PairArgs a) {
   float4 v[6];
   {
     float* red = smem_f + ((ng * 2 + ch) * 2) * 1536 + lane * 4;     // the input planes are dead (barrier at the end of the k loop)
-    if (KHu) pair_give<3, 1>(acc, red + 1536);
-    else pair_give<3, 0>(acc, red);
-    __syncthreads();
-    if (KHu) pair_keep<3, 1>(acc, v, red);
-    else pair_keep<3, 0>(acc, v, red + 1536);
+    if (KHu) pair_exchange<3, 1>(acc, v, red + 1536, red);
+    else pair_exchange<3, 0>(acc, v, red, red + 1536);
   }
   if (DBG) t_ex = __builtin_amdgcn_s_memtime();
   float mloc = 0.f;
@@ -449,12 +432,8 @@ conv3x3_pair_kernel(PairArgs a) {
 
   // ---- layer 2 -------------------------------------------------------------------------------------------------------------------
   const int ng2 = __builtin_amdgcn_readfirstlane(ng ^ kh);
-  L2State l2;
-  if (ng2) pair_layer2_kloop<EPI, 2>(a, smem, smem_f, y0, x0, 3, 1, ch, kh, lane, smi, ra, l2);
-  else pair_layer2_kloop<EPI, 3>(a, smem, smem_f, y0, x0, 0, 0, ch, kh, lane, smi, ra, l2);
-  __syncthreads();                                         // the ONE exchange barrier of layer 2, the same call site for every wave
-  if (ng2) pair_layer2_finish<EPI, 2>(a, smem_f, 1, ch, kh, lane, l2);
-  else pair_layer2_finish<EPI, 3>(a, smem_f, 0, ch, kh, lane, l2);
+  if (ng2) pair_layer2<EPI, 2>(a, smem, smem_f, y0, x0, 3, 1, ch, kh, lane, smi, ra);
+  else pair_layer2<EPI, 3>(a, smem, smem_f, y0, x0, 0, 0, ch, kh, lane, smi, ra);
   if (EPI != 1) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {

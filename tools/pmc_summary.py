@@ -16,7 +16,7 @@ for k, cs in sorted(res.items()):
     summary[k]['dispatches'] = max(len(v) for v in cs.values())
 json.dump(summary, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
 for k, v in summary.items():
-    if any(x in k for x in ('conv3x3_mfma_v2', 'conv3x3_split', 'conv3x3_pair', 'lbs_verts_fwd', 'gemm_nt16', 'smooth_loss')):
+    if any(x in k for x in ('conv3x3_mfma_v2', 'conv3x3_split', 'conv3x3_pair', 'lbs_verts_fwd', 'gemm_nt16', 'smooth_loss', 'enc_head', 'enc_tail')):
         print(k)
         for c, val in v.items():
             print('    %-28s %.4g' % (c, val))
