@@ -37,11 +37,11 @@ template <int END> struct HdSteps<END, END> { template <class F> static __device
 // L2 through a ring, B from the LDS planes at bbase (group stride GRP, piece stride PL, row pitch 18), one step ahead.
 // acc[p]: one accumulator per product (lo x hi, hi x lo, hi x hi); the caller adds them smallest first.
 #define HD_RA 4
-template <int GRP, int PL>
-__device__ __forceinline__ void hd_kloop(f32x16 (&acc)[3], const uint4* __restrict__ w, const unsigned char* bbase, int li, int lane) {
+template <int GRP, int PL, int MT = 1>
+__device__ __forceinline__ void hd_kloop(f32x16 (&acc)[3], const uint4* __restrict__ w, const unsigned char* bbase, int li, int lane, int mt = 0) {
   const int h = lane >> 5;
   uint4 ra[HD_RA][2], rb[2][2];
-#define HD_LOAD_A(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) ra[SET][s_] = w[(unsigned)((U) * 2 + s_) * 64u + lane];
+#define HD_LOAD_A(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) ra[SET][s_] = w[(unsigned)(((U) * MT + mt) * 2 + s_) * 64u + lane];
 #define HD_LOAD_B(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                          \
     rb[SET][s_] = *reinterpret_cast<const uint4*>(bbase + (2 * ((U) / 9) + h) * GRP + s_ * PL + (li + (((U) % 9) / 3 - 1) * HD_MIDP + (((U) % 9) % 3 - 1)) * 16);
 #pragma unroll
@@ -227,6 +227,241 @@ int enc_head(const FitConst& fc, const float* verts, int nrows, const float* Jtr
   a.ntx = (W + HD_TW - 1) / HD_TW;
   a.ntiles = a.ntx * ((H + HD_TH - 1) / HD_TH);
   hipLaunchKernelGGL(enc_head_kernel, dim3(a.ntiles), dim3(512), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// enc_head3 (conv variant 8): the head with layer 2 (32 -> 64) on top -- image tile with a halo of 3 (16 x 20), layer 0 on 14 x 18,
+// layer 1 on 12 x 16 (6 N-tiles, one wave each), layer 2 on the 10 x 14 tile (5 N-tiles x 2 M-tiles = 10 blocks on 8 waves: waves 0, 1
+// run two).  x0, act[1], act[2], act[3] are all written.  Five forward launches remain: head3, pairs (3,4) (5,6) (7,8), layer 9.
+constexpr int H3_IW = HD_TW + 6, H3_IH = HD_TH + 6, H3_NI = H3_IW * H3_IH;             // 20 x 16 = 320 image values
+constexpr int H3_PL1 = HD_NX * 16, H3_GRP1 = 2 * H3_PL1;                              // layer-0 output planes: 14 x 18 = 252 slots
+
+struct Head3Args {
+  HeadArgs h;
+  const uint4* w2; float w2inv; const float* b2;          // layer 2: split-f16 pack (cin 32, cout 64), inverse host scale, bias
+  float* act3;
+};
+
+__global__ void __launch_bounds__(512)
+enc_head3_kernel(Head3Args A3) {
+  __shared__ __attribute__((aligned(16))) unsigned char p1[4 * H3_GRP1];               // act[1] tile: [group 4][piece 2][252][8 x f16] = 32,256 B
+  __shared__ __attribute__((aligned(16))) unsigned char p2[4 * HD_GRP_MID];            // act[2] tile on pitch 18: 27,648 B
+  __shared__ float xs[H3_NI];
+  __shared__ float cn[12];
+  __shared__ float wmax[24];                              // [0..7] layer-0 maxima, [8..15] layer-1 maxima, [20] layer 0's inverse scale
+  const HeadArgs& a = A3.h;
+  const FitConst& fc = a.fc;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int D = 3 * fc.n81, H = D + 2, W = a.B - 1 + 16, Wp = W + 2, HWp = (H + 2) * Wp;
+  int tile = (int)blockIdx.x;
+  {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, xcd = tile & 7, k = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
+  const int y0 = ty * HD_TH, x0c = tx * HD_TW;
+  // ---- image tile with a halo of 3: reads first
+  float va[3] = {0.f, 0.f, 0.f}, vb[3] = {0.f, 0.f, 0.f}, xm = 0.f, xsd = 1.f;
+  int cc = 0;
+  bool inside = false;
+  const int ip = tid < H3_NI ? tid : H3_NI - 1;
+  const int ily = ip / H3_IW, ilx = ip - ily * H3_IW;
+  {
+    const int yy = y0 - 3 + ily, xx = x0c - 3 + ilx;
+    inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
+    const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+    const int d = reflect_idx(yc - 1, D), tp = reflect_idx(xc - 8, a.B - 1);
+    const int m = d / 3;
+    cc = d - 3 * m;
+    const float* v0 = a.verts + ((size_t)tp * a.nrows + fc.row81[m]) * 3;
+    const float* v1 = v0 + (size_t)a.nrows * 3;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { va[e] = v0[e]; vb[e] = v1[e]; }
+    xm = fc.Xmean[d]; xsd = fc.Xstd[d];
+  }
+  if (tid >= 512 - HD_MIDH * 2 * 8) {                      // zero pad columns of the act[2] planes
+    const int i = tid - (512 - HD_MIDH * 2 * 8), pl = i / (HD_MIDH * 2), rc = i - pl * (HD_MIDH * 2);
+    *reinterpret_cast<uint4*>(p2 + pl * HD_PL_MID + ((rc >> 1) * HD_MIDP + (rc & 1) * (HD_MIDP - 1)) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (tid == 0) {
+    canonical_frame(a.verts, a.nrows, fc.row81, a.Jtr, a.nj, a.transl, cn, fc.cam2world);
+    if (blockIdx.x == 0) for (int i = 0; i < 12; ++i) a.canon_out[i] = cn[i];
+  }
+  __syncthreads();
+  if (tid < H3_NI) {
+    const float g0 = (va[0] - cn[9]) * cn[cc] + (va[1] - cn[10]) * cn[3 + cc] + (va[2] - cn[11]) * cn[6 + cc];
+    const float g1 = (vb[0] - cn[9]) * cn[cc] + (vb[1] - cn[10]) * cn[3 + cc] + (vb[2] - cn[11]) * cn[6 + cc];
+    const float n0 = (g0 - xm) / xsd, n1 = (g1 - xm) / xsd;
+    const float v = inside ? n1 - n0 : 0.f;
+    xs[tid] = v;
+    if (inside && ily >= 3 && ily < 3 + HD_TH && ilx >= 3 && ilx < 3 + HD_TW)
+      a.x0[(size_t)(y0 + ily - 3 + 1) * Wp + (x0c + ilx - 3 + 1)] = v;
+  }
+  __syncthreads();
+  // ---- layer 0 on the 14 x 18 tile (halo 2): thread = (pixel, cout half); waves 0-3 couts 0-15, waves 4-7 couts 16-31
+  {
+    const int halfu = __builtin_amdgcn_readfirstlane(wave >> 2);
+    const int px = tid & 255;
+    const bool worker = px < HD_NX;
+    const int pc = worker ? px : 0;
+    const int r1 = pc / HD_XW, c1 = pc - r1 * HD_XW;
+    const int y = y0 - 2 + r1, x = x0c - 2 + c1;
+    const bool inimg = worker && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const bool inner = inimg && r1 >= 2 && r1 < 2 + HD_TH && c1 >= 2 && c1 < 2 + HD_TW;
+    float r[16];
+    float mloc = 0.f;
+    float xin[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) xin[tp] = xs[(r1 + tp / 3) * H3_IW + c1 + tp % 3];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float* wc = a.w0 + (size_t)(halfu * 16 + c) * 9;
+      float acc = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) acc = fmaf(wc[tp], xin[tp], acc);
+      const float v = lrelu(acc + a.b0[halfu * 16 + c]);
+      r[c] = inimg ? v : 0.f;
+      mloc = fmaxf(mloc, fabsf(r[c]));
+    }
+    mloc = wave_max(mloc);
+    if (lane == 0) wmax[wave] = mloc;
+    __syncthreads();
+    float sm, smi;
+    {
+      float mm = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[i]);
+      f16_scale_for(mm, sm, smi);
+    }
+    if (lane == 0 && wave == 0) wmax[20] = smi;            // layer 1's waves need the inverse scale
+    if (worker) {
+      const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+      const int poff = (yc + 1) * Wp + (xc + 1);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const float4 lo4 = make_float4(r[8 * g], r[8 * g + 1], r[8 * g + 2], r[8 * g + 3]);
+        const float4 hi4 = make_float4(r[8 * g + 4], r[8 * g + 5], r[8 * g + 6], r[8 * g + 7]);
+        if (inner) {
+          float* o = a.act1 + ((size_t)(2 * halfu + g) * HWp + poff) * 8;
+          st4(o, lo4); st4(o + 4, hi4);
+        }
+        uint2 a0, a1, b0, b1;
+        split2x4(lo4, sm, a0, a1);
+        split2x4(hi4, sm, b0, b1);
+        unsigned char* d = p1 + (2 * halfu + g) * H3_GRP1 + pc * 16;
+        *reinterpret_cast<uint4*>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+        *reinterpret_cast<uint4*>(d + H3_PL1) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- layer 1 (32 -> 32) on the 12 x 16 tile: wave T < 6 owns N-tile T (mid rows 2T, 2T + 1)
+  float4 v1[4];
+  float m1 = 0.f;
+  int mp2 = 0, mpoff = 0;
+  bool inner2 = false;
+  if (wave < 6) {
+    const int my = 2 * wave + (j >> 4), mx = hd_lane_col(j);
+    const int li = (my + 1) * HD_XW + mx + 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    hd_kloop<H3_GRP1, H3_PL1>(acc, a.w1, p1, li, lane);
+    const int y = y0 - 1 + my, x = x0c - 1 + mx;
+    const bool inimg = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    inner2 = inimg && my >= 1 && my <= HD_TH && mx >= 1 && mx <= HD_TW;
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    mpoff = (yc + 1) * Wp + (xc + 1);
+    mp2 = my * HD_MIDP + mx + 1;
+    const float f = wmax[20] * a.w1inv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bb = ld4(a.b1 + q * 8 + 4 * h);
+      float4 v;
+      v.x = lrelu(((acc[0][4 * q] + acc[1][4 * q]) + acc[2][4 * q]) * f + bb.x);
+      v.y = lrelu(((acc[0][4 * q + 1] + acc[1][4 * q + 1]) + acc[2][4 * q + 1]) * f + bb.y);
+      v.z = lrelu(((acc[0][4 * q + 2] + acc[1][4 * q + 2]) + acc[2][4 * q + 2]) * f + bb.z);
+      v.w = lrelu(((acc[0][4 * q + 3] + acc[1][4 * q + 3]) + acc[2][4 * q + 3]) * f + bb.w);
+      if (!inimg) v = make_float4(0.f, 0.f, 0.f, 0.f);                // zero padding of layer 2
+      v1[q] = v;
+      m1 = absmax4(v, m1);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v1[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  m1 = wave_max(m1);
+  if (lane == 0 && wave < 6) wmax[8 + wave] = m1;
+  if (lane == 0 && wave >= 6) wmax[8 + wave] = 0.f;
+  __syncthreads();
+  float sm2, smi2;
+  {
+    float mm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[8 + i]);
+    f16_scale_for(mm, sm2, smi2);
+  }
+  if (wave < 6) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = q * 8 + 4 * h;
+      if (inner2) st4(a.act2 + ((size_t)(c0 >> 3) * HWp + mpoff) * 8 + (c0 & 7), v1[q]);
+      uint2 s0, s1;
+      split2x4(v1[q], sm2, s0, s1);
+      unsigned char* d = p2 + q * HD_GRP_MID + mp2 * 16 + 8 * h;
+      *reinterpret_cast<uint2*>(d) = s0;
+      *reinterpret_cast<uint2*>(d + HD_PL_MID) = s1;
+    }
+  }
+  __syncthreads();
+  // ---- layer 2 (32 -> 64) on the 10 x 14 tile: block b = out N-tile (b % 5) x M-tile (b / 5); wave w runs block w, waves 0 and 1 also 8, 9
+  for (int b = wave; b < 10; b += 8) {
+    const int T = b % 5, mt = b / 5;
+    const int oy = 2 * T + (j >> 4), c = hd_lane_col(j), ox = c - 1;
+    const int lo = (oy + 1) * HD_MIDP + c + 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    hd_kloop<HD_GRP_MID, HD_PL_MID, 2>(acc, A3.w2, p2, lo, lane, mt);
+    const int yo = y0 + oy, xo = x0c + ox;
+    const bool ok = ox >= 0 && ox < HD_TW && yo < H && xo < W;
+    const int yoc = yo < H ? yo : H - 1, xoc = xo < 0 ? 0 : (xo < W ? xo : W - 1);
+    const int po = (yoc + 1) * Wp + (xoc + 1);
+    const float f = smi2 * A3.w2inv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = mt * 32 + q * 8 + 4 * h;
+      const float4 bb = ld4(A3.b2 + c0);
+      float4 v;
+      v.x = lrelu(((acc[0][4 * q] + acc[1][4 * q]) + acc[2][4 * q]) * f + bb.x);
+      v.y = lrelu(((acc[0][4 * q + 1] + acc[1][4 * q + 1]) + acc[2][4 * q + 1]) * f + bb.y);
+      v.z = lrelu(((acc[0][4 * q + 2] + acc[1][4 * q + 2]) + acc[2][4 * q + 2]) * f + bb.z);
+      v.w = lrelu(((acc[0][4 * q + 3] + acc[1][4 * q + 3]) + acc[2][4 * q + 3]) * f + bb.w);
+      if (ok) st4(A3.act3 + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), v);
+    }
+  }
+}
+
+int enc_head3(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B, const float* w0,
+              const float* b0, const void* w1pack, float w1inv, const float* b1, const void* w2pack, float w2inv, const float* b2,
+              float* x0, float* canon, float* act1, float* act2, float* act3, hipStream_t s) {
+  if (B < 10 || !w1pack || !w2pack || !(w1inv > 0.f) || !(w2inv > 0.f) || !verts || !x0 || !canon || !act1 || !act2 || !act3) return LEMO_ERR_ARG;
+  const int H = 3 * fc.n81 + 2, W = B - 1 + 16;
+  Head3Args A{};
+  HeadArgs& a = A.h;
+  a.fc = fc; a.verts = verts; a.nrows = nrows; a.Jtr = Jtr; a.nj = nj; a.transl = transl; a.B = B;
+  a.w0 = w0; a.b0 = b0; a.w1 = reinterpret_cast<const uint4*>(w1pack); a.w1inv = w1inv; a.b1 = b1;
+  a.x0 = x0; a.canon_out = canon; a.act1 = act1; a.act2 = act2;
+  a.ntx = (W + HD_TW - 1) / HD_TW;
+  a.ntiles = a.ntx * ((H + HD_TH - 1) / HD_TH);
+  A.w2 = reinterpret_cast<const uint4*>(w2pack); A.w2inv = w2inv; A.b2 = b2; A.act3 = act3;
+  hipLaunchKernelGGL(enc_head3_kernel, dim3(a.ntiles), dim3(512), 0, s, A);
   return (int)hipGetLastError();
 }
 

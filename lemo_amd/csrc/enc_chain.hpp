@@ -9,7 +9,11 @@ namespace lemo {
 
 // conv variant 7 = variant 5 + the fused head / tail (conv_head_kernels.hip): layers 0 and 1 ride with the marker image / the image gradient
 template <class D> static inline bool enc_fused_head(const D& d) {
-  return d.conv_variant == 7 && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
+  return (d.conv_variant == 7 || d.conv_variant == 8) && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
+}
+// conv variant 8 = variant 7 with layer 2 (32 -> 64) inside the head launch as well (enc_head3)
+template <class D> static inline bool enc_fused_head3(const D& d) {
+  return d.conv_variant == 8 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_w3[2];
 }
 
 // one layer (forward: act[l] -> act[l+1]; backward-data: d(pre-act l+1) -> d(pre-act l) with the saved activation act[l] as

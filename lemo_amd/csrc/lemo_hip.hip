@@ -366,12 +366,15 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   }
   // marker image + first encoder layer in one launch (x0 is still written: parity tests read it)
   if (stages & 4u) {
-  if (enc_fused_head(d))
+  if (enc_fused_head3(d))
+    CHK(enc_head3(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.enc_w3[1], d.enc_w3_inv[1], d.enc_b[1], d.enc_w3[2],
+                  d.enc_w3_inv[2], d.enc_b[2], d.x0, d.canon, d.act[1], d.act[2], d.act[3], s));
+  else if (enc_fused_head(d))
     CHK(enc_head(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.enc_w3[1], d.enc_w3_inv[1], d.enc_b[1], d.x0, d.canon,
                  d.act[1], d.act[2], s));
   else
     CHK(marker_c1(d.fit, d.verts, d.nrows, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.x0, d.canon, d.act[1], d.enc_ch[1], s));
-  CHK(enc_chain_fwd(d, H, W, s, enc_fused_head(d) ? 2 : 1));
+  CHK(enc_chain_fwd(d, H, W, s, enc_fused_head3(d) ? 3 : (enc_fused_head(d) ? 2 : 1)));
   }
   const double cnt = (double)d.enc_ch[10] * H * (W - 1);
   const float coef2 = (float)((double)d.weights_host[5] * 2.0 / cnt);

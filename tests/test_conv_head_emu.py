@@ -24,13 +24,17 @@ def test_engine_with_fused_head_and_tail_vs_variant_5_and_oracle(emu_lib, B):
     total, parts, _, _ = ofit.losses()
     total.backward()
     fits = {}
-    for v in (5, 7):
+    for v in (5, 7, 8):
         fit = AmassTemporalFitter(prob['model'], prob['vposer_w'], prob['enc_w'], prob['ids'], prob['Xmean'], prob['Xstd'], prob['B'], 'cpu',
                                   full_vertices=True, lib=emu_lib, conv_variant=v)
         assert fit.conv_variant == v
         fit.load_sequence(prob['seq']['init_params'], markers, prob['seq']['contact_lbl'])
         fit.forward(); fit.backward()
         fits[v] = fit
+    c = fits[8]                                                      # variant 8: layer 2 inside the head launch as well
+    assert torch.equal(c.ws['x0'], fits[5].ws['x0']) and torch.equal(c.act[1], fits[5].act[1])
+    assert rel_err(c.act[2], fits[5].act[2]) < 2e-6 and rel_err(c.act[3], fits[5].act[3]) < 2e-6 and rel_err(c.act[10], fits[5].act[10]) < 1e-5
+    assert rel_err(c.ws['dx0'], fits[5].ws['dx0']) < 1e-5
     a, b = fits[5], fits[7]
     assert torch.equal(a.ws['x0'], b.ws['x0']) and torch.equal(a.ws['canon'], b.ws['canon'])
     assert torch.equal(a.act[1], b.act[1])                           # layer 0: the same FMAs in the same order

@@ -419,7 +419,7 @@ def test_fused_pair_conv_full_size_vs_float64(dev, kernel):
     assert e_b < 2e-6
 
 
-@pytest.mark.parametrize('conv_variant', [5, 7, 6, 4, 3, 2])
+@pytest.mark.parametrize('conv_variant', [5, 7, 8, 6, 4, 3, 2])
 def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
