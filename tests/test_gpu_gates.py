@@ -179,7 +179,7 @@ def test_gradient_error_statistics_over_seeds(dev):
     and of the fp32 CPU oracle against the float64 oracle -- worst frame and median over frames of the per-frame maximum, per
     parameter group.  Asserted: the median over seeds of (GPU worst / CPU worst) <= 2 for the shipped families (measured 1.15), and the GPU's median-frame
     error <= 3 x the CPU's + 2e-6 on every seed (the arithmetic where nothing flipped).  The table is the evidence
-    (profiles/r04_gates.txt)."""
+    (profiles/r05_gates.txt; round 4: r04_gates.txt)."""
     from lemo_amd.fitting import AmassTemporalFitter
     from lemo_amd.vposer import make_vposer_weights
     from oracle import lemo_oracle as O
