@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '7'))
+DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '8'))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -903,6 +903,8 @@ def main():
             ab = {}
             if fit.conv_variant != 4:
                 ab['value_layer_by_layer_f16x2'] = variant_probe(rank, B, device, stream, 4, fit)
+            if fit.conv_variant != 7:
+                ab['value_head_without_layer_2'] = variant_probe(rank, B, device, stream, 7, fit)
             if fit.conv_variant != 5:
                 ab['value_pairs_without_fused_head_tail'] = variant_probe(rank, B, device, stream, 5, fit)
             if fit.conv_variant != 6:
@@ -910,7 +912,7 @@ def main():
             ab['value_fp32_mfma'] = variant_probe(rank, B, device, stream, 2, fit)
             ab['value_headline_again'] = max(timed_fit(fit, prob, stream, device) for _ in range(2))
             ab['note'] = ('fitting-iterations/s over 100 timed steps, same clip / process / box, interleaved: the encoder on conv variant 4 '
-                          '(one split-f16 launch per layer), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 6 (the fused pairs as two four-wave workgroups per CU on 5 x 14 tiles: measured slower, '
+                          '(one split-f16 launch per layer), on variant 7 (head = marker image + layers 0, 1; layer 2 a launch of its own), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 6 (the fused pairs as two four-wave workgroups per CU on 5 x 14 tiles: measured slower, '
                           'DESIGN 11), on variant 2 (v_mfma_f32_32x32x2_f32, fp32 operands) and the headline engine once more')
             out['variants'] = ab
         except Exception as e:       # noqa: BLE001

@@ -376,7 +376,7 @@ typedef struct lemo_fit_desc {
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
   int conv_variant;               /* 5: fused layer pairs (lemo_conv3x3_pair_f16) where three consecutive channel counts allow,
                                    * variant 4 for the remaining layers (default) ; 6: the same pairs through lemo_conv3x3_pair4_f16 (four-wave
-                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail (default) ; 8: 7 with layer 2 (32 -> 64) inside the head launch too (+0.4 %, selectable) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
+                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail ; 8 (default): 7 with layer 2 (32 -> 64) inside the head launch too (+0.9 %) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
                                    * 2: lemo_conv3x3_mfma_lds ; 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;

@@ -61,6 +61,34 @@ __device__ __forceinline__ void hd_kloop(f32x16 (&acc)[3], const uint4* __restri
 #undef HD_LOAD_B
 }
 
+// the same for TWO N-tiles that share their weight fragments (layer 2 of enc_head3: out tiles 3 and 4 of one M-tile in one wave)
+template <int GRP, int PL, int MT>
+__device__ __forceinline__ void hd_kloop2(f32x16 (&acc)[2][3], const uint4* __restrict__ w, const unsigned char* bbase, const int (&li)[2], int lane, int mt) {
+  const int h = lane >> 5;
+  uint4 ra[HD_RA][2], rb[2][2][2];
+#define HD_LOAD_A(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) ra[SET][s_] = w[(unsigned)(((U) * MT + mt) * 2 + s_) * 64u + lane];
+#define HD_LOAD_B(SET, U) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)            \
+    rb[SET][t_][s_] = *reinterpret_cast<const uint4*>(bbase + (2 * ((U) / 9) + h) * GRP + s_ * PL + (li[t_] + (((U) % 9) / 3 - 1) * HD_MIDP + (((U) % 9) % 3 - 1)) * 16);
+#pragma unroll
+  for (int u0 = 0; u0 < HD_RA - 1; ++u0) { HD_LOAD_A(u0, u0) }
+  HD_LOAD_B(0, 0)
+  HdSteps<0, 18>::run([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    if (u + HD_RA - 1 < 18) { HD_LOAD_A((u + HD_RA - 1) % HD_RA, (u + HD_RA - 1 < 18 ? u + HD_RA - 1 : 17)) }
+    if (u + 1 < 18) { HD_LOAD_B((u + 1) & 1, (u + 1 < 18 ? u + 1 : 17)) }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t_ = 0; t_ < 2; ++t_) {
+      acc[t_][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[u % HD_RA][0]), __builtin_bit_cast(f16x8, rb[u & 1][t_][1]), acc[t_][0], 0, 0, 0);
+      acc[t_][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[u % HD_RA][1]), __builtin_bit_cast(f16x8, rb[u & 1][t_][0]), acc[t_][1], 0, 0, 0);
+      acc[t_][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[u % HD_RA][0]), __builtin_bit_cast(f16x8, rb[u & 1][t_][0]), acc[t_][2], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+#undef HD_LOAD_A
+#undef HD_LOAD_B
+}
+
 struct HeadArgs {
   FitConst fc;
   const float* verts; int nrows;
@@ -418,32 +446,51 @@ enc_head3_kernel(Head3Args A3) {
     }
   }
   __syncthreads();
-  // ---- layer 2 (32 -> 64) on the 10 x 14 tile: block b = out N-tile (b % 5) x M-tile (b / 5); wave w runs block w, waves 0 and 1 also 8, 9
-  for (int b = wave; b < 10; b += 8) {
-    const int T = b % 5, mt = b / 5;
-    const int oy = 2 * T + (j >> 4), c = hd_lane_col(j), ox = c - 1;
-    const int lo = (oy + 1) * HD_MIDP + c + 1;
-    f32x16 acc[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    hd_kloop<HD_GRP_MID, HD_PL_MID, 2>(acc, A3.w2, p2, lo, lane, mt);
-    const int yo = y0 + oy, xo = x0c + ox;
-    const bool ok = ox >= 0 && ox < HD_TW && yo < H && xo < W;
-    const int yoc = yo < H ? yo : H - 1, xoc = xo < 0 ? 0 : (xo < W ? xo : W - 1);
-    const int po = (yoc + 1) * Wp + (xoc + 1);
+  // ---- layer 2 (32 -> 64) on the 10 x 14 tile: wave w = (M-tile w & 1, tile set w >> 1): out N-tiles {0}, {1}, {2}, {3, 4} -- the last
+  // set as ONE K loop over two tiles that share their weight fragments (ten blocks on eight waves with waves 0 and 1 running two K
+  // loops in a row measured 17.6 us for the launch: single-tile loops are latency chains)
+  {
+    const int mt = wave & 1, ts = wave >> 1;
     const float f = smi2 * A3.w2inv;
+    auto store_tile = [&](const f32x16 (&acc)[3], int T) {
+      const int oy = 2 * T + (j >> 4), c = hd_lane_col(j), ox = c - 1;
+      const int yo = y0 + oy, xo = x0c + ox;
+      const bool ok = ox >= 0 && ox < HD_TW && yo < H && xo < W;
+      const int yoc = yo < H ? yo : H - 1, xoc = xo < 0 ? 0 : (xo < W ? xo : W - 1);
+      const int po = (yoc + 1) * Wp + (xoc + 1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c0 = mt * 32 + q * 8 + 4 * h;
-      const float4 bb = ld4(A3.b2 + c0);
-      float4 v;
-      v.x = lrelu(((acc[0][4 * q] + acc[1][4 * q]) + acc[2][4 * q]) * f + bb.x);
-      v.y = lrelu(((acc[0][4 * q + 1] + acc[1][4 * q + 1]) + acc[2][4 * q + 1]) * f + bb.y);
-      v.z = lrelu(((acc[0][4 * q + 2] + acc[1][4 * q + 2]) + acc[2][4 * q + 2]) * f + bb.z);
-      v.w = lrelu(((acc[0][4 * q + 3] + acc[1][4 * q + 3]) + acc[2][4 * q + 3]) * f + bb.w);
-      if (ok) st4(A3.act3 + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), v);
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = mt * 32 + q * 8 + 4 * h;
+        const float4 bb = ld4(A3.b2 + c0);
+        float4 v;
+        v.x = lrelu(((acc[0][4 * q] + acc[1][4 * q]) + acc[2][4 * q]) * f + bb.x);
+        v.y = lrelu(((acc[0][4 * q + 1] + acc[1][4 * q + 1]) + acc[2][4 * q + 1]) * f + bb.y);
+        v.z = lrelu(((acc[0][4 * q + 2] + acc[1][4 * q + 2]) + acc[2][4 * q + 2]) * f + bb.z);
+        v.w = lrelu(((acc[0][4 * q + 3] + acc[1][4 * q + 3]) + acc[2][4 * q + 3]) * f + bb.w);
+        if (ok) st4(A3.act3 + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), v);
+      }
+    };
+    auto lo_of = [&](int T) { const int oy = 2 * T + (j >> 4), c = hd_lane_col(j); return (oy + 1) * HD_MIDP + c + 1; };
+    if (ts < 3) {
+      f32x16 acc[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+      hd_kloop<HD_GRP_MID, HD_PL_MID, 2>(acc, A3.w2, p2, lo_of(ts), lane, mt);
+      store_tile(acc, ts);
+    } else {
+      f32x16 acc[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[t][p][e] = 0.f;
+      const int li2[2] = {lo_of(3), lo_of(4)};
+      hd_kloop2<HD_GRP_MID, HD_PL_MID, 2>(acc, A3.w2, p2, li2, lane, mt);
+      store_tile(acc[0], 3);
+      store_tile(acc[1], 4);
     }
   }
 }

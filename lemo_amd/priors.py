@@ -174,9 +174,10 @@ class EncWeights:
 # Encoder as autograd ops over the C ABI
 # ----------------------------------------------------------------------------------------------
 
-DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '7'))
-"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 7 (default since round 5) = 5 plus the encoder's
-head and tail as one launch each (marker image + layers 0, 1 / their adjoints: csrc/conv_head_kernels.hip, +2.1 % iterations/s); 6 = 5 with
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '8'))
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 8 (default since round 5) = 7 with layer 2 (32 -> 64) inside the
+head launch as well (+0.9 %); 7 = 5 plus the encoder's head and tail as one launch each (marker image + layers 0, 1 / their adjoints:
+csrc/conv_head_kernels.hip, +2.1 % iterations/s); 6 = 5 with
 the pairs on four-wave workgroups (measured slower, kept selectable); 5 = the engines run consecutive 64 -> 64
 layers as fused PAIRS (one launch, intermediate in LDS; csrc/conv_pair_kernels.hip; the default since round 4) in the arithmetic
 of 4 = split-f16 kernel (two error-compensated fp16 pieces per fp32 operand, 3 products; layer by layer -- what the module /

@@ -477,7 +477,7 @@ def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     assert abs(fit.losses()['total'] - float(g['total_hist'][9])) < 1e-3 * float(g['total_hist'][9])
 
 
-@pytest.mark.parametrize('conv_variant', [5, 7])
+@pytest.mark.parametrize('conv_variant', [5, 7, 8])
 def test_fused_marker_image_and_first_layer(full_problem, dev, conv_variant):
     """the engine's one-launch marker image + first encoder layer (marker_c1_kernel; variant 7: enc_head_kernel, which also carries layer 1)
     against the stand-alone layer (C-ABI lemo_conv3x3_c1) applied to the image it published: identical activations, at the full
@@ -495,12 +495,17 @@ def test_fused_marker_image_and_first_layer(full_problem, dev, conv_variant):
     torch.cuda.synchronize()
     assert float(fit.ws['x0'].abs().max()) > 0
     assert torch.equal(ref1, fit.act[1])
-    if conv_variant == 7:
+    if conv_variant >= 7:
         from lemo_amd.priors import _conv_layer
         ref2 = torch.zeros_like(fit.act[2])
         _conv_layer(lib, fit.enc, 1, False, fit.act[1], ref2, None, fit.H, fit.W, 4, lib.stream(dev))
         torch.cuda.synchronize()
         assert rel_err(fit.act[2].cpu(), ref2.cpu()) < 1e-6
+    if conv_variant == 8:                                    # ... and layer 2 (32 -> 64) against the single-layer kernel on that act[2]
+        ref3 = torch.zeros_like(fit.act[3])
+        _conv_layer(lib, fit.enc, 2, False, fit.act[2], ref3, None, fit.H, fit.W, 4, lib.stream(dev))
+        torch.cuda.synchronize()
+        assert rel_err(fit.act[3].cpu(), ref3.cpu()) < 1e-6
 
 
 def test_compat_lbs_function(dev):
