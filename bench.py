@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '8'))
+DEFAULT_CONV_VARIANT = int(os.environ.get('LEMO_CONV_VARIANT', '9'))
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -846,7 +846,7 @@ def main():
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; algorithmic '
                                      'minimum %.1fe6)' % (alg_bytes / 1e6),
                      'peak_note': peak_note,
-                     'kernel': kname + (' 64->64->64ch 245x134, 6 of the 23 launches/iteration (12 of the 14 64->64 layers)' if pairs
+                     'kernel': kname + (' 64->64->64ch 245x134, 6 of the %d launches/iteration (12 of the 14 64->64 layers)' % {5: 25, 6: 25, 7: 23, 8: 22, 9: 21}.get(fit.conv_variant, 25) if pairs
                                         else ' 64->64ch 245x134, 14 of the 31 launches/iteration'),
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops,
                      'kernel_ms_source': ('HIP events around a captured replay of the iteration\'s own chain of the six fused launches (3 forward '
@@ -903,6 +903,8 @@ def main():
             ab = {}
             if fit.conv_variant != 4:
                 ab['value_layer_by_layer_f16x2'] = variant_probe(rank, B, device, stream, 4, fit)
+            if fit.conv_variant != 8:
+                ab['value_tail_without_layer_2'] = variant_probe(rank, B, device, stream, 8, fit)
             if fit.conv_variant != 7:
                 ab['value_head_without_layer_2'] = variant_probe(rank, B, device, stream, 7, fit)
             if fit.conv_variant != 5:
@@ -912,7 +914,7 @@ def main():
             ab['value_fp32_mfma'] = variant_probe(rank, B, device, stream, 2, fit)
             ab['value_headline_again'] = max(timed_fit(fit, prob, stream, device) for _ in range(2))
             ab['note'] = ('fitting-iterations/s over 100 timed steps, same clip / process / box, interleaved: the encoder on conv variant 4 '
-                          '(one split-f16 launch per layer), on variant 7 (head = marker image + layers 0, 1; layer 2 a launch of its own), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 6 (the fused pairs as two four-wave workgroups per CU on 5 x 14 tiles: measured slower, '
+                          '(one split-f16 launch per layer), on variant 8 (tail = layers 1, 0 backwards; layer 2\'s backward a launch of its own), on variant 7 (head = marker image + layers 0, 1; layer 2 forward and backward launches of their own), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 6 (the fused pairs as two four-wave workgroups per CU on 5 x 14 tiles: measured slower, '
                           'DESIGN 11), on variant 2 (v_mfma_f32_32x32x2_f32, fp32 operands) and the headline engine once more')
             out['variants'] = ab
         except Exception as e:       # noqa: BLE001

@@ -370,13 +370,18 @@ int lemo_enc_head(const lemo_fit_const* fc, const float* verts, int nrows, const
                   void* stream);
 int lemo_enc_tail(const float* din, const void* w1bpack, float w1binv, const float* act1, const float* w0, float* dx0, int H, int W,
                   void* stream);
+/* conv variant 9: the tail with layer 2's backward-data in front -- d(pre-act 3) (CG8P, 64 channels) -> conv^T 64 -> 32 x lrelu'(act2)
+ * (w2bpack = pack_conv3x3_bwd_split_f16 of layer 2) -> lemo_enc_tail's two stages -> dx0; replaces two single-layer launches +
+ * lemo_conv3x3_c1_bwd (models/AE_sep.py:16-21 backwards); d(pre-act 2) and d(pre-act 1) stay in LDS. */
+int lemo_enc_tail3(const float* din, const void* w2bpack, float w2binv, const float* act2, const void* w1bpack, float w1binv, const float* act1,
+                   const float* w0, float* dx0, int H, int W, void* stream);
 
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
   int conv_variant;               /* 5: fused layer pairs (lemo_conv3x3_pair_f16) where three consecutive channel counts allow,
                                    * variant 4 for the remaining layers (default) ; 6: the same pairs through lemo_conv3x3_pair4_f16 (four-wave
-                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail ; 8 (default): 7 with layer 2 (32 -> 64) inside the head launch too (+0.9 %) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
+                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail ; 8 (default): 7 with layer 2 (32 -> 64) inside the head launch too (+0.9 %) ; 9: 8 with layer 2's backward inside the tail launch (lemo_enc_tail3) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
                                    * 2: lemo_conv3x3_mfma_lds ; 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
   lemo_vposer_w vposer;
   lemo_body_const body;

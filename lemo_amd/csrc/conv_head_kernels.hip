@@ -37,20 +37,21 @@ template <int END> struct HdSteps<END, END> { template <class F> static __device
 // L2 through a ring, B from the LDS planes at bbase (group stride GRP, piece stride PL, row pitch 18), one step ahead.
 // acc[p]: one accumulator per product (lo x hi, hi x lo, hi x hi); the caller adds them smallest first.
 #define HD_RA 4
-template <int GRP, int PL, int MT = 1>
+// NST = 9 x (input channels / 16) steps; PITCH = row pitch of the B planes.
+template <int GRP, int PL, int MT = 1, int NST = 18, int PITCH = HD_MIDP>
 __device__ __forceinline__ void hd_kloop(f32x16 (&acc)[3], const uint4* __restrict__ w, const unsigned char* bbase, int li, int lane, int mt = 0) {
   const int h = lane >> 5;
   uint4 ra[HD_RA][2], rb[2][2];
 #define HD_LOAD_A(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) ra[SET][s_] = w[(unsigned)(((U) * MT + mt) * 2 + s_) * 64u + lane];
 #define HD_LOAD_B(SET, U) _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                          \
-    rb[SET][s_] = *reinterpret_cast<const uint4*>(bbase + (2 * ((U) / 9) + h) * GRP + s_ * PL + (li + (((U) % 9) / 3 - 1) * HD_MIDP + (((U) % 9) % 3 - 1)) * 16);
+    rb[SET][s_] = *reinterpret_cast<const uint4*>(bbase + (2 * ((U) / 9) + h) * GRP + s_ * PL + (li + (((U) % 9) / 3 - 1) * PITCH + (((U) % 9) % 3 - 1)) * 16);
 #pragma unroll
   for (int u0 = 0; u0 < HD_RA - 1; ++u0) { HD_LOAD_A(u0, u0) }
   HD_LOAD_B(0, 0)
-  HdSteps<0, 18>::run([&](auto uc) {
+  HdSteps<0, NST>::run([&](auto uc) {
     constexpr int u = decltype(uc)::value;
-    if (u + HD_RA - 1 < 18) { HD_LOAD_A((u + HD_RA - 1) % HD_RA, (u + HD_RA - 1 < 18 ? u + HD_RA - 1 : 17)) }
-    if (u + 1 < 18) { HD_LOAD_B((u + 1) & 1, (u + 1 < 18 ? u + 1 : 17)) }
+    if (u + HD_RA - 1 < NST) { HD_LOAD_A((u + HD_RA - 1) % HD_RA, (u + HD_RA - 1 < NST ? u + HD_RA - 1 : NST - 1)) }
+    if (u + 1 < NST) { HD_LOAD_B((u + 1) & 1, (u + 1 < NST ? u + 1 : NST - 1)) }
     __builtin_amdgcn_sched_barrier(0);
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[u % HD_RA][0]), __builtin_bit_cast(f16x8, rb[u & 1][1]), acc[0], 0, 0, 0);
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[u % HD_RA][1]), __builtin_bit_cast(f16x8, rb[u & 1][0]), acc[1], 0, 0, 0);
@@ -638,6 +639,204 @@ int enc_tail(const float* din, const void* w1bpack, float w1binv, const float* a
   a.ntx = (W + HD_TW - 1) / HD_TW;
   a.ntiles = a.ntx * ((H + HD_TH - 1) / HD_TH);
   hipLaunchKernelGGL(enc_tail_kernel, dim3(a.ntiles), dim3(512), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// enc_tail3 (conv variant 9): the tail with layer 2's backward-data (64 -> 32) in front -- d(pre-act 3) tile with a halo of 3 (16 x 20,
+// 64 channels: 80 KB of LDS as two fp16 pieces), layer 2 backward x lrelu'(act[2]) on the 14 x 18 tile, then enc_tail's two stages
+// (layer 1 backward x lrelu'(act[1]) on 12 x 16, layer 0 adjoint on 10 x 14).  d(pre-act 2) never leaves the CU; with enc_head3 no
+// 1-D-tiled launch is left on the 32-channel side of the encoder.  Layer 2's output pixels are the 252 positions of the 14 x 18 tile
+// in row-major order, 32 per N-tile (wave T = tile T, K = 36 steps): a tile's lanes cross rows of the pitch-20 input planes, which
+// costs two 2-way bank conflicts per fragment read -- the B reads of this loop are 8 cycles of LDS next to 96 of MFMA.
+constexpr int T3_IW = HD_TW + 6, T3_IH = HD_TH + 6, T3_NI = T3_IW * T3_IH;             // 20 x 16 = 320 input pixels
+constexpr int T3_PL = T3_NI * 16, T3_GRP = 2 * T3_PL;                                  // input planes: 5120 B each, 8 groups = 81,920 B
+constexpr int T3_MID_OFF = 8 * T3_GRP;                                                 // d(pre-act 2) planes (enc_tail's `inp`): 32,256 B
+constexpr int T3_WMAX_OFF = T3_MID_OFF + 4 * HD_GRP_IN;
+constexpr int T3_SMEM = T3_WMAX_OFF + 16 * 4;                                          // 114,240 B; d(pre-act 1) (27,648 B) reuses the input planes
+static_assert(32 * HD_NMIDP * 4 <= T3_MID_OFF, "d(pre-act 1) fits in the dead input planes");
+
+struct Tail3Args {
+  TailArgs t;                      // din = d(pre-act 3): CG8P, 64 channels
+  const uint4* w2b; float w2binv;  // layer 2 backward pack (pack_conv3x3_bwd_split_f16: cin 64, cout 32)
+  const float* act2;               // saved activation of layer 1 (lrelu' operand), CG8P 32 channels
+};
+
+__global__ void __launch_bounds__(512)
+enc_tail3_kernel(Tail3Args A3) {
+  LEMO_DYN_SMEM(smem_f);
+  unsigned char* smem = reinterpret_cast<unsigned char*>(smem_f);
+  unsigned char* inp = smem + T3_MID_OFF;
+  float* d1 = smem_f;
+  float* wmax = reinterpret_cast<float*>(smem + T3_WMAX_OFF);       // [0..7] input maxima, [8..15] d(pre-act 2) maxima
+  const TailArgs& a = A3.t;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, Wp = W + 2, HWp = (H + 2) * Wp;
+  int tile = (int)blockIdx.x;
+  {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, xcd = tile & 7, k = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
+  const int y0 = ty * HD_TH, x0c = tx * HD_TW;
+  // ---- staging: 16 x 20 input tile, 8 channel groups x 2 halves x 320 px = 5120 float4 chunks, 10 slots per thread (coordinates
+  // outside the image clamp onto the zero border ring of the CG8P map: no gradient there)
+  float sc, sci;
+  {
+    float4 st[10];
+    int dst[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const int c0 = tid + k * 512;
+      const int gg = c0 / (2 * T3_NI), c = c0 - gg * (2 * T3_NI);
+      const int px = c >> 1, half = c & 1;
+      const int r = px / T3_IW, col = px - r * T3_IW;
+      int gy = y0 - 3 + r, gx = x0c - 3 + col;
+      gy = (gy < -1 ? -1 : (gy > H ? H : gy)) + 1;
+      gx = (gx < -1 ? -1 : (gx > W ? W : gx)) + 1;
+      st[k] = ld4(a.din + ((size_t)gg * HWp + gy * Wp + gx) * 8 + 4 * half);
+      dst[k] = gg * T3_GRP + px * 16 + 8 * half;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m = absmax4(st[k], m);
+    m = wave_max(m);
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    float mm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[i]);
+    f16_scale_for(mm, sc, sci);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      uint2 s0, s1;
+      split2x4(st[k], sc, s0, s1);
+      *reinterpret_cast<uint2*>(smem + dst[k]) = s0;
+      *reinterpret_cast<uint2*>(smem + dst[k] + T3_PL) = s1;
+    }
+  }
+  __syncthreads();
+  // ---- layer 2 backward-data (64 -> 32) on the 14 x 18 tile: wave T owns positions 32 T .. 32 T + 31 of its row-major order
+  {
+    const int o = 32 * wave + j, oc = o < HD_NX ? o : HD_NX - 1;
+    const int r = oc / HD_XW, c = oc - r * HD_XW;
+    const int li = (r + 1) * T3_IW + c + 1;
+    const int y = y0 - 2 + r, x = x0c - 2 + c;
+    const bool inimg = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    const int poff = (yc + 1) * Wp + (xc + 1);
+    float4 aux[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c0 = q * 8 + 4 * h; aux[q] = ld4(A3.act2 + ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7)); }
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    hd_kloop<T3_GRP, T3_PL, 1, 36, T3_IW>(acc, A3.w2b, smem, li, lane);
+    const float f = sci * A3.w2binv;
+    float4 v2[4];
+    float m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float ax[4] = {aux[q].x, aux[q].y, aux[q].z, aux[q].w};
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = ((acc[0][4 * q + e] + acc[1][4 * q + e]) + acc[2][4 * q + e]) * f * lrelu_grad_from_out(ax[e]);
+        v[e] = inimg ? s : 0.f;                             // outside the image there is no d(pre-act 2)
+      }
+      v2[q] = make_float4(v[0], v[1], v[2], v[3]);
+      m2 = absmax4(v2[q], m2);
+    }
+    m2 = wave_max(m2);
+    if (lane == 0) wmax[8 + wave] = m2;
+    __syncthreads();
+    float mm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mm = fmaxf(mm, wmax[8 + i]);
+    f16_scale_for(mm, sc, sci);
+    if (o < HD_NX) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 s0, s1;
+        split2x4(v2[q], sc, s0, s1);
+        unsigned char* d = inp + q * HD_GRP_IN + o * 16 + 8 * h;
+        *reinterpret_cast<uint2*>(d) = s0;
+        *reinterpret_cast<uint2*>(d + HD_PL_IN) = s1;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- layer 1 backward-data (32 -> 32): wave T < 6 owns mid N-tile T = mid rows 2T, 2T + 1 (enc_tail's stage)
+  if (wave < 6) {
+    const int my = 2 * wave + (j >> 4), mx = hd_lane_col(j);
+    const int li = (my + 1) * HD_XW + mx + 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    const int y = y0 - 1 + my, x = x0c - 1 + mx;
+    const bool inimg = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    const int poff = (yc + 1) * Wp + (xc + 1);
+    float4 aux[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int c0 = q * 8 + 4 * h; aux[q] = ld4(a.act1 + ((size_t)(c0 >> 3) * HWp + poff) * 8 + (c0 & 7)); }
+    hd_kloop<HD_GRP_IN, HD_PL_IN>(acc, a.w1b, inp, li, lane);
+    const float f = sci * a.w1binv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = q * 8 + 4 * h;
+      float v[4];
+      const float ax[4] = {aux[q].x, aux[q].y, aux[q].z, aux[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = ((acc[0][4 * q + e] + acc[1][4 * q + e]) + acc[2][4 * q + e]) * f * lrelu_grad_from_out(ax[e]);
+        v[e] = inimg ? s : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d1[(c0 + e) * HD_NMIDP + my * HD_MIDP + mx + 1] = v[e];
+    }
+  }
+  __syncthreads();
+  // ---- layer 0 adjoint on the 10 x 14 tile, in conv3x3_c1_bwd_kernel's order (enc_tail's stage)
+  if (tid < HD_TH * HD_TW) {
+    const int oy = tid / HD_TW, ox = tid - oy * HD_TW;
+    const int y = y0 + oy, x = x0c + ox;
+    if (y < H && x < W) {
+      float acc = 0.f;
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int dy = t / 3 - 1, dx = t % 3 - 1;
+          const float* q = d1 + (size_t)(g * 8) * HD_NMIDP + (oy + 1 - dy) * HD_MIDP + (ox + 1 - dx) + 1;
+          const float* wc = a.w0 + (size_t)(g * 8) * 9 + t;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc = fmaf(q[c * HD_NMIDP], wc[9 * c], acc);
+        }
+      }
+      a.dx0[(size_t)y * W + x] = acc;
+    }
+  }
+}
+
+int enc_tail3(const float* din, const void* w2bpack, float w2binv, const float* act2, const void* w1bpack, float w1binv, const float* act1,
+              const float* w0, float* dx0, int H, int W, hipStream_t s) {
+  if (!din || !w2bpack || !(w2binv > 0.f) || !act2 || !w1bpack || !(w1binv > 0.f) || !act1 || !w0 || !dx0 || H < 1 || W < 1) return LEMO_ERR_ARG;
+  static int rc = -1;
+  if (rc < 0) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_tail3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T3_SMEM);
+  if (rc) return rc;
+  Tail3Args A{};
+  TailArgs& a = A.t;
+  a.din = din; a.w1b = reinterpret_cast<const uint4*>(w1bpack); a.w1binv = w1binv; a.act1 = act1; a.w0 = w0; a.dx0 = dx0;
+  a.H = H; a.W = W;
+  a.ntx = (W + HD_TW - 1) / HD_TW;
+  a.ntiles = a.ntx * ((H + HD_TH - 1) / HD_TH);
+  A.w2b = reinterpret_cast<const uint4*>(w2bpack); A.w2binv = w2binv; A.act2 = act2;
+  hipLaunchKernelGGL(enc_tail3_kernel, dim3(a.ntiles), dim3(512), T3_SMEM, s, A);
   return (int)hipGetLastError();
 }
 

@@ -9,11 +9,23 @@ namespace lemo {
 
 // conv variant 7 = variant 5 + the fused head / tail (conv_head_kernels.hip): layers 0 and 1 ride with the marker image / the image gradient
 template <class D> static inline bool enc_fused_head(const D& d) {
-  return (d.conv_variant == 7 || d.conv_variant == 8) && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
+  return d.conv_variant >= 7 && d.conv_variant <= 9 && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
 }
-// conv variant 8 = variant 7 with layer 2 (32 -> 64) inside the head launch as well (enc_head3)
+// conv variant 8 (and 9) = variant 7 with layer 2 (32 -> 64) inside the head launch as well (enc_head3)
 template <class D> static inline bool enc_fused_head3(const D& d) {
-  return d.conv_variant == 8 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_w3[2];
+  return d.conv_variant >= 8 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_w3[2];
+}
+// conv variant 9 = variant 8 with layer 2's backward-data (64 -> 32) inside the tail launch (enc_tail3)
+template <class D> static inline bool enc_fused_tail3(const D& d) {
+  return d.conv_variant == 9 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_wbwd3[2];
+}
+// the encoder's backward tail: d(pre-act l_last) in dact[cur] -> d(loss)/d(image); l_last as enc_chain_bwd was told
+template <class D> static inline int enc_bwd_l_last(const D& d) { return enc_fused_tail3(d) ? 3 : (enc_fused_head(d) ? 2 : 1); }
+template <class D> static inline int enc_bwd_tail(const D& d, int cur, int H, int W, hipStream_t s) {
+  if (enc_fused_tail3(d))
+    return enc_tail3(d.dact[cur], d.enc_wbwd3[2], d.enc_wbwd3_inv[2], d.act[2], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s);
+  if (enc_fused_head(d)) return enc_tail(d.dact[cur], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s);
+  return conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s);
 }
 
 // one layer (forward: act[l] -> act[l+1]; backward-data: d(pre-act l+1) -> d(pre-act l) with the saved activation act[l] as

@@ -186,6 +186,13 @@ gemm_nt16_splitk_kernel(const float* __restrict__ Am, int lda, const float* __re
 // re-read all of dvp -- 8 x 12.6 MB against 64 MB of A -- and a workgroup pulled 16 KB per step into its CU for 64 rows; a CU
 // takes in cold data at ~10 B/clk whatever is asked of it, so the launch lasted 42 us for a 12 us HBM floor.
 // MW = 4: 128 rows per workgroup, 8 waves, dvp read 4 times, half the partial slabs for the same number of workgroups.
+#ifndef LEMO_SK_RA
+#define LEMO_SK_RA 3
+#endif
+constexpr int SK_RA = LEMO_SK_RA;      // steps of A (and B) in flight per lane: the operands of step s + RA are requested in step s
+// (round 5, same box interleaved, PROX window it/s: RA = 3 2283 / 2273, RA = 5 2272 / 2285, RA = 7 2238 / 2249; 128 slabs instead of 64
+// (two workgroups per CU, 109 VGPRs allow it) 2260 / 2255, with RA = 5 2213 / 2211: the launch is not waiting for operands it could have
+// asked for earlier, and more partial-sum traffic costs more than a second resident workgroup hides -- profiles/r05_ab_variant9_gemm_ring.txt)
 template <int MW>
 __global__ void __launch_bounds__(128 * MW)
 gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float* __restrict__ Bm, int ldb, int M, int N, int K, int S,
@@ -222,9 +229,9 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   if (nst > 0) {
     auto clampc = [&](int c) { return c < c1 ? c : c1 - 1; };
-    float4 a[3][2], bg[2][NSLOT];                              // A of steps s, s+1, s+2 ; B (global) of steps s+1, s+2
+    float4 a[SK_RA][2], bg[SK_RA - 1][NSLOT];                  // A of steps s .. s+RA-1 ; B (global) of steps s+1 .. s+RA-1
 #pragma unroll
-    for (int u = 0; u < 3; ++u) { a[u][0] = ld4(ap + (size_t)clampc(c0 + u) * astep); a[u][1] = ld4(ap + (size_t)clampc(c0 + u) * astep + 4); }
+    for (int u = 0; u < SK_RA; ++u) { a[u][0] = ld4(ap + (size_t)clampc(c0 + u) * astep); a[u][1] = ld4(ap + (size_t)clampc(c0 + u) * astep + 4); }
 #define SK_STORE_B(BUFI, V)                                                                          \
     _Pragma("unroll") for (int r = 0; r < NSLOT; ++r) {                                            \
       uint2 p0, p1, p2;                                                                            \
@@ -237,7 +244,7 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
 #pragma unroll
       for (int r = 0; r < NSLOT; ++r) b0[r] = ld4(bsrc[r] + (size_t)c0 * 16);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < SK_RA - 1; ++u)
 #pragma unroll
         for (int r = 0; r < NSLOT; ++r) bg[u][r] = ld4(bsrc[r] + (size_t)clampc(c0 + 1 + u) * 16);
       SK_STORE_B(0, b0)
@@ -259,12 +266,17 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           bf[t][p] = *reinterpret_cast<const uint4*>(bs + buf * BUF + p * PIECE + ((h * (GEMM_SK_NT * 16)) + npair * 64 + t * 32 + j) * 16);
-      // publish step s+1 (held in registers since two steps ago) to the other buffer, refill the registers with step s+3
+      // publish step s+1 (held in registers since RA-1 steps ago) to the other buffer, refill the registers with step s+RA
       if (s_ + 1 < nst) { SK_STORE_B(buf ^ 1, bg[0]) }
 #pragma unroll
-      for (int r = 0; r < NSLOT; ++r) { bg[0][r] = bg[1][r]; bg[1][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + 3) * 16); }
-      a[0][0] = a[1][0]; a[0][1] = a[1][1]; a[1][0] = a[2][0]; a[1][1] = a[2][1];
-      a[2][0] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep); a[2][1] = ld4(ap + (size_t)clampc(c0 + s_ + 3) * astep + 4);
+      for (int u = 0; u + 1 < SK_RA - 1; ++u)
+#pragma unroll
+        for (int r = 0; r < NSLOT; ++r) bg[u][r] = bg[u + 1][r];
+#pragma unroll
+      for (int r = 0; r < NSLOT; ++r) bg[SK_RA - 2][r] = ld4(bsrc[r] + (size_t)clampc(c0 + s_ + SK_RA) * 16);
+#pragma unroll
+      for (int u = 0; u + 1 < SK_RA; ++u) { a[u][0] = a[u + 1][0]; a[u][1] = a[u + 1][1]; }
+      a[SK_RA - 1][0] = ld4(ap + (size_t)clampc(c0 + s_ + SK_RA) * astep); a[SK_RA - 1][1] = ld4(ap + (size_t)clampc(c0 + s_ + SK_RA) * astep + 4);
 #define SK_MFMA1(SA, SB)                                                                             \
       _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                \
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[SA]), __builtin_bit_cast(bf16x8, bf[t][SB]), acc[t], 0, 0, 0);

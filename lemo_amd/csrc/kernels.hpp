@@ -140,6 +140,8 @@ int enc_head3(const FitConst& fc, const float* verts, int nrows, const float* Jt
               const float* b0, const void* w1pack, float w1inv, const float* b1, const void* w2pack, float w2inv, const float* b2,
               float* x0, float* canon, float* act1, float* act2, float* act3, hipStream_t s);
 int enc_tail(const float* din, const void* w1bpack, float w1binv, const float* act1, const float* w0, float* dx0, int H, int W, hipStream_t s);
+int enc_tail3(const float* din, const void* w2bpack, float w2binv, const float* act2, const void* w1bpack, float w1binv, const float* act1,
+              const float* w0, float* dx0, int H, int W, hipStream_t s);
 int marker_feature(const FitConst& fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B,
                    float* x0, float* canon, hipStream_t s);
 // acc (f64[16], zeroed at the start of the iteration): [0] marker L1 sum, [1..4] contact sums, [5..8] contact

@@ -74,6 +74,10 @@ int lemo_enc_tail(const float* din, const void* w1bpack, float w1binv, const flo
                   void* stream) {
   return enc_tail(din, w1bpack, w1binv, act1, w0, dx0, H, W, S(stream));
 }
+int lemo_enc_tail3(const float* din, const void* w2bpack, float w2binv, const float* act2, const void* w1bpack, float w1binv, const float* act1,
+                   const float* w0, float* dx0, int H, int W, void* stream) {
+  return enc_tail3(din, w2bpack, w2binv, act2, w1bpack, w1binv, act1, w0, dx0, H, W, S(stream));
+}
 int lemo_conv3x3_mfma_split_census2(const float* in, const void* w, float winv, int pieces, const float* wt, const float* bias, float* out,
                                     int H, int W, int cin, int cout, unsigned long long* dbg, void* stream) {
   if (!in || !w || !wt || !bias || !out || !dbg) return LEMO_ERR_ARG;
@@ -394,9 +398,8 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
   int cur = 0;
   if (d.per_frame || !(stages & 16u)) goto vertex_stage;           // per_frame: no encoder (d.fit.u_m81 is all -1, dx0 is never read)
-  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_fused_head(d) ? 2 : 1));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
-  if (enc_fused_head(d)) CHK(enc_tail(d.dact[cur], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s));
-  else CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_bwd_l_last(d)));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
+  CHK(enc_bwd_tail(d, cur, H, W, s));
 vertex_stage:
   if (!(stages & 32u)) goto pose_stage;
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {

@@ -58,9 +58,8 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   CHK(smooth_loss(d.act[10], d.dact[0], nullptr, H, W, d.enc_ch[10], coef2, s, d.loss_acc + 32 * 32));
   // ---- backward
   int cur = 0;
-  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_fused_head(d) ? 2 : 1));
-  if (enc_fused_head(d)) CHK(enc_tail(d.dact[cur], d.enc_wbwd3[1], d.enc_wbwd3_inv[1], d.act[1], d.enc_w[0], d.dx0, H, W, s));
-  else CHK(conv3x3_c1_bwd(d.dact[cur], d.enc_w[0], d.dx0, H, W, d.enc_ch[1], s));
+  CHK(enc_chain_bwd(d, H, W, s, &cur, enc_bwd_l_last(d)));
+  CHK(enc_bwd_tail(d, cur, H, W, s));
   CHK(prox_sparse(d, cnt, s));
   CHK(lbs_verts_bwd(d.skin, d.uset, d.pose.A, nj, d.v_posed, d.V, d.dverts, B, d.Bp, d.dvp, d.dA, d.dtr_v, d.dX, s));
   lemo_pose_grad_in gi{d.dA, d.dJtr, d.dX, d.dfp_add};

@@ -174,9 +174,9 @@ class EncWeights:
 # Encoder as autograd ops over the C ABI
 # ----------------------------------------------------------------------------------------------
 
-DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '8'))
-"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 8 (default since round 5) = 7 with layer 2 (32 -> 64) inside the
-head launch as well (+0.9 %); 7 = 5 plus the encoder's head and tail as one launch each (marker image + layers 0, 1 / their adjoints:
+DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '9'))
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 9 (default since round 5) = 8 with layer 2's backward-data (64 -> 32) inside the
+tail launch (+0.5 %); 8 = 7 with layer 2 (32 -> 64) inside the head launch as well (0 .. +0.9 % box to box); 7 = 5 plus the encoder's head and tail as one launch each (marker image + layers 0, 1 / their adjoints:
 csrc/conv_head_kernels.hip, +2.1 % iterations/s); 6 = 5 with
 the pairs on four-wave workgroups (measured slower, kept selectable); 5 = the engines run consecutive 64 -> 64
 layers as fused PAIRS (one launch, intermediate in LDS; csrc/conv_pair_kernels.hip; the default since round 4) in the arithmetic

@@ -228,7 +228,7 @@ def test_split_f16_conv_error_is_fp32_sized(dev):
 DX0_GATE = 7e-6          # 3 x the largest measured value (round 5: 1.2e-6 .. 2.2e-6 across the seven families; was a silent 1e-4)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 9])
 def test_encoder_full_size_golden(dev, variant):
     """10-layer MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad.  Variants 0-2 run
     every layer on the fp32 MFMA; 3 / 4 run the nine MFMA layers (forward and backward-data) on the split-bf16 / split-f16 kernel;
@@ -249,7 +249,7 @@ def test_encoder_full_size_golden(dev, variant):
     act = [None] + [cg8p_alloc(ENC_CHANNELS[l], H, W, dev) for l in range(1, 11)]
     s = torch.cuda.current_stream(dev).cuda_stream
     lib.check(lib.conv3x3_c1(ptr(x0), ptr(enc.w[0]), ptr(enc.b[0]), ptr(act[1]), H, W, 32, s))
-    pair = {5: lib.conv3x3_pair_f16, 6: lib.conv3x3_pair4_f16, 7: lib.conv3x3_pair_f16}.get(variant)      # (7: + the fused tail below)
+    pair = {5: lib.conv3x3_pair_f16, 6: lib.conv3x3_pair4_f16, 7: lib.conv3x3_pair_f16, 9: lib.conv3x3_pair_f16}.get(variant)      # (7, 9: + the fused tails below)
     P = (lambda l, bwd: enc.split_pack(l, bwd, variant)) if pair else None
     for l in range(1, 10):
         if pair and l in (3, 5, 7):
@@ -273,7 +273,7 @@ def test_encoder_full_size_golden(dev, variant):
     assert abs(loss - float(g['loss_smooth'])) <= LOSS_TOL * float(g['loss_smooth'])
     cur = [d0, d1]
     ci = 0
-    for l in range(9, 1 if variant == 7 else 0, -1):
+    for l in range(9, {7: 1, 9: 2}.get(variant, 0), -1):
         if pair and l in (9, 7, 5):
             (pa, ia), (pb, ib) = P(l, True), P(l - 1, True)
             lib.check(pair(ptr(cur[ci]), ptr(pa), ia, None, ptr(act[l]), None, ptr(pb), ib, None, ptr(act[l - 1]), ptr(cur[1 - ci]), H, W, 1, None, s))
@@ -289,6 +289,9 @@ def test_encoder_full_size_golden(dev, variant):
     if variant == 7:             # layer 1 backward-data + layer 0 adjoint in one launch (csrc/conv_head_kernels.hip)
         pb, ib = P(1, True)
         lib.check(lib.enc_tail(ptr(cur[ci]), ptr(pb), ib, ptr(act[1]), ptr(enc.w[0]), ptr(dx0), H, W, s))
+    elif variant == 9:           # layer 2 and layer 1 backward-data + layer 0 adjoint in one launch
+        (p2, i2), (pb, ib) = P(2, True), P(1, True)
+        lib.check(lib.enc_tail3(ptr(cur[ci]), ptr(p2), i2, ptr(act[2]), ptr(pb), ib, ptr(act[1]), ptr(enc.w[0]), ptr(dx0), H, W, s))
     else:
         lib.check(lib.conv3x3_c1_bwd(ptr(cur[ci]), ptr(enc.w[0]), ptr(dx0), H, W, 32, s))
     e_dx0 = rel_err(dx0.view(H, W).cpu(), g['gx'][0, 0])
@@ -419,7 +422,7 @@ def test_fused_pair_conv_full_size_vs_float64(dev, kernel):
     assert e_b < 2e-6
 
 
-@pytest.mark.parametrize('conv_variant', [5, 7, 8, 6, 4, 3, 2])
+@pytest.mark.parametrize('conv_variant', [5, 7, 8, 9, 6, 4, 3, 2])
 def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
@@ -477,7 +480,7 @@ def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     assert abs(fit.losses()['total'] - float(g['total_hist'][9])) < 1e-3 * float(g['total_hist'][9])
 
 
-@pytest.mark.parametrize('conv_variant', [5, 7, 8])
+@pytest.mark.parametrize('conv_variant', [5, 7, 8, 9])
 def test_fused_marker_image_and_first_layer(full_problem, dev, conv_variant):
     """the engine's one-launch marker image + first encoder layer (marker_c1_kernel; variant 7: enc_head_kernel, which also carries layer 1)
     against the stand-alone layer (C-ABI lemo_conv3x3_c1) applied to the image it published: identical activations, at the full
@@ -501,7 +504,7 @@ def test_fused_marker_image_and_first_layer(full_problem, dev, conv_variant):
         _conv_layer(lib, fit.enc, 1, False, fit.act[1], ref2, None, fit.H, fit.W, 4, lib.stream(dev))
         torch.cuda.synchronize()
         assert rel_err(fit.act[2].cpu(), ref2.cpu()) < 1e-6
-    if conv_variant == 8:                                    # ... and layer 2 (32 -> 64) against the single-layer kernel on that act[2]
+    if conv_variant >= 8:                                    # ... and layer 2 (32 -> 64) against the single-layer kernel on that act[2]
         ref3 = torch.zeros_like(fit.act[3])
         _conv_layer(lib, fit.enc, 2, False, fit.act[2], ref3, None, fit.H, fit.W, 4, lib.stream(dev))
         torch.cuda.synchronize()

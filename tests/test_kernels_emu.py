@@ -571,10 +571,10 @@ def _splitk_case(lib, g, M, N, K, S, grouped):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize('variant', [5, 7])
+@pytest.mark.parametrize('variant', [5, 7, 9])
 def test_wide_clip_keeps_the_fused_pairs_and_matches_the_oracle(emu_lib, variant):
     """B = 130 (W = 145 > 134): the single-layer split kernels do not take the image, the fused pairs do -- the engine keeps conv
-    variant 5 / 7 (pairs fused -- 7: head and tail fused as well, any width -- the other encoder launches on the fp32-input kernel layer
+    variant 5 / 7 / 9 (pairs fused -- 7, 9: head and tail fused as well, any width -- the other encoder launches on the fp32-input kernel layer
     by layer) and the iteration still matches the oracle: losses, gradients, one Adam step"""
     import warnings
     import __graft_entry__ as ge

@@ -24,7 +24,8 @@ BUDGETS = {
     'conv3x3_pair4_kernelILi1ELb0E': ('conv_pair4_kernels.hip', 256, 256),
     'enc_head_kernel': ('conv_head_kernels.hip', 128, 512),                              # variant 7: fused head / tail of the encoder
     'enc_tail_kernel': ('conv_head_kernels.hip', 128, 512),
-    'enc_head3_kernel': ('conv_head_kernels.hip', 256, 512),                            # variant 8 (default): layers 0-2 in the head, one workgroup per CU
+    'enc_head3_kernel': ('conv_head_kernels.hip', 256, 512),
+    'enc_tail3_kernel': ('conv_head_kernels.hip', 256, 512),                            # variant 9: layers 2-0 backwards in the tail, one workgroup per CU (112 KB of LDS)                            # variant 8 (default): layers 0-2 in the head, one workgroup per CU
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),

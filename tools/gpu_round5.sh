@@ -23,6 +23,7 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_s
 for i in 1 2; do timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_driver_style_$i.json 2>> $OUT/bench.err; done
 for i in 1 2; do
   timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras > $OUT/bench_100_$i.json 2>> $OUT/bench.err
+  timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --conv-variant 8 > $OUT/bench_100_variant8_tail_without_layer_2_$i.json 2>> $OUT/bench.err
   timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --conv-variant 7 > $OUT/bench_100_variant7_head_without_layer_2_$i.json 2>> $OUT/bench.err
   timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --conv-variant 5 > $OUT/bench_100_variant5_pairs_without_fused_head_tail_$i.json 2>> $OUT/bench.err
   timeout 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --concurrent-clips 0 --no-extras --conv-variant 6 > $OUT/bench_100_variant6_four_wave_pairs_$i.json 2>> $OUT/bench.err
@@ -60,7 +61,7 @@ print('value', d['value'], 'v100', d.get('value_100_steps'), 'pair us', r['kerne
 print('stage_us', d.get('stage_us')); print('variants', {k: v for k, v in d.get('variants', {}).items() if k != 'note'})
 for k in ('prox_window','perframe','ae_finetune','concurrent_clips','cpu_baseline'):
     print(k, {kk: vv for kk, vv in d.get(k, {}).items() if kk in ('value','unit','error','one_clip_value','cores','bit_identical_to_solo','autograd_path_ms','side_by_side_ms_per_clip')})
-for f in ('bench_100_1','bench_100_variant7_head_without_layer_2_1','bench_100_variant7_head_without_layer_2_2','bench_100_variant5_pairs_without_fused_head_tail_1','bench_100_variant6_four_wave_pairs_1','bench_100_2','bench_100_variant5_pairs_without_fused_head_tail_2','bench_100_variant6_four_wave_pairs_2','bench_active','bench_prox'):
+for f in ('bench_100_1','bench_100_variant8_tail_without_layer_2_1','bench_100_variant8_tail_without_layer_2_2','bench_100_variant7_head_without_layer_2_1','bench_100_variant7_head_without_layer_2_2','bench_100_variant5_pairs_without_fused_head_tail_1','bench_100_variant6_four_wave_pairs_1','bench_100_2','bench_100_variant5_pairs_without_fused_head_tail_2','bench_100_variant6_four_wave_pairs_2','bench_active','bench_prox'):
     try:
         e=json.load(open('$OUT/'+f+'.json')); print(f, e['value'])
     except Exception as ex: print(f, 'ERR', ex)
