@@ -135,7 +135,7 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
         prob = prox_window_problem(base, s, e, start)
         eng = make_engine(prob, w == 0)
         assert PW.frozen_prefix(PROX_B, w == 0) == (0 if w == 0 else frozen)
-        worst_g = 0.0
+        worst_g, worst_at, worst_e64, worst_r64 = 0.0, None, 0.0, 0.0
         for k in steps:
             eng.load_state(prox_state_from_fixture(T, tag, k, names))
             eng.step(1, use_graph=False)
@@ -174,7 +174,13 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
                 bad = np.nonzero(err > bound)[0]
                 assert bad.size == 0, (tag, k, n, bad.tolist(), (err[bad] / max(scale, 1e-30)).tolist(), (bound[bad] / max(scale, 1e-30)).tolist())
                 E[:, o:o + d] = bound[:, None]
-                worst_g = max(worst_g, float(err.max()) / max(scale, 1e-30))
+                if float(err.max()) / max(scale, 1e-30) > worst_g:        # where the two fp32 paths are furthest apart: who is how far from float64 there
+                    f = int(err.argmax())
+                    worst_g = float(err[f]) / max(scale, 1e-30)
+                    worst_at = (k, n, f, float(np.abs(ge_[f] - gx[f]).max()) / max(scale, 1e-30), float(np.abs(gr[f] - gx[f]).max()) / max(scale, 1e-30),
+                                4.0 * float(np.broadcast_to(S[gi], err.shape)[f]))
+                worst_e64 = max(worst_e64, float(np.abs(ge_ - gx).max()) / max(scale, 1e-30))
+                worst_r64 = max(worst_r64, float(np.abs(gr - gx).max()) / max(scale, 1e-30))
                 o += d
             if w > 0:
                 assert not g_eng[:frozen].any() and not g_ref[:frozen].any()
@@ -186,7 +192,10 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
             assert reg <= flat_gate, (tag, k, reg)     # flat gate at 3 x the largest measured value (3.9e-3 lr, GPU, S3 window 2 step 2)
             if w > 0:                                  # frozen frames: parameters bit-identical to the loaded ones
                 assert np.array_equal(got['p'][:frozen], before['p'][:frozen])
-        report.append(f'{tag}: worst gradient group error vs the reference fp32 {worst_g:.1e} of the group maximum')
+        report.append(f'{tag}: worst gradient group error vs the reference fp32 {worst_g:.1e} of the group maximum'
+                      + (f' (step {worst_at[0]}, {worst_at[1]}, frame {worst_at[2]}: engine vs float64 {worst_at[3]:.1e}, reference vs float64 {worst_at[4]:.1e}, kink-exposure allowance 4 S {worst_at[5]:.1e})'
+                         if worst_at else '')
+                      + f'; anywhere: engine vs float64 {worst_e64:.1e}, reference vs float64 {worst_r64:.1e}')
 
 
 @pytest.mark.timeout(1800)
