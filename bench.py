@@ -392,7 +392,7 @@ def prox_probe(device, steps=300, stage='S3'):
     assert eng.nonfinite_step() == 0
     return eng, {'value': best, 'unit': 'PROX fitting-iterations/s (optimizer.step(closure), one window)', 'steps': steps,
                  'workload': f'temp_prox/fitting_temp_slide.py window, PROXD_temp_{stage}.yaml weights: B=100 frames, V=10475, 256^3 synthetic SDF, '
-                             '245x115 smoothness image, native engine (44 launches / iteration, graph replay)',
+                             '245x115 smoothness image, native engine (24 launches / iteration, graph replay)',
                  'total_loss': eng.loss_dict()['total_loss']}
 
 

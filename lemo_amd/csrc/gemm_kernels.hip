@@ -8,6 +8,7 @@
 // reduced through LDS in a fixed order (deterministic).
 #include <cstdlib>
 #include "kernels.hpp"
+#include "gemm_reduce.hpp"
 
 namespace lemo {
 
@@ -94,7 +95,7 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
 // (7 x 64 MB) -- 107 us.  Here a workgroup owns 64 rows of A x ALL frames x one K slab (A is streamed exactly once, the
 // B slab is shared by the 8 row blocks through L2), writes its partial tile, and a second launch adds the slabs in slab
 // order (deterministic).
-#define GEMM_SK_NT 8            // frame tiles of 16 (N <= 128)
+// GEMM_SK_NT (gemm_reduce.hpp): frame tiles of 16 (N <= 128)
 // Measured (rocprofv3, B = 100, K = 31440).  v1: 32 slabs, every wave loading its own A and all 8 B fragments of a step and
 // waiting for them: 101.8 us (no better than the 107 us it replaced).  v2: 96 slabs + operands of the next step requested
 // before the MFMAs of the current one: 76 us -- still 9 KB of global loads per wave and step for 32 MFMAs, one step
@@ -296,41 +297,17 @@ gemm_nt16_splitk_bf16_kernel(const float* __restrict__ Am, int lda, const float*
         st4(pp + (size_t)(npair * 64 + t * 32 + j) * M + mb * (32 * MW) + mtile * 32 + 8 * rq + 4 * h,
             make_float4(acc[t][4 * rq], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]));
 }
-// C = sum over the S slab partials, in a FIXED order (deterministic).  32 outputs (float4) x 8 slab groups per workgroup: group g adds
-// slabs g, g + 8, ... in order with eight loads in flight, the eight group sums are added in group order through LDS.  (Rounds 1-2:
-// one thread per output walking all S slabs -- 50 workgroups reading 25 MB: 11.7 us.)
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(const float* __restrict__ part, int M, int N, int S, float* __restrict__ C, int ldc) {
-  __shared__ float4 red[8][32];
-  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + o;                       // float4 index over [N][M / 4]
-  const int m4 = M >> 2, tot = N * m4;
-  const int ic = i < tot ? i : tot - 1;
-  const int n = ic / m4, mq = ic - n * m4;
-  const size_t stride = (size_t)(GEMM_SK_NT * 16) * M;
-  const float* p = part + (size_t)n * M + mq * 4;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s0 = g; s0 < S; s0 += 64) {                     // slabs g, g + 8, ..., eight in flight
-    float4 r[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = ld4(p + (size_t)(s0 + 8 * u < S ? s0 + 8 * u : g) * stride);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) if (s0 + 8 * u < S) { v.x += r[u].x; v.y += r[u].y; v.z += r[u].z; v.w += r[u].w; }
-  }
-  red[g][o] = v;
-  __syncthreads();
-  if (g == 0 && i < tot) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { const float4 w = red[k][o]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
-    st4(C + (size_t)n * ldc + mq * 4, v);
-  }
+  gemm_splitk_reduce_body(part, M, N, S, C, ldc, (int)blockIdx.x);
 }
 
 int gemm_nt16_splitk_part_floats(int M, int S) { return S * GEMM_SK_NT * 16 * M; }
 
-int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
-                     hipStream_t s, const float* A_grouped) {
-  if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || (ldc & 3) || S < 1 || S > (K >> 4) || !part)
+// the partial tiles only: the caller reduces them (gemm_splitk_reduce_body) in a launch of its own
+int gemm_nt16_splitk_partials(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* part, int S, hipStream_t s,
+                              const float* A_grouped) {
+  if (M <= 0 || N <= 0 || N > GEMM_SK_NT * 16 || K <= 0 || (M & 63) || (K & 15) || (lda & 3) || (ldb & 3) || S < 1 || S > (K >> 4) || !part)
     return LEMO_ERR_SHAPE;
   static const bool fp32_mfma = getenv("LEMO_SPLITK_FP32") != nullptr;       // A/B switch (diagnostics): v3, the fp32-MFMA kernel
   if (fp32_mfma) hipLaunchKernelGGL(gemm_nt16_splitk_kernel, dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part);
@@ -340,7 +317,14 @@ int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, in
   }
   else if (A_grouped) hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<2>), dim3((M >> 6) * S), dim3(256), 0, s, A_grouped, lda, B, ldb, M, N, K, S, part, 1);
   else hipLaunchKernelGGL((gemm_nt16_splitk_bf16_kernel<2>), dim3((M >> 6) * S), dim3(256), 0, s, A, lda, B, ldb, M, N, K, S, part, 0);
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((N * (M >> 2) + 31) / 32), dim3(256), 0, s, part, M, N, S, C, ldc);
+  return (int)hipGetLastError();
+}
+
+int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
+                     hipStream_t s, const float* A_grouped) {
+  if (ldc & 3) return LEMO_ERR_SHAPE;
+  if (int rc = gemm_nt16_splitk_partials(A, lda, B, ldb, M, N, K, part, S, s, A_grouped)) return rc;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gemm_splitk_reduce_blocks(M, N)), dim3(256), 0, s, part, M, N, S, C, ldc);
   return (int)hipGetLastError();
 }
 

@@ -57,6 +57,8 @@ int gemm_nt16(const float* A, int lda, const float* B, int ldb, int M, int N, in
 
 // long-K, few-outputs form (N <= 128, M % 64 == 0): S K-slabs, partial tiles in `part` (gemm_nt16_splitk_part_floats), fixed-order sum
 int gemm_nt16_splitk_part_floats(int M, int S);
+int gemm_nt16_splitk_partials(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* part, int S, hipStream_t s,
+                              const float* A_grouped = nullptr);
 int gemm_nt16_splitk(const float* A, int lda, const float* B, int ldb, int M, int N, int K, float* C, int ldc, float* part, int S,
                      hipStream_t s, const float* A_grouped = nullptr);   // A_grouped: A again as [K/16][M][16]
 int gemm_nt16_kg8(const float* A, int lda, const float* Xg, int rows, int M, int N, int K, float* C, int ldc, hipStream_t s);

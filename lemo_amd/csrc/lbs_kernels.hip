@@ -12,6 +12,7 @@
 // Skinning weights are held as ELL (<= KW non-zeros per vertex; real SMPL-X rows are sparse).
 #include "kernels.hpp"
 #include "loss_device.hpp"
+#include "gemm_reduce.hpp"
 
 namespace lemo {
 
@@ -1014,6 +1015,7 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
     d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
   }
+  if (ch == nchunk - 1 && t < u.NCs - 3 * u.n) dvp[(size_t)b * u.NCs + 3 * u.n + t] = 0.f;     // padding columns of the GEMM operand (< 16)
   float* part = u.part + ((size_t)b * nchunk + ch) * LBS_PART_STRIDE(nj);
   sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
   if ((t & 63) == 0) { red[3 * (t >> 6)] = sx; red[3 * (t >> 6) + 1] = sy; red[3 * (t >> 6) + 2] = sz; }
@@ -1048,9 +1050,10 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     if (lane < 12) part[j * 12 + lane] = tot;
   }
 }
-__global__ void __launch_bounds__(256)
-lbs_bwd_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
-  const int b = blockIdx.x, t = threadIdx.x, st = LBS_PART_STRIDE(nj);
+// frame b's chunk partials added in chunk order; `pad`: also zero the padding columns of the GEMM operand d(v_posed)
+__device__ __forceinline__ void lbs_bwd_reduce_body(const VertexSetBwd& u, int nj, int nchunk, float* __restrict__ dvp, float* __restrict__ dA,
+                                                    float* __restrict__ dtransl, int b, bool pad) {
+  const int t = threadIdx.x, st = LBS_PART_STRIDE(nj);
   const float* p = u.part + (size_t)b * nchunk * st;
   // one thread per output, its chunk partials loaded 8 at a time (a dependent load per addend was 21 L2 round trips:
   // 18 us for a kernel that moves 5 MB) and added in chunk order
@@ -1068,7 +1071,21 @@ lbs_bwd_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dv
     if (i < nj * 12) dA[(size_t)b * nj * 12 + i] = a;
     else dtransl[(size_t)b * 3 + (i - nj * 12)] = a;
   }
-  for (int i = 3 * u.n + t; i < u.NCs; i += 256) dvp[(size_t)b * u.NCs + i] = 0.f;     // padding columns of the GEMM operand
+  if (pad) for (int i = 3 * u.n + t; i < u.NCs; i += 256) dvp[(size_t)b * u.NCs + i] = 0.f;     // padding columns of the GEMM operand
+}
+__global__ void __launch_bounds__(256)
+lbs_bwd_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dvp, float* __restrict__ dA, float* __restrict__ dtransl) {
+  lbs_bwd_reduce_body(u, nj, nchunk, dvp, dA, dtransl, (int)blockIdx.x, true);
+}
+// ONE launch for the two fixed-order reductions that end the all-vertex backward (round 5): workgroups 0 .. B - 1 add the chunk partials
+// of d(A) / d(transl), the rest the slab partials of the feature-gradient GEMM dX = Dk . d(v_posed) -- the GEMM's partial kernel runs
+// BEFORE this launch, on d(v_posed) whose padding columns the chunk kernel has zeroed (one launch and one kernel boundary less)
+__global__ void __launch_bounds__(256)
+lbs_gemm_reduce_kernel(VertexSetBwd u, int nj, int nchunk, float* __restrict__ dA, float* __restrict__ dtransl, int B,
+                       const float* __restrict__ part, int M, int S, float* __restrict__ C, int ldc) {
+  const int id = (int)blockIdx.x;
+  if (id < B) lbs_bwd_reduce_body(u, nj, nchunk, nullptr, dA, dtransl, id, false);
+  else gemm_splitk_reduce_body(part, M, B, S, C, ldc, id - B);
 }
 
 // the staged (frame in LDS) kernel takes the set; only that one has the fused d(verts) form
@@ -1091,6 +1108,16 @@ int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int
   else if (nj <= 64 && u.jcsr_chunk && u.jc_u && u.jc_w && u.part && B <= u.part_frames) {
     const int nchunk = (u.n + LBS_DENSE_CHUNK - 1) / LBS_DENSE_CHUNK;
     hipLaunchKernelGGL(lbs_bwd_chunk_kernel, dim3(nchunk, B), dim3(256), 0, s, c, u, A, nj, v_posed, vp_rows, dverts, dvp);
+    static const bool two = getenv("LEMO_LBS_TWO_REDUCES") != nullptr;       // A/B switch: the form up to round 4 (reduce, GEMM, reduce)
+    if (!two && u.gemm_part && u.gemm_slabs > 0 && B <= 128) {               // chunk partials and GEMM slab partials reduced in ONE launch
+      int e = (int)hipGetLastError();
+      if (e) return e;
+      e = gemm_nt16_splitk_partials(u.Dk, u.NCs, dvp, u.NCs, 512, B, u.NCs, u.gemm_part, u.gemm_slabs, s, u.DkG);
+      if (e) return e;
+      hipLaunchKernelGGL(lbs_gemm_reduce_kernel, dim3(B + gemm_splitk_reduce_blocks(512, B)), dim3(256), 0, s, u, nj, nchunk, dA, dtransl, B,
+                         u.gemm_part, 512, u.gemm_slabs, dX, 512);
+      return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(lbs_bwd_reduce_kernel, dim3(B), dim3(256), 0, s, u, nj, nchunk, dvp, dA, dtransl);
   }
   else if (nj <= 64) {

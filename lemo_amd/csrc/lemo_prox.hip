@@ -6,10 +6,10 @@
 #include <new>
 
 namespace lemo {
-int prox_frame(const lemo_prox_desc& d, hipStream_t s);
-int prox_dense(const lemo_prox_desc& d, hipStream_t s);
+int prox_frame_dense(const lemo_prox_desc& d, hipStream_t s);
 int prox_sparse(const lemo_prox_desc& d, double smooth_count, hipStream_t s);
 int prox_adam(const lemo_prox_desc& d, hipStream_t s);
+int prox_tail(const lemo_prox_desc& d, bool update, hipStream_t s);
 }
 using namespace lemo;
 
@@ -25,11 +25,12 @@ struct ProxEngine {
 };
 
 // forward + backward of one iteration (fitting_func :239-311 without the erase, which the update applies)
-static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
+// `fused_tail`: h1 (first VPoser layer) is already there and the last layer of the VPoser backward is left to prox_tail
+static int prox_closure(const lemo_prox_desc& d, hipStream_t s, bool fused_tail = false) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   // ---- body: VPoser decode (:243), ONE SMPL-X forward for both joint sets (:248, :253-258)
-  CHK(gemm_nt16(d.vposer.w1, 32, d.pose_embedding, 32, 512, B, 32, d.h1, 512, d.vposer.b1, nullptr, 0, 1, s));
+  if (!fused_tail) CHK(gemm_nt16(d.vposer.w1, 32, d.pose_embedding, 32, 512, B, 32, d.h1, 512, d.vposer.b1, nullptr, 0, 1, s));
   CHK(gemm_nt16(d.vposer.w2, 512, d.h1, 512, 512, B, 512, d.h2, 512, d.vposer.b2, nullptr, 0, 1, s));
   CHK(gemm_nt16(d.vposer.w3, 512, d.h2, 512, 128, B, 512, d.vo, 128, d.vposer.b3, nullptr, 0, 2, s));
   lemo_pose_in in{};
@@ -42,8 +43,7 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   // ---- loss: per-frame terms, dense SDF term, smoothness prior through the encoder
-  CHK(prox_frame(d, s));
-  CHK(prox_dense(d, s));
+  CHK(prox_frame_dense(d, s));
   if (enc_fused_head3(d))
     CHK(enc_head3(d.fit, d.verts, d.V, d.pose.Jtr, nj, d.transl, B, d.enc_w[0], d.enc_b[0], d.enc_w3[1], d.enc_w3_inv[1], d.enc_b[1], d.enc_w3[2],
                   d.enc_w3_inv[2], d.enc_b[2], d.x0, d.canon, d.act[1], d.act[2], d.act[3], s));
@@ -68,20 +68,29 @@ static int prox_closure(const lemo_prox_desc& d, hipStream_t s) {
   go.d_lh = d.g_lh; go.d_rh = d.g_rh; go.hand_stride = 12; go.d_expr = d.g_expr;
   go.vposer_o = d.vo; go.d_vposer_o = d.vp_scratch;
   CHK(smplx_pose_bwd(d.body, d.pose, gi, go, B, s));
-  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, d.g_pe, 32, d.vp_scratch, s));
+  CHK(vposer_mlp_bwd(d.vposer, d.h1, d.h2, B, fused_tail ? nullptr : d.g_pe, 32, d.vp_scratch, s));
   return 0;
 }
 
-static int prox_iteration(const lemo_prox_desc& d, hipStream_t s) {
-  CHK(prox_closure(d, s));
-  return prox_adam(d, s);
+// one optimiser iteration.  Default (round 5): the last VPoser backward layer, Adam and the NEXT iteration's first VPoser layer share
+// one launch (prox_tail; `first`: the run / graph opens with the h1-only form of it) -- 3 launches and 2 kernel boundaries less per
+// iteration; LEMO_PROX_SEPARATE_ADAM: closure + prox_adam as up to round 4 (A/B switch)
+static int prox_iteration(const lemo_prox_desc& d, hipStream_t s, bool first) {
+  static const bool separate = getenv("LEMO_PROX_SEPARATE_ADAM") != nullptr;
+  if (separate || !d.vposer.w1t) {
+    CHK(prox_closure(d, s));
+    return prox_adam(d, s);
+  }
+  if (first) CHK(prox_tail(d, false, s));
+  CHK(prox_closure(d, s, true));
+  return prox_tail(d, true, s);
 }
 
 static int prox_capture(ProxEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int i = 0; i < iters && !rc; ++i) rc = prox_iteration(e->d, s);
+  for (int i = 0; i < iters && !rc; ++i) rc = prox_iteration(e->d, s, i == 0);
   const int ec = (int)hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   CHK(ec);
@@ -125,7 +134,7 @@ int lemo_prox_step(void* h, int n, int use_graph, void* stream) {
   if (!e || n < 0) return LEMO_ERR_ARG;
   hipStream_t s = S(stream);
   if (!use_graph) {
-    for (int i = 0; i < n; ++i) CHK(prox_iteration(e->d, s));
+    for (int i = 0; i < n; ++i) CHK(prox_iteration(e->d, s, i == 0));
     return 0;
   }
   // graphs are stream-agnostic once instantiated: kept across stream changes (see fit_graphs)

@@ -10,6 +10,7 @@
 //   prox_sparse_kernel  block per frame, thread per "special" vertex: friction / infill / contact / smoothness / vertex-
 //                       joint gradients added onto the dense d(verts); block 0 finalises the 14 loss_dict entries
 //   prox_adam_kernel    priors' own gradients, erase of the first int(0.15 B) frames (:282-289), torch.optim.Adam
+// prox_frame and prox_dense share ONE launch (prox_frame_dense_kernel: workgroup roles by index).
 // Every data-dependent branch of the reference (`.item()` at :690,:719,:730,:736,:974-987) is a device-side count.
 #include "scene_device.hpp"
 #include "loss_device.hpp"
@@ -47,19 +48,20 @@ struct ProxFrameIn {
 struct ProxFrameOut { double* acc; float *dJtr, *dJv, *dtr_j, *gp, *dfp_add; };
 
 #define PROX_MAXJ 160
-__global__ void __launch_bounds__(256)
-prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, SdfVol vol) {
+// body of a frame-role workgroup: frame b, part `part` of `nparts` (see below)
+__device__ __forceinline__ void prox_frame_body(const ProxConst& pc, const ProxFrameIn& in, const ProxFrameOut& out, const Cam2World& cw,
+                                                const SdfVol& vol, int b, int part, int nparts) {
   __shared__ float J[PROX_MAXJ * 3], gj[PROX_MAXJ * 3], dJ[PROX_MAXJ * 3];
   __shared__ float h45[90];
   __shared__ float red[4][PA_COUNT];
-  const int b = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const int nj = in.nj, V = in.V, B = in.B, nsj = pc.n_sj;
   float acc[PA_COUNT];
 #pragma unroll
   for (int i = 0; i < PA_COUNT; ++i) acc[i] = 0.f;
-  // blockIdx.y splits the frame's work over two workgroups: 0 = joints, priors, infill and contact sums; 1 = the
+  // the frame's work is split over two workgroups: part 0 = joints, priors, infill and contact sums; part 1 = the
   // friction sums (~1000 vertices x 2 world transforms + an SDF lookup: half of the kernel's time when one block did both)
-  const bool do_main = blockIdx.y == 0, do_fric = blockIdx.y == gridDim.y - 1;
+  const bool do_main = part == 0, do_fric = part == nparts - 1;
   if (do_main) {
   // ---- the 127 smplx joints of this frame: posed skeleton + transl | vertex picks | barycentric landmarks
   for (int w = t; w < nsj * 3; w += 256) {
@@ -196,11 +198,13 @@ prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, 
 }
 
 // ---- dense part: SDF penetration for every vertex ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-prox_dense_kernel(const float* __restrict__ verts, int N, Cam2World cw, SdfVol vol, const float* __restrict__ weights,
-                  float* __restrict__ dverts, double* __restrict__ acc) {
+struct ProxDenseIn { const float* verts; int N; const float* weights; float* dverts; double* acc; };
+__device__ __forceinline__ void prox_dense_body(const ProxDenseIn& dn, const Cam2World& cw, const SdfVol& vol, int blk) {
   __shared__ float red[4];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* __restrict__ verts = dn.verts; const float* __restrict__ weights = dn.weights;
+  float* __restrict__ dverts = dn.dverts; double* __restrict__ acc = dn.acc;
+  const int N = dn.N;
+  const int i = blk * 256 + threadIdx.x;
   float s = 0.f;
   if (i < N) {
     float w[3], g[3], gc[3] = {0.f, 0.f, 0.f};
@@ -215,7 +219,16 @@ prox_dense_kernel(const float* __restrict__ verts, int N, Cam2World cw, SdfVol v
     dverts[(size_t)i * 3] = gc[0]; dverts[(size_t)i * 3 + 1] = gc[1]; dverts[(size_t)i * 3 + 2] = gc[2];
   }
   const float tot = block_sum(s, red);
-  if (threadIdx.x == 0 && tot != 0.f) atomicAdd(acc + (blockIdx.x & 31) * PROX_ACC_STRIDE + PA_SDF, (double)tot);
+  if (threadIdx.x == 0 && tot != 0.f) atomicAdd(acc + (blk & 31) * PROX_ACC_STRIDE + PA_SDF, (double)tot);
+}
+// ONE launch for the two loss stages that read only the vertices and joints (round 5): workgroups 0 .. 2 B - 1 are the frame roles
+// (latency chains on 2 B of the 256 CUs for ~16 us when launched alone), the rest the dense SDF roles, which fill the other CUs
+// meanwhile -- no fork / join (the graph-branch form of this overlap lost 3 %), one kernel boundary less
+__global__ void __launch_bounds__(256)
+prox_frame_dense_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, ProxDenseIn dn, Cam2World cw, SdfVol vol, int nparts) {
+  const int id = (int)blockIdx.x, nf = in.B * nparts;
+  if (id < nf) prox_frame_body(pc, in, out, cw, vol, id % in.B, id / in.B, nparts);
+  else prox_dense_body(dn, cw, vol, id - nf);
 }
 
 // ---- loss record ------------------------------------------------------------------------------------------------------------
@@ -270,6 +283,37 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
   __shared__ float inv[8];
   __shared__ float dummy_losses[12];
   const int b = blockIdx.x, t = threadIdx.x, V = in.V, B = in.B;
+  if (t < 12) dummy_losses[t] = 0.f;
+  // target / contact are only dereferenced (clamped reads), never used: m67 = -1, fm = 0 -> any buffer of >= B * max(n67 * 3, 4) floats
+  const DvertsIn din = {in.verts, V, in.verts, in.verts, in.dx0, in.canon, in.weights, B, B};
+  const bool has_next = b < B - 1, has_prev = b >= 1;
+  // ---- everything of a vertex that does not need the loss totals: positions, the two contact decisions of the friction term (SDF
+  // lookups), the smoothness gradient through the marker image.  The first vertex of a thread is taken through this BEFORE the totals
+  // are read: the kernel is one dependent chain per thread (index -> vertex -> SDF gathers -> image gradient -> joint gradients ->
+  // read-modify-write), and the totals' own chain (32 slots -> barrier -> 1 / count -> barrier) used to sit in front of it.
+  struct Pre { int vid; float w0[3], wn[3], wp[3], s[3]; bool c0, cp; };
+  auto vertex_pre = [&](int u) {
+    Pre r;
+    r.vid = pc.s_vid[u];
+    const float* p = in.verts + ((size_t)b * V + r.vid) * 3;
+    to_world(cw, p, r.w0);
+    r.wn[0] = r.wn[1] = r.wn[2] = 0.f; r.wp[0] = r.wp[1] = r.wp[2] = 0.f;
+    if (has_next) to_world(cw, p + (size_t)V * 3, r.wn);
+    if (has_prev) to_world(cw, p - (size_t)V * 3, r.wp);
+    const bool fric = pc.s_fric[u] >= 0;
+    r.c0 = fric && has_next && sdf_at(vol, r.w0[0], r.w0[1], r.w0[2], nullptr) < 0.01f;
+    r.cp = fric && has_prev && sdf_at(vol, r.wp[0], r.wp[1], r.wp[2], nullptr) < 0.01f;
+    r.s[0] = r.s[1] = r.s[2] = 0.f;
+    const int m81 = pc.s_m81[u];
+    if (m81 >= 0) {                                          // smoothness prior through the marker image (canon already folds the cam -> world rotation)
+      const DvIdx ix = {r.vid, -1, 0, m81};
+      dverts_vertex(fc, din, dummy_losses, b, ix, r.s[0], r.s[1], r.s[2]);
+    }
+    return r;
+  };
+  const int u_first = blockIdx.y * 256 + t;
+  Pre first;
+  if (u_first < pc.n_s) first = vertex_pre(u_first);
   if (t < PA_COUNT) {
     if (t == PA_SMOOTH) {          // the smoothness kernel (smooth_loss_body) adds into its own [32][16] block behind the main one
       double v = 0.0;
@@ -277,7 +321,6 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
       tots[t] = v;
     } else tots[t] = prox_slot_total(in.acc, t);
   }
-  if (t < 12) dummy_losses[t] = 0.f;
   __syncthreads();
   if (t == 0) inv[0] = tots[PA_FT_N] >= 1.0 ? in.weights[PW_FRIC_T] / (float)tots[PA_FT_N] : 0.f;
   if (t == 1) inv[1] = tots[PA_FN_N] >= 1.0 ? in.weights[PW_FRIC_N] / (float)tots[PA_FN_N] : 0.f;
@@ -289,32 +332,23 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
     for (int i = 0; i < 16; ++i) losses_out[i] = rec[i];
   }
   __syncthreads();
-  // target / contact are only dereferenced (clamped reads), never used: m67 = -1, fm = 0 -> any buffer of >= B * max(n67 * 3, 4) floats
-  const DvertsIn din = {in.verts, V, in.verts, in.verts, in.dx0, in.canon, in.weights, B, B};
-  for (int u = blockIdx.y * 256 + t; u < pc.n_s; u += 256 * gridDim.y) {     // (frame, quarter of S) per workgroup
-    const int vid = pc.s_vid[u];
-    const float* p = in.verts + ((size_t)b * V + vid) * 3;
+  for (int u = u_first; u < pc.n_s; u += 256 * gridDim.y) {     // (frame, quarter of S) per workgroup
+    const Pre r = u == u_first ? first : vertex_pre(u);
+    const int vid = r.vid;
+    const float *w0 = r.w0, *wn = r.wn, *wp = r.wp;
     float g[3] = {0.f, 0.f, 0.f}, gw[3] = {0.f, 0.f, 0.f};
-    float w0[3];
-    to_world(cw, p, w0);
-    const bool has_next = b < B - 1, has_prev = b >= 1;
-    float wn[3] = {0.f, 0.f, 0.f}, wp[3] = {0.f, 0.f, 0.f};
-    if (has_next) to_world(cw, p + (size_t)V * 3, wn);
-    if (has_prev) to_world(cw, p - (size_t)V * 3, wp);
     // friction: this vertex is the `b` end of pair (b, b+1) [contact decided at frame b] and the `b+1` end of (b-1, b)
-    if (pc.s_fric[u] >= 0) {
-      if (has_next && sdf_at(vol, w0[0], w0[1], w0[2], nullptr) < 0.01f) {
-        const float vx = wn[0] - w0[0], vy = wn[1] - w0[1], vz = wn[2] - w0[2];
-        const float gt_ = sqrtf(vx * vx + vy * vy);
-        if (gt_ - 0.0001f > 0.f) { gw[0] -= inv[0] * vx / gt_; gw[1] -= inv[0] * vy / gt_; }
-        if (vz < 0.f) gw[2] += inv[1];                     // d mean(-v.z) / d z_b = +1 / count
-      }
-      if (has_prev && sdf_at(vol, wp[0], wp[1], wp[2], nullptr) < 0.01f) {
-        const float vx = w0[0] - wp[0], vy = w0[1] - wp[1], vz = w0[2] - wp[2];
-        const float gt_ = sqrtf(vx * vx + vy * vy);
-        if (gt_ - 0.0001f > 0.f) { gw[0] += inv[0] * vx / gt_; gw[1] += inv[0] * vy / gt_; }
-        if (vz < 0.f) gw[2] -= inv[1];
-      }
+    if (r.c0) {
+      const float vx = wn[0] - w0[0], vy = wn[1] - w0[1], vz = wn[2] - w0[2];
+      const float gt_ = sqrtf(vx * vx + vy * vy);
+      if (gt_ - 0.0001f > 0.f) { gw[0] -= inv[0] * vx / gt_; gw[1] -= inv[0] * vy / gt_; }
+      if (vz < 0.f) gw[2] += inv[1];                       // d mean(-v.z) / d z_b = +1 / count
+    }
+    if (r.cp) {
+      const float vx = w0[0] - wp[0], vy = w0[1] - wp[1], vz = w0[2] - wp[2];
+      const float gt_ = sqrtf(vx * vx + vy * vy);
+      if (gt_ - 0.0001f > 0.f) { gw[0] += inv[0] * vx / gt_; gw[1] += inv[0] * vy / gt_; }
+      if (vz < 0.f) gw[2] -= inv[1];
     }
     // infill L1 on occluded markers
     const int m67 = pc.s_m67[u];
@@ -322,8 +356,8 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
       const float om = 1.f - in.marker_mask[(size_t)b * pc.n67 + m67];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float r = in.rec[((size_t)b * pc.n67 + m67) * 3 + c] - w0[c];
-        if (fabsf(r) * om > 0.f) gw[c] -= inv[2] * om * (r > 0.f ? 1.f : -1.f);
+        const float rr = in.rec[((size_t)b * pc.n67 + m67) * 3 + c] - w0[c];
+        if (fabsf(rr) * om > 0.f) gw[c] -= inv[2] * om * (rr > 0.f ? 1.f : -1.f);
       }
     }
     // contact velocity of the heel / toe sets
@@ -345,14 +379,7 @@ prox_sparse_kernel(ProxConst pc, FitConst fc, ProxSparseIn in, Cam2World cw, Sdf
       }
     }
     to_cam_grad(cw, gw, g);
-    // smoothness prior through the marker image (canon already folds the cam -> world rotation)
-    const int m81 = pc.s_m81[u];
-    if (m81 >= 0) {
-      float sx, sy, sz;
-      const DvIdx ix = {vid, -1, 0, m81};
-      dverts_vertex(fc, din, dummy_losses, b, ix, sx, sy, sz);
-      g[0] += sx; g[1] += sy; g[2] += sz;
-    }
+    g[0] += r.s[0]; g[1] += r.s[1]; g[2] += r.s[2];          // (the smoothness gradient: zeros when the vertex is no marker of the image)
     // vertex-pick joints and landmarks that read this vertex
     for (int q = pc.s_jstart[u]; q < pc.s_jstart[u + 1]; ++q) {
       const float w = pc.s_jw[q];
@@ -404,10 +431,129 @@ prox_adam_kernel(ProxParams P, int B, int erase_n, double lr, int* __restrict__ 
   *pp = pv;
 }
 
+// ---- tail of one PROX iteration, one workgroup per frame (three launches -> one; fit_tail_kernel of loss_kernels.hip is the AMASS twin):
+//   dz   = dh1 . W1              the last layer of the VPoser decoder backward (vposer_smpl.py:107-115 transposed) = d(loss)/d(pose_embedding)
+//   Adam on this frame's 81 parameters (prox_adam_kernel above: same arithmetic, same erase / latch / counter protocol)
+//   h1'  = lrelu(W1 z' + b1)     the FIRST layer of the NEXT iteration's decoder forward, on the updated embedding
+// The launch that opens a graph (or an eager run) runs this kernel with do_dz = do_adam = 0: h1 has the same bits whichever launch made it.
+struct ProxTail {
+  ProxParams P;
+  const float *w1, *w1t, *b1, *dh1;
+  float *g_pe, *h1;
+  int B, erase_n, do_dz, do_adam;
+  double lr;
+  int* step_ctr; const int* step_cur; int* nonfinite; const float* losses;
+};
+__global__ void __launch_bounds__(256)
+prox_tail_kernel(ProxTail a) {
+  __shared__ __attribute__((aligned(16))) float dh[512];
+  __shared__ float zs[32], dzs[32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  // every global read first, with clamped (never predicated) addresses: the phases below depend on each other
+  const int m_dz = t >> 3, part = t & 7;
+  float dh_a = 0.f, dh_b = 0.f;
+  float4 wv[16];
+  if (a.do_dz) {
+    dh_a = a.dh1[(size_t)b * 512 + t];
+    dh_b = a.dh1[(size_t)b * 512 + t + 256];
+    const float* wr = a.w1t + (size_t)m_dz * 512 + 4 * part;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wv[i] = ld4(wr + 32 * i);
+  }
+  float4 w8[2][8];
+  float bias[2] = {0.f, 0.f};
+  if (a.h1) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const float* wr = a.w1 + (size_t)(t + 256 * r) * 32;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w8[r][i] = ld4(wr + 4 * i);
+      bias[r] = a.b1[t + 256 * r];
+    }
+  }
+  // this thread's parameter (threads >= 81 shadow element 80: same addresses, nothing stored)
+  const int k = t < PROX_NP ? t : PROX_NP - 1;
+  const int off[10] = {0, 3, 6, 18, 30, 33, 36, 39, 49, 81};
+  int sgm = 0;
+#pragma unroll
+  for (int q = 1; q < 9; ++q) sgm += k >= off[q] ? 1 : 0;
+  const int dim = off[sgm + 1] - off[sgm], e = k - off[sgm];
+  float* pp = a.P.p[sgm] + (size_t)b * dim + e;
+  const int i = b * PROX_NP + k;
+  float p_old = *pp, m_old = 0.f, v_old = 0.f, g_in = 0.f, g_prior = 0.f, g_trj = 0.f, tot = 0.f;
+  int step = 0, nf0 = 0, nf1 = 0;
+  if (a.do_adam) {
+    m_old = a.P.m[i]; v_old = a.P.v[i];
+    g_in = a.P.g[sgm][(size_t)b * dim + e];                   // (pose_embedding: replaced by dz below)
+    g_prior = a.P.gp[i];
+    g_trj = a.P.dtr_j[(size_t)b * 3 + (sgm == 1 ? e : 0)];
+    step = *a.step_cur;
+    if (a.nonfinite) { nf0 = a.nonfinite[0]; nf1 = a.nonfinite[1]; tot = a.losses[0]; }
+  }
+  AdamCoef coef{0.f, 1.f};
+  if (a.do_adam) coef = adam_coef_t(step + 1, a.lr);
+  LEMO_PIN(p_old); LEMO_PIN(m_old); LEMO_PIN(v_old); LEMO_PIN(g_in); LEMO_PIN(g_prior); LEMO_PIN(g_trj); LEMO_PIN(tot);
+  LEMO_PIN(bias[0]); LEMO_PIN(bias[1]);
+  if (a.do_dz) {
+    // dz[m] = sum_k w1t[m][k] dh1[b][k] : thread = (m = t >> 3, part = t & 7) takes k = 4 part + 32 i .. + 3
+    dh[t] = dh_a;
+    dh[t + 256] = dh_b;
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int i2 = 0; i2 < 16; ++i2) {
+      const float4 d4 = ld4(&dh[4 * part + 32 * i2]);
+      acc = fmaf(wv[i2].x, d4.x, acc); acc = fmaf(wv[i2].y, d4.y, acc); acc = fmaf(wv[i2].z, d4.z, acc); acc = fmaf(wv[i2].w, d4.w, acc);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (part == 0) { a.g_pe[(size_t)b * 32 + m_dz] = acc; dzs[m_dz] = acc; }
+  }
+  __syncthreads();
+  float p_new = p_old;
+  if (a.do_adam) {
+    if (b == 0 && t == 0) {
+      *a.step_ctr = step + 1;
+      if (a.nonfinite && nf0 == 0 && !(fabsf(tot) <= 3.402823466e38f)) a.nonfinite[0] = step + 1;
+    }
+    if (t < PROX_NP && nf1 == 0) {
+      float grad = ((a.do_dz && sgm == 8) ? dzs[e] : g_in) + g_prior;
+      if (sgm == 1) grad += g_trj;
+      if (b < a.erase_n) grad = 0.f;                         // "erase gradient for first 15 frames" (:282-289)
+      float mm = m_old, vv = v_old;
+      adam_update_torch(p_new, mm, vv, grad, coef);
+      a.P.m[i] = mm; a.P.v[i] = vv;
+      *pp = p_new;
+    }
+  }
+  if (!a.h1) return;
+  if (t >= 49 && t < PROX_NP) zs[t - 49] = p_new;            // the embedding of this frame, as updated above
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    float acc = bias[r];
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      acc = fmaf(w8[r][i2].x, zs[4 * i2], acc); acc = fmaf(w8[r][i2].y, zs[4 * i2 + 1], acc);
+      acc = fmaf(w8[r][i2].z, zs[4 * i2 + 2], acc); acc = fmaf(w8[r][i2].w, zs[4 * i2 + 3], acc);
+    }
+    a.h1[(size_t)b * 512 + t + 256 * r] = lrelu(acc);
+  }
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
 static Cam2World make_cw(const float* c) { Cam2World w; for (int i = 0; i < 9; ++i) w.R[i] = c[i]; for (int i = 0; i < 3; ++i) w.t[i] = c[9 + i]; return w; }
 
-int prox_frame(const lemo_prox_desc& d, hipStream_t s) {
+// the two roles as launches of their own (A/B switch LEMO_PROX_TWO_LAUNCHES: the form up to round 4)
+__global__ void __launch_bounds__(256)
+prox_frame_kernel(ProxConst pc, ProxFrameIn in, ProxFrameOut out, Cam2World cw, SdfVol vol) {
+  prox_frame_body(pc, in, out, cw, vol, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+__global__ void __launch_bounds__(256)
+prox_dense_kernel(ProxDenseIn dn, Cam2World cw, SdfVol vol) { prox_dense_body(dn, cw, vol, (int)blockIdx.x); }
+
+int prox_frame_dense(const lemo_prox_desc& d, hipStream_t s) {
   if (d.pc.n_sj > PROX_MAXJ || d.pc.n_op > PROX_MAXJ) return LEMO_ERR_SHAPE;
   ProxFrameIn in{};
   in.Jtr = d.pose.Jtr; in.transl = d.transl; in.verts = d.verts; in.full_pose = d.pose.full_pose; in.pose_embedding = d.pose_embedding;
@@ -417,15 +563,15 @@ int prox_frame(const lemo_prox_desc& d, hipStream_t s) {
   in.nj = d.body.nj; in.ncomp = d.body.ncomp; in.V = d.V; in.B = d.B; in.T = d.T; in.use_infill = d.use_infill;
   in.fx = d.cam[0]; in.fy = d.cam[1]; in.cx = d.cam[2]; in.cy = d.cam[3];
   ProxFrameOut out{d.loss_acc, d.dJtr, d.dJv, d.dtr_j, d.gp, d.dfp_add};
-  hipLaunchKernelGGL(prox_frame_kernel, dim3(d.B, 2), dim3(256), 0, s, d.pc, in, out, make_cw(d.cam2world),
-                     make_sdf_vol(d.sdf, d.sdf_dim[0], d.sdf_dim[1], d.sdf_dim[2], d.grid_min, d.grid_max));
-  return (int)hipGetLastError();
-}
-
-int prox_dense(const lemo_prox_desc& d, hipStream_t s) {
   const int N = d.B * d.V;
-  hipLaunchKernelGGL(prox_dense_kernel, dim3((N + 255) / 256), dim3(256), 0, s, d.verts, N, make_cw(d.cam2world),
-                     make_sdf_vol(d.sdf, d.sdf_dim[0], d.sdf_dim[1], d.sdf_dim[2], d.grid_min, d.grid_max), d.weights, d.dverts, d.loss_acc);
+  ProxDenseIn dn{d.verts, N, d.weights, d.dverts, d.loss_acc};
+  static const bool two = getenv("LEMO_PROX_TWO_LAUNCHES") != nullptr;
+  const SdfVol vol = make_sdf_vol(d.sdf, d.sdf_dim[0], d.sdf_dim[1], d.sdf_dim[2], d.grid_min, d.grid_max);
+  if (two) {
+    hipLaunchKernelGGL(prox_frame_kernel, dim3(d.B, 2), dim3(256), 0, s, d.pc, in, out, make_cw(d.cam2world), vol);
+    hipLaunchKernelGGL(prox_dense_kernel, dim3((N + 255) / 256), dim3(256), 0, s, dn, make_cw(d.cam2world), vol);
+  } else
+    hipLaunchKernelGGL(prox_frame_dense_kernel, dim3(2 * d.B + (N + 255) / 256), dim3(256), 0, s, d.pc, in, out, dn, make_cw(d.cam2world), vol, 2);
   return (int)hipGetLastError();
 }
 
@@ -448,6 +594,24 @@ int prox_adam(const lemo_prox_desc& d, hipStream_t s) {
   const int n = d.B * PROX_NP;
   const int erase_n = d.first_batch_flag ? 0 : (int)(d.B * 0.15);
   hipLaunchKernelGGL(prox_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, s, P, d.B, erase_n, lr_decimal(d.lr), d.step_ctr, d.step_cur, d.nonfinite, d.losses);
+  return (int)hipGetLastError();
+}
+
+// update = false: only h1 = first VPoser layer of the current embedding (opens a graph / an eager run); update = true: the whole tail
+int prox_tail(const lemo_prox_desc& d, bool update, hipStream_t s) {
+  ProxTail a{};
+  float* p[9] = {d.global_orient, d.transl, d.left_hand_pose, d.right_hand_pose, d.jaw_pose, d.leye_pose, d.reye_pose, d.expression, d.pose_embedding};
+  const float* g[9] = {d.g_go, d.dtr_v, d.g_lh, d.g_rh, d.g_jaw, d.g_leye, d.g_reye, d.g_expr, d.g_pe};
+  for (int i = 0; i < 9; ++i) { a.P.p[i] = p[i]; a.P.g[i] = g[i]; }
+  a.P.dtr_j = d.dtr_j; a.P.gp = d.gp; a.P.m = d.adam_m; a.P.v = d.adam_v;
+  a.w1 = d.vposer.w1; a.w1t = d.vposer.w1t; a.b1 = d.vposer.b1;
+  a.dh1 = d.vp_scratch + (size_t)d.B * (128 + 512);          // vposer_mlp_bwd's layout: dout [B][128] | dh2 [B][512] | dh1 [B][512]
+  a.g_pe = d.g_pe; a.h1 = d.h1;
+  a.B = d.B; a.erase_n = d.first_batch_flag ? 0 : (int)(d.B * 0.15);
+  a.do_dz = a.do_adam = update ? 1 : 0;
+  a.lr = lr_decimal(d.lr); a.step_ctr = d.step_ctr; a.step_cur = d.step_cur; a.nonfinite = d.nonfinite; a.losses = d.losses;
+  if (!a.w1 || !a.w1t || !a.b1 || !a.h1 || !d.vp_scratch || !a.g_pe) return LEMO_ERR_ARG;
+  hipLaunchKernelGGL(prox_tail_kernel, dim3(d.B), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 
