@@ -630,8 +630,14 @@ struct AeLayer { int cin, cout, cin_pad, cout_pad, deconv, level, w_off, b_off, 
 
 // slabs of padded interior pixels for the weight gradients: equal parts of at most AE_SLAB pixels, a multiple of 32 long (27 x 19
 // = 513 padded pixels is ONE slab, not 512 + 1)
-static int ae_slabs(int H, int W, int* len) {
-  const int n_px = H * (W + 2), n = (n_px + AE_SLAB - 1) / AE_SLAB;
+// `scale` (round 5, measured and NOT adopted): with k clips side by side the launch has k x the waves, so a clip's slabs could be k x
+// longer for the same number of waves in flight (fewer partial tiles written by the weight-gradient launch and read back by the
+// optimiser launch).  8 clips per engine, ms per clip: x1 16.40, x2 16.69, x4 17.24, x8 18.07, x16 20.51; 16 clips: x1 15.43, x4 15.76,
+// x8 16.32 (profiles/r05_ab_ae_slab_scale.txt) -- the launch wants MANY SHORT waves (its cost is the spread between a level-0 wave
+// and a level-4 one, not the 40 MB of partials per clip), so the scale stays 1; LEMO_AE_SLAB_SCALE keeps the switch
+static int ae_slabs(int H, int W, int* len, int scale = 1) {
+  const int cap = AE_SLAB * (scale < 1 ? 1 : scale);
+  const int n_px = H * (W + 2), n = (n_px + cap - 1) / cap;
   *len = ((n_px + n - 1) / n + 31) / 32 * 32;
   return (n_px + *len - 1) / *len;
 }
@@ -670,7 +676,14 @@ struct Bump {
 };
 
 // the same routine sizes the workspace (base == nullptr) and carves it
-static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
+static int ae_slab_scale(int nclip) {
+  static const char* ev = getenv("LEMO_AE_SLAB_SCALE");        // A/B switch: slab length in units of AE_SLAB pixels, whatever the clip count
+  if (ev && atoi(ev) >= 1) return atoi(ev);
+  (void)nclip;
+  return 1;
+}
+
+static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total, int slab_scale = 1) {
   e->H[0] = H0; e->W[0] = W0;
   for (int k = 0; k < 5; ++k) { e->H[k + 1] = (e->H[k] - 1) / 2 + 1; e->W[k + 1] = (e->W[k] - 1) / 2 + 1; }
   int n = 0;
@@ -692,7 +705,7 @@ static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total) {
     l.wb_off = i == 0 ? -1 : wbo; if (i) wbo += 9 * l.cin_pad * l.cout_pad;      // the first layer needs no backward-data
     l.flat_w = flat; flat += 9 * l.cin * l.cout;
     l.flat_b = flat; flat += l.cout;
-    l.nslab = ae_slabs(e->H[l.level], e->W[l.level], &l.slab_len);
+    l.nslab = ae_slabs(e->H[l.level], e->W[l.level], &l.slab_len, slab_scale);
     l.part_off = part; part += (size_t)l.nslab * 9 * l.cin_pad * l.cout_pad;
     l.dbp_off = dbp; dbp += (size_t)l.nslab * 2 * l.cout_pad;
   }
@@ -876,8 +889,8 @@ void* lemo_ae_create(const lemo_ae_desc* d) {
   AeEngine* e = new (std::nothrow) AeEngine();
   if (!e) return nullptr;
   size_t total = 0;
-  ae_layout(e, d->H, d->W, d->ws, &total);
   e->nclip = d->clips > 1 ? d->clips : 1;
+  ae_layout(e, d->H, d->W, d->ws, &total, ae_slab_scale(e->nclip));     // (longer slabs only shrink the layout: lemo_ae_ws_floats stays the bound)
   e->cs = total;                                            // clip c = the same layout, c * total floats further
   if (e->nclip > 64 || (long long)(total * (size_t)e->nclip) > d->ws_floats) { delete e; return nullptr; }
   e->lr = d->lr;
