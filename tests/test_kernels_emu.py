@@ -354,13 +354,16 @@ def test_conv3x3_split_f16_forward_and_backward_data(emu_lib, H, W, ci, co):
     assert torch.equal(from_cg8p(out, H, W), F.leaky_relu(b, 0.2)[:, None, None].expand(co, H, W))
 
 
-def test_dense_vertex_backward_large_set(emu_lib):
+@pytest.mark.parametrize('coherent', [False, True])
+def test_dense_vertex_backward_large_set(emu_lib, coherent):
     """vertex sets above 1024 vertices (the PROX window differentiates through all of them) take the chunked dense
     backward (joint-major gather per 512-vertex chunk, per-chunk partials reduced in order: no atomics): every input
-    gradient against the oracle's autograd"""
+    gradient against the oracle's autograd.  i.i.d. skinning weights: ~35 entries per joint and chunk (the thread-per-output
+    form of the joint-major sums, LBS_JOINT_SMALL); weights with index locality: a few joints with hundreds of entries each (a
+    wave per joint) next to joints with a handful -- both forms in one chunk"""
     from lemo_amd.body_model import create
     from oracle import lemo_oracle as O
-    m = synthetic.make_synthetic_smplx(seed=5, V=1300, F=600)
+    m = synthetic.make_synthetic_smplx(seed=5, V=1300, F=600, coherent=coherent)
     B = 3
     g = torch.Generator().manual_seed(4)
     mk = lambda *s, sc=0.3: (torch.randn(*s, generator=g) * sc)
