@@ -44,6 +44,27 @@ PEAK_HBM_TBS = 8.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_FILE = os.path.join('profiles', 'r05_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
 
 
+def arithmetic_label(conv_variant):
+    """``config.arithmetic`` of the bench line: what the encoder's multiplies run on for a given ``conv_variant`` (include/lemo_hip.h,
+    lemo_fit_desc.conv_variant).  Every variant >= 4 is the split-f16 scheme (variants 5-9 differ in which layers share a launch, not in
+    arithmetic); tests/test_bench_line.py pins that the string says so (variants 6-9 fell through to the fp32-MFMA string)."""
+    split_f16 = ('fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
+                 'error-compensated fp16 pieces (split-f16: 3 f16-MFMA products, per-workgroup power-of-two scaling; measured error vs '
+                 'float64 at the level of an fp32 convolution)')
+    fusion = {4: 'one layer per launch (conv_split_kernels.hip)',
+              5: 'consecutive 64->64 layers run as fused pairs (conv_pair_kernels.hip)',
+              6: 'fused pairs on four-wave workgroups (conv_pair4_kernels.hip)',
+              7: 'fused pairs + encoder head (image, layers 0-1) and tail (their backward) one launch each (conv_head_kernels.hip)',
+              8: 'fused pairs + encoder head with layer 2 (enc_head3) + tail (conv_head_kernels.hip)',
+              9: 'fused pairs + encoder head with layer 2 (enc_head3) and tail with layer 2\'s backward (enc_tail3), conv_head_kernels.hip'}
+    if conv_variant >= 4:
+        return split_f16 + '; ' + fusion.get(conv_variant, 'fused launches (variant %d)' % conv_variant)
+    if conv_variant == 3:
+        return ('fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
+                'each (6 bf16-MFMA products, fp32 accumulate; error vs float64 <= the fp32-MFMA kernel\'s)')
+    return 'fp32 throughout (fp32-input MFMA)'
+
+
 def build_problem(seq_id, B, device, full_vertices, conv_variant=1):
     from lemo_amd import synthetic
     from lemo_amd.assets import load_assets
@@ -828,15 +849,7 @@ def main():
                    'synthetic_model': args.model + (' (skinning joints i.i.d. per vertex: every 512-vertex chunk touches all 55 joints -- the worst case)'
                                                      if args.model == 'iid' else ' (index locality of the licensed model: a 512-vertex chunk touches 4-17 joints)'),
                    'sequences': world, 'conv_variant': fit.conv_variant,
-                   'arithmetic': {5: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
-                                     'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured error vs '
-                                     'float64 at the level of an fp32 convolution); consecutive 64->64 layers run as fused pairs (conv_pair_kernels.hip)',
-                                  4: 'fp32 values and fp32 accumulation throughout; the encoder\'s MFMA layers multiply each fp32 operand as two '
-                                     'error-compensated fp16 pieces (3 f16-MFMA products, per-workgroup power-of-two scaling; measured '
-                                     'error vs float64 at the level of an fp32 convolution, conv_split_kernels.hip)',
-                                  3: 'fp32 throughout; the 64->64 encoder layers multiply exact fp32 operands as 3 bf16 pieces '
-                                     'each (6 bf16-MFMA products, fp32 accumulate; error vs float64 <= the fp32-MFMA kernel\'s)'}.get(
-                                         fit.conv_variant, 'fp32 throughout (fp32-input MFMA)'),
+                   'arithmetic': arithmetic_label(fit.conv_variant),
                    'parallelism': f'seq-shard x{world} + 1 all_gather', 'hip_graph': use_graph},
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',

@@ -17,6 +17,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* liblemo_hip.so is built with -fvisibility=hidden: the declarations of this header are its ONLY exports (tests/test_abi.py
+ * compares `nm -D` with the prototypes below). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define LEMO_ERR_SHAPE 10001
 #define LEMO_ERR_ARG 10002
@@ -579,6 +584,9 @@ typedef struct lemo_prox_state {
 int lemo_prox_load_state(void* h, const lemo_prox_state* st, void* stream);
 int lemo_prox_save_state(void* h, const lemo_prox_state* st, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,9 @@ class BodyModelData:
         self.lmk_rows = np.ascontiguousarray(self.faces[lmk_idx], np.int32)                  # [51,3] vertex ids
         self.lmk_bary = np.ascontiguousarray(model['lmk_bary_coords'], f32)
         ids = EXTRA_JOINT_VERTEX_IDS if extra_joint_ids is None else list(extra_joint_ids)
+        if len(ids) and (min(ids) < 0 or max(ids) >= V):
+            raise ValueError(f'extra joint vertex ids reach {max(ids)} but the model has {V} vertices (the default ids are SMPL-X\'s: '
+                             'pass extra_joint_ids for a smaller model)')
         self.extra_ids = np.asarray(ids, np.int32)
         self.n_joints_out = nj + len(ids) + self.lmk_rows.shape[0]
 

@@ -826,9 +826,19 @@ enc_tail3_kernel(Tail3Args A3) {
 int enc_tail3(const float* din, const void* w2bpack, float w2binv, const float* act2, const void* w1bpack, float w1binv, const float* act1,
               const float* w0, float* dx0, int H, int W, hipStream_t s) {
   if (!din || !w2bpack || !(w2binv > 0.f) || !act2 || !w1bpack || !(w1binv > 0.f) || !act1 || !w0 || !dx0 || H < 1 || W < 1) return LEMO_ERR_ARG;
-  static int rc = -1;
-  if (rc < 0) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_tail3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T3_SMEM);
-  if (rc) return rc;
+  // the opt-in to T3_SMEM bytes of dynamic LDS is a per-device attribute of the function: once per device of this process,
+  // after checking that the device has that much (gfx950: 160 KiB; anything smaller fails loudly here, not at the launch)
+  static int rcs[64];                                       // 0 = not asked yet, 1 = ok, else -(hipError_t) - 1
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LEMO_ERR_ARG;
+  if (rcs[dev] == 0) {
+    int lds = 0;
+    hipError_t e = hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    if (e == hipSuccess && lds < T3_SMEM) e = hipErrorInvalidValue;
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&enc_tail3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T3_SMEM);
+    rcs[dev] = e == hipSuccess ? 1 : -(int)e - 1;
+  }
+  if (rcs[dev] != 1) return -(rcs[dev] + 1);
   Tail3Args A{};
   TailArgs& a = A.t;
   a.din = din; a.w1b = reinterpret_cast<const uint4*>(w1bpack); a.w1binv = w1binv; a.act1 = act1; a.w0 = w0; a.dx0 = dx0;

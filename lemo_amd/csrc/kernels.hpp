@@ -89,6 +89,12 @@ int vposer_decode_fwd(const VPoserW& w, const float* z, int z_stride, int B, flo
 int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const float* o, const float* matrot,
                       const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, float* scratch /*[B][1152]*/,
                       hipStream_t s);
+// layout of the VPoser backward's scratch [B][1152]: d(out) [B][128] | d(h2) [B][512] | d(h1) [B][512].  The fused tail launches of the
+// two engines (fit_tail, prox_tail) read d(h1) out of it: they and vposer_mlp_bwd share THESE helpers.
+constexpr int VP_HIDDEN = 512, VP_OUT_PAD = 128;
+static inline float* vposer_scratch_dout(float* scratch, int) { return scratch; }
+static inline float* vposer_scratch_dh2(float* scratch, int B) { return scratch + (size_t)B * VP_OUT_PAD; }
+static inline float* vposer_scratch_dh1(float* scratch, int B) { return scratch + (size_t)B * (VP_OUT_PAD + VP_HIDDEN); }
 int vposer_mlp_bwd(const VPoserW& w, const float* h1, const float* h2, int B, float* dz, int dz_stride, float* scratch,
                    hipStream_t s);
 int rot6d_to_aa_fwd(const float* x6, int stride, int N, float* aa, hipStream_t s);

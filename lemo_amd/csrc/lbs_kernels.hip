@@ -1018,7 +1018,8 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
     d[1] = T[1] * gx + T[4] * gy + T[7] * gz;
     d[2] = T[2] * gx + T[5] * gy + T[8] * gz;
   }
-  if (ch == nchunk - 1 && t < u.NCs - 3 * u.n) dvp[(size_t)b * u.NCs + 3 * u.n + t] = 0.f;     // padding columns of the GEMM operand (< 16)
+  if (ch == nchunk - 1)                                                                          // padding columns of the GEMM operand: any width
+    for (int i = 3 * u.n + t; i < u.NCs; i += 256) dvp[(size_t)b * u.NCs + i] = 0.f;          // (a C-API caller may pad wider than 16)
   float* part = u.part + ((size_t)b * nchunk + ch) * LBS_PART_STRIDE(nj);
   sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
   if ((t & 63) == 0) { red[3 * (t >> 6)] = sx; red[3 * (t >> 6) + 1] = sy; red[3 * (t >> 6) + 2] = sz; }

@@ -324,7 +324,7 @@ static int fit_graphs(FitEngine* e, hipStream_t s, int n, bool launch) {
 static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1) {
   FitTail a{};
   a.w1 = d.vposer.w1; a.w1t = d.vposer.w1t; a.b1 = d.vposer.b1;
-  a.dh1 = d.vp_scratch + (size_t)d.B * 128 + (size_t)d.B * 512;       // vposer_mlp_bwd's layout: dout | dh2 | dh1
+  a.dh1 = vposer_scratch_dh1(d.vp_scratch, d.B);                      // kernels.hpp: the layout vposer_mlp_bwd writes
   a.g_other = d.g_other; a.h1 = h1 ? d.h1 : nullptr;
   a.transl = d.transl; a.rot6d = d.rot6d; a.other = d.other; a.g_transl = d.g_transl; a.g_rot6d = d.g_rot6d;
   a.m0 = d.adam_m[0]; a.v0 = d.adam_v[0]; a.m1 = d.adam_m[1]; a.v1 = d.adam_v[1]; a.m2 = d.adam_m[2]; a.v2 = d.adam_v[2];

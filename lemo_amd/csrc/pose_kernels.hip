@@ -75,14 +75,11 @@ int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const 
                       const float* d_aa, const float* d_matrot, int B, float* dz, int dz_stride, float* scratch, hipStream_t s) {
   (void)matrot;
   if (B <= 0 || !scratch) return LEMO_ERR_SHAPE;
-  float* dout = scratch;
-  float* dh2 = scratch + (size_t)B * 128;
-  float* dh1 = dh2 + (size_t)B * VP_H;
+  float* dout = vposer_scratch_dout(scratch, B);
   const int n = B * 22;
   hipLaunchKernelGGL(vposer_rot_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, o, d_aa, d_matrot, B, dout);
   int e = (int)hipGetLastError();
   if (e) return e;
-  (void)dh2; (void)dh1;
   return vposer_mlp_bwd(w, h1, h2, B, dz, dz_stride, scratch, s);
 }
 
@@ -90,9 +87,10 @@ int vposer_decode_bwd(const VPoserW& w, const float* h1, const float* h2, const 
 int vposer_mlp_bwd(const VPoserW& w, const float* h1, const float* h2, int B, float* dz, int dz_stride, float* scratch,
                    hipStream_t s) {
   if (B <= 0 || !scratch) return LEMO_ERR_SHAPE;
-  float* dout = scratch;
-  float* dh2 = scratch + (size_t)B * 128;
-  float* dh1 = dh2 + (size_t)B * VP_H;
+  static_assert(VP_H == VP_HIDDEN, "scratch layout helpers (kernels.hpp)");
+  float* dout = vposer_scratch_dout(scratch, B);
+  float* dh2 = vposer_scratch_dh2(scratch, B);
+  float* dh1 = vposer_scratch_dh1(scratch, B);
   int e;
   if ((e = gemm_nt16(w.w3t, 128, dout, 128, VP_H, B, 128, dh2, VP_H, nullptr, h2, VP_H, 3, s))) return e;
   if ((e = gemm_nt16(w.w2t, VP_H, dh2, VP_H, VP_H, B, VP_H, dh1, VP_H, nullptr, h1, VP_H, 3, s))) return e;

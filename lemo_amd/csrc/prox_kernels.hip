@@ -484,7 +484,10 @@ prox_tail_kernel(ProxTail a) {
   int step = 0, nf0 = 0, nf1 = 0;
   if (a.do_adam) {
     m_old = a.P.m[i]; v_old = a.P.v[i];
-    g_in = a.P.g[sgm][(size_t)b * dim + e];                   // (pose_embedding: replaced by dz below)
+    // pose_embedding under do_dz: its gradient is the dz computed below and g_pe has not been written yet (vposer_mlp_bwd ran with
+    // dz = nullptr) -- the load stays unconditional (one address select, no branch) but reads an initialised word
+    const float* g_src = (a.do_dz && sgm == 8) ? a.P.gp + i : a.P.g[sgm] + (size_t)b * dim + e;
+    g_in = *g_src;
     g_prior = a.P.gp[i];
     g_trj = a.P.dtr_j[(size_t)b * 3 + (sgm == 1 ? e : 0)];
     step = *a.step_cur;
@@ -605,7 +608,7 @@ int prox_tail(const lemo_prox_desc& d, bool update, hipStream_t s) {
   for (int i = 0; i < 9; ++i) { a.P.p[i] = p[i]; a.P.g[i] = g[i]; }
   a.P.dtr_j = d.dtr_j; a.P.gp = d.gp; a.P.m = d.adam_m; a.P.v = d.adam_v;
   a.w1 = d.vposer.w1; a.w1t = d.vposer.w1t; a.b1 = d.vposer.b1;
-  a.dh1 = d.vp_scratch + (size_t)d.B * (128 + 512);          // vposer_mlp_bwd's layout: dout [B][128] | dh2 [B][512] | dh1 [B][512]
+  a.dh1 = vposer_scratch_dh1(d.vp_scratch, d.B);             // kernels.hpp: the layout vposer_mlp_bwd writes
   a.g_pe = d.g_pe; a.h1 = d.h1;
   a.B = d.B; a.erase_n = d.first_batch_flag ? 0 : (int)(d.B * 0.15);
   a.do_dz = a.do_adam = update ? 1 : 0;

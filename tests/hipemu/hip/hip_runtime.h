@@ -515,6 +515,8 @@ static inline float atomicAdd(float* p, double v) { return atomicAdd(p, (float)v
 // ---- buffer resources / cache-policy loads & stores / scoped atomics (plain memory on the host) ------------
 struct hipDeviceProp_t { int multiProcessorCount; };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 74 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }
 // (workgroups run one after another here: multi-layer chains cannot make progress -- the CPU tests use n = 1)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 1 << 20; return hipSuccess; }
 struct hipemu_rsrc { char* p; };

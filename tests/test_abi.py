@@ -26,6 +26,15 @@ def test_gfx950_library_exports_every_declared_symbol(hip_lib_built):
     assert dll.lemo_abi_version() == 4
 
 
+def test_library_exports_nothing_but_the_header(hip_lib_built):
+    """built with -fvisibility=hidden + csrc/exports.map: the dynamic symbol table IS the header (117 C++ launchers and
+    the kernel handles used to be exported next to the 84 C names)"""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', hip_lib_built], check=True, capture_output=True, text=True).stdout
+    exported = sorted(line.split()[-1] for line in out.strip().split('\n') if line.strip())
+    assert exported == _declared(), sorted(set(exported) ^ set(_declared()))
+
+
 def test_python_binding_covers_header():
     from lemo_amd import _hip
     assert sorted(_hip.EXPORTED_SYMBOLS) == _declared()

@@ -145,10 +145,15 @@ def prox_teacher_check(T, stage, make_engine, report, steps=None, to_np=lambda t
             # fitting_temp_slide.py:699-739, 944-992) additionally get the jump float64 computes at this state when an element within fp32
             # rounding of its threshold changes sides (make_teacher.prox_loss_jumps; both implementations may flip: factor 2) -- at
             # B = 100 / V = 10475 tens of thousands of elements are selected and one of them sits that close in some state
+            # (the allowance is CAPPED at 1e-3 of the entry -- a computed jump larger than that means the fixture state is
+            # degenerate, not that the gate should open -- and at most three entries besides the total may use it at one state)
             jump = dict(zip(LOSS_KEYS, T[f'{tag}_lossjump{k}'])) if f'{tag}_lossjump{k}' in T else {}
-            jump['total_loss'] = sum(v for kk, v in jump.items() if kk != 'total_loss')
+            slack = {kk: min(2.0 * v, 1e-3 * abs(ref.get(kk, 0.0))) for kk, v in jump.items() if kk != 'total_loss'}
+            slack['total_loss'] = min(sum(slack.values()), 1e-3 * abs(ref['total_loss']))
+            used = [key for key, r in ref.items() if key != 'total_loss' and abs(L[key] - r) > 1e-5 * abs(r) + 1e-12]
+            assert len(used) <= 3, (tag, k, used)
             for key, r in ref.items():
-                assert abs(L[key] - r) <= 1e-5 * abs(r) + 2.0 * jump.get(key, 0.0) + 1e-12, (tag, k, key, L[key], r, jump.get(key, 0.0))
+                assert abs(L[key] - r) <= 1e-5 * abs(r) + slack.get(key, 0.0) + 1e-12, (tag, k, key, L[key], r, jump.get(key, 0.0))
                 if jump.get(key, 0.0) > 1e-5 * abs(r):
                     report.append(f'{tag} step {k}: {key} carries a threshold jump of {jump[key] / max(abs(r), 1e-30):.1e} of its value (engine vs reference {abs(L[key] - r) / max(abs(r), 1e-30):.1e})')
             g = eng.grads(erase=True)
