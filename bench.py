@@ -56,7 +56,9 @@ def arithmetic_label(conv_variant):
               6: 'fused pairs on four-wave workgroups (conv_pair4_kernels.hip)',
               7: 'fused pairs + encoder head (image, layers 0-1) and tail (their backward) one launch each (conv_head_kernels.hip)',
               8: 'fused pairs + encoder head with layer 2 (enc_head3) + tail (conv_head_kernels.hip)',
-              9: 'fused pairs + encoder head with layer 2 (enc_head3) and tail with layer 2\'s backward (enc_tail3), conv_head_kernels.hip'}
+              9: 'fused pairs + encoder head with layer 2 (enc_head3) and tail with layer 2\'s backward (enc_tail3), conv_head_kernels.hip',
+              10: 'every 64->64 layer ONE Winograd F(2x2, 3x3) launch (fp32 transforms, the 16 position GEMMs split-f16; conv_wino_kernels.hip) '
+                  'between the fused head (enc_head3) and tail (enc_tail3)'}
     if conv_variant >= 4:
         return split_f16 + '; ' + fusion.get(conv_variant, 'fused launches (variant %d)' % conv_variant)
     if conv_variant == 3:
@@ -106,7 +108,7 @@ def build_problem_emu(seq_id):
 def conv_launcher(fit, stream):
     """closure that launches the engine's dominant kernel on the engine's own buffers with a scratch output: the 64->64 conv
     (layer 10's shape), or -- conv variant 5 -- the fused forward pair of layers (7, 8) (intermediate into a scratch map too)"""
-    if fit.conv_variant >= 5:
+    if 5 <= fit.conv_variant <= 9:
         return lambda: _conv_pair(fit, 7, False, fit.act[7], fit.dact[0], fit.dact[1], stream)
     return lambda: _conv_layer(fit, 9, False, fit.act[9], fit.dact[1], stream)
 
@@ -138,7 +140,7 @@ def time_dominant_kernel(fit, stream, reps=50, use_graph=True):
     costs inside the iteration, see :func:`time_conv_chain`)."""
     ms = events_ms(stream, conv_launcher(fit, stream), reps, lambda: fit.step(20, use_graph=use_graph))
     fit.dact[0].zero_(); fit.dact[1].zero_()     # scratch again (border must stay zero; interior rewritten each step)
-    return ms, 2.0 * fit.H * fit.W * 64 * 64 * 9 * (2 if fit.conv_variant >= 5 else 1)
+    return ms, 2.0 * fit.H * fit.W * 64 * 64 * 9 * (2 if 5 <= fit.conv_variant <= 9 else 1)
 
 
 def _conv_layer(fit, l, bwd, src, dst, stream):
@@ -149,8 +151,11 @@ def _conv_layer(fit, l, bwd, src, dst, stream):
     ci, co = (ENC_CHANNELS[l + 1], ENC_CHANNELS[l]) if bwd else (ENC_CHANNELS[l], ENC_CHANNELS[l + 1])
     bias, aux, epi = (None, ptr(fit.act[l]), 1) if bwd else (ptr(e.b[l]), None, 0)
     w, w2, w3 = (e.wbwd, e.wbwd2, e.wbwd3) if bwd else (e.w, e.w2, e.w3)
-    if fit.conv_variant >= 4:
-        pack, winv = e.split_pack(l, bwd, fit.conv_variant)
+    if fit.conv_variant == 10 and ci == 64 and co == 64:
+        pack, winv = e.split_pack(l, bwd, 10)
+        rc = lib.conv3x3_wino_f16(ptr(src), ptr(pack), winv, ptr(w[l]), bias, aux, ptr(dst), H, W, epi, None, stream.cuda_stream)
+    elif fit.conv_variant >= 4:
+        pack, winv = e.split_pack(l, bwd, 4)
         rc = lib.conv3x3_mfma_split_f16(ptr(src), ptr(pack), winv, ptr(w[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
     elif fit.conv_variant == 3:
         rc = lib.conv3x3_mfma_split(ptr(src), ptr(w3[l]), ptr(w[l]), bias, aux, ptr(dst), H, W, ci, co, epi, stream.cuda_stream)
@@ -802,7 +807,8 @@ def main():
             stage_us = fit.stage_census(20)
         torch.cuda.synchronize(device)
     b2b_ms, kern_flops = time_dominant_kernel(fit, stream, use_graph=use_graph)
-    pairs = fit.conv_variant >= 5
+    pairs = 5 <= fit.conv_variant <= 9
+    wino = fit.conv_variant == 10
     if pairs:
         # conv variant 5: the dominant kernel is the fused PAIR (two 64 -> 64 layers per launch, 6 launches per iteration); its
         # algorithmic work is two layers' (the halo recompute of the intermediate tile is overhead, not work)
@@ -821,9 +827,14 @@ def main():
         peak = PEAK_BF16_MATRIX_TFLOPS / 3.0
         kname = ('conv3x3_pair_kernel (variant 5: TWO 64->64 layers per launch on 10x14 tiles, intermediate in LDS; two fp16 pieces per fp32 '
                  'operand, 3 products on v_mfma_f32_32x32x16_f16)' if pairs else
+                 'conv3x3_wino_kernel (variant 10: ONE 64->64 layer per launch as Winograd F(2x2, 3x3): 32 tiles of 2x2 outputs per workgroup, fp32 '
+                 'transforms, the 16 position GEMMs on two fp16 pieces per operand, 3 products on v_mfma_f32_32x32x16_f16)' if wino else
                  'conv3x3_split_kernel<NP=2> (variant 4: two fp16 pieces per fp32 operand, 3 products on v_mfma_f32_32x32x16_f16)')
         peak_note = ('algorithmic fp32 FLOP/s against f16 dense MFMA peak %.0f TF / 3 products per fp32-accurate MAC (variant 3, 6 bf16 '
                      'products: peak / 6; the fp32-MFMA kernel (--conv-variant 2): %.1f TF)' % (PEAK_BF16_MATRIX_TFLOPS, PEAK_FP32_MATRIX_TFLOPS))
+        if wino:
+            peak_note += ('.  ALGORITHMIC = the direct convolution\'s 2*H*W*64*576 FLOP per layer (SURVEY 8(d)); the Winograd form issues 16/36 of '
+                          'those multiplies (issued f16-MFMA work: achieved * 3 * 4/9 TFLOP/s of the %.0f TF dense peak)' % PEAK_BF16_MATRIX_TFLOPS)
     elif fit.conv_variant == 3:
         # every fp32 multiply-accumulate is 6 bf16 MFMA products (exact 3-way operand split, fp32 accumulate):
         # the pipe that bounds the kernel is the bf16 matrix pipe at 1/6 of its dense peak
@@ -854,12 +865,14 @@ def main():
         'final_total_loss': losses['total'],
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                      'frac': achieved / peak, 'traffic': pmc_traffic('lemo::conv3x3_pair_kernel<0' if pairs else
+                                                                         'lemo::conv3x3_wino_kernel<0' if wino else
                                                                          ('lemo::conv3x3_split_kernel<0, 64, 64' if fit.conv_variant >= 3
                                                                           else 'lemo::conv3x3_mfma_v2_kernel<0')),
                      'traffic_unit': 'bytes/launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 gfx950 correction; algorithmic '
                                      'minimum %.1fe6)' % (alg_bytes / 1e6),
                      'peak_note': peak_note,
                      'kernel': kname + (' 64->64->64ch 245x134, 6 of the %d launches/iteration (12 of the 14 64->64 layers)' % {5: 25, 6: 25, 7: 23, 8: 22, 9: 21}.get(fit.conv_variant, 25) if pairs
+                                        else ' 64->64ch 245x134, 14 of the 27 launches/iteration' if wino
                                         else ' 64->64ch 245x134, 14 of the 31 launches/iteration'),
                      'kernel_ms': kern_ms, 'flop_per_launch': kern_flops,
                      'kernel_ms_source': ('HIP events around a captured replay of the iteration\'s own chain of the six fused launches (3 forward '

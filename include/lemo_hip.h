@@ -86,6 +86,16 @@ int lemo_conv3x3_pair_supported(int H, int W, int c0, int c1, int c2);
 int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
                           const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
                           unsigned long long* dbg, void* stream);
+/* variant 10 (round 6): ONE 64 -> 64 layer (forward, epi 0, models/AE_sep.py:11-30; backward-data, epi 1) as a Winograd F(2x2, 3x3)
+ * convolution: 16 instead of 36 multiplies per 2 x 2 output tile and (cin, cout), the 16 [64 x 64 x tiles] GEMMs in the split-f16
+ * arithmetic of variant 4 (fp32 transforms, two fp16 pieces per operand, 3 MFMA products, fp32 accumulate).  A workgroup owns 32
+ * consecutive 2 x 2 tiles of the even part of the image; the last row of an odd H is a direct fp32 convolution from `wt`.
+ * wU = pack_conv3x3_wino_f16 / pack_conv3x3_bwd_wino_f16 (G g G^T in float64, split on the host; winv = its inverse scale),
+ * wt = the fp32 tap-major pack of the same weights (pack_conv3x3 / pack_conv3x3_bwd).  dbg (epi 0 only, may be NULL): per wave
+ * {start, loads issued, transformed, planes written, GEMMs done, exchanged, end, HW_ID} shader-clock stamps (tools/wino_check.py). */
+int lemo_conv3x3_wino_supported(int H, int W, int cin, int cout);
+int lemo_conv3x3_wino_f16(const float* in, const void* wU, float winv, const float* wt, const float* bias, const float* aux, float* out,
+                          int H, int W, int epi, unsigned long long* dbg, void* stream);
 /* variant 6 (round 5): the same contract on 5 x 14 tiles by four-wave workgroups, two per CU (csrc/conv_pair4_kernels.hip) -- one
  * workgroup's staging / epilogue / conversion phases run under the other's MFMAs.  dbg: 8 stamps per wave, FOUR waves per workgroup. */
 int lemo_conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,

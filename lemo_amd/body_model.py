@@ -126,9 +126,8 @@ class BodyModelData:
         self.lmk_rows = np.ascontiguousarray(self.faces[lmk_idx], np.int32)                  # [51,3] vertex ids
         self.lmk_bary = np.ascontiguousarray(model['lmk_bary_coords'], f32)
         ids = EXTRA_JOINT_VERTEX_IDS if extra_joint_ids is None else list(extra_joint_ids)
-        if len(ids) and (min(ids) < 0 or max(ids) >= V):
-            raise ValueError(f'extra joint vertex ids reach {max(ids)} but the model has {V} vertices (the default ids are SMPL-X\'s: '
-                             'pass extra_joint_ids for a smaller model)')
+        # (the fit engines never gather these rows; the module route does: SMPLX.__init__ refuses ids beyond the model)
+        self.extra_ids_in_range = not len(ids) or (min(ids) >= 0 and max(ids) < V)
         self.extra_ids = np.asarray(ids, np.int32)
         self.n_joints_out = nj + len(ids) + self.lmk_rows.shape[0]
 
@@ -363,6 +362,9 @@ class SMPLX(nn.Module):
         assert dtype == torch.float32, 'the LEMO fitting path is fp32'
         self.data = BodyModelData(load_model_dict(model_path, gender, ext), num_pca_comps, use_pca, flat_hand_mean,
                                   num_betas, extra_joint_ids)
+        if not self.data.extra_ids_in_range:
+            raise ValueError(f'extra joint vertex ids reach {int(self.data.extra_ids.max())} but the model has {self.data.V} vertices '
+                             '(the default ids are SMPL-X\'s: pass extra_joint_ids for a smaller model)')
         self.batch_size, self.joint_mapper, self.use_pca = batch_size, joint_mapper, use_pca
         self.num_pca_comps, self.gender, self.dtype = num_pca_comps, gender, dtype
         self._lib_override = _lib

@@ -9,7 +9,7 @@ namespace lemo {
 
 // conv variant 7 = variant 5 + the fused head / tail (conv_head_kernels.hip): layers 0 and 1 ride with the marker image / the image gradient
 template <class D> static inline bool enc_fused_head(const D& d) {
-  return d.conv_variant >= 7 && d.conv_variant <= 9 && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
+  return d.conv_variant >= 7 && d.conv_variant <= 10 && d.enc_ch[1] == 32 && d.enc_ch[2] == 32 && d.enc_w3[1] && d.enc_wbwd3[1];
 }
 // conv variant 8 (and 9) = variant 7 with layer 2 (32 -> 64) inside the head launch as well (enc_head3)
 template <class D> static inline bool enc_fused_head3(const D& d) {
@@ -17,7 +17,7 @@ template <class D> static inline bool enc_fused_head3(const D& d) {
 }
 // conv variant 9 = variant 8 with layer 2's backward-data (64 -> 32) inside the tail launch (enc_tail3)
 template <class D> static inline bool enc_fused_tail3(const D& d) {
-  return d.conv_variant == 9 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_wbwd3[2];
+  return d.conv_variant >= 9 && enc_fused_head(d) && d.enc_ch[3] == 64 && d.enc_wbwd3[2];
 }
 // the encoder's backward tail: d(pre-act l_last) in dact[cur] -> d(loss)/d(image); l_last as enc_chain_bwd was told
 template <class D> static inline int enc_bwd_l_last(const D& d) { return enc_fused_tail3(d) ? 3 : (enc_fused_head(d) ? 2 : 1); }
@@ -39,6 +39,10 @@ static inline int enc_layer(const D& d, int l, bool bwd, const float* src, float
   const float* bias = bwd ? nullptr : d.enc_b[l];
   const float* aux = bwd ? d.act[l] : nullptr;
   const int epi = bwd ? 1 : 0;
+  // conv variant 10 = variant 9 with every 64 -> 64 layer as ONE Winograd F(2x2, 3x3) launch (conv_wino_kernels.hip) instead of the
+  // fused pairs: enc_w3 / enc_wbwd3 of those layers hold the Winograd packs (pack_conv3x3_wino_f16), the 32-channel layers' the split-f16 packs
+  if (d.conv_variant == 10 && w3 && conv3x3_wino_supported(H, W, cin, cout))
+    return conv3x3_wino_f16(src, w3, bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l], wt, bias, aux, dst, H, W, epi, s);
   if (d.conv_variant >= 3 && w3 && conv3x3_split_supported(H, W, cin, cout))
     return conv3x3_mfma_split(src, w3, wt, bias, aux, dst, H, W, cin, cout, epi, s, nullptr, d.conv_variant >= 4 ? 2 : 3,
                               bwd ? d.enc_wbwd3_inv[l] : d.enc_w3_inv[l]);
@@ -54,7 +58,7 @@ template <class D>
 static inline int enc_chain_fwd(const D& d, int H, int W, hipStream_t s, int l_first = 1) {
   int l = l_first;                 // (2 when enc_head produced act[2] already: conv variant 7)
   while (l < 10) {
-    if (d.conv_variant >= 5 && l + 1 < 10 && d.enc_w3[l] && d.enc_w3[l + 1] &&
+    if (d.conv_variant >= 5 && d.conv_variant != 10 && l + 1 < 10 && d.enc_w3[l] && d.enc_w3[l + 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1], d.enc_ch[l + 2])) {
       ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.act[l], d.enc_w3[l], d.enc_w3_inv[l], d.enc_b[l], nullptr, d.act[l + 1],
                                                                            d.enc_w3[l + 1], d.enc_w3_inv[l + 1], d.enc_b[l + 1], nullptr, d.act[l + 2],
@@ -74,7 +78,7 @@ template <class D>
 static inline int enc_chain_bwd(const D& d, int H, int W, hipStream_t s, int* cur_out, int l_last = 1) {
   int cur = 0, l = 9;              // (l_last = 2: enc_tail takes d(pre-act 2) from here: conv variant 7)
   while (l >= l_last) {
-    if (d.conv_variant >= 5 && l - 1 >= l_last && d.enc_wbwd3[l] && d.enc_wbwd3[l - 1] &&
+    if (d.conv_variant >= 5 && d.conv_variant != 10 && l - 1 >= l_last && d.enc_wbwd3[l] && d.enc_wbwd3[l - 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l], d.enc_ch[l - 1])) {
       ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd3_inv[l], nullptr, d.act[l], nullptr,
                                                                            d.enc_wbwd3[l - 1], d.enc_wbwd3_inv[l - 1], nullptr, d.act[l - 1],

@@ -39,6 +39,11 @@ bool conv3x3_pair_supported(int H, int W, int c0, int c1, int c2);
 int conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid, const void* wB,
                      float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi, hipStream_t s,
                      unsigned long long* dbg = nullptr);
+// ---------------- conv_wino_kernels.hip ----------------
+// variant 10: ONE 64 -> 64 layer as a Winograd F(2x2, 3x3) convolution, its 16 GEMMs in the split-f16 arithmetic of variant 4
+bool conv3x3_wino_supported(int H, int W, int cin, int cout);
+int conv3x3_wino_f16(const float* in, const void* wU, float winv, const float* wt, const float* bias, const float* aux, float* out,
+                     int H, int W, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
 // ---------------- conv_pair4_kernels.hip ----------------
 // variant 6: the same pair on 5 x 14 tiles by FOUR-wave workgroups, two per CU (one's non-matrix phases under the other's MFMAs)
 int conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid, const void* wB,

@@ -53,6 +53,11 @@ int lemo_conv3x3_mfma_split_f16(const float* in, const void* w2, float winv, con
   if (!in || !w2 || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux)) return LEMO_ERR_ARG;
   return conv3x3_mfma_split(in, w2, wt, bias, aux, out, H, W, cin, cout, epi, S(stream), nullptr, 2, winv);
 }
+int lemo_conv3x3_wino_supported(int H, int W, int cin, int cout) { return conv3x3_wino_supported(H, W, cin, cout) ? 1 : 0; }
+int lemo_conv3x3_wino_f16(const float* in, const void* wU, float winv, const float* wt, const float* bias, const float* aux, float* out,
+                          int H, int W, int epi, unsigned long long* dbg, void* stream) {
+  return conv3x3_wino_f16(in, wU, winv, wt, bias, aux, out, H, W, epi, S(stream), dbg);
+}
 int lemo_conv3x3_pair_supported(int H, int W, int c0, int c1, int c2) { return conv3x3_pair_supported(H, W, c0, c1, c2) ? 1 : 0; }
 int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
                           const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,

@@ -113,6 +113,35 @@ def pack_conv3x3_bwd_split_f16(w: np.ndarray):
     return pack_conv3x3_split_f16(np.ascontiguousarray(wf))
 
 
+WINO_VARIANT = 10
+_WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], np.float64)
+
+
+def pack_conv3x3_wino_f16(w: np.ndarray):
+    """[64][64][3][3] fp32 -> (uint16 (f16 bits) wU[pos 16][kstep 4][mt 2][piece 2][lane 64][8], winv) for lemo_conv3x3_wino_f16
+    (conv variant 10): U = G g G^T, the 4 x 4 Winograd F(2x2, 3x3) transform of every (cout, cin) filter, evaluated in float64 and
+    split into two fp16 pieces of U * 2^k (one scale for the layer, max|U| -> [2^14, 2^15)); MFMA A-fragment order: lane l holds
+    cout 32 mt + (l & 31), channels 16 kstep + 8 (l >> 5) .. + 7."""
+    co, ci = w.shape[:2]
+    assert co == 64 and ci == 64 and w.shape[2:] == (3, 3)
+    U = np.einsum('ij,ocjk,lk->ocil', _WINO_G, np.asarray(w, np.float64), _WINO_G).reshape(co, ci, 16)
+    m = float(np.abs(U).max())
+    k = 14 - int(np.floor(np.log2(m))) if m > 0 else 0
+    xs = U * 2.0 ** k
+    hi = xs.astype(np.float16)
+    lo = (xs - hi.astype(np.float64)).astype(np.float16)
+    assert np.isfinite(hi).all()
+    bits = np.stack([hi, lo], 0).view(np.uint16)              # [s][co][ci][pos]
+    t = bits.reshape(2, co // 32, 32, ci // 16, 2, 8, 16)     # [s][mt][i][ks][h][e][pos]
+    t = t.transpose(6, 3, 1, 0, 4, 2, 5)                      # [pos][ks][mt][s][h][i][e]
+    return np.ascontiguousarray(t).reshape(16, ci // 16, co // 32, 2, 64, 8), float(2.0 ** -k)
+
+
+def pack_conv3x3_bwd_wino_f16(w: np.ndarray):
+    wf = w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)
+    return pack_conv3x3_wino_f16(np.ascontiguousarray(wf))
+
+
 def cg8p_alloc(C_: int, H: int, W: int, device) -> torch.Tensor:
     """zeroed CG8P activation buffer [C/8][(H+2)*(W+2)][8] (border stays zero forever)."""
     return torch.zeros(max(C_ // 8, 1), (H + 2) * (W + 2), 8, dtype=torch.float32, device=device)
@@ -136,6 +165,8 @@ class EncWeights:
 
     def split_pack(self, l: int, bwd: bool, variant: int):
         """(device pack, winv) of layer l for the split kernels: f16 x 2 pieces for variant >= 4, bf16 x 3 for 3"""
+        if variant == WINO_VARIANT and self.w10[l] is not None:        # 64 -> 64 layers: the Winograd packs (pack_conv3x3_wino_f16)
+            return (self.wbwd10[l], self.wbwd10_inv[l]) if bwd else (self.w10[l], self.w10_inv[l])
         if variant >= 4:
             return (self.wbwd4[l], self.wbwd4_inv[l]) if bwd else (self.w4[l], self.w4_inv[l])
         return ((self.wbwd3[l] if bwd else self.w3[l]), 1.0)
@@ -146,6 +177,7 @@ class EncWeights:
         self.w, self.b, self.wbwd, self.w2, self.wbwd2 = [], [], [], [], []
         self.w3, self.wbwd3 = [], []                       # split-bf16 packs (layer 0: None)
         self.w4, self.wbwd4, self.w4_inv, self.wbwd4_inv = [], [], [], []     # split-f16 packs + inverse host scales (variant 4)
+        self.w10, self.wbwd10, self.w10_inv, self.wbwd10_inv = [], [], [], []  # Winograd packs of the 64 -> 64 layers (variant 10), else None
         t16 = lambda a: torch.from_numpy(a.view(np.int16)).to(device)
         for li, k in enumerate(self.keys):
             w = np.asarray(state[k + '.weight'], np.float32)
@@ -157,6 +189,7 @@ class EncWeights:
                 self.w2.append(self.w[0]); self.wbwd2.append(self.w[0])
                 self.w3.append(None); self.wbwd3.append(None)
                 self.w4.append(None); self.wbwd4.append(None); self.w4_inv.append(1.0); self.wbwd4_inv.append(1.0)
+                self.w10.append(None); self.wbwd10.append(None); self.w10_inv.append(1.0); self.wbwd10_inv.append(1.0)
             else:
                 self.w.append(t(pack_conv3x3(w)))
                 self.wbwd.append(t(pack_conv3x3_bwd(w)))
@@ -167,6 +200,12 @@ class EncWeights:
                 pf, fi = pack_conv3x3_split_f16(w)
                 pb, bi = pack_conv3x3_bwd_split_f16(w)
                 self.w4.append(t16(pf)); self.wbwd4.append(t16(pb)); self.w4_inv.append(fi); self.wbwd4_inv.append(bi)
+                if w.shape[0] == 64 and w.shape[1] == 64:
+                    uf, ufi = pack_conv3x3_wino_f16(w)
+                    ub, ubi = pack_conv3x3_bwd_wino_f16(w)
+                    self.w10.append(t16(uf)); self.wbwd10.append(t16(ub)); self.w10_inv.append(ufi); self.wbwd10_inv.append(ubi)
+                else:
+                    self.w10.append(None); self.wbwd10.append(None); self.w10_inv.append(1.0); self.wbwd10_inv.append(1.0)
             self.b.append(t(b))
 
 
@@ -193,8 +232,11 @@ def _conv_layer(lib, enc: EncWeights, l: int, bwd: bool, x, out, aux, H, W, vari
     wt, wt2, w3 = (enc.wbwd[l], enc.wbwd2[l], enc.wbwd3[l]) if bwd else (enc.w[l], enc.w2[l], enc.w3[l])
     bias, epi = (None, 1) if bwd else (ptr(enc.b[l]), 0)
     auxp = ptr(aux) if bwd else None
-    if variant >= 4 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
-        w4, winv = enc.split_pack(l, bwd, variant)
+    if variant == WINO_VARIANT and enc.w10[l] is not None and lib.conv3x3_wino_supported(H, W, cin, cout):
+        wu, winv = enc.split_pack(l, bwd, variant)
+        lib.check(lib.conv3x3_wino_f16(ptr(x), ptr(wu), winv, ptr(wt), bias, auxp, ptr(out), H, W, epi, None, s), 'conv3x3_wino_f16')
+    elif variant >= 4 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
+        w4, winv = enc.split_pack(l, bwd, 4)
         lib.check(lib.conv3x3_mfma_split_f16(ptr(x), ptr(w4), winv, ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_split_f16')
     elif variant >= 3 and w3 is not None and lib.conv3x3_split_supported(H, W, cin, cout):
         lib.check(lib.conv3x3_mfma_split(ptr(x), ptr(w3), ptr(wt), bias, auxp, ptr(out), H, W, cin, cout, epi, s), 'conv3x3_mfma_split')

@@ -228,7 +228,7 @@ def test_split_f16_conv_error_is_fp32_sized(dev):
 DX0_GATE = 7e-6          # 3 x the largest measured value (round 5: 1.2e-6 .. 2.2e-6 across the seven families; was a silent 1e-4)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_encoder_full_size_golden(dev, variant):
     """10-layer MFMA conv stack at 245x134 with the real runs/15217 weights: z, loss, input grad.  Variants 0-2 run
     every layer on the fp32 MFMA; 3 / 4 run the nine MFMA layers (forward and backward-data) on the split-bf16 / split-f16 kernel;
@@ -275,7 +275,7 @@ def test_encoder_full_size_golden(dev, variant):
     assert abs(loss - float(g['loss_smooth'])) <= LOSS_TOL * float(g['loss_smooth'])
     cur = [d0, d1]
     ci = 0
-    for l in range(9, {7: 1, 8: 1, 9: 2}.get(variant, 0), -1):
+    for l in range(9, {7: 1, 8: 1, 9: 2, 10: 2}.get(variant, 0), -1):
         if pair and l in (9, 7, 5):
             (pa, ia), (pb, ib) = P(l, True), P(l - 1, True)
             lib.check(pair(ptr(cur[ci]), ptr(pa), ia, None, ptr(act[l]), None, ptr(pb), ib, None, ptr(act[l - 1]), ptr(cur[1 - ci]), H, W, 1, None, s))
@@ -291,7 +291,8 @@ def test_encoder_full_size_golden(dev, variant):
     if variant in (7, 8):        # layer 1 backward-data + layer 0 adjoint in one launch (csrc/conv_head_kernels.hip)
         pb, ib = P(1, True)
         lib.check(lib.enc_tail(ptr(cur[ci]), ptr(pb), ib, ptr(act[1]), ptr(enc.w[0]), ptr(dx0), H, W, s))
-    elif variant == 9:           # layer 2 and layer 1 backward-data + layer 0 adjoint in one launch
+    elif variant in (9, 10):     # layer 2 and layer 1 backward-data + layer 0 adjoint in one launch (10: behind seven Winograd launches)
+        P = P or (lambda l, bwd: enc.split_pack(l, bwd, variant))
         (p2, i2), (pb, ib) = P(2, True), P(1, True)
         lib.check(lib.enc_tail3(ptr(cur[ci]), ptr(p2), i2, ptr(act[2]), ptr(pb), ib, ptr(act[1]), ptr(enc.w[0]), ptr(dx0), H, W, s))
     else:
@@ -359,6 +360,55 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert abs(fit.losses()['total'] - ref_total) < 2e-3 * ref_total
 
 
+def test_wino_conv_full_size_vs_float64(dev):
+    """conv variant 10 (csrc/conv_wino_kernels.hip) at the encoder's own size (245 x 134: 256 workgroups of 32 tiles + the direct last
+    row of the odd H), real runs/15217 weights of layer 5: forward and backward-data against torch float64 on the host -- error of the
+    size of an fp32 convolution's own rounding -- agreement with the split-f16 direct kernel (variant 4), zero border kept, ten launches
+    bit-identical (fixed summation orders)"""
+    from lemo_amd import _hip
+    from lemo_amd._hip import ptr
+    from lemo_amd.priors import EncWeights, cg8p_alloc, from_cg8p, to_cg8p, enc_layer_keys
+    lib = _hip.get_lib()
+    A = load_assets()
+    enc = EncWeights(A['enc_w'], dev)
+    keys = enc_layer_keys()
+    H, W, l = 245, 134, 5
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(64, H, W, generator=g) * 0.3
+    w, b = torch.from_numpy(A['enc_w'][keys[l] + '.weight']), torch.from_numpy(A['enc_w'][keys[l] + '.bias'])
+    y64 = F.leaky_relu(F.conv2d(x[None].double(), w.double(), b.double(), padding=1), 0.2)[0]
+    y32 = F.leaky_relu(F.conv2d(x[None], w, b, padding=1), 0.2)[0]
+    s = torch.cuda.current_stream(dev).cuda_stream
+    xin, out, ref4 = to_cg8p(x).to(dev), cg8p_alloc(64, H, W, dev), cg8p_alloc(64, H, W, dev)
+    pu, iu = enc.split_pack(l, False, 10)
+    p4, i4 = enc.split_pack(l, False, 4)
+    assert lib.conv3x3_wino_supported(H, W, 64, 64) == 1
+    assert lib.conv3x3_wino_f16(ptr(xin), ptr(pu), iu, ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(out), H, W, 0, None, s) == 0
+    assert lib.conv3x3_mfma_split_f16(ptr(xin), ptr(p4), i4, ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(ref4), H, W, 64, 64, 0, s) == 0
+    torch.cuda.synchronize()
+    for _ in range(10):
+        o2 = cg8p_alloc(64, H, W, dev)
+        assert lib.conv3x3_wino_f16(ptr(xin), ptr(pu), iu, ptr(enc.w[l]), ptr(enc.b[l]), None, ptr(o2), H, W, 0, None, s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(o2, out)
+    e, f = rel_err(from_cg8p(out.cpu(), H, W).double(), y64), rel_err(y32.double(), y64)
+    print(f'\nWinograd layer forward vs float64: {e:.2e} (torch fp32 conv: {f:.2e}); vs the split-f16 direct kernel {rel_err(out.cpu(), ref4.cpu()):.2e}')
+    assert e < 2e-6 and e < 3 * f + 2e-7 and rel_err(out.cpu(), ref4.cpu()) < 2e-6
+    o = out.cpu().reshape(8, H + 2, W + 2, 8)
+    assert float(o[:, 0].abs().max()) == 0 and float(o[:, -1].abs().max()) == 0 and float(o[:, :, 0].abs().max()) == 0 and float(o[:, :, -1].abs().max()) == 0
+    d1 = torch.randn(64, H, W, generator=g) * 1e-6
+    a0 = torch.randn(64, H, W, generator=g)
+    refb = F.conv_transpose2d(d1[None].double(), w.double(), padding=1)[0] * torch.where(a0 > 0, 1.0, 0.2).double()
+    fb = rel_err((F.conv_transpose2d(d1[None], w, padding=1)[0] * torch.where(a0 > 0, 1.0, 0.2)).double(), refb)
+    pub, iub = enc.split_pack(l, True, 10)
+    d0 = cg8p_alloc(64, H, W, dev)
+    assert lib.conv3x3_wino_f16(ptr(to_cg8p(d1).to(dev)), ptr(pub), iub, ptr(enc.wbwd[l]), None, ptr(to_cg8p(a0).to(dev)), ptr(d0), H, W, 1, None, s) == 0
+    torch.cuda.synchronize()
+    eb = rel_err(from_cg8p(d0.cpu(), H, W).double(), refb)
+    print(f'Winograd layer backward-data vs float64: {eb:.2e} (torch fp32: {fb:.2e})')
+    assert eb < 2e-6 and eb < 3 * fb + 2e-7
+
+
 @pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
 def test_fused_pair_conv_full_size_vs_float64(dev, kernel):
     """conv variant 5 (csrc/conv_pair_kernels.hip) and variant 6 (four-wave workgroups, csrc/conv_pair4_kernels.hip: same arithmetic and
@@ -424,7 +474,7 @@ def test_fused_pair_conv_full_size_vs_float64(dev, kernel):
     assert e_b < 2e-6
 
 
-@pytest.mark.parametrize('conv_variant', [5, 7, 8, 9, 6, 4, 3, 2])
+@pytest.mark.parametrize('conv_variant', [5, 7, 8, 9, 10, 6, 4, 3, 2])
 def test_fit_full_size_golden(full_problem, kink_exposure, dev, conv_variant):
     """golden (6): B=119, V=10475, real encoder weights: six losses + total, verts, grads, params after
     1 and 10 Adam steps (graph replay); with the default split-bf16 encoder kernels (3) and the fp32-MFMA ones (2)."""
