@@ -349,6 +349,12 @@ int lemo_ae_wgrad_probe(void* h, int mode, void* stream);
  * 2: 32 x 64, 3: 16 x 16) with pt pixel tiles x ks K-slices = pt * ks <= 16 waves per workgroup. */
 int lemo_ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
                  int in_s, int out_s, int cin, int cout, int epi, int mt, int pt, int ks, void* stream);
+/* ... on the split-f16 kernels (round 6, the engine's default arithmetic): both operands are read as fp32 and split in registers into two
+ * error-compensated fp16 pieces, three f16 MFMA products, fp32 accumulate.  amax_in [1] = max |in| (or a bound, multiplied by in_fac >= 1),
+ * wmax [1] = max |wt|, amax_out [1] receives max |out| of the launch (atomicMax: zero it first).  cin >= 16 (mt 3: cin >= 32). */
+int lemo_ae_conv_f16(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
+                     int in_s, int out_s, int cin, int cout, int epi, int mt, int pt, int ks, const float* amax_in, float in_fac,
+                     const float* wmax, float* amax_out, void* stream);
 
 /* ---- stream capture helpers: record everything a host-side step enqueues on `stream` (HIP kernels of this library
  * and the caller's own device work alike) into an executable graph, replay it with one call.  Relaxed capture mode;

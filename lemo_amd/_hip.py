@@ -243,6 +243,7 @@ _SIGS = {
     'lemo_ae_params_clip': (C.c_int, [vp, C.c_int, vp, vp]),
     'lemo_ae_wgrad_probe': (C.c_int, [vp, C.c_int, vp]),
     'lemo_ae_conv': (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 12 + [vp]),
+    'lemo_ae_conv_f16': (C.c_int, [vp, vp, vp, vp, vp] + [C.c_int] * 12 + [vp, C.c_float, vp, vp, vp]),
     'lemo_sdf_sample': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp, vp]),
     'lemo_fit_create': (vp, [C.POINTER(FitDesc)]),
     'lemo_fit_destroy': (None, [vp]),

@@ -20,6 +20,7 @@
 //     bias corrections on the device so that a captured step can be replayed).
 // Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), every sum in a fixed order -> results do not depend on concurrency.
 #include "conv_common.hpp"
+#include "conv_f16.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -27,6 +28,17 @@
 #include <new>
 
 #define CHK_(e) do { int _e = (e); if (_e) return _e; } while (0)
+
+// slots of AeEngine::amax.  0 .. AE_SLOT_DYN - 1 are rewritten every step (zeroed by the optimiser launch and at load)
+#define AE_SLOT_ACT(i) (i)                /* max |output of layer i| (forward) */
+#define AE_SLOT_DP(i) (20 + (i))          /* max |d(pre-activation) of layer i| where a convolution wrote it */
+#define AE_SLOT_DPOOL(b) (40 + (b))       /* max |d(pooled output of encoder block b)| */
+#define AE_SLOT_DYN 45
+#define AE_SLOT_X8 45                     /* the clip image */
+#define AE_SLOT_LOSS 46                   /* max (mask / count): the loss gradient is +-1 x that */
+#define AE_SLOT_W(i) (48 + (i))           /* max |weights of layer i| (forward and backward pack hold the same values) */
+#define AE_SLOT_SCRATCH 70
+#define AE_NSLOT 128
 
 namespace lemo {
 
@@ -49,8 +61,10 @@ struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; in
 template <int MT, int EPI>          // MT x 32 couts per workgroup; EPI: conv_common.hpp (0 lrelu(acc + bias), 1 acc * lrelu'(aux), 2 acc + bias)
 __global__ void __launch_bounds__(1024)
 ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
-               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs) {
+               const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs,
+               float* __restrict__ amax_out /* may be null: max |out| of the launch, for a split-f16 consumer (ae_conv_f16_kernel) */) {
   AE_CLIP_OFFSET5(in, wt, bias, aux, out, cs);                 // clip = blockIdx.z: every operand lives in that clip's workspace
+  if (amax_out) amax_out += (size_t)blockIdx.z * cs;
   LEMO_DYN_SMEM(red);                                          // [wave][MT][4][64 lanes] float4
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;   // (scalar: see the ring below)
   // wave -> (pixel tile pt of the workgroup's 2^pt_lg, K slice ks of KS): the waves of one slice share the weights they load
@@ -122,8 +136,9 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
     for (int q = 0; q < 4; ++q)
       r4[((wave * MT + m) * 4 + q) * 64 + lane] = make_float4(acc[m][4 * q], acc[m][4 * q + 1], acc[m][4 * q + 2], acc[m][4 * q + 3]);
   __syncthreads();
-  if (p >= P) return;
+  float mloc = 0.f;
   // unit u -> (cout tile m, row quad q) of this lane's pixel; the KS waves of the pixel tile share its 4 MT units
+  if (p < P)
   for (int u = ks; u < 4 * MT; u += KS) {
     const int m = u >> 2, q = u & 3;
     float4 v = r4[((pt * MT + m) * 4 + q) * 64 + lane];
@@ -144,6 +159,11 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
       v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
     }
     st4(out + o, v);
+    mloc = absmax4(v, mloc);
+  }
+  if (amax_out) {                                             // (uniform: every lane of every wave arrives here)
+    mloc = wave_max(mloc);
+    if (lane == 0 && mloc > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, mloc));
   }
 }
 
@@ -231,12 +251,247 @@ ae_conv16_kernel(const float* __restrict__ in, const float* __restrict__ wt, con
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the same convolutions on the f16 matrix cores ("split-f16", round 6)
+// ---------------------------------------------------------------------------------------------------------------------
+// The fp32-input MFMA above issues at 1/16 of the f16 rate.  Here a step is 16 channels x 1 tap: both operands are read as fp32 (the
+// activations and the parameter vector stay fp32 -- Adam, the weight gradients and the layouts are untouched), split IN REGISTERS into
+// two error-compensated fp16 pieces (conv_f16.hpp: x s = hi + lo, 2 x 11 significand bits) and multiplied with three
+// v_mfma_f32_32x32x16_f16 per cout tile (hi lo + lo hi + hi hi, fp32 accumulate): 96 matrix-pipe cycles per 16 channels and tile
+// instead of 512.  The power-of-two scales come from TENSOR maxima instead of a workgroup's tile (there is no LDS staging here):
+//   activations  every convolution's epilogue leaves max |out| of its launch in a per-clip slot (atomicMax on the bit pattern, one per
+//                wave); the consumer scales by it.  Inputs that are not convolution outputs carry a bound instead: max-pool / zero
+//                stuffing keep the maximum, the max-pool adjoint sums at most four window gradients (x 4), the clip image and the loss
+//                gradient's magnitude (mask / count) are reduced once at load.  A bound that is 2^k too large costs nothing while
+//                k <= ~10: an element keeps its full 2^-22 relative precision down to 2^-17 of the scaled maximum, below that its error is
+//                2^-40 of the maximum (conv_f16.hpp).
+//   weights      max |w| per layer, reduced when a clip's parameters are loaded, with one bit of headroom: the finetune moves a weight by
+//                <= 60 x lr 3e-6 x ~10 = 2e-3, far from the factor 2 (fp16 itself overflows another factor 4 later).
+struct AeF16 { const float* amax_in; const float* wmax; float* amax_out; float in_fac; };       // per-clip slots (offset by the clip stride like every operand)
+
+__device__ __forceinline__ void ae_split8(float4 lo4, float4 hi4, float s, f16x8& ph, f16x8& pl) {
+  uint2 h0, l0, h1, l1;
+  split2x4(lo4, s, h0, l0);
+  split2x4(hi4, s, h1, l1);
+  ph = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+  pl = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+// maximum of |v| over the wave's stored lanes -> the launch's slot (bit pattern of a non-negative float orders like the float)
+__device__ __forceinline__ void ae_amax_publish(float m, float* slot) {
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
+}
+
+template <int MT, int EPI>          // MT x 32 couts per workgroup (MT 2: at most 8 waves)
+__global__ void __launch_bounds__(MT == 2 ? 512 : 1024)
+ae_conv_f16_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                   const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs, AeF16 q) {
+  AE_CLIP_OFFSET5(in, wt, bias, aux, out, cs);
+  { const size_t o_ = (size_t)blockIdx.z * cs; q.amax_in += o_; q.wmax += o_; q.amax_out += o_; }
+  LEMO_DYN_SMEM(red);                                          // [wave][MT][4][64 lanes] float4
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int PT = 1 << pt_lg, pt = wave & (PT - 1), ks = wave >> pt_lg, KS = NW >> pt_lg;
+  const int j = lane & 31, h = lane >> 5;
+  const int P = g.H * g.W;
+  const int m_base = blockIdx.y * (MT * 32);
+  const int p = (blockIdx.x * PT + pt) * 32 + j;
+  const int pc = p < P ? p : P - 1;
+  const int y = pc / g.W, x = pc - y * g.W;
+  // a step = one tap x 16 channels: lane half h carries channel group 2 gp + h (8 channels = 32 contiguous bytes in both operands)
+  const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
+  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + (size_t)h * in_gstride;
+  const float* wt_l = wt + (size_t)(m_base + j) * 8 + (size_t)h * wt_itstride;
+  const int gp_lg = cin_lg - 1, gm = (1 << gp_lg) - 1, nit = 9 << gp_lg;
+  const int lo = nit * ks / KS, hi = nit * (ks + 1) / KS;
+  float sA, sAi, sB, sBi;
+  f16_scale_for(q.wmax[0] * 2.f, sA, sAi);
+  f16_scale_for(q.amax_in[0] * q.in_fac, sB, sBi);
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+  constexpr int D = MT == 1 ? 5 : 4;
+  float4 ra[D][MT][2], rb[D][2];
+#define AE_LD(IT, SLOT)                                                                                     \
+  {                                                                                                         \
+    const int it_ = (IT);                                                                                   \
+    const int tap_ = it_ >> gp_lg, gp_ = it_ & gm;                                                          \
+    const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
+    const float* bq_ = in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)(2 * gp_) * in_gstride;   \
+    rb[SLOT][0] = ld4(bq_); rb[SLOT][1] = ld4(bq_ + 4);                                                     \
+    const float* aq_ = wt_l + (size_t)((tap_ << cin_lg) + 2 * gp_) * wt_itstride;                           \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) { ra[SLOT][m_][0] = ld4(aq_ + (size_t)m_ * 256); ra[SLOT][m_][1] = ld4(aq_ + (size_t)m_ * 256 + 4); } \
+  }
+#define AE_MF(SLOT)                                                                                         \
+  {                                                                                                         \
+    f16x8 bh_, bl_;                                                                                         \
+    ae_split8(rb[SLOT][0], rb[SLOT][1], sB, bh_, bl_);                                                      \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                     \
+      f16x8 ah_, al_;                                                                                       \
+      ae_split8(ra[SLOT][m_][0], ra[SLOT][m_][1], sA, ah_, al_);                                            \
+      acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, acc[m_], 0, 0, 0);                          \
+      acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, acc[m_], 0, 0, 0);                          \
+      acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, acc[m_], 0, 0, 0);                          \
+    }                                                                                                       \
+  }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) AE_LD(lo + d < hi ? lo + d : hi - 1, d)
+  int it = lo;
+  for (; it + D <= hi; it += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      AE_LD(it + u + D - 1 < hi ? it + u + D - 1 : hi - 1, (u + D - 1) % D)
+      __builtin_amdgcn_sched_barrier(0);
+      AE_MF(u)
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < D - 1; ++u)
+    if (it + u < hi) AE_MF(u)
+#undef AE_LD
+#undef AE_MF
+
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      r4[((wave * MT + m) * 4 + qd) * 64 + lane] = make_float4(acc[m][4 * qd], acc[m][4 * qd + 1], acc[m][4 * qd + 2], acc[m][4 * qd + 3]);
+  __syncthreads();
+  const float unscale = sAi * sBi;                               // exact: powers of two
+  float mloc = 0.f;
+  if (p < P)
+  for (int u = ks; u < 4 * MT; u += KS) {
+    const int m = u >> 2, qd = u & 3;
+    float4 v = r4[((pt * MT + m) * 4 + qd) * 64 + lane];
+    for (int k2 = 1; k2 < KS; ++k2) {                            // slice order: deterministic
+      const float4 t = r4[((((k2 << pt_lg) + pt) * MT + m) * 4 + qd) * 64 + lane];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    v.x *= unscale; v.y *= unscale; v.z *= unscale; v.w *= unscale;
+    const int c0 = m_base + m * 32 + qd * 8 + 4 * h;
+    const size_t o = ((size_t)(c0 >> 3) * g.out_HWp + (size_t)((g.out_s * y + 1) * g.out_Wp + g.out_s * x + 1)) * 8 + (c0 & 7);
+    if (EPI == 0 || EPI == 2) {
+      const float4 bb = ld4(bias + c0);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+    } else {
+      const size_t oa = ((size_t)(c0 >> 3) * g.aux_HWp + (size_t)((g.aux_s * y + 1) * g.aux_Wp + g.aux_s * x + 1)) * 8 + (c0 & 7);
+      const float4 yy = ld4(aux + oa);
+      v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
+      v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
+    }
+    st4(out + o, v);
+    mloc = absmax4(v, mloc);
+  }
+  ae_amax_publish(mloc, q.amax_out);
+}
+
+// ... and on 16 px x 16 cout tiles (v_mfma_f32_16x16x32_f16: a step = one tap x 32 channels, lane quarter q4 carries channel group 4 gq + q4)
+template <int EPI>
+__global__ void __launch_bounds__(1024)
+ae_conv16_f16_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
+                     const float* __restrict__ aux, float* __restrict__ out, AeGeo g, int cin_lg, int cout, int pt_lg, size_t cs, AeF16 q) {
+  AE_CLIP_OFFSET5(in, wt, bias, aux, out, cs);
+  { const size_t o_ = (size_t)blockIdx.z * cs; q.amax_in += o_; q.wmax += o_; q.amax_out += o_; }
+  LEMO_DYN_SMEM(red);                                          // [wave][64 lanes] float4
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+  const int PT = 1 << pt_lg, pt = wave & (PT - 1), ks = wave >> pt_lg, KS = NW >> pt_lg;
+  const int j = lane & 15, q4 = lane >> 4;
+  const int P = g.H * g.W;
+  const int m_base = blockIdx.y * 16;
+  const int p = (blockIdx.x * PT + pt) * 16 + j;
+  const int pc = p < P ? p : P - 1;
+  const int y = pc / g.W, x = pc - y * g.W;
+  const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
+  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + (size_t)q4 * in_gstride;
+  const float* wt_l = wt + (size_t)(m_base + j) * 8 + (size_t)q4 * wt_itstride;
+  const int gq_lg = cin_lg - 2, gm = (1 << gq_lg) - 1, nit = 9 << gq_lg;           // steps of 32 channels (host: cin >= 32)
+  const int lo = nit * ks / KS, hi = nit * (ks + 1) / KS;
+  float sA, sAi, sB, sBi;
+  f16_scale_for(q.wmax[0] * 2.f, sA, sAi);
+  f16_scale_for(q.amax_in[0] * q.in_fac, sB, sBi);
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int D = 6;
+  float4 ra[D][2], rb[D][2];
+#define AE_LD(IT, SLOT)                                                                                     \
+  {                                                                                                         \
+    const int it_ = (IT);                                                                                   \
+    const int tap_ = it_ >> gq_lg, gq_ = it_ & gm;                                                          \
+    const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
+    const float* bq_ = in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)(4 * gq_) * in_gstride;   \
+    rb[SLOT][0] = ld4(bq_); rb[SLOT][1] = ld4(bq_ + 4);                                                     \
+    const float* aq_ = wt_l + (size_t)((tap_ << cin_lg) + 4 * gq_) * wt_itstride;                           \
+    ra[SLOT][0] = ld4(aq_); ra[SLOT][1] = ld4(aq_ + 4);                                                     \
+  }
+#define AE_MF(SLOT)                                                                                         \
+  {                                                                                                         \
+    f16x8 bh_, bl_, ah_, al_;                                                                               \
+    ae_split8(rb[SLOT][0], rb[SLOT][1], sB, bh_, bl_);                                                      \
+    ae_split8(ra[SLOT][0], ra[SLOT][1], sA, ah_, al_);                                                      \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_, bl_, acc, 0, 0, 0);                                    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al_, bh_, acc, 0, 0, 0);                                    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah_, bh_, acc, 0, 0, 0);                                    \
+  }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d) AE_LD(lo + d < hi ? lo + d : hi - 1, d)
+  int it = lo;
+  for (; it + D <= hi; it += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      AE_LD(it + u + D - 1 < hi ? it + u + D - 1 : hi - 1, (u + D - 1) % D)
+      __builtin_amdgcn_sched_barrier(0);
+      AE_MF(u)
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < D - 1; ++u)
+    if (it + u < hi) AE_MF(u)
+#undef AE_LD
+#undef AE_MF
+
+  float4* r4 = reinterpret_cast<float4*>(red);
+  r4[wave * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  float mloc = 0.f;
+  if (p < P && ks == 0) {
+    float4 v = r4[pt * 64 + lane];
+    for (int k2 = 1; k2 < KS; ++k2) {
+      const float4 t = r4[((k2 << pt_lg) + pt) * 64 + lane];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float unscale = sAi * sBi;
+    v.x *= unscale; v.y *= unscale; v.z *= unscale; v.w *= unscale;
+    const int c0 = m_base + 4 * q4;                              // D rows 4 q4 + r -> four consecutive couts
+    const size_t o = ((size_t)(c0 >> 3) * g.out_HWp + (size_t)((g.out_s * y + 1) * g.out_Wp + g.out_s * x + 1)) * 8 + (c0 & 7);
+    if (EPI == 0 || EPI == 2) {
+      const float4 bb = ld4(bias + c0);
+      v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      if (EPI == 0) { v.x = lrelu(v.x); v.y = lrelu(v.y); v.z = lrelu(v.z); v.w = lrelu(v.w); }
+    } else {
+      const size_t oa = ((size_t)(c0 >> 3) * g.aux_HWp + (size_t)((g.aux_s * y + 1) * g.aux_Wp + g.aux_s * x + 1)) * 8 + (c0 & 7);
+      const float4 yy = ld4(aux + oa);
+      v.x *= lrelu_grad_from_out(yy.x); v.y *= lrelu_grad_from_out(yy.y);
+      v.z *= lrelu_grad_from_out(yy.z); v.w *= lrelu_grad_from_out(yy.w);
+    }
+    st4(out + o, v);
+    mloc = absmax4(v, mloc);
+  }
+  ae_amax_publish(mloc, q.amax_out);
+}
+
+
 static int ae_conv_init() {
   static int rc = -1;
   if (rc >= 0) return rc;
   rc = 0;
-#define OPTIN(MT_, EPI_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ae_conv_kernel<MT_, EPI_>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); if (e != hipSuccess) rc = (int)e; }
-  OPTIN(1, 0) OPTIN(1, 1) OPTIN(1, 2) OPTIN(2, 0) OPTIN(2, 1) OPTIN(2, 2)
+#define OPTIN(K_) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); if (e != hipSuccess) rc = (int)e; }
+  OPTIN((ae_conv_kernel<1, 0>)) OPTIN((ae_conv_kernel<1, 1>)) OPTIN((ae_conv_kernel<1, 2>)) OPTIN((ae_conv_kernel<2, 0>)) OPTIN((ae_conv_kernel<2, 1>)) OPTIN((ae_conv_kernel<2, 2>))
+  OPTIN((ae_conv_f16_kernel<1, 0>)) OPTIN((ae_conv_f16_kernel<1, 1>)) OPTIN((ae_conv_f16_kernel<1, 2>))
+  OPTIN((ae_conv_f16_kernel<2, 0>)) OPTIN((ae_conv_f16_kernel<2, 1>)) OPTIN((ae_conv_f16_kernel<2, 2>))
 #undef OPTIN
   return rc;
 }
@@ -253,14 +508,15 @@ static int ae_conv_init() {
 // chosen for what is actually in flight (a small layer of ONE clip needs 16 x 16 tiles and K slices to reach enough CUs; eight clips
 // of it do not).  A clip's results then depend on the engine's clip count through the summation order of the K slices: bit-identical
 // for equal nclip (and between the slots of one engine), equal to a solo run to rounding (tests/test_infill_emu.py, test_gpu_r2.py).
-static void ae_conv_shape(int P, int cin, int cout, int nclip, int* mt_out, int* pt_out, int* ks_out) {
+static void ae_conv_shape(int P, int cin, int cout, int nclip, int* mt_out, int* pt_out, int* ks_out, bool f16 = false) {
   static const bool solo_shapes = getenv("LEMO_AE_SHAPE_SOLO") && atoi(getenv("LEMO_AE_SHAPE_SOLO")) != 0;      // A/B knob: round 4's rule
   if (solo_shapes || nclip < 1) nclip = 1;
   double best = -1;
   for (int mt = 3; mt >= 1; --mt) {
     const int px = mt == 3 ? 16 : 32, co = mt == 3 ? 16 : 32 * mt;
-    if (cout % co || (mt == 3 && cin < 16)) continue;
-    const int nit = mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8);
+    if (cout % co || (mt == 3 && cin < (f16 ? 32 : 16))) continue;
+    // (f16: a step is 32 / 16 channels instead of 16 / 8 -- half the steps; the per-step costs below keep their RATIOS, which is all the choice uses)
+    const int nit = (mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8)) / (f16 ? 2 : 1);
     const long tiles = (long)((P + px - 1) / px) * (cout / co) * nclip;
     int pt = 1;
     while (pt < 4 && tiles / (2 * pt) >= 200) pt *= 2;
@@ -277,15 +533,36 @@ static void ae_conv_shape(int P, int cin, int cout, int nclip, int* mt_out, int*
   }
 }
 
+// f16 != nullptr (and cin >= 16): the split-f16 kernels with the scales of *f16; else the fp32-input MFMA kernels
 int ae_conv(const float* in, const float* wt, const float* bias, const float* aux, float* out, const AeGeo& g, int cin, int cout,
-            int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0, int nclip = 1, size_t cs = 0) {
+            int epi, hipStream_t s, int force_mt = 0, int force_pt = 0, int force_ks = 0, int nclip = 1, size_t cs = 0, const AeF16* f16 = nullptr) {
   if (cin % 8 || (cin & (cin - 1)) || cout % 32 || g.H < 1 || g.W < 1 || epi < 0 || epi > 2) return LEMO_ERR_SHAPE;
+  float* amax_only = nullptr;                                 // fp32-input kernel that still publishes max |out| for its split-f16 consumer
+  if (f16 && cin < 16) { amax_only = f16->amax_out; f16 = nullptr; }      // the 8-channel first layer keeps the fp32-input kernel (2 % of a step's flops)
+  if (f16 && (!f16->amax_in || !f16->wmax || !f16->amax_out)) return LEMO_ERR_ARG;
   int mt = 1, pt = 1, ks = 1;
-  ae_conv_shape(g.H * g.W, cin, cout, nclip, &mt, &pt, &ks);
+  ae_conv_shape(g.H * g.W, cin, cout, nclip, &mt, &pt, &ks, f16 != nullptr);
   if (force_mt) { mt = force_mt; pt = force_pt; ks = force_ks; }
   const int lg = ilog2(cin / 8), nw = pt * ks;
   if (pt < 1 || (pt & (pt - 1)) || ks < 1 || nw > 16) return LEMO_ERR_ARG;
   const int pt_lg = ilog2(pt);
+  if (f16) {
+    if (mt == 3) {
+      if (cin < 32 || ks > 9 * (cin / 32)) return LEMO_ERR_ARG;
+      const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16, nclip);
+#define LAUNCH16(EPI_) hipLaunchKernelGGL((ae_conv16_f16_kernel<EPI_>), grid, dim3(64 * nw), (size_t)nw * 1024, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs, *f16)
+      if (epi == 0) LAUNCH16(0); else if (epi == 1) LAUNCH16(1); else LAUNCH16(2);
+#undef LAUNCH16
+      return (int)hipGetLastError();
+    }
+    if ((mt != 1 && mt != 2) || cout % (32 * mt) || nw > (mt == 2 ? 8 : 16) || ks > 9 * (cin / 16)) return LEMO_ERR_ARG;
+    const dim3 grid(((g.H * g.W + 31) / 32 + pt - 1) / pt, cout / (32 * mt), nclip);
+#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_f16_kernel<MT_, EPI_>), grid, dim3(64 * nw), (size_t)nw * mt * 4096, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs, *f16)
+    if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
+    else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
+#undef LAUNCH
+    return (int)hipGetLastError();
+  }
   if (mt == 3) {
     if (cin < 16 || ks > 9 * (cin / 16)) return LEMO_ERR_ARG;
     const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16, nclip);
@@ -298,7 +575,7 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
   if ((mt != 1 && mt != 2) || cout % (32 * mt) || nw * mt > 16 || ks > 9 * (cin / 8)) return LEMO_ERR_ARG;
   const dim3 grid(((g.H * g.W + 31) / 32 + pt - 1) / pt, cout / (32 * mt), nclip);
   const size_t lds = (size_t)nw * mt * 4096;
-#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs)
+#define LAUNCH(MT_, EPI_) hipLaunchKernelGGL((ae_conv_kernel<MT_, EPI_>), grid, dim3(64 * nw), lds, s, in, wt, bias, aux, out, g, lg, cout, pt_lg, cs, amax_only)
   if (mt == 2) { if (epi == 0) LAUNCH(2, 0); else if (epi == 1) LAUNCH(2, 1); else LAUNCH(2, 2); }
   else         { if (epi == 0) LAUNCH(1, 0); else if (epi == 1) LAUNCH(1, 1); else LAUNCH(1, 2); }
 #undef LAUNCH
@@ -453,6 +730,7 @@ struct AeAdamLayer { const float* partial; const float* dbp; int nslab, w_off, b
 struct AeAdamArgs {
   AeAdamLayer L[AE_NLAYER];
   float* theta; float* m; float* v; float* wb; const float* ctr;    // ctr: [1] = -lr / (1 - b1^t), [2] = sqrt(1 - b2^t) (floats)
+  float* amax;                                                      // the step's tensor maxima: slots 0 .. AE_SLOT_DYN - 1 zeroed here for the next step
   int n_w, n_all; float lr;
   size_t cs;                                                        // clip stride (clip = blockIdx.y)
 };
@@ -467,6 +745,7 @@ ae_adam_kernel(AeAdamArgs A) {
   // one thread = four consecutive entries (one half of an 8-channel group of one (tap, cout)): dwordx4 everywhere but the
   // scatter into the backward pack
   const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (blockIdx.x == 0 && threadIdx.x < AE_SLOT_DYN) A.amax[(size_t)blockIdx.y * A.cs + threadIdx.x] = 0.f;     // (last launch of the step: every reader is done)
   if (idx >= A.n_all) return;
   const size_t clip_off = (size_t)blockIdx.y * A.cs;                // (the argument struct itself stays read-only: a kernel that
   float* const theta = A.theta + clip_off;                          //  writes to it gets a private copy in scratch -- 30 -> 250 us)
@@ -557,6 +836,18 @@ ae_loss_grad_kernel(const float* __restrict__ rec, const float* __restrict__ x8,
   const float d = rec[o] - x8[o];
   const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);            // torch.sign; NaN -> 0 like the comparison chain
   dpre[o] = sg * moc[p];
+}
+
+// max |src[0 .. n)| per job into its slot (load time: the clip image, mask / count, every layer's weights)
+struct AeAbsJobs { const float* src[24]; int n[24]; float* dst[24]; };
+__global__ void __launch_bounds__(256)
+ae_absmax_kernel(AeAbsJobs J) {
+  const float* src = J.src[blockIdx.y];
+  const int n = J.n[blockIdx.y];
+  float m = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(J.dst[blockIdx.y]), __builtin_bit_cast(unsigned, m));
 }
 
 // plain [C][H][W] -> CG8P (channels >= C of the last group stay as they are: zero)
@@ -665,7 +956,10 @@ struct AeEngine {
   int forward_valid = 0;           // an eval forward of all clips ran after the last step / load (what forward_clip(c > 0) copies from)
   int nclip = 1;               // clips side by side: clip c's buffers are the pointers above + c * cs floats
   size_t cs = 0;
+  float* amax = nullptr;       // [AE_NSLOT] per clip: tensor maxima / bounds the split-f16 convolutions scale by (slots below)
+  int f16 = 1;                 // 1: split-f16 convolutions (round 6, default) ; 0: fp32-input MFMA (LEMO_AE_ARITH=fp32)
 };
+
 
 // every buffer is wrapped in AE_GUARD zeroed floats that nothing writes: the weight-gradient kernel's operand windows may
 // reach up to 17 pixels (136 floats) past either end of a CG8P buffer, at positions whose products are multiplied by zero
@@ -715,7 +1009,7 @@ static void ae_layout(AeEngine* e, int H0, int W0, float* base, size_t* total, i
   e->n_b = b;
   Bump B{base};
   e->theta = B.take(e->n_w + e->n_b); e->m = B.take(e->n_w + e->n_b); e->v = B.take(e->n_w + e->n_b);
-  e->wb = B.take(e->n_wb); e->dbp = B.take(e->n_dbp); e->zero_bias = B.take(256); e->ctr = B.take(64);
+  e->wb = B.take(e->n_wb); e->dbp = B.take(e->n_dbp); e->zero_bias = B.take(256); e->ctr = B.take(64); e->amax = B.take(AE_NSLOT);
   e->part = B.take(e->n_part); e->moc = B.take((size_t)H0 * W0);
   e->x8 = B.take(cg8p_floats(8, H0, W0));
   for (int bk = 0; bk < 5; ++bk) {
@@ -747,24 +1041,33 @@ static AeGeo geo_plain(int H, int W) { const int Wp = W + 2, HWp = (H + 2) * Wp;
 
 // engine launches carry every clip: ae_conv(..., s) -> ae_conv(..., s, 0, 0, 0, e->nclip, e->cs)
 #define AE_CONV(e_, ...) ae_conv(__VA_ARGS__, 0, 0, 0, (e_)->nclip, (e_)->cs)
+// ... with the scale slots of a split-f16 launch: input maximum (x fac: a bound, see the kernel's header), weights of layer LW, output slot
+#define AE_CONVS(e_, SIN, FAC, LW, SOUT, ...)                                                                                   \
+  [&]() { const AeF16 q_{(e_)->amax + (SIN), (e_)->amax + AE_SLOT_W(LW), (e_)->amax + (SOUT), (FAC)};                           \
+          return ae_conv(__VA_ARGS__, 0, 0, 0, (e_)->nclip, (e_)->cs, (e_)->f16 ? &q_ : nullptr); }()
 
 static int ae_forward(AeEngine* e, hipStream_t s) {
   for (int b = 0; b < 5; ++b) {
     const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
     const AeGeo g = geo_plain(H, W);
-    CHK_(AE_CONV(e, e->xin[i0], e->theta + e->L[i0].w_off, e->theta + e->n_w + e->L[i0].b_off, nullptr, e->act[i0], g, e->L[i0].cin_pad, e->L[i0].cout_pad, 0, s));
-    CHK_(AE_CONV(e, e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, 0, s));
+    // (pooling and zero stuffing keep the maximum: the pooled / stuffed inputs scale by their source's slot)
+    CHK_(AE_CONVS(e, b == 0 ? AE_SLOT_X8 : AE_SLOT_ACT(i0 - 1), 1.f, i0, AE_SLOT_ACT(i0),
+                  e->xin[i0], e->theta + e->L[i0].w_off, e->theta + e->n_w + e->L[i0].b_off, nullptr, e->act[i0], g, e->L[i0].cin_pad, e->L[i0].cout_pad, 0, s));
+    CHK_(AE_CONVS(e, AE_SLOT_ACT(i0), 1.f, i2, AE_SLOT_ACT(i2),
+                  e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, 0, s));
     CHK_(maxpool3s2_fwd(e->act[i2], H, W, e->P[b], e->idx[b], e->L[i2].cout_pad, s, e->nclip, e->cs));
   }
   CHK_(stuff2_fwd(e->P[4], e->H[5], e->W[5], e->S[0], e->H[4], e->W[4], e->L[10].cin_pad, s, e->nclip, e->cs));
   for (int b = 0; b < 5; ++b) {
     const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
     AeGeo g = geo_plain(H, W);
-    CHK_(AE_CONV(e, e->xin[i1], e->theta + e->L[i1].w_off, e->theta + e->n_w + e->L[i1].b_off, nullptr, e->act[i1], g, e->L[i1].cin_pad, e->L[i1].cout_pad, 0, s));
+    CHK_(AE_CONVS(e, AE_SLOT_ACT(i1 - 1), 1.f, i1, AE_SLOT_ACT(i1),
+                  e->xin[i1], e->theta + e->L[i1].w_off, e->theta + e->n_w + e->L[i1].b_off, nullptr, e->act[i1], g, e->L[i1].cin_pad, e->L[i1].cout_pad, 0, s));
     if (b < 4) {       // straight into the stuffed input of the next block: pixel (y, x) -> (2y, 2x) of the next finer level
       g.out_Wp = e->W[lv - 1] + 2; g.out_HWp = (e->H[lv - 1] + 2) * g.out_Wp; g.out_s = 2;
     }
-    CHK_(AE_CONV(e, e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, b < 4 ? 0 : 2, s));
+    CHK_(AE_CONVS(e, AE_SLOT_ACT(i1), 1.f, i2, AE_SLOT_ACT(i2),
+                  e->xin[i2], e->theta + e->L[i2].w_off, e->theta + e->n_w + e->L[i2].b_off, nullptr, e->act[i2], g, e->L[i2].cin_pad, e->L[i2].cout_pad, b < 4 ? 0 : 2, s));
   }
   return 0;
 }
@@ -781,7 +1084,8 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
   for (int b = 4; b >= 0; --b) {
     const int lv = 4 - b, H = e->H[lv], W = e->W[lv], i1 = 10 + 2 * b, i2 = 11 + 2 * b;
     const AeGeo g = geo_plain(H, W);
-    CHK_(AE_CONV(e, e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i1], e->dp[i1], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));     // * lrelu'(act[i1])
+    CHK_(AE_CONVS(e, i2 == 19 ? AE_SLOT_LOSS : AE_SLOT_DP(i2), 1.f, i2, AE_SLOT_DP(i1),
+                  e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i1], e->dp[i1], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));     // * lrelu'(act[i1])
     // adjoint of (stuffing, transposed conv): only the even pixels of d(stuffed input) exist downstream -> enumerate the
     // coarse grid, centre taps at (2i, 2j); times lrelu' of the previous block's output (read where it lives: stuffed in S[b])
     const int h = e->H[lv + 1], w = e->W[lv + 1];
@@ -789,16 +1093,21 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     gs.in_Wp = W + 2; gs.in_HWp = (H + 2) * (W + 2); gs.in_s = 2;
     gs.aux_Wp = gs.in_Wp; gs.aux_HWp = gs.in_HWp; gs.aux_s = 2;
     float* dst = b > 0 ? e->dp[i1 - 1] : e->dP[4];
-    if (b > 0) CHK_(AE_CONV(e, e->dp[i1], e->wb + e->L[i1].wb_off, nullptr, e->S[b], dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 1, s));
-    else       CHK_(AE_CONV(e, e->dp[i1], e->wb + e->L[i1].wb_off, e->zero_bias, nullptr, dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 2, s));   // the latent has no activation
+    if (b > 0) CHK_(AE_CONVS(e, AE_SLOT_DP(i1), 1.f, i1, AE_SLOT_DP(i1 - 1),
+                             e->dp[i1], e->wb + e->L[i1].wb_off, nullptr, e->S[b], dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 1, s));
+    else       CHK_(AE_CONVS(e, AE_SLOT_DP(i1), 1.f, i1, AE_SLOT_DPOOL(4),
+                             e->dp[i1], e->wb + e->L[i1].wb_off, e->zero_bias, nullptr, dst, gs, e->L[i1].cout_pad, e->L[i1].cin_pad, 2, s));   // the latent has no activation
   }
   // ---- encoder, last block first
   for (int b = 4; b >= 0; --b) {
     const int H = e->H[b], W = e->W[b], i0 = 2 * b, i2 = 2 * b + 1;
     const AeGeo g = geo_plain(H, W);
     CHK_(maxpool3s2_bwd(e->dP[b], e->idx[b], e->act[i2], e->dp[i2], H, W, e->L[i2].cout_pad, s, e->nclip, e->cs));
-    CHK_(AE_CONV(e, e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i0], e->dp[i0], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));
-    if (b > 0) CHK_(AE_CONV(e, e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
+    // (the max-pool adjoint adds at most four window gradients into one pixel, times lrelu' <= 1: dp[i2] is bounded by 4 x the pooled gradient's maximum)
+    CHK_(AE_CONVS(e, AE_SLOT_DPOOL(b), 4.f, i2, AE_SLOT_DP(i0),
+                  e->dp[i2], e->wb + e->L[i2].wb_off, nullptr, e->act[i0], e->dp[i0], g, e->L[i2].cout_pad, e->L[i2].cin_pad, 1, s));
+    if (b > 0) CHK_(AE_CONVS(e, AE_SLOT_DP(i0), 1.f, i0, AE_SLOT_DPOOL(b - 1),
+                             e->dp[i0], e->wb + e->L[i0].wb_off, e->zero_bias, nullptr, e->dP[b - 1], g, e->L[i0].cout_pad, e->L[i0].cin_pad, 2, s));
   }
   // ---- all weight and bias gradients
   CHK_(ae_wgrad_launch(e, s, 0));
@@ -808,7 +1117,7 @@ static int ae_train_step(AeEngine* e, hipStream_t s) {
     const AeLayer& l = e->L[i];
     A.L[i] = AeAdamLayer{e->part + l.part_off, e->dbp + l.dbp_off, l.nslab, l.w_off, l.b_off, l.wb_off, ilog2(l.cin_pad / 8), ilog2(l.cout_pad), l.cin, l.cout};
   }
-  A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.ctr = e->ctr;
+  A.theta = e->theta; A.m = e->m; A.v = e->v; A.wb = e->wb; A.ctr = e->ctr; A.amax = e->amax;
   A.n_w = e->n_w; A.n_all = e->n_w + e->n_b; A.lr = e->lr; A.cs = e->cs;
   hipLaunchKernelGGL(ae_adam_kernel, dim3((A.n_all / 4 + 255) / 256, e->nclip), dim3(256), 0, s, A);        // (n_w and n_b are multiples of 4)
   return (int)hipGetLastError();
@@ -894,6 +1203,7 @@ void* lemo_ae_create(const lemo_ae_desc* d) {
   e->cs = total;                                            // clip c = the same layout, c * total floats further
   if (e->nclip > 64 || (long long)(total * (size_t)e->nclip) > d->ws_floats) { delete e; return nullptr; }
   e->lr = d->lr;
+  if (const char* a = getenv("LEMO_AE_ARITH")) e->f16 = strcmp(a, "fp32") != 0;       // A/B and parity tests: the fp32-input MFMA convolutions of rounds 3-5
   return e;
 }
 
@@ -918,6 +1228,17 @@ int lemo_ae_load_clip(void* h, int clip, const float* flat, const float* x, cons
   if ((rc = (int)hipMemsetAsync(e->ctr + o, 0, sizeof(float) * 64, s))) return rc;
   if ((rc = (int)hipMemcpyAsync(e->moc + o, moc, sizeof(float) * H * W, hipMemcpyDeviceToDevice, s))) return rc;
   hipLaunchKernelGGL(ae_to_cg8p_kernel, dim3((4 * H * W + 255) / 256), dim3(256), 0, s, x, 4, H, W, e->x8 + o);
+  // tensor maxima the split-f16 convolutions scale by: everything that no convolution of a step writes
+  if ((rc = (int)hipMemsetAsync(e->amax + o, 0, sizeof(float) * AE_NSLOT, s))) return rc;
+  {
+    AeAbsJobs J{};
+    J.src[0] = x; J.n[0] = 4 * H * W; J.dst[0] = e->amax + o + AE_SLOT_X8;
+    J.src[1] = e->moc + o; J.n[1] = H * W; J.dst[1] = e->amax + o + AE_SLOT_LOSS;
+    for (int i = 0; i < AE_NLAYER; ++i) {
+      J.src[2 + i] = e->theta + o + e->L[i].w_off; J.n[2 + i] = 9 * e->L[i].cin_pad * e->L[i].cout_pad; J.dst[2 + i] = e->amax + o + AE_SLOT_W(i);
+    }
+    hipLaunchKernelGGL(ae_absmax_kernel, dim3(64, 2 + AE_NLAYER), dim3(256), 0, s, J);
+  }
   e->loaded |= 1ull << clip;
   e->forward_valid = 0;
   return (int)hipGetLastError();
@@ -993,6 +1314,21 @@ int lemo_ae_conv(const float* in, const float* wt, const float* bias, const floa
   if (in_s == 2) { g.in_Wp = fineW + 2; g.in_HWp = (fineH + 2) * (fineW + 2); g.in_s = 2; g.aux_Wp = g.in_Wp; g.aux_HWp = g.in_HWp; g.aux_s = 2; }
   if (out_s == 2) { g.out_Wp = fineW + 2; g.out_HWp = (fineH + 2) * (fineW + 2); g.out_s = 2; }
   return ae_conv(in, wt, bias, aux, out, g, cin, cout, epi, (hipStream_t)stream, mt, pt, ks);
+}
+
+/* the same on the split-f16 kernels (round 6): amax_in [1] = max |in| (or a bound: x in_fac), wmax [1] = max |wt|, amax_out [1] receives
+   max |out| of the launch by atomicMax (zero it first); cin >= 16 (mt 3: >= 32) */
+int lemo_ae_conv_f16(const float* in, const float* wt, const float* bias, const float* aux, float* out, int H, int W, int fineH, int fineW,
+                     int in_s, int out_s, int cin, int cout, int epi, int mt, int pt, int ks, const float* amax_in, float in_fac,
+                     const float* wmax, float* amax_out, void* stream) {
+  if (!in || !wt || !out || (epi != 1 && !bias) || (epi == 1 && !aux) || (in_s != 1 && in_s != 2) || (out_s != 1 && out_s != 2)) return LEMO_ERR_ARG;
+  if (!amax_in || !wmax || !amax_out || !(in_fac >= 1.f) || cin < 16) return LEMO_ERR_ARG;
+  if (ae_conv_init()) return LEMO_ERR_STATE;
+  AeGeo g = geo_plain(H, W);
+  if (in_s == 2) { g.in_Wp = fineW + 2; g.in_HWp = (fineH + 2) * (fineW + 2); g.in_s = 2; g.aux_Wp = g.in_Wp; g.aux_HWp = g.in_HWp; g.aux_s = 2; }
+  if (out_s == 2) { g.out_Wp = fineW + 2; g.out_HWp = (fineH + 2) * (fineW + 2); g.out_s = 2; }
+  const AeF16 q{amax_in, wmax, amax_out, in_fac};
+  return ae_conv(in, wt, bias, aux, out, g, cin, cout, epi, (hipStream_t)stream, mt, pt, ks, 1, 0, &q);
 }
 
 }  // extern "C"

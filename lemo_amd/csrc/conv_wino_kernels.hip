@@ -52,33 +52,37 @@ struct WinoArgs {
   unsigned long long* dbg;
 };
 
-// the last row of an image with odd H: out[H-1][x][co] as a direct fp32 convolution, W * 64 outputs dealt to the workgroups in
-// equal runs, one output per 16-lane row (lane = 4 input channels, 9 taps), DPP row sum; a few hundred instructions per workgroup
-template <int EPI>
-__device__ __forceinline__ void wn_odd_row(const WinoArgs& a, int tid) {
-  const int H = a.H, W = a.W, Wp = W + 2, HWp = (H + 2) * Wp;
-  const int total = W * 64, per = (total + a.nwg - 1) / a.nwg;
-  const int o_begin = (int)blockIdx.x * per, o_end = o_begin + per < total ? o_begin + per : total;
-  const int gi = tid >> 4, sub = tid & 15, g = sub >> 1, half = sub & 1;
-  for (int base = o_begin; base < o_end; base += 32) {
-    const int oi = base + gi;
-    const bool ok = oi < o_end;
-    const int oc = ok ? oi : o_end - 1;
-    const int x = oc >> 6, co = oc & 63;
-    const float* ip = a.in + ((size_t)g * HWp + (size_t)(H - 1) * Wp + x) * 8 + 4 * half;      // padded (row H - 1, col x) = tap (-1, -1)
-    const float* wp = a.wt + ((size_t)g * 64 + co) * 8 + 4 * half;
-    float acc = 0.f;
+// the last row of an image with odd H: out[H-1][x][co] as a direct fp32 convolution, W * 64 outputs, one per 16-lane row (lane = 4 input
+// channels x 9 taps, DPP row sum): every workgroup takes 32 of them with operands requested before anything else in the kernel (their
+// round trip overlaps the patch loads'), the outputs beyond 32 per workgroup go to the first few workgroups at the END of the kernel.
+struct WnOdd { float4 v[9], w[9]; int x, co; bool ok; };
+__device__ __forceinline__ void wn_odd_load(const WinoArgs& a, int tid, int oi, WnOdd& r) {
+  const int H = a.H, W = a.W, Wp = W + 2, HWp = (H + 2) * Wp, total = W * 64;
+  const int sub = tid & 15, g = sub >> 1, half = sub & 1;
+  r.ok = oi < total;
+  const int oc = r.ok ? oi : total - 1;
+  r.x = oc >> 6; r.co = oc & 63;
+  const float* ip = a.in + ((size_t)g * HWp + (size_t)(H - 1) * Wp + r.x) * 8 + 4 * half;      // padded (row H - 1, col x) = tap (-1, -1)
+  const float* wp = a.wt + ((size_t)g * 64 + r.co) * 8 + 4 * half;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float4 v = ld4(ip + ((t / 3) * Wp + (t % 3)) * 8);
-      const float4 w = ld4(wp + (size_t)t * 8 * 64 * 8);
-      acc = fmaf(v.x, w.x, acc); acc = fmaf(v.y, w.y, acc); acc = fmaf(v.z, w.z, acc); acc = fmaf(v.w, w.w, acc);
-    }
-    acc = row16_sum(acc);
-    if (ok && sub == 0) {
-      const size_t o = ((size_t)(co >> 3) * HWp + (size_t)H * Wp + x + 1) * 8 + (co & 7);
-      conv_store1<EPI>(a.out, a.bias, a.aux, o, co, acc);
-    }
+  for (int t = 0; t < 9; ++t) {
+    r.v[t] = ld4(ip + ((t / 3) * Wp + (t % 3)) * 8);
+    r.w[t] = ld4(wp + (size_t)t * 8 * 64 * 8);
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void wn_odd_finish(const WinoArgs& a, int tid, const WnOdd& r) {
+  const int H = a.H, Wp = a.W + 2, HWp = (H + 2) * Wp;
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc = fmaf(r.v[t].x, r.w[t].x, acc); acc = fmaf(r.v[t].y, r.w[t].y, acc);
+    acc = fmaf(r.v[t].z, r.w[t].z, acc); acc = fmaf(r.v[t].w, r.w[t].w, acc);
+  }
+  acc = row16_sum(acc);
+  if (r.ok && (tid & 15) == 0) {
+    const size_t o = ((size_t)(r.co >> 3) * HWp + (size_t)H * Wp + r.x + 1) * 8 + (r.co & 7);
+    conv_store1<EPI>(a.out, a.bias, a.aux, o, r.co, acc);
   }
 }
 
@@ -99,7 +103,13 @@ conv3x3_wino_kernel(WinoArgs a) {
     grp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
   }
 
-  // ---- phase 2's first weight fragments: nothing depends on them, requested before anything else -----------------------------
+  const bool odd = a.H2 < H;
+  WnOdd orow;
+  // (unconditional: a branch here lets hipcc merge it with the one around wn_odd_finish and wait for these loads BEFORE the patch loads
+  // are issued; an even H computes one row of throw-away sums from valid addresses)
+  wn_odd_load(a, tid, (int)blockIdx.x * 32 + (tid >> 4), orow);              // the oldest loads of the kernel: back first
+  orow.ok = orow.ok && odd;
+  // ---- phase 2's first weight fragments: nothing depends on them either ---------------------------------------------------------
   const int mt = wave & 1, fi = wave >> 1;
   uint4 ra[2][4][2];                                       // [step parity][j][piece]
 #define WN_LOAD_A(SET, KS)                                                                                      \
@@ -125,7 +135,9 @@ conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) d[r][c] = ld4(ip + ((size_t)r * Wp + col[c]) * 8);
   }
-  if (a.H2 < H) wn_odd_row<EPI>(a, tid);                   // (its loads queue behind the patch loads: it runs while those are in flight)
+  __builtin_amdgcn_sched_barrier(0);
+  wn_odd_finish<EPI>(a, tid, orow);                        // waits for ITS loads only (the patch loads and weight fragments stay in flight)
+  __builtin_amdgcn_sched_barrier(0);
   if (DBG) t_ld = __builtin_amdgcn_s_memtime();
   // V = B^T d B per channel: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
   float4 V[4][4];
@@ -267,6 +279,12 @@ conv3x3_wino_kernel(WinoArgs a) {
       }
       const int c0 = mt2 * 32 + q * 8 + 4 * h;
       if (ok) st4(a.out + ((size_t)(c0 >> 3) * HWp + po) * 8 + (c0 & 7), v);
+    }
+  }
+  if (odd) {                                                // outputs 32 nwg .. W * 64 - 1 of the odd row, 32 per workgroup and round
+    for (int o0 = (a.nwg + (int)blockIdx.x) * 32; o0 < W * 64; o0 += a.nwg * 32) {      // (245 x 134: one round on the first 12 workgroups)
+      wn_odd_load(a, tid, o0 + (tid >> 4), orow);
+      wn_odd_finish<EPI>(a, tid, orow);
     }
   }
   if (DBG && lane == 0) {

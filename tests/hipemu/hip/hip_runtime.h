@@ -497,6 +497,26 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16(hipemu_f16x8 
   return d;
 }
 
+// gfx950 v_mfma_f32_16x16x32_f16: A[i = l&15][k = 8*(l>>4)+e], B[k][j = l&15], D[i = 4*(l>>4)+r][j = l&15] (r = 0..3); the 32
+// products of one instruction are exact, summed in double here and rounded once
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+  hipemu::WaveBuf& w = hipemu::mywave();
+  const int l = hipemu::me().lane;
+  for (int e = 0; e < 8; ++e) { w.a8[l][e] = (float)a[e]; w.b8[l][e] = (float)b[e]; }
+  hipemu::barrier(w.g);
+  hipemu_f32x4 d;
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (l >> 4) + r;
+    double acc = c[r];
+    for (int q = 0; q < 4; ++q)
+      for (int e = 0; e < 8; ++e) acc += (double)w.a8[row + 16 * q][e] * (double)w.b8[col + 16 * q][e];
+    d[r] = (float)acc;
+  }
+  hipemu::barrier(w.g);
+  return d;
+}
+
 // ---- atomics: atomicAdd on GLOBAL memory is deferred to the end of the launch (see hipemu::launch); its return value is
 // NOT the old value (no kernel uses it).  Integer fetch-adds whose result IS used (last-block detection) are real atomics.
 template <typename T> static void hipemu_apply_add(void* p, const void* v) { T a; memcpy(&a, v, sizeof(T)); *(T*)p = *(T*)p + a; }
@@ -511,6 +531,17 @@ template <typename T> static inline T atomicAdd(T* p, T v) {
   return T();
 }
 static inline float atomicAdd(float* p, double v) { return atomicAdd(p, (float)v); }
+// atomicMax on unsigned (the kernels use it on the bit patterns of non-negative floats): deferred like atomicAdd, order-independent
+static void hipemu_apply_umax(void* p, const void* v) { unsigned a; memcpy(&a, v, 4); if (a > *(unsigned*)p) *(unsigned*)p = a; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+  if (hipemu::is_lds(p)) { unsigned o = *p; if (v > o) *p = v; return o; }
+  hipemu::State& s = hipemu::st();
+  hipemu::AtomicRec r;
+  r.key = s.block_key; r.p = (void*)p; r.apply = &hipemu_apply_umax;
+  memcpy(r.val, &v, 4);
+  s.atomics.push_back(r);
+  return 0u;
+}
 
 // ---- buffer resources / cache-policy loads & stores / scoped atomics (plain memory on the host) ------------
 struct hipDeviceProp_t { int multiProcessorCount; };

@@ -226,6 +226,83 @@ def test_engine_conv_all_geometries(emu_lib, mt, pt, ks):
     assert rel_err(from_cg8p(out, H, W), want) < 2e-6
 
 
+@pytest.mark.parametrize('mt,pt,ks', [(0, 0, 0), (1, 1, 1), (1, 1, 4), (1, 4, 2), (2, 2, 2), (1, 2, 8), (2, 1, 8), (3, 1, 1), (3, 4, 1), (3, 2, 8)])
+def test_engine_conv_f16_all_geometries(emu_lib, mt, pt, ks):
+    """lemo_ae_conv_f16 (round 6: the engine's convolutions on two fp16 pieces per operand, scales from tensor maxima) in the three
+    geometries of test_engine_conv_all_geometries, every epilogue, against torch in FLOAT64: error of the size of an fp32 convolution's
+    own rounding (2^-22 operands), also with the input's maximum given as a bound 4 x too large (the max-pool adjoint's case) and with an
+    input whose magnitudes span six decades; the launch leaves max |out| in its slot"""
+    import torch.nn.functional as F
+    from lemo_amd.priors import cg8p_alloc, from_cg8p, to_cg8p, pack_conv3x3
+    g = torch.Generator().manual_seed(12)
+    cin, cout, H, W = 32, 64, 7, 9
+    x = torch.randn(cin, H, W, generator=g) * torch.logspace(0, -6, H).view(1, H, 1)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 1e-3
+    wt = torch.from_numpy(pack_conv3x3(w.numpy()))
+    wmax = w.abs().max().reshape(1).clone()
+    ref = F.conv2d(x[None].double(), w.double(), b.double(), padding=1)[0]
+    f32 = F.conv2d(x[None], w, b, padding=1)[0]
+    aux = torch.randn(cout, H, W, generator=g)
+    for fac in (1.0, 4.0):
+        amax_in = (x.abs().max() / (1.0 if fac == 1.0 else 3.3)).reshape(1).clone() if fac == 4.0 else x.abs().max().reshape(1).clone()
+        for epi, want in ((0, F.leaky_relu(ref, 0.2)), (2, ref),
+                          (1, F.conv2d(x[None].double(), w.double(), None, padding=1)[0] * torch.where(aux > 0, 1.0, 0.2).double())):
+            out, amax_out = cg8p_alloc(cout, H, W, 'cpu'), torch.zeros(1)
+            assert emu_lib.ae_conv_f16(ptr(to_cg8p(x)), ptr(wt), ptr(b), ptr(to_cg8p(aux)), ptr(out), H, W, 0, 0, 1, 1, cin, cout, epi, mt, pt, ks,
+                                       ptr(amax_in), fac, ptr(wmax), ptr(amax_out), None) == 0
+            got = from_cg8p(out, H, W)
+            assert rel_err(got.double(), want) < 1e-6, (epi, fac, rel_err(got.double(), want), rel_err(f32.double(), ref))
+            assert float(amax_out) == float(got.abs().max())
+    amax_in = x.abs().max().reshape(1).clone()
+    # stuffed output
+    fH, fW = 14, 17
+    out, amax_out = cg8p_alloc(cout, fH, fW, 'cpu'), torch.zeros(1)
+    assert emu_lib.ae_conv_f16(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, fH, fW, 1, 2, cin, cout, 0, mt, pt, ks,
+                               ptr(amax_in), 1.0, ptr(wmax), ptr(amax_out), None) == 0
+    S = from_cg8p(out, fH, fW)
+    want = torch.zeros(cout, fH, fW, dtype=torch.float64)
+    want[:, 0:2 * H:2, 0:2 * W:2] = F.leaky_relu(ref, 0.2)
+    assert rel_err(S.double(), want) < 1e-6 and float(S[:, 1::2].abs().max()) == 0.0 and float(S[:, :, 1::2].abs().max()) == 0.0
+    # strided input with the stuffed epilogue operand
+    xf = torch.randn(cin, fH, fW, generator=g)
+    auxf = torch.zeros(cout, fH, fW)
+    auxf[:, 0:2 * H:2, 0:2 * W:2] = aux
+    full = F.conv2d(xf[None].double(), w.double(), None, padding=1)[0]
+    want = full[:, 0:2 * H:2, 0:2 * W:2] * torch.where(aux > 0, 1.0, 0.2).double()
+    out, amax_out = cg8p_alloc(cout, H, W, 'cpu'), torch.zeros(1)
+    assert emu_lib.ae_conv_f16(ptr(to_cg8p(xf)), ptr(wt), None, ptr(to_cg8p(auxf)), ptr(out), H, W, fH, fW, 2, 1, cin, cout, 1, mt, pt, ks,
+                               ptr(xf.abs().max().reshape(1).clone()), 1.0, ptr(wmax), ptr(amax_out), None) == 0
+    assert rel_err(from_cg8p(out, H, W).double(), want) < 1e-6
+    # refusals: 8 input channels belong to the fp32-input kernel, a bound factor below 1 is not a bound
+    assert emu_lib.ae_conv_f16(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, 0, 0, 1, 1, 8, cout, 0, 0, 0, 0, ptr(amax_in), 1.0, ptr(wmax), ptr(amax_out), None) != 0
+    assert emu_lib.ae_conv_f16(ptr(to_cg8p(x)), ptr(wt), ptr(b), None, ptr(out), H, W, 0, 0, 1, 1, cin, cout, 0, 0, 0, 0, ptr(amax_in), 0.5, ptr(wmax), ptr(amax_out), None) != 0
+
+
+def test_engine_f16_and_fp32_arithmetic_agree(emu_lib, monkeypatch):
+    """the step engine on its split-f16 convolutions (default) and on the fp32-input MFMA ones (LEMO_AE_ARITH=fp32, rounds 3-5): same
+    reconstruction, latent and parameters after 3 visible steps to fp32 rounding -- the weight gradients, Adam and every layout are shared"""
+    from lemo_amd import infill
+    from lemo_amd.infill import AE, finetune_and_infill
+    w = _weights()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 4, 34, 21, generator=g)
+    mask = torch.rand(34, 21, generator=g) > 0.3
+    res = {}
+    for arith in ('f16', 'fp32'):
+        monkeypatch.setenv('LEMO_AE_ARITH', arith)
+        infill._SESSIONS.clear()
+        m = AE(_lib=emu_lib)
+        r, z = finetune_and_infill(m, w, x, mask, steps=3, lr=1e-3, engine=True)
+        res[arith] = (r, z, {k: p.detach().clone() for k, p in m.named_parameters()})
+    infill._SESSIONS.clear()
+    (ra, za, pa), (rb, zb, pb) = res['f16'], res['fp32']
+    assert not torch.equal(ra, rb)                                        # two arithmetics, not one
+    assert rel_err(ra, rb) < 2e-5 and rel_err(za, zb) < 2e-5
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 2e-5, k
+
+
 @pytest.mark.timeout(900)
 def test_engine_equals_autograd_path(emu_lib):
     """the native step engine (packed parameter vector, fused stuffing, one weight-gradient launch, fused reduce + Adam) and the
