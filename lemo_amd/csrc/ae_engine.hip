@@ -58,6 +58,17 @@ struct AeGeo { int H, W; int in_Wp, in_HWp, in_s; int out_Wp, out_HWp, out_s; in
   { const size_t o_ = (size_t)blockIdx.z * (cs_); in_ += o_; wt_ += o_; out_ += o_;                   \
     if (bias_) bias_ += o_; if (aux_) aux_ += o_; }
 
+// maximum of |v| over the wave's stored lanes -> the launch's slot (bit pattern of a non-negative float orders like the float)
+// (one atomic per wave on ONE word cost a launch ~11 ns each -- 2.7 k waves = the whole 29 us of a launch, which is how the first version
+// of these kernels ran no faster than the fp32-input ones, and 49 vs 29 ms per solo clip: the slot is READ first and the atomic issued
+// only by a wave that would raise it -- a handful per launch; a stale read only costs a redundant atomic)
+__device__ __forceinline__ void ae_amax_publish(float m, float* slot) {
+  m = wave_max(m);
+  unsigned* us = reinterpret_cast<unsigned*>(slot);            // (non-negative floats order like their bit patterns)
+  const unsigned um = __builtin_bit_cast(unsigned, m);
+  if ((threadIdx.x & 63) == 0 && um > __hip_atomic_load(us, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(us, um);
+}
+
 template <int MT, int EPI>          // MT x 32 couts per workgroup; EPI: conv_common.hpp (0 lrelu(acc + bias), 1 acc * lrelu'(aux), 2 acc + bias)
 __global__ void __launch_bounds__(1024)
 ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const float* __restrict__ bias,
@@ -161,10 +172,7 @@ ae_conv_kernel(const float* __restrict__ in, const float* __restrict__ wt, const
     st4(out + o, v);
     mloc = absmax4(v, mloc);
   }
-  if (amax_out) {                                             // (uniform: every lane of every wave arrives here)
-    mloc = wave_max(mloc);
-    if (lane == 0 && mloc > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __builtin_bit_cast(unsigned, mloc));
-  }
+  if (amax_out) ae_amax_publish(mloc, amax_out);              // (uniform: every lane of every wave arrives here)
 }
 
 // The same convolution on 16 px x 16 cout tiles (v_mfma_f32_16x16x4_f32, same flops per cycle): the 256-channel layers at
@@ -252,7 +260,8 @@ ae_conv16_kernel(const float* __restrict__ in, const float* __restrict__ wt, con
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// the same convolutions on the f16 matrix cores ("split-f16", round 6)
+// the same convolutions on the f16 matrix cores ("split-f16", round 6): built, parity-tested, SELECTABLE, not the
+// default -- see AeEngine::f16 for the measurement
 // ---------------------------------------------------------------------------------------------------------------------
 // The fp32-input MFMA above issues at 1/16 of the f16 rate.  Here a step is 16 channels x 1 tap: both operands are read as fp32 (the
 // activations and the parameter vector stay fp32 -- Adam, the weight gradients and the layouts are untouched), split IN REGISTERS into
@@ -269,17 +278,25 @@ static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 //                <= 60 x lr 3e-6 x ~10 = 2e-3, far from the factor 2 (fp16 itself overflows another factor 4 later).
 struct AeF16 { const float* amax_in; const float* wmax; float* amax_out; float in_fac; };       // per-clip slots (offset by the clip stride like every operand)
 
+// Both operands of a 16-channel step are 32 contiguous bytes per lane (8 fp32 channels of one pixel / one cout) and the wave's two halves
+// read two different channel groups.  Read as [16 B | 16 B] per lane, each dwordx4 instruction touches every line of both groups half --
+// twice the L1 requests of the fp32-input kernel for the same bytes (the first version of these kernels: no faster than fp32, 45 vs 29 ms
+// per solo clip).  Instead instruction g reads group g with lane j taking the FIRST 16 bytes and lane j + 32 the SECOND (1 KiB contiguous
+// per instruction), and one v_permlane32_swap per register puts the halves where the MFMA wants them:
+//   before: lanes 0-31 hold {G0[0:4], G1[0:4]}, lanes 32-63 {G0[4:8], G1[4:8]}   after: lanes 0-31 {G0[0:4], G0[4:8]}, lanes 32-63 {G1[0:4], G1[4:8]}
+__device__ __forceinline__ void ae_swap_halves(float4& g0, float4& g1) {
+#define AE_SW(c)                                                                                             \
+  { const auto r_ = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, g0.c), __builtin_bit_cast(unsigned, g1.c), false, false); \
+    g0.c = __builtin_bit_cast(float, (unsigned)r_[0]); g1.c = __builtin_bit_cast(float, (unsigned)r_[1]); }
+  AE_SW(x) AE_SW(y) AE_SW(z) AE_SW(w)
+#undef AE_SW
+}
 __device__ __forceinline__ void ae_split8(float4 lo4, float4 hi4, float s, f16x8& ph, f16x8& pl) {
   uint2 h0, l0, h1, l1;
   split2x4(lo4, s, h0, l0);
   split2x4(hi4, s, h1, l1);
   ph = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
   pl = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-}
-// maximum of |v| over the wave's stored lanes -> the launch's slot (bit pattern of a non-negative float orders like the float)
-__device__ __forceinline__ void ae_amax_publish(float m, float* slot) {
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot), __builtin_bit_cast(unsigned, m));
 }
 
 template <int MT, int EPI>          // MT x 32 couts per workgroup (MT 2: at most 8 waves)
@@ -299,8 +316,8 @@ ae_conv_f16_kernel(const float* __restrict__ in, const float* __restrict__ wt, c
   const int y = pc / g.W, x = pc - y * g.W;
   // a step = one tap x 16 channels: lane half h carries channel group 2 gp + h (8 channels = 32 contiguous bytes in both operands)
   const size_t in_gstride = (size_t)g.in_HWp * 8, wt_itstride = (size_t)cout * 8;
-  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + (size_t)h * in_gstride;
-  const float* wt_l = wt + (size_t)(m_base + j) * 8 + (size_t)h * wt_itstride;
+  const float* in_l = in + (size_t)((g.in_s * y + 1) * g.in_Wp + g.in_s * x + 1) * 8 + 4 * h;       // lane half h: bytes 16 h .. 16 h + 15 of a group (ae_swap_halves)
+  const float* wt_l = wt + (size_t)(m_base + j) * 8 + 4 * h;
   const int gp_lg = cin_lg - 1, gm = (1 << gp_lg) - 1, nit = 9 << gp_lg;
   const int lo = nit * ks / KS, hi = nit * (ks + 1) / KS;
   float sA, sAi, sB, sBi;
@@ -320,16 +337,18 @@ ae_conv_f16_kernel(const float* __restrict__ in, const float* __restrict__ wt, c
     const int tap_ = it_ >> gp_lg, gp_ = it_ & gm;                                                          \
     const int dy_ = (tap_ * 11 >> 5) - 1, dx_ = tap_ - (dy_ + 1) * 3 - 1;                                   \
     const float* bq_ = in_l + (std::ptrdiff_t)(dy_ * g.in_Wp + dx_) * 8 + (size_t)(2 * gp_) * in_gstride;   \
-    rb[SLOT][0] = ld4(bq_); rb[SLOT][1] = ld4(bq_ + 4);                                                     \
+    rb[SLOT][0] = ld4(bq_); rb[SLOT][1] = ld4(bq_ + in_gstride);                                            \
     const float* aq_ = wt_l + (size_t)((tap_ << cin_lg) + 2 * gp_) * wt_itstride;                           \
-    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) { ra[SLOT][m_][0] = ld4(aq_ + (size_t)m_ * 256); ra[SLOT][m_][1] = ld4(aq_ + (size_t)m_ * 256 + 4); } \
+    _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) { ra[SLOT][m_][0] = ld4(aq_ + (size_t)m_ * 256); ra[SLOT][m_][1] = ld4(aq_ + (size_t)m_ * 256 + wt_itstride); } \
   }
 #define AE_MF(SLOT)                                                                                         \
   {                                                                                                         \
     f16x8 bh_, bl_;                                                                                         \
+    ae_swap_halves(rb[SLOT][0], rb[SLOT][1]);                                                               \
     ae_split8(rb[SLOT][0], rb[SLOT][1], sB, bh_, bl_);                                                      \
     _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) {                                                     \
       f16x8 ah_, al_;                                                                                       \
+      ae_swap_halves(ra[SLOT][m_][0], ra[SLOT][m_][1]);                                                     \
       ae_split8(ra[SLOT][m_][0], ra[SLOT][m_][1], sA, ah_, al_);                                            \
       acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, acc[m_], 0, 0, 0);                          \
       acc[m_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, acc[m_], 0, 0, 0);                          \
@@ -515,8 +534,10 @@ static void ae_conv_shape(int P, int cin, int cout, int nclip, int* mt_out, int*
   for (int mt = 3; mt >= 1; --mt) {
     const int px = mt == 3 ? 16 : 32, co = mt == 3 ? 16 : 32 * mt;
     if (cout % co || (mt == 3 && cin < (f16 ? 32 : 16))) continue;
-    // (f16: a step is 32 / 16 channels instead of 16 / 8 -- half the steps; the per-step costs below keep their RATIOS, which is all the choice uses)
-    const int nit = (mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8)) / (f16 ? 2 : 1);
+    // (f16: a step is 32 / 16 channels instead of 16 / 8, but the launch is bound by per-wave latency, not by the matrix pipe (round 6:
+    // SQ_VALU_MFMA_BUSY 9 % of the launch, 2.7 waves per SIMD) -- the shape is chosen as for the fp32-input kernel, i.e. the SAME K
+    // slices with half the steps each; choosing from the halved step count gave half the waves and 49 vs 29 ms per solo clip)
+    const int nit = mt == 3 ? 9 * (cin / 16) : 9 * (cin / 8);
     const long tiles = (long)((P + px - 1) / px) * (cout / co) * nclip;
     int pt = 1;
     while (pt < 4 && tiles / (2 * pt) >= 200) pt *= 2;
@@ -547,6 +568,8 @@ int ae_conv(const float* in, const float* wt, const float* bias, const float* au
   if (pt < 1 || (pt & (pt - 1)) || ks < 1 || nw > 16) return LEMO_ERR_ARG;
   const int pt_lg = ilog2(pt);
   if (f16) {
+    if (!force_mt) { const int nit16 = mt == 3 ? 9 * (cin / 32) : 9 * (cin / 16); while (ks > 1 && ks > nit16) ks >>= 1; }
+    const int nw = pt * ks;
     if (mt == 3) {
       if (cin < 32 || ks > 9 * (cin / 32)) return LEMO_ERR_ARG;
       const dim3 grid(((g.H * g.W + 15) / 16 + pt - 1) / pt, cout / 16, nclip);
@@ -957,7 +980,10 @@ struct AeEngine {
   int nclip = 1;               // clips side by side: clip c's buffers are the pointers above + c * cs floats
   size_t cs = 0;
   float* amax = nullptr;       // [AE_NSLOT] per clip: tensor maxima / bounds the split-f16 convolutions scale by (slots below)
-  int f16 = 1;                 // 1: split-f16 convolutions (round 6, default) ; 0: fp32-input MFMA (LEMO_AE_ARITH=fp32)
+  int f16 = 0;                 // 0: fp32-input MFMA convolutions (shipped) ; 1: split-f16 convolutions (round 6; LEMO_AE_ARITH=f16).  Measured
+                               // (profiles/r06_ae_f16_vs_fp32.txt): 16.05 vs 16.4 ms per clip at 8 clips per engine, 14.4 vs 15.45 at 16, but 44.5 vs
+                               // 28.8 for a solo clip -- the launches are bound by L2 re-reads of the direct-from-global operands (every input element
+                               // 9 taps x cout / 32 MT times) and per-wave latency, not by the matrix pipe: SQ_VALU_MFMA_BUSY 9 % (f16) / 48 % (fp32)
 };
 
 
@@ -1203,7 +1229,7 @@ void* lemo_ae_create(const lemo_ae_desc* d) {
   e->cs = total;                                            // clip c = the same layout, c * total floats further
   if (e->nclip > 64 || (long long)(total * (size_t)e->nclip) > d->ws_floats) { delete e; return nullptr; }
   e->lr = d->lr;
-  if (const char* a = getenv("LEMO_AE_ARITH")) e->f16 = strcmp(a, "fp32") != 0;       // A/B and parity tests: the fp32-input MFMA convolutions of rounds 3-5
+  if (const char* a = getenv("LEMO_AE_ARITH")) e->f16 = strcmp(a, "f16") == 0;        // A/B and parity tests: the split-f16 convolutions
   return e;
 }
 

@@ -417,6 +417,17 @@ static inline int __builtin_amdgcn_update_dpp(int, int src, int ctrl, int, int, 
   return hipemu_exchange(src, from);
 }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_exchange(v, lane); }
+// gfx950 v_permlane32_swap: the upper 32 lanes of the first operand trade places with the lower 32 lanes of the second;
+// returns {new first, new second}
+typedef unsigned hipemu_u32x2s __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2s __builtin_amdgcn_permlane32_swap(unsigned a, unsigned b, bool, bool) {
+  const int lane = hipemu::me().lane;
+  const unsigned a_from = hipemu_exchange(a, lane ^ 32), b_from = hipemu_exchange(b, lane ^ 32);
+  hipemu_u32x2s r;
+  r[0] = lane < 32 ? a : b_from;         // a[32..63] <- b[0..31]
+  r[1] = lane < 32 ? a_from : b;         // b[0..31] <- a[32..63]
+  return r;
+}
 
 // ---- MFMA (f32 in / f32 acc) ----------------------------------------------------------------
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));

@@ -280,7 +280,7 @@ def test_engine_conv_f16_all_geometries(emu_lib, mt, pt, ks):
 
 
 def test_engine_f16_and_fp32_arithmetic_agree(emu_lib, monkeypatch):
-    """the step engine on its split-f16 convolutions (default) and on the fp32-input MFMA ones (LEMO_AE_ARITH=fp32, rounds 3-5): same
+    """the step engine on its split-f16 convolutions (LEMO_AE_ARITH=f16, round 6) and on the fp32-input MFMA ones (default): same
     reconstruction, latent and parameters after 3 visible steps to fp32 rounding -- the weight gradients, Adam and every layout are shared"""
     from lemo_amd import infill
     from lemo_amd.infill import AE, finetune_and_infill
