@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0      # dense bf16 MFMA (guide: ~2.5 PF; AMD's 5 PF headline is 2:1 sparse)
 PEAK_HBM_TBS = 8.0                    # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PMC_FILE = os.path.join('profiles', 'r05_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
+PMC_FILE = os.path.join('profiles', 'r06_pmc_summary.json')   # rocprofv3 --pmc passes of THIS round's final code
 
 
 def arithmetic_label(conv_variant):
@@ -53,7 +53,6 @@ def arithmetic_label(conv_variant):
                  'float64 at the level of an fp32 convolution)')
     fusion = {4: 'one layer per launch (conv_split_kernels.hip)',
               5: 'consecutive 64->64 layers run as fused pairs (conv_pair_kernels.hip)',
-              6: 'fused pairs on four-wave workgroups (conv_pair4_kernels.hip)',
               7: 'fused pairs + encoder head (image, layers 0-1) and tail (their backward) one launch each (conv_head_kernels.hip)',
               8: 'fused pairs + encoder head with layer 2 (enc_head3) + tail (conv_head_kernels.hip)',
               9: 'fused pairs + encoder head with layer 2 (enc_head3) and tail with layer 2\'s backward (enc_tail3), conv_head_kernels.hip',
@@ -935,13 +934,13 @@ def main():
                 ab['value_head_without_layer_2'] = variant_probe(rank, B, device, stream, 7, fit)
             if fit.conv_variant != 5:
                 ab['value_pairs_without_fused_head_tail'] = variant_probe(rank, B, device, stream, 5, fit)
-            if fit.conv_variant != 6:
-                ab['value_pairs_four_wave_workgroups'] = variant_probe(rank, B, device, stream, 6, fit)
+            if fit.conv_variant != 10:
+                ab['value_winograd_layers'] = variant_probe(rank, B, device, stream, 10, fit)
             ab['value_fp32_mfma'] = variant_probe(rank, B, device, stream, 2, fit)
             ab['value_headline_again'] = max(timed_fit(fit, prob, stream, device) for _ in range(2))
             ab['note'] = ('fitting-iterations/s over 100 timed steps, same clip / process / box, interleaved: the encoder on conv variant 4 '
-                          '(one split-f16 launch per layer), on variant 8 (tail = layers 1, 0 backwards; layer 2\'s backward a launch of its own), on variant 7 (head = marker image + layers 0, 1; layer 2 forward and backward launches of their own), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 6 (the fused pairs as two four-wave workgroups per CU on 5 x 14 tiles: measured slower, '
-                          'DESIGN 11), on variant 2 (v_mfma_f32_32x32x2_f32, fp32 operands) and the headline engine once more')
+                          '(one split-f16 launch per layer), on variant 8 (tail = layers 1, 0 backwards; layer 2\'s backward a launch of its own), on variant 7 (head = marker image + layers 0, 1; layer 2 forward and backward launches of their own), on variant 5 (round 4\'s default: fused pairs, head and tail layer by layer), on variant 10 (round 6: every 64->64 layer one Winograd F(2x2, 3x3) launch instead of the fused pairs: 2.25 x fewer MFMAs, measured slower, '
+                          'DESIGN 5), on variant 2 (v_mfma_f32_32x32x2_f32, fp32 operands) and the headline engine once more')
             out['variants'] = ab
         except Exception as e:       # noqa: BLE001
             out['variants'] = {'error': f'{type(e).__name__}: {e}'}

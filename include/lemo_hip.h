@@ -96,11 +96,6 @@ int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const fl
 int lemo_conv3x3_wino_supported(int H, int W, int cin, int cout);
 int lemo_conv3x3_wino_f16(const float* in, const void* wU, float winv, const float* wt, const float* bias, const float* aux, float* out,
                           int H, int W, int epi, unsigned long long* dbg, void* stream);
-/* variant 6 (round 5): the same contract on 5 x 14 tiles by four-wave workgroups, two per CU (csrc/conv_pair4_kernels.hip) -- one
- * workgroup's staging / epilogue / conversion phases run under the other's MFMAs.  dbg: 8 stamps per wave, FOUR waves per workgroup. */
-int lemo_conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
-                           const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
-                           unsigned long long* dbg, void* stream);
 /* first layer, 1 input channel: x0 padded [(H+2)*(W+2)], w [Cout][9] */
 int lemo_conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, void* stream);
 int lemo_conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, void* stream);

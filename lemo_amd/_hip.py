@@ -193,7 +193,6 @@ _SIGS = {
     'lemo_conv3x3_wino_supported': (C.c_int, [C.c_int] * 4),
     'lemo_conv3x3_wino_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_conv3x3_pair_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
-    'lemo_conv3x3_pair4_f16': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     'lemo_enc_head': (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp]),
     'lemo_enc_tail': (C.c_int, [vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, vp]),
     'lemo_enc_tail3': (C.c_int, [vp, vp, C.c_float, vp, vp, C.c_float, vp, vp, vp, C.c_int, C.c_int, vp]),

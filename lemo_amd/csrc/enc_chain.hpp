@@ -60,7 +60,7 @@ static inline int enc_chain_fwd(const D& d, int H, int W, hipStream_t s, int l_f
   while (l < 10) {
     if (d.conv_variant >= 5 && d.conv_variant != 10 && l + 1 < 10 && d.enc_w3[l] && d.enc_w3[l + 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l], d.enc_ch[l + 1], d.enc_ch[l + 2])) {
-      ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.act[l], d.enc_w3[l], d.enc_w3_inv[l], d.enc_b[l], nullptr, d.act[l + 1],
+      ENC_CHK(conv3x3_pair_f16(d.act[l], d.enc_w3[l], d.enc_w3_inv[l], d.enc_b[l], nullptr, d.act[l + 1],
                                                                            d.enc_w3[l + 1], d.enc_w3_inv[l + 1], d.enc_b[l + 1], nullptr, d.act[l + 2],
                                                                            H, W, 0, s, nullptr));
       l += 2;
@@ -80,7 +80,7 @@ static inline int enc_chain_bwd(const D& d, int H, int W, hipStream_t s, int* cu
   while (l >= l_last) {
     if (d.conv_variant >= 5 && d.conv_variant != 10 && l - 1 >= l_last && d.enc_wbwd3[l] && d.enc_wbwd3[l - 1] &&
         conv3x3_pair_supported(H, W, d.enc_ch[l + 1], d.enc_ch[l], d.enc_ch[l - 1])) {
-      ENC_CHK((d.conv_variant == 6 ? conv3x3_pair4_f16 : conv3x3_pair_f16)(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd3_inv[l], nullptr, d.act[l], nullptr,
+      ENC_CHK(conv3x3_pair_f16(d.dact[cur], d.enc_wbwd3[l], d.enc_wbwd3_inv[l], nullptr, d.act[l], nullptr,
                                                                            d.enc_wbwd3[l - 1], d.enc_wbwd3_inv[l - 1], nullptr, d.act[l - 1],
                                                                            d.dact[1 - cur], H, W, 1, s, nullptr));
       l -= 2;

@@ -44,11 +44,6 @@ int conv3x3_pair_f16(const float* in, const void* wA, float winvA, const float* 
 bool conv3x3_wino_supported(int H, int W, int cin, int cout);
 int conv3x3_wino_f16(const float* in, const void* wU, float winv, const float* wt, const float* bias, const float* aux, float* out,
                      int H, int W, int epi, hipStream_t s, unsigned long long* dbg = nullptr);
-// ---------------- conv_pair4_kernels.hip ----------------
-// variant 6: the same pair on 5 x 14 tiles by FOUR-wave workgroups, two per CU (one's non-matrix phases under the other's MFMAs)
-int conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid, const void* wB,
-                      float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi, hipStream_t s,
-                      unsigned long long* dbg = nullptr);
 int conv3x3_c1(const float* x0, const float* w, const float* bias, float* out, int H, int W, int cout, hipStream_t s);
 int conv3x3_c1_bwd(const float* dpre, const float* w, float* dx0, int H, int W, int cout, hipStream_t s);
 int smooth_loss_blocks(int H, int W, int C);

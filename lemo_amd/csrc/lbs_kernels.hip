@@ -913,9 +913,6 @@ lbs_bwd_dense_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
 // added in chunk order by lbs_bwd_reduce_kernel.  No atomics anywhere: two runs give identical bits.
 #define LBS_PART_STRIDE(nj) ((nj) * 12 + 4)
 #define LBS_CHUNK_NNZ 2560       // staged (position, weight) pairs per chunk: 512 vertices x <= 5 weights (20 KB); above: global reads
-#ifndef LBS_JOINT_SMALL
-#define LBS_JOINT_SMALL 0        // entries of a joint in a chunk up to which a thread per output adds them (above: a wave per joint)
-#endif
 __global__ void __launch_bounds__(256)
 lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, int nj, const float* __restrict__ v_posed,
                      int vp_rows, const float* __restrict__ dverts, float* __restrict__ dvp) {
@@ -1026,34 +1023,15 @@ lbs_bwd_chunk_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ A, i
   __syncthreads();
   if (t < 3) part[nj * 12 + t] = ((red[t] + red[3 + t]) + red[6 + t]) + red[9 + t];
   // ---- joint-major: dA[j][r][:] = sum over the chunk's entries of joint j of  w g_r (x) [v, 1]
-  // Joints with at most LBS_JOINT_SMALL entries in this chunk: one THREAD per output (j, e = 4 r + c), its entries added in list
-  // order; the others: a wave per joint.  Shipped with LBS_JOINT_SMALL = 0 (only the empty joints, which just store zeros, take the
-  // thread form).  Round 5 built the thread form for joints with few entries on the argument that the kernel is bound by the vector
-  // instructions it issues and a wave per joint pays ~220 of them however few entries there are (i.i.d. skinning weights: ~37
-  // entries per joint and chunk, 14 joints per wave) against ~10 per entry on 12 lanes -- and measured it SLOWER: PROX window
-  // 2434 / 2397 it/s with 0, 2259 / 2264 with 64, 2268 / 2279 with 32, 2285 / 2262 with 128 (model with index locality: 2595 / 2555,
-  // 2523 / 2534, 2547 / 2535, 2350 / 2344; profiles/r05_ab_lbs_bwd_joint_threads.txt): `lbs_bwd_chunk` 41 -> 69 us.  A thread's loop
-  // is a chain of dependent LDS reads (entry -> position -> g, v) that four waves per SIMD do not cover; the wave form reads them all at once.
-  for (int o = t; o < nj * 12; o += 256) {
-    const int j = o / 12, e = o - 12 * j;
-    const int q0 = tabs[j], q1 = tabs[j + 1];
-    if (q1 - q0 > LBS_JOINT_SMALL) continue;
-    const int r = e >> 2, c = e & 3, cc = c < 3 ? c : 0;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-      const int l = (staged ? cus[q - e0] : u.jc_u[q]) - s0;
-      const float w = staged ? cws[q - e0] : u.jc_w[q];
-      const float gv = gs[3 * l + r] * w;
-      const float vv = c < 3 ? vs[3 * l + cc] : 1.f;
-      acc = fmaf(gv, vv, acc);
-    }
-    part[o] = acc;
-  }
+  // A wave per joint; joints without entries in this chunk store zeros.  (Round 5 also built a thread-per-output form for joints with
+  // few entries and measured it slower -- `lbs_bwd_chunk` 41 -> 69 us, a thread's loop is a chain of dependent LDS reads --
+  // profiles/r05_ab_lbs_bwd_joint_threads.txt; the code was deleted in round 6.)
+  for (int o = t; o < nj * 12; o += 256)
+    if (tabs[o / 12 + 1] == tabs[o / 12]) part[o] = 0.f;
   const int wave = t >> 6, lane = t & 63;
   for (int j = wave; j < nj; j += 4) {
     const int q0 = tabs[j], q1 = tabs[j + 1];
-    if (q1 - q0 <= LBS_JOINT_SMALL) continue;                    // wave-uniform: taken above
+    if (q1 == q0) continue;                                      // wave-uniform: zeroed above
     float acc[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;

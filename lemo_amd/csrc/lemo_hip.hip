@@ -64,11 +64,6 @@ int lemo_conv3x3_pair_f16(const float* in, const void* wA, float winvA, const fl
                           unsigned long long* dbg, void* stream) {
   return conv3x3_pair_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
 }
-int lemo_conv3x3_pair4_f16(const float* in, const void* wA, float winvA, const float* biasA, const float* auxA, float* mid,
-                           const void* wB, float winvB, const float* biasB, const float* auxB, float* out, int H, int W, int epi,
-                           unsigned long long* dbg, void* stream) {
-  return conv3x3_pair4_f16(in, wA, winvA, biasA, auxA, mid, wB, winvB, biasB, auxB, out, H, W, epi, S(stream), dbg);
-}
 int lemo_enc_head(const lemo_fit_const* fc, const float* verts, int nrows, const float* Jtr, int nj, const float* transl, int B, const float* w0,
                   const float* b0, const void* w1pack, float w1inv, const float* b1, float* x0, float* canon, float* act1, float* act2,
                   void* stream) {

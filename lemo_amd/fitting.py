@@ -126,7 +126,8 @@ class AmassTemporalFitter(_hip.StreamOrdered):
             conv_variant = 1                      # LDS tile of variant 2 holds W <= 139 (B <= 124); the single-layer split kernels W <= 134
         # (variant 5 stays: the fused pairs take any width -- 12 of the 14 64 -> 64 layers; the engine sends the other launches to the
         # fp32-input kernel layer by layer, lemo_amd/csrc/enc_chain.hpp::enc_layer.  Round 4: all 18 launches used to fall back.)
-        self.conv_variant = d.conv_variant = int(conv_variant)
+        from .priors import check_conv_variant
+        self.conv_variant = d.conv_variant = check_conv_variant(conv_variant)
         if not self.per_frame:
             from .priors import warn_if_wide_image
             warn_if_wide_image(self.lib, H, W, self.conv_variant)

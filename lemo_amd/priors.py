@@ -225,6 +225,18 @@ exact bf16 pieces, 6 products), LDS-tiled fp32-MFMA kernel (2) for shapes they d
 The environment override exists for A/B runs of the parity suite."""
 
 
+def check_conv_variant(v: int) -> int:
+    """conv variants the library carries (include/lemo_hip.h, lemo_fit_desc.conv_variant); 6 -- the fused pairs on four-wave workgroups,
+    measured 12 % slower in round 5 -- moved to csrc/attic in round 6"""
+    v = int(v)
+    if v == 6:
+        raise ValueError('conv variant 6 (four-wave fused pairs) was removed in round 6: measured slower than variant 5 '
+                         '(profiles/r05_pair4_check.txt); the source is in lemo_amd/csrc/attic')
+    if v < 0 or v > WINO_VARIANT:
+        raise ValueError(f'unknown conv variant {v}')
+    return v
+
+
 def _conv_layer(lib, enc: EncWeights, l: int, bwd: bool, x, out, aux, H, W, variant, s):
     """one MFMA layer (forward: epi 0 with bias; backward-data: epi 1 with the saved activation) on the best
     kernel family `variant` allows for its shape"""

@@ -412,7 +412,8 @@ class ProxWindowEngine(_hip.StreamOrdered):
         cv = DEFAULT_CONV_VARIANT if conv_variant is None else int(conv_variant)
         if cv in (2, 3, 4) and 127 + 2 * (127 // W + 1) + 2 * (W + 2) + 3 > 416:
             cv = 1                                 # (variant 5 stays for wide windows: the fused pairs take any width, fitting.py)
-        self.conv_variant = d.conv_variant = cv
+        from .priors import check_conv_variant
+        self.conv_variant = d.conv_variant = check_conv_variant(cv)
         d.first_batch_flag, d.use_infill, d.T = int(bool(first_batch_flag)), int(self.use_infill), B - 1
         d.vposer, d.body, d.skin, d.uset, d.fit, d.pc = self.vposer_struct, self.dbody.body, self.dbody.skin, uset, fitc, pc
         for i, c in enumerate(ENC_CHANNELS): d.enc_ch[i] = c

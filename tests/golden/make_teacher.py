@@ -33,6 +33,7 @@ from lemo_amd import synthetic                           # noqa: E402
 torch.set_num_threads(8)
 
 AMASS_STEPS = (0, 1, 10, 30, 60, 61, 62, 99)
+AMASS_EXTRA_STATES = (15, 67)      # states only (round 6): where five graph-replayed steps from states 10 / 62 must land (test_gpu_teacher.py)
 """recorded iterations of the 100-step loop: the start, the first update with history, mid-run, both sides of the lr switch
 (``if step > 60: lr = 0.005``, opt_amass_temp.py:350-352: iteration 60 is the last at 0.01, 61 the first at 0.005) and the
 last one"""
@@ -64,7 +65,7 @@ def amass():
     gold = np.load(os.path.join(HERE, 'amass_iter.npz'))
     t0 = time.time()
     recs, p72 = RH.run_amass_loop_text(so, vw, A['ids'], A['Xmean'], A['Xstd'], seq['init_params'], gold['markers_rec'],
-                                       seq['contact_lbl'], AMASS_STEPS)
+                                       seq['contact_lbl'], tuple(sorted(AMASS_STEPS + AMASS_EXTRA_STATES)))
     print(f'reference loop text: 100 steps in {time.time() - t0:.0f} s')
     # consistency with the committed one-iteration fixture (written by the oracle, pinned to the same text at 0.0)
     assert np.array_equal(recs[0]['before']['params'][0], seq['init_params'][:, 0:3])
@@ -74,6 +75,9 @@ def amass():
     out = dict(steps=np.asarray(AMASS_STEPS, np.int32), p72_final=p72)
     vwn = {k: v.numpy() for k, v in vw.items()}
     o64 = amass_fit_oracle_f64(m, vwn, A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], seq['init_params'], gold['markers_rec'], seq['contact_lbl'])
+    for k in AMASS_EXTRA_STATES:
+        assert recs[k]['before']['step'] == k
+        out.update(_state_arrays(f's{k}', recs[k]['before']))
     for k in AMASS_STEPS:
         r = recs[k]
         assert r['before']['step'] == k and r['after']['step'] == k + 1

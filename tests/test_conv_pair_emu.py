@@ -24,11 +24,11 @@ def _border_is_zero(buf, H, W):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16'])
 @pytest.mark.parametrize('H,W', [(10, 14), (7, 9), (23, 31), (36, 57)])
 def test_pair_forward_and_backward_vs_float64(emu_lib, H, W, kernel):
     """one tile exactly / less than one tile / ragged edges in both directions / several tiles per XCD run -- for the 8-wave kernel on
-    10 x 14 tiles (variant 5) and the 4-wave kernel on 5 x 14 tiles (variant 6, csrc/conv_pair4_kernels.hip)"""
+    10 x 14 tiles (variant 5; its four-wave twin, variant 6, moved to csrc/attic in round 6)"""
     pair = getattr(emu_lib, kernel)
     g = torch.Generator().manual_seed(H * 100 + W)
     x = torch.randn(64, H, W, generator=g)
@@ -73,7 +73,7 @@ def test_pair_forward_and_backward_vs_float64(emu_lib, H, W, kernel):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16'])
 def test_pair_range_homogeneity_and_zero_input(emu_lib, kernel):
     """per-workgroup power-of-two scales: magnitudes falling by 8 orders across the image keep fp32-sized errors row by row, the
     result is exactly homogeneous under power-of-two scalings (zero bias), and an all-zero input gives lrelu(conv(lrelu(b1)) + b2)"""
@@ -105,7 +105,7 @@ def test_pair_range_homogeneity_and_zero_input(emu_lib, kernel):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16', 'conv3x3_pair4_f16'])
+@pytest.mark.parametrize('kernel', ['conv3x3_pair_f16'])
 @pytest.mark.parametrize('case', ['second_phase_zero', 'second_phase_tiny', 'first_phase_zero'])
 def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case, kernel):
     """the kernels stage channels {0-15, 32-47} and {16-31, 48-63} in two phases with their own power-of-two
@@ -116,11 +116,8 @@ def test_pair_and_single_layer_with_a_vanishing_staging_phase(emu_lib, case, ker
     g = torch.Generator().manual_seed(77)
     x = torch.randn(64, H, W, generator=g)
     second = torch.zeros(64, dtype=torch.bool)
-    if kernel == 'conv3x3_pair4_f16':
-        second[32:64] = True                # the 4-wave kernel stages channel groups 0-3, then 4-7
-    else:
-        second[16:32] = True
-        second[48:64] = True
+    second[16:32] = True                    # the second staging phase: channel groups 2-3 and 6-7
+    second[48:64] = True
     if case == 'second_phase_zero':
         x[second] = 0.0
     elif case == 'second_phase_tiny':

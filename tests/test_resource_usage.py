@@ -20,12 +20,15 @@ BUDGETS = {
     'conv3x3_split_kernelILi1ELi64ELi64ELi3ELb0E': ('conv_split_kernels.hip', 256, 512),
     'conv3x3_pair_kernelILi0ELb0E': ('conv_pair_kernels.hip', 256, 512),                # fused layer pairs (variant 5): forward / backward-data
     'conv3x3_pair_kernelILi1ELb0E': ('conv_pair_kernels.hip', 256, 512),
-    'conv3x3_pair4_kernelILi0ELb0E': ('conv_pair4_kernels.hip', 256, 256),              # variant 6: four waves, TWO workgroups per CU -> 2 waves per SIMD
-    'conv3x3_pair4_kernelILi1ELb0E': ('conv_pair4_kernels.hip', 256, 256),
     'enc_head_kernel': ('conv_head_kernels.hip', 128, 512),                              # variant 7: fused head / tail of the encoder
     'enc_tail_kernel': ('conv_head_kernels.hip', 128, 512),
     'enc_head3_kernel': ('conv_head_kernels.hip', 256, 512),
-    'enc_tail3_kernel': ('conv_head_kernels.hip', 256, 512),                            # variant 9: layers 2-0 backwards in the tail, one workgroup per CU (112 KB of LDS)                            # variant 8 (default): layers 0-2 in the head, one workgroup per CU
+    'enc_tail3_kernel': ('conv_head_kernels.hip', 256, 512),
+    'conv3x3_wino_kernelILi0ELb0E': ('conv_wino_kernels.hip', 256, 512),              # variant 10: Winograd layer, one 8-wave workgroup per CU (128 KB of LDS)
+    'conv3x3_wino_kernelILi1ELb0E': ('conv_wino_kernels.hip', 256, 512),
+    'ae_conv_f16_kernelILi1ELi0E': ('ae_engine.hip', 128, 1024),                        # split-f16 AE convolutions: 16 waves (MT 1) / 8 waves (MT 2)
+    'ae_conv_f16_kernelILi2ELi0E': ('ae_engine.hip', 256, 512),
+    'ae_conv16_f16_kernelILi0E': ('ae_engine.hip', 128, 1024),                            # variant 9: layers 2-0 backwards in the tail, one workgroup per CU (112 KB of LDS)                            # variant 8 (default): layers 0-2 in the head, one workgroup per CU
     'lbs_verts_fwd_kernelILb0ELb1E': ('lbs_kernels.hip', 256, 512),
     'lbs_bwd_frame_kernelILb1ELb1E': ('lbs_kernels.hip', 128, 1024),                   # 16 waves: 128 VGPRs is the hard limit
     'lbs_bwd_frame_kernelILb1ELb0E': ('lbs_kernels.hip', 128, 1024),
