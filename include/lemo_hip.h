@@ -395,10 +395,16 @@ int lemo_enc_tail3(const float* din, const void* w2bpack, float w2binv, const fl
 typedef struct lemo_fit_desc {
   int B, Bp, V, nrows;            /* frames, padded frames, model vertices, rows of `verts` (V or n) */
   int full_vertices;              /* 1: regress all V vertices per frame (reference behaviour) ; 0: only the set U */
-  int conv_variant;               /* 5: fused layer pairs (lemo_conv3x3_pair_f16) where three consecutive channel counts allow,
-                                   * variant 4 for the remaining layers (default) ; 6: the same pairs through lemo_conv3x3_pair4_f16 (four-wave
-                                   * workgroups, two per CU: same bits, measured slower -- kept selectable) ; 7: variant 5 + lemo_enc_head / lemo_enc_tail ; 8 (default): 7 with layer 2 (32 -> 64) inside the head launch too (+0.9 %) ; 9: 8 with layer 2's backward inside the tail launch (lemo_enc_tail3) ; 4: split-f16 ; 0/1: lemo_conv3x3_mfma variants ;
-                                   * 2: lemo_conv3x3_mfma_lds ; 3: lemo_conv3x3_mfma_split where it takes the shape, else variant 2 */
+  int conv_variant;               /* kernel family of the encoder's MFMA layers (the struct has no default: 0 selects lemo_conv3x3_mfma variant 0;
+                                   * lemo_amd.priors.DEFAULT_CONV_VARIANT = 9 is what the Python fitters pass and what every gate runs on):
+                                   * 9 (shipped): lemo_enc_head3 (image + layers 0-2) + fused 64 -> 64 pairs (lemo_conv3x3_pair_f16) + lemo_enc_tail3
+                                   *    (layers 2-0 backwards), split-f16 arithmetic throughout ; 8: 9 with layer 2's backward a launch of its own ;
+                                   * 7: head / tail without layer 2 (lemo_enc_head / lemo_enc_tail) ; 5: pairs only, head and tail layer by layer ;
+                                   * 10 (round 6): 9 with every 64 -> 64 layer ONE Winograd launch (lemo_conv3x3_wino_f16) instead of the pairs --
+                                   *    parity-green, measured slower, enc_w3 / enc_wbwd3 of those layers then hold the Winograd packs ;
+                                   * 4: split-f16, one launch per layer ; 3: split-bf16 (lemo_conv3x3_mfma_split) where it takes the shape, else 2 ;
+                                   * 2: lemo_conv3x3_mfma_lds ; 0 / 1: lemo_conv3x3_mfma variants (the any-shape fallback of all the others).
+                                   * (6, the pairs on four-wave workgroups, left the library in round 6: csrc/attic) */
   lemo_vposer_w vposer;
   lemo_body_const body;
   lemo_skin_const skin;

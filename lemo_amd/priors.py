@@ -214,10 +214,10 @@ class EncWeights:
 # ----------------------------------------------------------------------------------------------
 
 DEFAULT_CONV_VARIANT = int(__import__('os').environ.get('LEMO_CONV_VARIANT', '9'))
-"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 9 (default since round 5) = 8 with layer 2's backward-data (64 -> 32) inside the
+"""Kernel family of the encoder's MFMA layers (``conv_variant`` of include/lemo_hip.h): 10 (round 6, selectable, measured slower: DESIGN 5) = 9 with every
+64 -> 64 layer one Winograd F(2x2, 3x3) launch (csrc/conv_wino_kernels.hip) instead of the fused pairs; 9 (default since round 5) = 8 with layer 2's backward-data (64 -> 32) inside the
 tail launch (+0.5 %); 8 = 7 with layer 2 (32 -> 64) inside the head launch as well (0 .. +0.9 % box to box); 7 = 5 plus the encoder's head and tail as one launch each (marker image + layers 0, 1 / their adjoints:
-csrc/conv_head_kernels.hip, +2.1 % iterations/s); 6 = 5 with
-the pairs on four-wave workgroups (measured slower, kept selectable); 5 = the engines run consecutive 64 -> 64
+csrc/conv_head_kernels.hip, +2.1 % iterations/s); (6, the pairs on four-wave workgroups, was removed in round 6: csrc/attic); 5 = the engines run consecutive 64 -> 64
 layers as fused PAIRS (one launch, intermediate in LDS; csrc/conv_pair_kernels.hip; the default since round 4) in the arithmetic
 of 4 = split-f16 kernel (two error-compensated fp16 pieces per fp32 operand, 3 products; layer by layer -- what the module /
 autograd path runs for 4 and 5 alike), 3 = split-bf16 kernel (three

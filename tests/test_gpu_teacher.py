@@ -17,7 +17,7 @@ from lemo_amd.assets import load_assets
 pytestmark = pytest.mark.gpu
 GROUPS = (('transl', 0, 3), ('rot6d', 3, 9), ('other', 9, 65))
 REPORT = []
-MULTI_STEP_GATE = {0: 0.5, 60: 1.2e-2, 10: None, 62: None}     # x lr: 3 x the measured 1.6e-1 (0 -> 2: noise-level entries, Adam divides by sqrt(v) ~ 0) and 3.7e-3 (60 -> 63)
+MULTI_STEP_GATE = {0: 0.5, 60: 1.2e-2, 10: 4.5e-2, 62: 2.5e-2}     # (10 -> 15, 62 -> 67, five steps each, round 6: 3 x the measured 1.5e-2 / 8.2e-3 lr on either kernel family)     # x lr: 3 x the measured 1.6e-1 (0 -> 2: noise-level entries, Adam divides by sqrt(v) ~ 0) and 3.7e-3 (60 -> 63)
 
 
 @pytest.fixture(scope='module')
@@ -156,7 +156,7 @@ def test_amass_loop_teacher_forced_full_size(dev, conv_variant):
         REPORT.append(f'amass[v{conv_variant}] {n} replayed steps from reference state {k0}: max |dp|/lr {dp:.2e}, exp_avg max-rel {dm:.2e}')
         # measured 1.6e-1 lr (0 -> 2: 4843 of the 7735 entries are noise-level at step 0, see above) and 3.7e-3 lr (60 -> 63), exp_avg
         # 4e-4 / 3e-3; a lost update or a wrong lr level is >= 1 lr on every entry
-        assert MULTI_STEP_GATE[k0] is None or (dp <= MULTI_STEP_GATE[k0] and dm <= 1e-2), (k0, n, dp, dm)
+        assert dp <= MULTI_STEP_GATE[k0] and dm <= (1e-2 if n <= 3 else 2e-2), (k0, n, dp, dm)      # (exp_avg after five steps: measured 5.8e-3)
     # body_params_opt_t_72 of the reference's LAST forward (opt_amass_temp.py:457) = state 99 through the 6-D -> aa conversion
     fit.load_state(_state(T, '', 99))
     fit.forward()
