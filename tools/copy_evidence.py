@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>/ (written by tools/gpu_round3.sh / gpu_round4.sh / gpu_round5.sh) -> profiles/<round>_*: json / csv files replace their predecessors, text
+"""gpurun_out/<tag>/ (written by tools/gpu_round3.sh .. gpu_round6.sh) -> profiles/<round>_*: json / csv files replace their predecessors, text
 files keep the previous visit's content below a separator (one generation).  Usage: python tools/copy_evidence.py r04final r04"""
 import os, shutil, sys
 tag = sys.argv[1]
