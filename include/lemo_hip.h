@@ -457,6 +457,14 @@ typedef struct lemo_fit_desc {
                                    * encoder, no contact term), any B >= 1 */
   float lr2;                      /* third learning-rate level: lr = lr2 when step > lr_switch2 > 0 (opt_amass_perframe.py:316-321) */
   int lr_switch2;
+  /* ---- round-6 addition (appended; NULL = previous behaviour): the all-vertex forward OFF the iteration's critical path ---- */
+  float* verts_side;              /* [B][V][3] or NULL.  With full_vertices = 0 (the loss path forwards only the set U): every iteration ALSO regresses
+                                   * all V vertices of its pose into this buffer (what the reference's smplx forward returns: utils/utils.py:152), by a
+                                   * launch on the engine's own side stream that starts behind the encoder's backward tail and runs beside the per-frame
+                                   * launches of the iteration's end (119 of 256 CUs); it is joined before the next iteration's pose stage overwrites its
+                                   * operands, and at the end of every call / graph.  Same kernel, same bits as the in-line forward of full_vertices = 1. */
+  float* transl_side;             /* [B][3], required with verts_side: the translation of the iteration's forward (the Adam launch updates `transl` while
+                                   * the side launch is in flight; the set-U forward leaves a copy here) */
 } lemo_fit_desc;
 
 /* Opaque engine: holds a copy of the descriptor (pointers only) and, optionally, a captured hipGraph. */

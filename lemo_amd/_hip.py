@@ -107,6 +107,7 @@ class FitDesc(C.Structure):
         ('dA', vp), ('dX', vp), ('loss_acc', vp), ('step_cur', vp),
         ('g_transl', vp), ('g_rot6d', vp), ('g_other', vp), ('g_go', vp), ('g_body', vp),
         ('snap', vp), ('nonfinite', vp), ('per_frame', C.c_int), ('lr2', C.c_float), ('lr_switch2', C.c_int),
+        ('verts_side', vp), ('transl_side', vp),
     ]
 
 

@@ -106,10 +106,10 @@ int smplx_pose_bwd(const BodyConst& c, const PoseWs& ws, const PoseGradIn& gi, c
 int lbs_init();
 // verts[b][slot] for slot < n ; ids == null => slot == vertex id, n == V
 int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
-                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s);
+                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s, float* transl_copy = nullptr);
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg = nullptr,
-                  const unsigned short* XgS = nullptr);
+                  const unsigned short* XgS = nullptr, int max_blocks_x = 0 /* > 0: at most this many workgroups, each looping over its tiles */);
 bool lbs_verts_bwd_fusable(const SkinConst& c, const VertexSetBwd& u, int nj);
 int lbs_verts_bwd(const SkinConst& c, const VertexSetBwd& u, const float* A, int nj, const float* v_posed, int vp_rows,
                   const float* dverts /*[B][n][3]*/, int B, int Bp, float* dvp /*[B][NCs] scratch*/,

@@ -53,7 +53,11 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   if (DBG) t_start = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int s0 = blockIdx.x * LBS_VPB;                 // first vertex slot of this tile
+  // a workgroup takes vertex tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one tile each in the in-line launch; the fit engine's
+  // side-branch launch runs 125 workgroups x 2 tiles so that the per-frame launches it overlaps keep half of the CUs: round 6)
+  const int ntile_x = (n + LBS_VPB - 1) / LBS_VPB;
+  for (int tile_x = blockIdx.x; tile_x < ntile_x; tile_x += gridDim.x) {
+  const int s0 = tile_x * LBS_VPB;                     // first vertex slot of this tile
   const int f0 = blockIdx.y * LBS_FR;                  // first frame of this pass
   const int nt = wave & 3, mp = wave >> 2;
   // ---- staging plan: thread -> fixed (column, half) of A and (frame, half) of B; groups (tid>>8) + 2k
@@ -477,6 +481,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
 #undef LBS_ALOAD
 #undef LBS_ASTORE
+  }   // tile loop (its last statement is a workgroup barrier: the next tile may overwrite LDS)
   if (DBG && lane == 0) {
     unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
     r[0] = t_start; r[1] = t_pro; r[2] = t_gemm; r[3] = __builtin_amdgcn_s_memtime();
@@ -498,12 +503,13 @@ int lbs_init() {
 
 int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, int nj, const float* transl,
                   const int* ids, int n, int B, float* verts, float* v_posed, hipStream_t s, unsigned long long* dbg,
-                  const unsigned short* XgS) {
+                  const unsigned short* XgS, int max_blocks_x) {
   if (n <= 0 || B <= 0 || B > Bp || (Bp % 32) || (!ids && n != c.V)) return LEMO_ERR_SHAPE;
   if (lbs_init()) return LEMO_ERR_STATE;
   if (nj > 64 || 3 * nj * 12 > 5 * 512) return LEMO_ERR_SHAPE;
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
+  if (max_blocks_x > 0 && (int)grid.x > max_blocks_x) grid.x = max_blocks_x;      // the kernel loops over its tiles (same arithmetic per tile: same bits)
 #define LAUNCH(DBG_, SPLIT_, PRE_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
 #define LAUNCHH(DBG_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, true, true, true>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
   if (!c.blend_fp32 && XgS && c.DgH) { if (dbg) LAUNCHH(true); else LAUNCHH(false); }      // (XgS in its fp16 form: lemo_pose_ws.xgs_f16)
@@ -524,10 +530,12 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 lbs_skin_active_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ blend, const float* __restrict__ A, int nj,
-                       const float* __restrict__ transl, int B, float* __restrict__ verts, float* __restrict__ v_posed) {
+                       const float* __restrict__ transl, int B, float* __restrict__ verts, float* __restrict__ v_posed,
+                       float* __restrict__ transl_copy) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * u.n) return;
   const int b = idx / u.n, s = idx - b * u.n;
+  if (transl_copy && transl && s < 3) transl_copy[b * 3 + s] = transl[b * 3 + s];      // the forward's translation, for the fit engine's side-branch launch
   const int vid = u.ids[s];
   const float* bl = blend + (size_t)b * u.NCs + 3 * s;
   const float px = bl[0] + c.v_template[(size_t)vid * 3], py = bl[1] + c.v_template[(size_t)vid * 3 + 1],
@@ -566,10 +574,10 @@ lbs_skin_active_kernel(SkinConst c, VertexSetBwd u, const float* __restrict__ bl
 }
 
 int lbs_verts_fwd_active(const SkinConst& c, const VertexSetBwd& u, const float* Xg, int Bp, const float* A, int nj,
-                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s) {
-  if (u.n <= 0 || B <= 0 || B > Bp || (u.NCs % 16) || u.NCs < 3 * u.n || !u.DkT || !blend) return LEMO_ERR_SHAPE;
+                         const float* transl, int B, float* blend, float* verts, float* v_posed, hipStream_t s, float* transl_copy) {
+  if (u.n <= 0 || B <= 0 || B > Bp || (u.NCs % 16) || u.NCs < 3 * u.n || !u.DkT || !blend || (transl_copy && u.n < 3)) return LEMO_ERR_SHAPE;
   if (int e = gemm_nt16_kg8(u.DkT, 512, Xg, Bp, u.NCs, B, 512, blend, u.NCs, s)) return e;
-  hipLaunchKernelGGL(lbs_skin_active_kernel, dim3((B * u.n + 255) / 256), dim3(256), 0, s, c, u, blend, A, nj, transl, B, verts, v_posed);
+  hipLaunchKernelGGL(lbs_skin_active_kernel, dim3((B * u.n + 255) / 256), dim3(256), 0, s, c, u, blend, A, nj, transl, B, verts, v_posed, transl_copy);
   return (int)hipGetLastError();
 }
 

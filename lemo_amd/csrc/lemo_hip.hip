@@ -13,7 +13,7 @@ using namespace lemo;
 
 extern "C" {
 
-int lemo_abi_version(void) { return 4; }
+int lemo_abi_version(void) { return 5; }
 int lemo_build_flags(void) {
 #ifdef LEMO_NO_PACKED_FP32
   return 1;
@@ -272,19 +272,21 @@ int lemo_local_markers_4chan(const float* body, const float* contact, int T, int
 // Graphs of 1 .. FIT_MAXG iterations are captured on first use (lemo_fit_prepare) and kept.
 static const int FIT_MAXG = 20;     // iterations per graph, at most (20: 372.4 vs 374.4 us per iteration with 5 only, same box)
 
+struct FitSide { hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool pending = false; };      // (see fit_side_launch below)
 struct FitEngine {
   lemo_fit_desc d;
   hipGraphExec_t exec[FIT_MAXG + 1] = {};      // exec[k] = k iterations
   int head = 5;     // > 0: a call opens with a 1-iteration and a `head`-iteration graph (LEMO_FIT_HEAD overrides; 0 = largest graphs first)
+  FitSide fs;       // side stream + events of the all-vertex side launch (lemo_fit_desc.verts_side); unused otherwise
 };
 
-static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last);
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last, FitSide* fs);
 
 static int capture_iterations(FitEngine* e, hipStream_t s, int iters, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   CHK((int)hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = 0;
-  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s, i == 0, i == iters - 1);
+  for (int i = 0; i < iters && !rc; ++i) rc = fit_iteration(e->d, s, i == 0, i == iters - 1, &e->fs);
   const int ec = (int)hipStreamEndCapture(s, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   CHK(ec);
@@ -336,10 +338,37 @@ static FitTail fit_tail_args(const lemo_fit_desc& d, bool dz, bool adam, bool h1
   return a;
 }
 
+// The all-vertex forward off the critical path (lemo_fit_desc.verts_side, round 6).  Only the 253 vertices of the set U feed the losses; the
+// other 10222 rows of the reference's `vertices` output have no consumer inside the iteration.  The launch that regresses them (30 us on all
+// 250 CUs, a tenth of the iteration) is issued on the engine's own side stream behind the encoder's backward tail, on 125 workgroups of two
+// tiles each, so that it runs BESIDE the eight per-frame launches that close the iteration (one workgroup per frame: 119 of 256 CUs, ~56 us)
+// instead of in front of the encoder; it is joined before the next iteration's pose kernel overwrites its operands (Xg, XgS, A; the
+// translation it adds is the copy the set-U forward left in transl_side, because the Adam launch rewrites `transl` meanwhile), and at the
+// end of every run / captured graph.  Round 5 measured the same idea with the 250-workgroup launch and lost 3-8 %: its one-per-CU
+// workgroups took the CUs the per-frame launches needed (DESIGN_HISTORY 11.7).
+// MEASURED (round 6, profiles/r06_side_forward.txt): bit-identical vertices, the launches DO overlap (side launch 50.9 us beside the tail's
+// 68 us) -- and the iteration is 333 us instead of 309 (3001-3016 against 3222-3254 it/s; 3507 without the all-vertex forward at all): the
+// graph runs the two branches on two hardware queues and every cross-queue edge costs ~6-12 us of idle time on the branch that waits (fork:
+// the per-frame chain starts 12 us behind the encoder's tail; join: the next pose kernel 10 us behind the last GEMM although the side launch
+// had finished 24 us earlier), while the per-frame launches run 15 us longer beside it.  Two edges per iteration cost what the overlap
+// buys.  The path is kept -- tested, selectable (AmassTemporalFitter(side_full_forward=True), LEMO_SIDE_FULL_FORWARD=1) -- and OFF.
+#define FIT_SIDE_BLOCKS 125
+static int fit_side_launch(const lemo_fit_desc& d, hipStream_t s) {      // the launch itself, on whatever stream
+  static const int blocks = getenv("LEMO_FIT_SIDE_BLOCKS") ? atoi(getenv("LEMO_FIT_SIDE_BLOCKS")) : FIT_SIDE_BLOCKS;      // A/B knob
+  return lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, d.body.nj, d.transl_side, nullptr, d.V, d.B, d.verts_side, nullptr, s, nullptr, d.pose.XgS,
+                       blocks);
+}
+static int fit_side_join(FitSide* fs, hipStream_t s) {
+  if (!fs || !fs->pending) return 0;
+  fs->pending = false;
+  return fs->side ? (int)hipStreamWaitEvent(s, fs->join, 0) : 0;
+}
+
 // compute_h1: the first VPoser layer is launched here (a bare forward, or the first iteration of a graph / call); inside
 // a run of iterations the previous iteration's tail launch has already produced it from the updated latent
 // `stages` (diagnostics, lemo_fit_census): bit 0 VPoser + pose stage, 1 vertex stage, 2 marker image + encoder forward, 3 losses
-static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true, unsigned stages = ~0u) {
+// fs: the side-branch context of a run of iterations (null: a bare forward -- the all-vertex forward of verts_side then runs in line)
+static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, bool compute_h1 = true, unsigned stages = ~0u, FitSide* fs = nullptr) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   // VPoser MLP (3 MFMA GEMMs); its rotation head and the 6-D -> axis-angle conversion of the global
@@ -355,13 +384,18 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
   in.betas = d.shape; in.betas_stride = 10;
   in.zero_f64 = d.loss_acc; in.n_zero = 512; in.step_ctr = d.step_ctr; in.step_cur = d.step_cur;
   in.nonfinite = d.nonfinite;
+  CHK(fit_side_join(fs, s));                               // the previous iteration's side launch still reads Xg / XgS / A
   CHK(smplx_pose_fwd(d.body, in, d.pose, B, s));
   }
   if (stages & 2u) {
   if (d.full_vertices) CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, nullptr, d.V, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
   else if (d.uset.DkT && d.uset.n == d.fit.n)      // the loss-carrying set IS the backward set U (same order): small-set path
-    CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s));
-  else CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
+    CHK(lbs_verts_fwd_active(d.skin, d.uset, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, B, d.dvp, d.verts, d.v_posed, s, d.verts_side ? d.transl_side : nullptr));
+  else {
+    CHK(lbs_verts_fwd(d.skin, d.pose.Xg, d.Bp, d.pose.A, nj, d.transl, d.fwd_ids, d.fit.n, B, d.verts, d.v_posed, s, nullptr, d.pose.XgS));
+    if (d.verts_side && !d.full_vertices) CHK((int)hipMemcpyAsync(d.transl_side, d.transl, sizeof(float) * 3 * B, hipMemcpyDeviceToDevice, s));
+  }
+  if (d.verts_side && !d.full_vertices && !fs) CHK(fit_side_launch(d, s));      // bare forward: in line
   }
   if (d.per_frame) {       // opt_amass_perframe.py:324-351: marker L1 + the three L2 priors, nothing temporal
     CHK(vertex_loss_accumulate(d.fit, d.verts, d.nrows, d.target, d.contact, d.shape, d.other, B, d.loss_acc, s));
@@ -392,7 +426,7 @@ static int fit_forward(const lemo_fit_desc& d, hipStream_t s, bool finalize, boo
 // update = false: gradients only (lemo_fit_backward).  update = true: the tail launch also runs Adam and, with next_h1,
 // the first VPoser layer of the next iteration.
 // `stages`: bit 4 encoder backward-data + first-layer adjoint, 5 vertex-stage backward, 6 pose / VPoser backward + tail
-static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false, unsigned stages = ~0u) {
+static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = false, bool next_h1 = false, unsigned stages = ~0u, FitSide* fs = nullptr) {
   const int B = d.B, nj = d.body.nj;
   const int H = 3 * d.fit.n81 + 2, W = B - 1 + 16;
   const double cnt = d.per_frame ? 1.0 : (double)d.enc_ch[10] * H * (W - 1);
@@ -400,6 +434,15 @@ static int fit_backward(const lemo_fit_desc& d, hipStream_t s, bool update = fal
   if (d.per_frame || !(stages & 16u)) goto vertex_stage;           // per_frame: no encoder (d.fit.u_m81 is all -1, dx0 is never read)
   CHK(enc_chain_bwd(d, H, W, s, &cur, enc_bwd_l_last(d)));          // d(pre-act of layer 10) -> ... -> d(pre-act of layer 1)
   CHK(enc_bwd_tail(d, cur, H, W, s));
+  if (fs && d.verts_side && !d.full_vertices) {            // fork: the all-vertex forward beside the per-frame launches below
+    if (fs->side) {
+      CHK((int)hipEventRecord(fs->fork, s));
+      CHK((int)hipStreamWaitEvent(fs->side, fs->fork, 0));
+      CHK(fit_side_launch(d, fs->side));
+      CHK((int)hipEventRecord(fs->join, fs->side));
+    } else CHK(fit_side_launch(d, s));                     // (host emulation: no second stream)
+    fs->pending = true;
+  }
 vertex_stage:
   if (!(stages & 32u)) goto pose_stage;
   if (lbs_verts_bwd_fusable(d.skin, d.uset, nj) && d.fit.n == d.uset.n) {
@@ -424,9 +467,12 @@ pose_stage:
 }
 
 // first / last: position inside the run of iterations issued together (one graph, or one eager call)
-static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last) {
-  CHK(fit_forward(d, s, false, first));
-  CHK(fit_backward(d, s, true, !last));
+static int fit_iteration(const lemo_fit_desc& d, hipStream_t s, bool first, bool last, FitSide* fs) {
+  const bool side = d.verts_side && !d.full_vertices && !d.per_frame;
+  CHK(fit_forward(d, s, false, first, ~0u, side ? fs : nullptr));
+  if (side && !fs) return LEMO_ERR_STATE;
+  CHK(fit_backward(d, s, true, !last, ~0u, side ? fs : nullptr));
+  if (last) CHK(fit_side_join(fs, s));                     // a run / a captured graph ends with everything on the caller's stream
   return 0;
 }
 
@@ -442,6 +488,14 @@ void* lemo_fit_create(const lemo_fit_desc* d) {
     // and the host thread is what limits several clips in lockstep (tools/perframe_concurrent.py)
     if (d->per_frame) e->head = 0;
     if (const char* h = getenv("LEMO_FIT_HEAD")) e->head = atoi(h);       // diagnostics: A/B of the replay schedule
+    if (d->verts_side && !d->full_vertices) {
+      if (!d->transl_side || d->per_frame) { delete e; return nullptr; }
+      // (the host emulation hands back a null stream: FitSide::side == nullptr = "no second stream", the launch then runs in line)
+      // (default priority: on the LOWEST priority the captured branch starves -- 1930 instead of 3000 it/s, profiles/r06_side_forward.txt)
+      if (hipStreamCreateWithPriority(&e->fs.side, hipStreamNonBlocking, getenv("LEMO_FIT_SIDE_PRIO") ? atoi(getenv("LEMO_FIT_SIDE_PRIO")) : 0) != hipSuccess ||
+          hipEventCreateWithFlags(&e->fs.fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e->fs.join, hipEventDisableTiming) != hipSuccess) { lemo_fit_destroy(e); return nullptr; }
+    }
   }
   return e;
 }
@@ -450,6 +504,9 @@ void lemo_fit_destroy(void* h) {
   FitEngine* e = (FitEngine*)h;
   if (!e) return;
   for (int l = 0; l <= FIT_MAXG; ++l) if (e->exec[l]) (void)hipGraphExecDestroy(e->exec[l]);
+  if (e->fs.fork) (void)hipEventDestroy(e->fs.fork);
+  if (e->fs.join) (void)hipEventDestroy(e->fs.join);
+  if (e->fs.side) { (void)hipStreamSynchronize(e->fs.side); (void)hipStreamDestroy(e->fs.side); }
   delete e;
 }
 
@@ -470,7 +527,7 @@ int lemo_fit_step(void* h, int n, int use_graph, void* stream) {
   if (!e || n < 0) return LEMO_ERR_ARG;
   hipStream_t s = S(stream);
   if (!use_graph) {
-    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s, i == 0, i == n - 1));
+    for (int i = 0; i < n; ++i) CHK(fit_iteration(e->d, s, i == 0, i == n - 1, &e->fs));
     return 0;
   }
   CHK(fit_graphs(e, s, n, false));

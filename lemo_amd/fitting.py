@@ -32,18 +32,31 @@ FOOT_SETS = ('left_heel', 'right_heel', 'left_toe', 'right_toe')
 LOSS_NAMES = ('marker', 'vposer', 'shape', 'hand', 'contact', 'smooth', 'total')
 
 
+DEFAULT_SIDE_FULL_FORWARD = __import__('os').environ.get('LEMO_SIDE_FULL_FORWARD', '0') != '0'
+"""all-vertex forward on the engine's side stream (AmassTemporalFitter.side_full_forward); the environment switch exists for A/B runs"""
+
+
 class AmassTemporalFitter(_hip.StreamOrdered):
     def __init__(self, body, vposer_weights: Dict[str, np.ndarray], enc_state: Dict[str, np.ndarray],
                  ids: Dict[str, np.ndarray], Xmean: np.ndarray, Xstd: np.ndarray, B: int, device,
                  weights: Optional[dict] = None, full_vertices: bool = True, num_pca_comps: int = 12,
                  lr0: float = 0.01, lr1: float = 0.005, lr_switch: int = 60, conv_variant: Optional[int] = None,
                  lbs_blend_fp32: bool = False, per_frame: bool = False, lr2: float = 0.0, lr_switch2: int = 0,
-                 lib: Optional[_hip.HipLib] = None):
+                 lib: Optional[_hip.HipLib] = None, side_full_forward: Optional[bool] = None):
+        """``side_full_forward`` (round 6, with ``full_vertices``): every iteration still regresses all V vertices (``vertices()`` returns them), but by a launch on
+        the engine's side stream beside the per-frame launches that close the iteration instead of in front of the encoder; the loss path forwards the 253
+        vertices it reads.  Same kernels, same bits (lemo_fit_desc.verts_side).  None = ``DEFAULT_SIDE_FULL_FORWARD``."""
         self.lib = lib or _hip.get_lib()
         self.device = torch.device(device)
         if not self.lib.is_emu and self.device.type != 'cuda':
             raise _hip.LemoHipError('AmassTemporalFitter needs a HIP device (no CPU fallback)')
         self.B, self.full = int(B), bool(full_vertices)
+        if side_full_forward is None:
+            side_full_forward = DEFAULT_SIDE_FULL_FORWARD
+        self.side_full = bool(side_full_forward) and self.full and not per_frame
+        self.full_output = self.full                         # what vertices() returns: every vertex of the model
+        if self.side_full:
+            self.full = False                                # the loss path: the set U only (index tables, verts / v_posed layouts, backward set)
         data = body if isinstance(body, BodyModelData) else BodyModelData(load_model_dict(body), num_pca_comps=num_pca_comps)
         assert data.ncomp == 12, 'the AMASS parameter vector carries 12 PCA coefficients per hand'
         self.data = data
@@ -156,6 +169,9 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         d.snap, d.nonfinite = ptr(self.snap), ptr(self.nonfinite)
         d.per_frame, d.lr2, d.lr_switch2 = int(self.per_frame), float(lr2), int(lr_switch2)
         self._stepped = False
+        if self.side_full:
+            self.ws['verts_side'], self.ws['transl_side'] = z(B, data.V, 3), z(B, 3)
+            d.verts_side, d.transl_side = ptr(self.ws['verts_side']), ptr(self.ws['transl_side'])
         for l in range(1, 11): d.act[l] = ptr(self.act[l])
         d.dact[0], d.dact[1] = ptr(self.dact[0]), ptr(self.dact[1])
         self.desc = d
@@ -368,8 +384,9 @@ class AmassTemporalFitter(_hip.StreamOrdered):
         return torch.cat([tr, self.ws['go_aa'], self.P['shape'], ot], dim=-1)
 
     def vertices(self) -> torch.Tensor:
+        """[B, V, 3] (``full_vertices``) or [B, n, 3] (the set U) of the last forward"""
         self._before_read()
-        return self.ws['verts']
+        return self.ws['verts_side'] if self.side_full else self.ws['verts']
 
     def marker_vertices(self) -> torch.Tensor:
         """the 67 marker vertices of the last forward, [B,67,3] (whatever the vertex layout of the loss path is)"""

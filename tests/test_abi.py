@@ -23,7 +23,7 @@ def test_gfx950_library_exports_every_declared_symbol(hip_lib_built):
     dll = ctypes.CDLL(hip_lib_built)
     missing = [n for n in _declared() if not hasattr(dll, n)]
     assert not missing, missing
-    assert dll.lemo_abi_version() == 4
+    assert dll.lemo_abi_version() == 5
 
 
 def test_library_exports_nothing_but_the_header(hip_lib_built):
@@ -61,7 +61,7 @@ def test_descriptor_layouts_match_the_header():
     import subprocess
     import tempfile
     from lemo_amd import _hip
-    fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame']),
+    fields = {'lemo_fit_desc': (_hip.FitDesc, ['enc_w3', 'enc_w3_inv', 'target', 'transl', 'act', 'per_frame', 'verts_side', 'transl_side']),
               'lemo_prox_desc': (_hip.ProxDesc, ['enc_w3_inv', 'sdf', 'pose_embedding', 'losses']),
               'lemo_ae_desc': (_hip.AeDesc, ['lr', 'ws', 'ws_floats'])}
     src = '#include <cstdio>\n#include <cstddef>\n#include "lemo_hip.h"\nint main(){\n'

@@ -360,6 +360,53 @@ def test_fit_small_vs_oracle_eager_and_graph(dev):
         assert abs(fit.losses()['total'] - ref_total) < 2e-3 * ref_total
 
 
+def test_side_full_forward_full_size(full_problem, dev):
+    """lemo_fit_desc.verts_side (round 6) at BASELINE size, real second stream, graph replay: the engine whose all-vertex forward runs beside
+    the per-frame launches must walk the set-U engine's trajectory bit for bit (same loss path), and after 1, 25 and 100 replayed iterations
+    vertices() must be -- bit for bit, all 119 x 10475 rows -- the in-line all-vertex forward at the parameters the last iteration's forward
+    saw, although Adam has rewritten the translation since and the next pose stage is what the side launch is joined in front of (a race
+    with either would show here); ten repetitions of the 25-iteration graph give the same bits"""
+    from lemo_amd.fitting import AmassTemporalFitter
+    from lemo_amd.vposer import make_vposer_weights
+    A, g, seq, model = full_problem['A'], full_problem['g'], full_problem['seq'], full_problem['model']
+    mk = lambda full, side: AmassTemporalFitter(model, make_vposer_weights(2), A['enc_w'], A['ids'], A['Xmean'], A['Xstd'], 119, dev,
+                                                full_vertices=full, side_full_forward=side)
+    side, active, ref = mk(True, True), mk(False, False), mk(True, False)
+    assert side.side_full and tuple(side.vertices().shape) == (119, 10475, 3)
+    for f in (side, active):
+        f.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    ref.load_sequence(seq['init_params'], g['markers_rec'], seq['contact_lbl'])
+    s = torch.cuda.Stream(dev)
+    B = 119
+
+    def check(tag):
+        torch.cuda.synchronize()
+        assert torch.equal(side.params75(), active.params75()), tag
+        ref.P['transl'].copy_(side.snap[:B * 3].view(B, 3)); ref.P['rot6d'].copy_(side.snap[B * 3:B * 9].view(B, 6))
+        ref.P['other'].copy_(side.snap[B * 9:].view(B, 56))
+        ref._after_write() if hasattr(ref, '_after_write') else None
+        ref.forward()
+        torch.cuda.synchronize()
+        assert torch.equal(side.vertices(), ref.vertices()), (tag, float((side.vertices() - ref.vertices()).abs().max()))
+
+    done = 0
+    for n in (1, 24, 75):
+        with torch.cuda.stream(s):
+            side.step(n, use_graph=True); active.step(n, use_graph=True)
+        done += n
+        check(f'after {done} iterations')
+    st = side.save_state()
+    first = None
+    for _ in range(10):
+        side.load_state(st)
+        with torch.cuda.stream(s):
+            side.step(25, use_graph=True)
+        torch.cuda.synchronize()
+        v = side.vertices().clone()
+        first = v if first is None else first
+        assert torch.equal(v, first)
+
+
 def test_wino_conv_full_size_vs_float64(dev):
     """conv variant 10 (csrc/conv_wino_kernels.hip) at the encoder's own size (245 x 134: 256 workgroups of 32 tiles + the direct last
     row of the odd H), real runs/15217 weights of layer 5: forward and backward-data against torch float64 on the host -- error of the
