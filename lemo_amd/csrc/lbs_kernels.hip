@@ -42,7 +42,7 @@ typedef _Float16 lbs_f16x8 __attribute__((ext_vector_type(8)));
 // kernel (XgS in its fp16 form) -- so the staging threads only move bytes (no conversion: the 3-piece bf16 split of the streamed
 // operand was ~130 vector-ALU instructions per thread and 64-feature stage) and a 16-deep k-chunk is THREE fp16 MFMA products
 // (hi hi + hi lo + lo hi, operands carried to 2^-22, fp32 accumulate) instead of six bf16 ones.
-template <bool DBG, bool SPLIT, bool PRE = false, bool F16 = false>
+template <bool DBG, bool SPLIT, bool PRE = false, bool F16 = false, bool LOOP = false>
 __global__ void __launch_bounds__(512)
 lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const float* __restrict__ A, int nj,
                      const float* __restrict__ transl, const int* __restrict__ ids, int n, int B,
@@ -55,8 +55,11 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   const int j = lane & 31, h = lane >> 5;
   // a workgroup takes vertex tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one tile each in the in-line launch; the fit engine's
   // side-branch launch runs 125 workgroups x 2 tiles so that the per-frame launches it overlaps keep half of the CUs: round 6)
+  // (LOOP is a template flag: the in-line instantiations keep the straight-line body and its register allocation -- the looping bf16
+  // instantiation spilled 56 registers, tests/test_resource_usage.py)
   const int ntile_x = (n + LBS_VPB - 1) / LBS_VPB;
-  for (int tile_x = blockIdx.x; tile_x < ntile_x; tile_x += gridDim.x) {
+  int tile_x = blockIdx.x;
+  do {                                                 // `while (LOOP && ...)`: no loop at all in the in-line instantiations
   const int s0 = tile_x * LBS_VPB;                     // first vertex slot of this tile
   const int f0 = blockIdx.y * LBS_FR;                  // first frame of this pass
   const int nt = wave & 3, mp = wave >> 2;
@@ -481,7 +484,7 @@ lbs_verts_fwd_kernel(SkinConst c, const float* __restrict__ Xg, int Bp, const fl
   }
 #undef LBS_ALOAD
 #undef LBS_ASTORE
-  }   // tile loop (its last statement is a workgroup barrier: the next tile may overwrite LDS)
+  } while (LOOP && (tile_x += (int)gridDim.x) < ntile_x);      // (the body's last statement is a workgroup barrier: the next tile may overwrite LDS)
   if (DBG && lane == 0) {
     unsigned long long* r = dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4;
     r[0] = t_start; r[1] = t_pro; r[2] = t_gemm; r[3] = __builtin_amdgcn_s_memtime();
@@ -498,6 +501,7 @@ int lbs_init() {
 #define OPTINH(DBG_) if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<DBG_, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
   OPTINH(false) OPTINH(true)
 #undef OPTINH
+  if (!rc) rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lbs_verts_fwd_kernel<false, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LBS_SMEM_MAX);
   return rc;
 }
 
@@ -509,7 +513,12 @@ int lbs_verts_fwd(const SkinConst& c, const float* Xg, int Bp, const float* A, i
   if (nj > 64 || 3 * nj * 12 > 5 * 512) return LEMO_ERR_SHAPE;
   const int smem_bytes = lbs_smem_bytes(nj);
   dim3 grid((n + LBS_VPB - 1) / LBS_VPB, (B + LBS_FR - 1) / LBS_FR);
-  if (max_blocks_x > 0 && (int)grid.x > max_blocks_x) grid.x = max_blocks_x;      // the kernel loops over its tiles (same arithmetic per tile: same bits)
+  if (max_blocks_x > 0 && (int)grid.x > max_blocks_x) {      // fewer workgroups, each looping over its tiles (same arithmetic per tile: same bits)
+    if (c.blend_fp32 || !XgS || !c.DgH || dbg) return LEMO_ERR_ARG;      // only the shipped arithmetic (pre-split fp16 operands) has the looping instantiation
+    grid.x = max_blocks_x;
+    hipLaunchKernelGGL((lbs_verts_fwd_kernel<false, true, true, true, true>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS);
+    return (int)hipGetLastError();
+  }
 #define LAUNCH(DBG_, SPLIT_, PRE_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, SPLIT_, PRE_>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
 #define LAUNCHH(DBG_) hipLaunchKernelGGL((lbs_verts_fwd_kernel<DBG_, true, true, true>), grid, dim3(512), smem_bytes, s, c, Xg, Bp, A, nj, transl, ids, n, B, verts, v_posed, dbg, XgS)
   if (!c.blend_fp32 && XgS && c.DgH) { if (dbg) LAUNCHH(true); else LAUNCHH(false); }      // (XgS in its fp16 form: lemo_pose_ws.xgs_f16)
